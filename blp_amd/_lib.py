@@ -1,0 +1,103 @@
+"""ctypes binding of libblp_hip.so (include/blp_hip.h).
+
+The library is the product: there is no Python or CPU fallback behind it.  If it is missing the
+import of anything that needs it raises ``HipLibraryError`` telling the user to build it
+(``python -m blp_amd.build``).  ctypes releases the GIL during calls, so nn.DataParallel replica
+threads overlap their launches.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblp_hip.so")
+
+MODEL_IDS = {"transe": 0, "distmult": 1, "complex": 2, "simple": 3}
+LOSS_IDS = {"margin": 0, "nll": 1}
+
+BLP_OK = 0
+STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM", -3: "BLP_ERR_HIP",
+                -4: "BLP_ERR_WORKSPACE"}
+
+# every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
+SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
+           "blp_rank_all_workspace_bytes", "blp_rank_all", "blp_profile_next_rank_kernel", "blp_rank_metrics", "blp_score_fwd",
+           "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd")
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class BlpCaps(ctypes.Structure):
+    _fields_ = [("compute_units", ctypes.c_int), ("wavefront_size", ctypes.c_int),
+                ("lds_bytes_per_cu", ctypes.c_int), ("clock_mhz", ctypes.c_int),
+                ("hbm_bytes", ctypes.c_int64), ("arch", ctypes.c_char * 32)]
+
+
+_lib = None
+_vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+
+def lib():
+    """Load libblp_hip.so once.  Raises HipLibraryError (never falls back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch first: its bundled libamdhip64 (SONAME libamdhip64.so.7) must already be mapped so that the
+    # dynamic loader binds libblp_hip.so to the SAME HIP runtime instance torch's streams and
+    # allocations belong to (two runtimes in one process cannot share hipStream_t handles).
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m blp_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback for "
+            "CUDA/HIP tensors.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    L.blp_version.restype = _i
+    L.blp_version.argtypes = []
+    L.blp_last_error.restype = ctypes.c_char_p
+    L.blp_last_error.argtypes = []
+    L.blp_device_caps.restype = _i
+    L.blp_device_caps.argtypes = [_i, ctypes.POINTER(BlpCaps)]
+    L.blp_dim_supported.restype = _i
+    L.blp_dim_supported.argtypes = [_i, _i]
+    L.blp_rank_all_workspace_bytes.restype = _sz
+    L.blp_rank_all_workspace_bytes.argtypes = [_i, _i, _i64, _i64]
+    L.blp_rank_all.restype = _i
+    L.blp_rank_all.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
+                               _vp, _sz, _i, _vp]
+    L.blp_profile_next_rank_kernel.restype = _i
+    L.blp_profile_next_rank_kernel.argtypes = [_vp, _vp]
+    L.blp_rank_metrics.restype = _i
+    L.blp_rank_metrics.argtypes = [_vp, _i64, ctypes.POINTER(ctypes.c_int32), _vp, _vp, _i, _vp]
+    L.blp_score_fwd.restype = _i
+    L.blp_score_fwd.argtypes = [_i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                                _vp, _i, _vp]
+    L.blp_score_bwd.restype = _i
+    L.blp_score_bwd.argtypes = [_i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                                _vp, _vp, _vp, _vp, _i, _vp]
+    L.blp_inbatch_loss_fwd.restype = _i
+    L.blp_inbatch_loss_fwd.argtypes = [_i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]
+    L.blp_inbatch_loss_bwd.restype = _i
+    L.blp_inbatch_loss_bwd.argtypes = [_i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
+                                       _i, _vp]
+    _lib = L
+    return L
+
+
+def check(status, what):
+    """Map a non-zero C status to RuntimeError(blp_last_error()) (SURVEY 8b error convention)."""
+    if status != BLP_OK:
+        msg = lib().blp_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed with {STATUS_NAMES.get(status, status)}: {msg}")
+
+
+def device_caps(device=0):
+    caps = BlpCaps()
+    check(lib().blp_device_caps(device, ctypes.byref(caps)), "blp_device_caps")
+    return {"compute_units": caps.compute_units, "wavefront_size": caps.wavefront_size,
+            "lds_bytes_per_cu": caps.lds_bytes_per_cu, "clock_mhz": caps.clock_mhz,
+            "hbm_bytes": caps.hbm_bytes, "arch": caps.arch.decode()}

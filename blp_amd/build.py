@@ -1,0 +1,61 @@
+"""Build libblp_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build(); also runnable
+as ``python -m blp_amd.build``.  hipcc cross-compiles without a GPU.  The .so stays next to this
+file (git-ignored, but it travels with the tree to the GPU box)."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libblp_hip.so")
+SOURCES = ["rank_all.hip", "score.hip", "inbatch_loss.hip", "api.cpp"]
+HEADERS = ["score_core.h", "score_direct.h", "launch.h", os.path.join("..", "..", "include", "blp_hip.h")]
+# -ffp-contract=off: the kernels restate the reference's per-operation rounding; an FMA would change
+# the last bit of a score and with it a rank.  No fast-math for the same reason.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC); blp_amd needs the ROCm toolchain to build libblp_hip.so")
+
+
+def _newest_header():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    dep_time = max(_newest_header(), os.path.getmtime(__file__))
+    jobs = []
+    for src in SOURCES:
+        src_path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, src + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src_path), dep_time):
+            cmd = [cc, *FLAGS, "-x", "hip", "-c", src_path, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            list(pool.map(run, jobs))
+    objs = [os.path.join(OBJ, s + ".o") for s in SOURCES]
+    if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        run(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,251 @@
+// api.cpp -- the C-ABI of libblp_hip.so (include/blp_hip.h): argument checking, device selection,
+// error reporting and dispatch to the launchers in the .hip files.  No kernel code here.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/blp_hip.h"
+#include "launch.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // blp_profile_next_rank_kernel
+
+int fail(int status, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+int hip_fail(hipError_t err, const char* what) {
+    return fail(BLP_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+}
+
+// Make `device` current for the duration of a call, restore the caller's device afterwards
+// (torch keeps its own notion of the current device per thread).
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device) {
+        err_ = hipGetDevice(&prev_);
+        if (err_ == hipSuccess && prev_ != device) {
+            err_ = hipSetDevice(device);
+            switched_ = err_ == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched_) (void)hipSetDevice(prev_);
+    }
+    hipError_t error() const { return err_; }
+
+  private:
+    int prev_ = 0;
+    bool switched_ = false;
+    hipError_t err_ = hipSuccess;
+};
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool valid_model(int m) { return m >= BLP_TRANSE && m <= BLP_SIMPLE; }
+
+int compute_units(int device, int* out) {
+    // Cached per device: hipDeviceGetAttribute is cheap but not free, and blp_rank_all is called
+    // per query block.  Plain ints written once; a race only repeats the query.
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device] > 0) {
+        *out = cached[device];
+        return BLP_OK;
+    }
+    int cu = 0;
+    hipError_t err = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device);
+    if (err != hipSuccess) return hip_fail(err, "hipDeviceGetAttribute(MultiprocessorCount)");
+    if (device >= 0 && device < 64) cached[device] = cu;
+    *out = cu;
+    return BLP_OK;
+}
+
+blp::StridedRows rows(const float* p, int64_t s0, int64_t s1) { return blp::StridedRows{p, s0, s1}; }
+
+// score_fn operands: D floats readable at every addressed row; the bilinear models use the
+// torch.sum order implemented for widths that are multiples of 32 below 512.
+int check_score_dim(int model, int D) {
+    if (D <= 0) return fail(BLP_ERR_BAD_ARG, "D must be positive (got %d)", D);
+    if (model == BLP_TRANSE) return BLP_OK;
+    const int n = model == BLP_DISTMULT ? D : D / 2;
+    if ((model != BLP_DISTMULT && D % 2) || n % 32 || n >= 512)
+        return fail(BLP_ERR_UNSUPPORTED_DIM,
+                    "model %d: reduction width %d must be a multiple of 32 below 512 (D = %d)", model, n, D);
+    return BLP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blp_version(void) { return BLP_HIP_VERSION; }
+
+const char* blp_last_error(void) { return g_error; }
+
+int blp_device_caps(int device, blp_caps* out) {
+    if (!out) return fail(BLP_ERR_BAD_ARG, "blp_device_caps: out is NULL");
+    hipDeviceProp_t prop;
+    hipError_t err = hipGetDeviceProperties(&prop, device);
+    if (err != hipSuccess) return hip_fail(err, "hipGetDeviceProperties");
+    out->compute_units = prop.multiProcessorCount;
+    out->wavefront_size = prop.warpSize;
+    out->lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    out->clock_mhz = prop.clockRate / 1000;
+    out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    std::memset(out->arch, 0, sizeof(out->arch));
+    std::strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    return BLP_OK;
+}
+
+int blp_dim_supported(int model, int D) {
+    if (!valid_model(model)) return 0;
+    if (D != 64 && D != 128 && D != 256) return 0;
+    return 1;
+}
+
+size_t blp_rank_all_workspace_bytes(int model, int D, int64_t q_head, int64_t q_tail) {
+    (void)model;
+    if (D <= 0 || q_head < 0 || q_tail < 0) return 0;
+    return blp::rank_all_workspace_bytes(D, q_head, q_tail);
+}
+
+int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
+                 const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                 int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                 void* workspace, size_t workspace_bytes, int device, void* stream) {
+    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
+    if (!blp_dim_supported(model, D))
+        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_rank_all: D = %d not compiled (supported: 64, 128, 256)", D);
+    if (N < 0 || q_head < 0 || q_tail < 0 || ld < D)
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: negative size or ld < D (N=%lld q_head=%lld q_tail=%lld ld=%lld)",
+                    (long long)N, (long long)q_head, (long long)q_tail, (long long)ld);
+    const int64_t Q = q_head + q_tail;
+    if (Q == 0) return BLP_OK;
+    if (Q > (1ll << 30) || N > (1ll << 36))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: Q or N too large for one call; split the query block");
+    if (!q_fixed || !q_rel || !counts) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL q_fixed / q_rel / counts");
+    if (N > 0 && !table) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL table");
+    if ((true_row == nullptr) == (q_true == nullptr))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: exactly one of true_row / q_true must be given");
+    if ((filt_rowptr == nullptr) != (filt_col == nullptr))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filt_rowptr and filt_col must both be given or both NULL");
+    if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: table / q_true / counts must be 16-byte aligned and ld %% 4 == 0");
+    const size_t need = blp::rank_all_workspace_bytes(D, q_head, q_tail);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail(BLP_ERR_WORKSPACE, "blp_rank_all: workspace must be 256-byte aligned and >= %zu bytes (got %zu)",
+                    need, workspace_bytes);
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    int cu = 0;
+    if (int rc = compute_units(device, &cu)) return rc;
+    hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
+    hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
+                                          filt_rowptr, filt_col, counts, workspace, cu,
+                                          static_cast<hipStream_t>(stream), ev0, ev1);
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_all launch");
+    return BLP_OK;
+}
+
+int blp_profile_next_rank_kernel(void* start_event, void* stop_event) {
+    if ((start_event == nullptr) != (stop_event == nullptr))
+        return fail(BLP_ERR_BAD_ARG, "blp_profile_next_rank_kernel: give both events or neither");
+    g_prof_start = static_cast<hipEvent_t>(start_event);
+    g_prof_stop = static_cast<hipEvent_t>(stop_event);
+    return BLP_OK;
+}
+
+int blp_rank_metrics(const int32_t* counts, int64_t Q, const int32_t k_values[3], float* rr, uint8_t* hits,
+                     int device, void* stream) {
+    if (Q < 0 || (Q > 0 && (!counts || !rr || !hits || !k_values)))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_metrics: NULL argument or negative Q");
+    if (!aligned16(counts)) return fail(BLP_ERR_BAD_ARG, "blp_rank_metrics: counts must be 16-byte aligned");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_rank_metrics(counts, Q, k_values, rr, hits, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_metrics launch");
+    return BLP_OK;
+}
+
+int blp_score_fwd(int model, int D, int64_t M0, int64_t M1, const float* heads, int64_t h_s0, int64_t h_s1,
+                  const float* tails, int64_t t_s0, int64_t t_s1, const float* rels, int64_t r_s0, int64_t r_s1,
+                  float* out, int device, void* stream) {
+    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_score_fwd: unknown model %d", model);
+    if (int rc = check_score_dim(model, D)) return rc;
+    if (M0 < 0 || M1 < 0) return fail(BLP_ERR_BAD_ARG, "blp_score_fwd: negative output shape");
+    if (M0 * M1 == 0) return BLP_OK;
+    if (!heads || !tails || !rels || !out) return fail(BLP_ERR_BAD_ARG, "blp_score_fwd: NULL pointer");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_score_fwd(model, D, M0, M1, rows(heads, h_s0, h_s1), rows(tails, t_s0, t_s1),
+                                           rows(rels, r_s0, r_s1), out, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_score_fwd launch");
+    return BLP_OK;
+}
+
+int blp_score_bwd(int model, int D, int64_t M0, int64_t M1, const float* heads, int64_t h_s0, int64_t h_s1,
+                  const float* tails, int64_t t_s0, int64_t t_s1, const float* rels, int64_t r_s0, int64_t r_s1,
+                  const float* grad_out, float* grad_heads, float* grad_tails, float* grad_rels, int device,
+                  void* stream) {
+    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_score_bwd: unknown model %d", model);
+    if (int rc = check_score_dim(model, D)) return rc;
+    if (M0 < 0 || M1 < 0) return fail(BLP_ERR_BAD_ARG, "blp_score_bwd: negative output shape");
+    if (M0 * M1 == 0) return BLP_OK;
+    if (!heads || !tails || !rels || !grad_out) return fail(BLP_ERR_BAD_ARG, "blp_score_bwd: NULL pointer");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_score_bwd(model, D, M0, M1, rows(heads, h_s0, h_s1), rows(tails, t_s0, t_s1),
+                                           rows(rels, r_s0, r_s1), grad_out, grad_heads, grad_tails, grad_rels,
+                                           static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_score_bwd launch");
+    return BLP_OK;
+}
+
+static int check_inbatch(const char* who, int model, int loss, const void* ent, const void* rel, const void* neg_idx,
+                         int B, int K, int D) {
+    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "%s: unknown model %d", who, model);
+    if (loss != BLP_LOSS_MARGIN && loss != BLP_LOSS_NLL) return fail(BLP_ERR_BAD_ARG, "%s: unknown loss %d", who, loss);
+    if (B <= 0 || K <= 0) return fail(BLP_ERR_BAD_ARG, "%s: B and K must be positive (B=%d K=%d)", who, B, K);
+    if (int rc = check_score_dim(model, D)) return rc;
+    if (D > 768) return fail(BLP_ERR_UNSUPPORTED_DIM, "%s: D = %d > 768", who, D);
+    if (!ent || !rel || !neg_idx) return fail(BLP_ERR_BAD_ARG, "%s: NULL pointer", who);
+    return BLP_OK;
+}
+
+int blp_inbatch_loss_fwd(int model, int loss, const float* ent_embs, const float* rel_vecs, const int64_t* neg_idx,
+                         int B, int K, int D, float regularizer, float* out_loss, float* save_pos, float* save_neg,
+                         int device, void* stream) {
+    if (int rc = check_inbatch("blp_inbatch_loss_fwd", model, loss, ent_embs, rel_vecs, neg_idx, B, K, D)) return rc;
+    if (!out_loss || !save_pos || !save_neg) return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_fwd: NULL output");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_inbatch_loss_fwd(model, loss, ent_embs, rel_vecs, neg_idx, B, K, D, regularizer,
+                                                  out_loss, save_pos, save_neg, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_inbatch_loss_fwd launch");
+    return BLP_OK;
+}
+
+int blp_inbatch_loss_bwd(int model, int loss, const float* ent_embs, const float* rel_vecs, const int64_t* neg_idx,
+                         int B, int K, int D, float regularizer, const float* grad_loss, const float* save_pos,
+                         const float* save_neg, float* grad_ent, float* grad_rel, int device, void* stream) {
+    if (int rc = check_inbatch("blp_inbatch_loss_bwd", model, loss, ent_embs, rel_vecs, neg_idx, B, K, D)) return rc;
+    if (!grad_loss || !save_pos || !save_neg || !grad_ent || !grad_rel)
+        return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_bwd: NULL pointer");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_inbatch_loss_bwd(model, loss, ent_embs, rel_vecs, neg_idx, B, K, D, regularizer,
+                                                  grad_loss, save_pos, save_neg, grad_ent, grad_rel,
+                                                  static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_inbatch_loss_bwd launch");
+    return BLP_OK;
+}
+
+}  // extern "C"

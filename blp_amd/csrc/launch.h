@@ -1,0 +1,42 @@
+// launch.h -- host-side launchers implemented in the .hip files, called by the C-ABI in api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace blp {
+
+size_t rank_all_workspace_bytes(int D, int64_t q_head, int64_t q_tail);
+
+hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
+                           const float* q_fixed, const float* q_rel, const int64_t* true_row,
+                           const float* q_true, int64_t q_head, int64_t q_tail,
+                           const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                           void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                           hipEvent_t ev_stop = nullptr);
+
+hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,
+                               uint8_t* hits, hipStream_t stream);
+
+struct StridedRows {  // row(i0, i1) = base + i0 * s0 + i1 * s1   (strides in floats)
+    const float* base;
+    int64_t s0, s1;
+};
+
+hipError_t launch_score_fwd(int model, int D, int64_t M0, int64_t M1, StridedRows h, StridedRows t,
+                            StridedRows r, float* out, hipStream_t stream);
+hipError_t launch_score_bwd(int model, int D, int64_t M0, int64_t M1, StridedRows h, StridedRows t,
+                            StridedRows r, const float* grad_out, float* grad_h, float* grad_t,
+                            float* grad_r, hipStream_t stream);
+
+hipError_t launch_inbatch_loss_fwd(int model, int loss, const float* ent, const float* rel,
+                                   const int64_t* neg_idx, int B, int K, int D, float regularizer,
+                                   float* out_loss, float* save_pos, float* save_neg,
+                                   hipStream_t stream);
+hipError_t launch_inbatch_loss_bwd(int model, int loss, const float* ent, const float* rel,
+                                   const int64_t* neg_idx, int B, int K, int D, float regularizer,
+                                   const float* grad_loss, const float* save_pos,
+                                   const float* save_neg, float* grad_ent, float* grad_rel,
+                                   hipStream_t stream);
+
+}  // namespace blp

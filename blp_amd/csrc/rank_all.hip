@@ -1,0 +1,378 @@
+// rank_all.hip -- all-entities ranking on gfx950: stream the (N, D) candidate table once and turn
+// every query into its rank counts without materialising the (Q, N) score matrix.
+// Replaces train.py:146-171 + utils.py:103-105 of the reference (see include/blp_hip.h).
+//
+// Kernel pipeline of one blp_rank_all call (all on the caller's stream, no host sync):
+//   1. prep_coef    (q, i) elementwise: hoist the query-only part of the score into C coefficients
+//   2. true_key     one lane per query: score of the true entity, by the same Scorer<> routine
+//   3. rank_tiles   the hot kernel, below
+//   4. filt_counts  one wave per query: scores of the CSR-listed (filtered) rows vs the true score
+//   5. finalize     counts[q] = {gt, ge, gt - fgt, ge - fge}
+//
+// rank_tiles layout.  One wavefront owns a tile of 64 consecutive table rows, one row per lane, held
+// in D VGPRs (the sequential f32 sum of the reference forces one lane per (candidate, query) chain).
+// The tile is fetched with coalesced 16-B/lane loads (8 rows x 128 B per wave instruction, full
+// cache lines), transposed through a wave-private, bank-conflict-free LDS slab (row stride 36
+// dwords), and then every query of the wave's query chunk is applied to it: the query coefficients
+// are wave-uniform, so they arrive through the scalar cache as SGPR operands and cost no VGPRs and
+// no LDS bandwidth.  Per query the wave does 2-3 VALU ops per element, two v_cmp + s_bcnt1 for the
+// counts, and adds them to a per-wave LDS counter; counters are flushed once per wave with 64-bit
+// atomics (gt in the low word, ge in the high word).
+//   - few queries, huge table (Wikidata5M scale): the kernel is HBM-bound; waves grid-stride over
+//     tiles and the table is read exactly once.
+//   - many queries, small table (FB15k-237 test set): the table is L2/MALL-resident and the kernel
+//     is f32-VALU-bound; parallelism comes from (tile x query chunk).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch.h"
+#include "score_core.h"
+
+#pragma clang fp contract(off)
+
+namespace blp {
+
+constexpr int kWaves = 4;            // waves per workgroup
+constexpr int kTileRows = 64;        // candidates per wave tile (one per lane)
+constexpr int kSubCols = 32;         // floats per row per LDS pass (128 B = one cache line)
+constexpr int kLdsStride = 36;       // dwords; 36*l mod 64 is conflict-free for ds_read_b128
+constexpr int kQueryChunk = 256;     // queries per wave pass over its tiles
+constexpr int kSlabFloats = kTileRows * kLdsStride;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from
+    // moving LDS accesses across the hand-off point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, int D>
+__global__ void prep_coef_kernel(const float* __restrict__ q_fixed, const float* __restrict__ q_rel,
+                                 int64_t q_head, int64_t q_tail, float* __restrict__ coef_head,
+                                 float* __restrict__ coef_tail) {
+    using SH = Scorer<MODEL, HEAD, D>;
+    using ST = Scorer<MODEL, TAIL, D>;
+    const int64_t n_head = q_head * SH::C;
+    const int64_t total = n_head + q_tail * ST::C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_head) {
+            const int64_t q = i / SH::C;
+            coef_head[i] = SH::coef(q_fixed + q * D, q_rel + q * D, (int)(i % SH::C));
+        } else {
+            const int64_t k = i - n_head, q = k / ST::C;
+            coef_tail[k] = ST::coef(q_fixed + (q_head + q) * D, q_rel + (q_head + q) * D, (int)(k % ST::C));
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void load_row(float (&e)[D], const float* __restrict__ row) {
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + d);
+        e[d] = v.x; e[d + 1] = v.y; e[d + 2] = v.z; e[d + 3] = v.w;
+    }
+}
+
+template <int MODEL, int D>
+__global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ table, int64_t ld,
+                                const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
+                                const float* __restrict__ coef_head, const float* __restrict__ coef_tail,
+                                int64_t q_head, int64_t q_tail, float* __restrict__ key_true) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= q_head + q_tail) return;
+    float e[D];
+    load_row<D>(e, true_row ? table + true_row[q] * ld : q_true + q * D);
+    key_true[q] = q < q_head
+        ? Scorer<MODEL, HEAD, D>::template score<false>(e, coef_head + q * Scorer<MODEL, HEAD, D>::C)
+        : Scorer<MODEL, TAIL, D>::template score<false>(e, coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fetch rows [row0, row0 + 64) of the table into e[] (lane l <- row row0 + l) through the wave's LDS
+// slab.  Rows past the table end are clamped to the last row (their counts are masked by `valid`).
+template <int D>
+__device__ __forceinline__ void load_tile(float (&e)[D], const float* __restrict__ table, int64_t N,
+                                          int64_t ld, int64_t row0, float* slab, int lane) {
+    const int sub_row = lane >> 3;        // 8 rows per wave instruction
+    const int sub_col = (lane & 7) * 4;   // 8 x 16 B = one 128-B line per row
+    const float* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int64_t row = row0 + 8 * i + sub_row;
+        row = row < N ? row : N - 1;
+        src[i] = table + row * ld + sub_col;
+    }
+    float* wr = slab + sub_row * kLdsStride + sub_col;
+    const float* rd = slab + lane * kLdsStride;
+#pragma unroll
+    for (int s = 0; s < D / kSubCols; ++s) {
+        if (s > 0) wave_lds_sync();  // previous pass' reads are done before the slab is rewritten
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(src[i] + s * kSubCols);
+            *reinterpret_cast<float4*>(wr + 8 * i * kLdsStride) = v;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < kSubCols / 4; ++j) {
+            const float4 w = *reinterpret_cast<const float4*>(rd + 4 * j);
+            e[s * kSubCols + 4 * j] = w.x; e[s * kSubCols + 4 * j + 1] = w.y;
+            e[s * kSubCols + 4 * j + 2] = w.z; e[s * kSubCols + 4 * j + 3] = w.w;
+        }
+    }
+}
+
+template <int MODEL, int SIDE, int D>
+__device__ __forceinline__ void apply_queries(const float (&e)[D], bool valid, const float* __restrict__ coef,
+                                              const float* __restrict__ key_true, int n_queries,
+                                              unsigned* cnt, int lane) {
+    using S = Scorer<MODEL, SIDE, D>;
+    // j is wave-uniform, so the coefficient loads below are scalar loads (s_load_dwordx16) and the
+    // coefficients are SGPR operands of the VALU instructions.
+    for (int j = 0; j < n_queries; ++j) {
+        const float key = S::template score<false>(e, coef + (size_t)j * S::C);
+        const float kt = key_true[j];
+        const unsigned gt = __popcll(__ballot(valid && key > kt));
+        const unsigned ge = __popcll(__ballot(valid && key >= kt));
+        if (lane == 0) {  // ds_add_u32 without return: fire and forget
+            __hip_atomic_fetch_add(cnt + 2 * j, gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(cnt + 2 * j + 1, ge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+}
+
+template <int MODEL, int D>
+__global__ __launch_bounds__(kWaves * 64) void rank_tiles_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
+    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
+    int n_tiles, int n_tile_groups, int n_chunks, unsigned long long* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    float* slab = smem + wave * kSlabFloats;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem + kWaves * kSlabFloats) + wave * (2 * kQueryChunk);
+
+    // wave id -> (query chunk, tile group); the 4 waves of a workgroup share the chunk (same
+    // coefficients in the scalar cache) and take adjacent tile groups.
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wave);
+    if (wid >= (unsigned)n_tile_groups * (unsigned)n_chunks) return;
+    const int chunk = __builtin_amdgcn_readfirstlane(wid / (unsigned)n_tile_groups);
+    const int tg = __builtin_amdgcn_readfirstlane(wid % (unsigned)n_tile_groups);
+    const int Q = q_head + q_tail;
+    const int qa = chunk * kQueryChunk;
+    const int qb = qa + kQueryChunk < Q ? qa + kQueryChunk : Q;
+    // [qa, qb) split at q_head: head-replacing queries first (train.py:149 order)
+    const int h_lo = qa < q_head ? qa : q_head, h_hi = qb < q_head ? qb : q_head;
+    const int t_lo = qa > q_head ? qa : q_head, t_hi = qb > q_head ? qb : q_head;
+    const float* ch = coef_head + (size_t)h_lo * Scorer<MODEL, HEAD, D>::C;
+    const float* ct = coef_tail + (size_t)(t_lo - q_head) * Scorer<MODEL, TAIL, D>::C;
+
+    for (int i = lane; i < 2 * kQueryChunk; i += 64) cnt[i] = 0;
+    wave_lds_sync();
+
+    for (int tile = tg; tile < n_tiles; tile += n_tile_groups) {
+        float e[D];
+        const int64_t row0 = (int64_t)tile * kTileRows;
+        load_tile<D>(e, table, N, ld, row0, slab, lane);
+        const bool valid = row0 + lane < N;
+        apply_queries<MODEL, HEAD, D>(e, valid, ch, key_true + h_lo, h_hi - h_lo, cnt + 2 * (h_lo - qa), lane);
+        apply_queries<MODEL, TAIL, D>(e, valid, ct, key_true + t_lo, t_hi - t_lo, cnt + 2 * (t_lo - qa), lane);
+    }
+
+    wave_lds_sync();
+    for (int j = lane; j < qb - qa; j += 64) {
+        const unsigned long long v = (unsigned long long)cnt[2 * j] | ((unsigned long long)cnt[2 * j + 1] << 32);
+        if (v) atomicAdd(acc + qa + j, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Filtered setting: one wave per query, lanes stride over the query's CSR-listed rows.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void filt_counts_kernel(
+    const float* __restrict__ table, int64_t ld, const float* __restrict__ coef_head,
+    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int64_t q_head,
+    int64_t q_tail, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+    unsigned long long* __restrict__ acc_f) {
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= q_head + q_tail) return;
+    const int64_t lo = rowptr[q], hi = rowptr[q + 1];
+    const float kt = key_true[q];
+    unsigned gt = 0, ge = 0;
+    for (int64_t k = lo + lane; k < hi; k += 64) {
+        float e[D];
+        load_row<D>(e, table + col[k] * ld);
+        const float key = q < q_head
+            ? Scorer<MODEL, HEAD, D>::template score<false>(e, coef_head + q * Scorer<MODEL, HEAD, D>::C)
+            : Scorer<MODEL, TAIL, D>::template score<false>(e, coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C);
+        gt += key > kt;
+        ge += key >= kt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gt += __shfl_down(gt, off);
+        ge += __shfl_down(ge, off);
+    }
+    if (lane == 0) acc_f[q] = (unsigned long long)gt | ((unsigned long long)ge << 32);
+}
+
+__global__ void finalize_counts_kernel(const unsigned long long* __restrict__ acc,
+                                       const unsigned long long* __restrict__ acc_f, int64_t Q,
+                                       int32_t* __restrict__ counts) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const unsigned long long a = acc[q];
+    const unsigned long long f = acc_f ? acc_f[q] : 0ull;
+    const int32_t gt = (int32_t)(a & 0xffffffffull), ge = (int32_t)(a >> 32);
+    const int32_t fgt = (int32_t)(f & 0xffffffffull), fge = (int32_t)(f >> 32);
+    reinterpret_cast<int4*>(counts)[q] = make_int4(gt, ge, gt - fgt, ge - fge);
+}
+
+// utils.py:104-109 from the counts
+__global__ void rank_metrics_kernel(const int32_t* __restrict__ counts, int64_t Q, int k0, int k1, int k2,
+                                    float* __restrict__ rr, uint8_t* __restrict__ hits) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int4 c = reinterpret_cast<const int4*>(counts)[q];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int64_t best = (int64_t)(v ? c.z : c.x) + 1, worst = v ? c.w : c.y;
+        const float avg = (float)(best + worst) * 0.5f;
+        rr[2 * q + v] = __fdiv_rn(1.0f, avg);
+        hits[6 * q + 3 * v + 0] = avg <= (float)k0;
+        hits[6 * q + 3 * v + 1] = avg <= (float)k1;
+        hits[6 * q + 3 * v + 2] = avg <= (float)k2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct RankWorkspace {
+    float* coef_head;
+    float* coef_tail;
+    float* key_true;
+    unsigned long long* acc;
+    unsigned long long* acc_f;
+    size_t bytes;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t q_tail) {
+    // Both sides are sized for the larger coefficient layout (2 * D floats per query).
+    RankWorkspace w;
+    const int64_t Q = q_head + q_tail;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    w.coef_head = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_head * max_coef(D) * 4, 256);
+    w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * max_coef(D) * 4, 256);
+    w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
+    w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
+    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
+    w.bytes = off;
+    return w;
+}
+
+size_t rank_all_workspace_bytes(int D, int64_t q_head, int64_t q_tail) {
+    return carve_workspace(nullptr, D, q_head, q_tail).bytes;
+}
+
+template <int MODEL, int D>
+static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                                const float* q_rel, const int64_t* true_row, const float* q_true,
+                                int64_t q_head, int64_t q_tail, const int64_t* filt_rowptr,
+                                const int64_t* filt_col, int32_t* counts, void* workspace,
+                                int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const int64_t Q = q_head + q_tail;
+    if (Q == 0) return hipSuccess;
+    RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
+    hipError_t err = hipMemsetAsync(w.acc, 0, (size_t)Q * 8, stream);
+    if (err != hipSuccess) return err;
+
+    {
+        const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
+        const int64_t blocks = (total + 255) / 256;
+        const int grid = (int)(blocks < 8192 ? blocks : 8192);
+        prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail);
+        true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(
+            table, ld, true_row, q_true, w.coef_head, w.coef_tail, q_head, q_tail, w.key_true);
+    }
+
+    if (N > 0) {
+        const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
+        const int64_t n_chunks = (Q + kQueryChunk - 1) / kQueryChunk;
+        // Resident waves: 3 per SIMD at ~144 VGPRs.  With plenty of (tile, chunk) pairs give every
+        // wave one tile (many short waves -> no tail); otherwise grid-stride a few thousand waves.
+        const int64_t resident = (int64_t)n_cu * 12;
+        int64_t groups = n_tiles;
+        if (n_tiles * n_chunks > 8 * resident) {
+            groups = n_tiles;
+        } else {
+            const int64_t want = (2 * resident + n_chunks - 1) / n_chunks;
+            groups = n_tiles < want ? n_tiles : want;
+        }
+        const int64_t waves = groups * n_chunks;
+        const int64_t blocks = (waves + kWaves - 1) / kWaves;
+        const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)kWaves * 2 * kQueryChunk * 4;
+        if (ev_start) (void)hipEventRecord(ev_start, stream);
+        rank_tiles_kernel<MODEL, D><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
+            table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
+            (int)groups, (int)n_chunks, w.acc);
+        if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+    }
+
+    const bool filtered = filt_rowptr != nullptr;
+    if (filtered)
+        filt_counts_kernel<MODEL, D><<<(int)((Q + 3) / 4), 256, 0, stream>>>(
+            table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filt_rowptr, filt_col, w.acc_f);
+    finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(w.acc, filtered ? w.acc_f : nullptr, Q, counts);
+    return hipGetLastError();
+}
+
+template <int MODEL>
+static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                               const float* q_rel, const int64_t* true_row, const float* q_true,
+                               int64_t q_head, int64_t q_tail, const int64_t* filt_rowptr,
+                               const int64_t* filt_col, int32_t* counts, void* workspace, int n_cu,
+                               hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+#define BLP_RANK_CASE(DD)                                                                              \
+    case DD:                                                                                           \
+        return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, \
+                                        filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    switch (D) {
+        BLP_RANK_CASE(64)
+        BLP_RANK_CASE(128)
+        BLP_RANK_CASE(256)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef BLP_RANK_CASE
+}
+
+hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
+                           const float* q_fixed, const float* q_rel, const int64_t* true_row,
+                           const float* q_true, int64_t q_head, int64_t q_tail,
+                           const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                           void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                           hipEvent_t ev_stop) {
+    switch (model) {
+    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    default:       return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,
+                               uint8_t* hits, hipStream_t stream) {
+    if (Q == 0) return hipSuccess;
+    rank_metrics_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(counts, Q, k[0], k[1], k[2], rr, hits);
+    return hipGetLastError();
+}
+
+}  // namespace blp

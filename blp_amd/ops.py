@@ -1,0 +1,260 @@
+"""Torch-facing operators over the C-ABI (libblp_hip.so).  PyTorch is plumbing here: it owns the
+device memory and the stream; every arithmetic step of the hot path runs in the HIP kernels.
+
+    rank_all(...)       all-entities ranking counts        (train.py:146-171, utils.py:103-105)
+    rank_metrics(...)   counts -> reciprocal ranks, hits   (utils.py:104-109)
+    score(...)          score_fn(heads, tails, rels)       (models.py:222-248), differentiable
+    inbatch_loss(...)   compute_loss on in-batch negatives (models.py:51-70), differentiable
+
+Tensors must live on a HIP device; there is no CPU implementation behind these functions (CPU
+tensors are handled one level up, in blp_amd.models, with plain torch expressions).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_K_VALUES = (ctypes.c_int32 * 3)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("blp_amd.ops works on HIP device tensors only (got a CPU tensor); "
+                               "there is no CPU fallback in the product path")
+
+
+def _f32_rows(t, name):
+    """float32, unit stride along the last dim (rows may be strided)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        t = t.contiguous()
+    return t
+
+
+def dim_supported(rel_model, dim):
+    """True if the fused ranking kernels are compiled for this embedding width."""
+    return bool(_lib.lib().blp_dim_supported(_lib.MODEL_IDS[rel_model], int(dim)))
+
+
+def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
+             filt_rowptr=None, filt_col=None, out=None):
+    """Rank-count every query against every row of ``table`` in one pass over the table.
+
+    table (N, D) f32; q_fixed, q_rel (Q, D) f32; queries [0, q_head) replace the head (q_fixed is the
+    tail embedding), queries [q_head, Q) replace the tail (q_fixed is the head embedding).
+    true_row (Q,) int64 rows of the true entities in ``table``  -- or -- q_true (Q, D) their vectors
+    (sharded ranking).  filt_rowptr (Q+1,), filt_col (nnz,) int64: CSR of filtered rows per query.
+    Returns counts (Q, 4) int32: gt, ge, gt_filtered, ge_filtered.
+    """
+    _require_device(table, q_fixed, q_rel, true_row, q_true, filt_rowptr, filt_col)
+    table = _f32_rows(table, "table")
+    if table.dim() != 2:
+        raise ValueError(f"table must be (N, D), got {tuple(table.shape)}")
+    N, D = table.shape
+    q_fixed = _f32_rows(q_fixed, "q_fixed").reshape(-1, D).contiguous()
+    q_rel = _f32_rows(q_rel, "q_rel").reshape(-1, D).contiguous()
+    Q = q_fixed.shape[0]
+    if q_rel.shape[0] != Q:
+        raise ValueError("q_fixed and q_rel must have the same number of rows")
+    if not 0 <= q_head <= Q:
+        raise ValueError(f"q_head = {q_head} outside [0, {Q}]")
+    if (true_row is None) == (q_true is None):
+        raise ValueError("give exactly one of true_row / q_true")
+    if true_row is not None:
+        true_row = true_row.reshape(-1).to(torch.int64).contiguous()
+        if true_row.shape[0] != Q:
+            raise ValueError("true_row must have one entry per query")
+    else:
+        q_true = _f32_rows(q_true, "q_true").reshape(-1, D).contiguous()
+        if q_true.shape[0] != Q:
+            raise ValueError("q_true must have one row per query")
+    if (filt_rowptr is None) != (filt_col is None):
+        raise ValueError("filt_rowptr and filt_col go together")
+    if filt_rowptr is not None:
+        filt_rowptr = filt_rowptr.to(torch.int64).contiguous()
+        filt_col = filt_col.to(torch.int64).contiguous()
+        if filt_rowptr.shape[0] != Q + 1:
+            raise ValueError("filt_rowptr must have Q + 1 entries")
+    dev = table.device
+    counts = out if out is not None else torch.empty((Q, 4), dtype=torch.int32, device=dev)
+    if counts.shape != (Q, 4) or counts.dtype != torch.int32 or not counts.is_contiguous():
+        raise ValueError("out must be a contiguous (Q, 4) int32 tensor")
+    if Q == 0:
+        return counts
+    L = _lib.lib()
+    model = _lib.MODEL_IDS[rel_model]
+    ws_bytes = L.blp_rank_all_workspace_bytes(model, D, q_head, Q - q_head)
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    status = L.blp_rank_all(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
+                            _ptr(q_rel), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
+                            _ptr(filt_rowptr), _ptr(filt_col), _ptr(counts), _ptr(workspace), ws_bytes,
+                            dev.index, _stream(dev))
+    _lib.check(status, "blp_rank_all")
+    return counts
+
+
+def rank_metrics(counts, k_values=(1, 3, 10)):
+    """counts (Q, 4) int32 -> rr (Q, 2) f32 [raw, filtered], hits (Q, 2, 3) bool."""
+    _require_device(counts)
+    Q = counts.shape[0]
+    dev = counts.device
+    rr = torch.empty((Q, 2), dtype=torch.float32, device=dev)
+    hits = torch.empty((Q, 2, 3), dtype=torch.uint8, device=dev)
+    if Q:
+        status = _lib.lib().blp_rank_metrics(_ptr(counts.contiguous()), Q, _K_VALUES(*k_values), _ptr(rr),
+                                             _ptr(hits), dev.index, _stream(dev))
+        _lib.check(status, "blp_rank_metrics")
+    return rr, hits.bool()
+
+
+# ------------------------------------------------------------------------------------- score_fn
+def _collapse(sizes, strides):
+    """Collapse a group of dims into (size, stride) or None if not expressible with one stride."""
+    size, stride = 1, 0
+    for n, st in zip(sizes, strides):
+        if n == 1:
+            continue
+        if size == 1:
+            size, stride = n, st
+        elif stride == st * n:   # outer stride == inner stride * inner size
+            size, stride = size * n, st
+        else:
+            return None
+    return size, stride
+
+
+def _two_level(shape, operands):
+    """Find a split of the broadcast leading shape into (M0, M1) such that every operand's rows are
+    base + i0*s0 + i1*s1.  Returns (M0, M1, [(tensor, s0, s1), ...]); copies an operand only if
+    its layout cannot be expressed that way."""
+    nd = len(shape)
+    expanded = [op.expand(*shape, op.shape[-1]) for op in operands]
+    for split in range(nd + 1):
+        plan = []
+        for op in expanded:
+            outer = _collapse(shape[:split], op.stride()[:split])
+            inner = _collapse(shape[split:], op.stride()[split:nd])
+            if outer is None or inner is None:
+                plan = None
+                break
+            plan.append((op, outer[1], inner[1]))
+        if plan is not None:
+            m0 = 1
+            for n in shape[:split]:
+                m0 *= n
+            m1 = 1
+            for n in shape[split:]:
+                m1 *= n
+            return m0, m1, plan
+    total = 1
+    for n in shape:
+        total *= n
+    D = operands[0].shape[-1]
+    return total, 1, [(op.contiguous(), D, 0) for op in expanded]
+
+
+class _ScoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rel_model, heads, tails, rels):
+        _require_device(heads, tails, rels)
+        D = heads.shape[-1]
+        if tails.shape[-1] != D or rels.shape[-1] != D:
+            raise ValueError("heads, tails, rels must share the last dimension")
+        ops = [_f32_rows(x, n) for x, n in ((heads, "heads"), (tails, "tails"), (rels, "rels"))]
+        shape = torch.broadcast_shapes(*(x.shape[:-1] for x in ops))
+        m0, m1, plan = _two_level(tuple(shape), ops)
+        dev = heads.device
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        (h, hs0, hs1), (t, ts0, ts1), (r, rs0, rs1) = plan
+        status = _lib.lib().blp_score_fwd(_lib.MODEL_IDS[rel_model], D, m0, m1, _ptr(h), hs0, hs1,
+                                          _ptr(t), ts0, ts1, _ptr(r), rs0, rs1, _ptr(out), dev.index,
+                                          _stream(dev))
+        _lib.check(status, "blp_score_fwd")
+        ctx.rel_model = rel_model
+        ctx.shapes = (heads.shape, tails.shape, rels.shape)
+        ctx.geometry = (m0, m1, D, tuple(shape))
+        ctx.strides = ((hs0, hs1), (ts0, ts1), (rs0, rs1))
+        ctx.save_for_backward(h, t, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h, t, r = ctx.saved_tensors
+        m0, m1, D, shape = ctx.geometry
+        dev = grad_out.device
+        grad_out = grad_out.contiguous()
+        need = ctx.needs_input_grad[1:4]
+        grads = [torch.empty((*shape, D), dtype=torch.float32, device=dev) if n else None for n in need]
+        (hs0, hs1), (ts0, ts1), (rs0, rs1) = ctx.strides
+        status = _lib.lib().blp_score_bwd(_lib.MODEL_IDS[ctx.rel_model], D, m0, m1, _ptr(h), hs0, hs1,
+                                          _ptr(t), ts0, ts1, _ptr(r), rs0, rs1, _ptr(grad_out),
+                                          _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), dev.index,
+                                          _stream(dev))
+        _lib.check(status, "blp_score_bwd")
+        outs = [g.sum_to_size(s) if g is not None else None for g, s in zip(grads, ctx.shapes)]
+        return (None, *outs)
+
+
+def score(rel_model, heads, tails, rels):
+    """score_fn(heads, tails, rels) with the reference's broadcasting; bit-identical forward."""
+    return _ScoreFn.apply(rel_model, heads, tails, rels)
+
+
+# --------------------------------------------------------------------------------- in-batch loss
+class _InBatchLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rel_model, loss_fn, regularizer, ent_embs, rel_vecs, neg_idx):
+        _require_device(ent_embs, rel_vecs, neg_idx)
+        if ent_embs.dim() != 3 or ent_embs.shape[1] != 2:
+            raise ValueError(f"ent_embs must be (B, 2, D), got {tuple(ent_embs.shape)}")
+        B, _, D = ent_embs.shape
+        if neg_idx.dim() != 3 or neg_idx.shape[0] != B or neg_idx.shape[2] != 2:
+            raise ValueError(f"neg_idx must be (B, K, 2), got {tuple(neg_idx.shape)}")
+        K = neg_idx.shape[1]
+        if ent_embs.dtype != torch.float32 or rel_vecs.dtype != torch.float32:
+            raise TypeError("ent_embs and rel_vecs must be float32")
+        ent = ent_embs.contiguous()
+        rel = rel_vecs.reshape(B, D).contiguous()
+        idx = neg_idx.to(torch.int64).contiguous()
+        dev = ent.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        pos = torch.empty(B, dtype=torch.float32, device=dev)
+        neg = torch.empty((B, K), dtype=torch.float32, device=dev)
+        status = _lib.lib().blp_inbatch_loss_fwd(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], _ptr(ent),
+                                                 _ptr(rel), _ptr(idx), B, K, D, float(regularizer),
+                                                 _ptr(loss), _ptr(pos), _ptr(neg), dev.index, _stream(dev))
+        _lib.check(status, "blp_inbatch_loss_fwd")
+        ctx.meta = (rel_model, loss_fn, float(regularizer), B, K, D, rel_vecs.shape)
+        ctx.save_for_backward(ent, rel, idx, pos, neg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        ent, rel, idx, pos, neg = ctx.saved_tensors
+        rel_model, loss_fn, regularizer, B, K, D, rel_shape = ctx.meta
+        dev = ent.device
+        grad_loss = grad_loss.to(torch.float32).contiguous()
+        grad_ent = torch.empty((B, 2, D), dtype=torch.float32, device=dev)
+        grad_rel = torch.empty((B, D), dtype=torch.float32, device=dev)
+        status = _lib.lib().blp_inbatch_loss_bwd(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], _ptr(ent),
+                                                 _ptr(rel), _ptr(idx), B, K, D, regularizer, _ptr(grad_loss),
+                                                 _ptr(pos), _ptr(neg), _ptr(grad_ent), _ptr(grad_rel),
+                                                 dev.index, _stream(dev))
+        _lib.check(status, "blp_inbatch_loss_bwd")
+        return None, None, None, grad_ent, grad_rel.reshape(rel_shape), None
+
+
+def inbatch_loss(rel_model, loss_fn, ent_embs, rel_vecs, neg_idx, regularizer=0.0):
+    """compute_loss on in-batch negatives (fused forward + deterministic backward)."""
+    return _InBatchLoss.apply(rel_model, loss_fn, regularizer, ent_embs, rel_vecs, neg_idx)

@@ -1,0 +1,158 @@
+/*
+ * blp_hip.h -- C-ABI of libblp_hip.so: MI355X (gfx950) kernels for the link-prediction
+ * scoring / ranking hot path of dfdazac/blp.
+ *
+ * The reference is Python/PyTorch and has no FFI of its own; this is the boundary a maintainer
+ * binds with ctypes (INTEGRATION.md shows the stub).  Each entry point names the reference
+ * expression it replaces (file:line under the reference checkout).
+ *
+ * Conventions (every call):
+ *   - plain C types; every pointer except `workspace`-free host outputs is a DEVICE pointer owned
+ *     by the caller (torch: tensor.data_ptr()); nothing is allocated or freed inside a call;
+ *   - `device` is the HIP device ordinal the pointers live on, `stream` a hipStream_t (torch:
+ *     torch.cuda.current_stream().cuda_stream; NULL = the legacy default stream).  Calls only
+ *     enqueue work on `stream`: no host synchronisation, safe to capture in a hipGraph;
+ *   - re-entrant: no global mutable state; one thread per device (nn.DataParallel replicas) may
+ *     call concurrently.  ctypes releases the GIL for the duration of the call;
+ *   - return 0 (BLP_OK) or a negative blp_status; blp_last_error() gives the thread-local message;
+ *   - f32 tensors, int64 indices exactly as the reference produces them (neg_idx, true_idx);
+ *   - arithmetic follows the torch-CPU evaluation order of the reference expressions (see
+ *     oracle/blp_oracle.c), so scores are bit-identical and rank counts are exact.
+ */
+#ifndef BLP_HIP_H
+#define BLP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLP_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef enum blp_status {
+    BLP_OK = 0,
+    BLP_ERR_BAD_ARG = -1,         /* null / misaligned pointer, negative size, bad enum     */
+    BLP_ERR_UNSUPPORTED_DIM = -2, /* D not in the compiled set (see blp_dim_supported)      */
+    BLP_ERR_HIP = -3,             /* a HIP runtime call failed; message has hipGetErrorString */
+    BLP_ERR_WORKSPACE = -4        /* workspace NULL / too small / misaligned                */
+} blp_status;
+
+/* rel_model of models.py:16-26 */
+typedef enum blp_model { BLP_TRANSE = 0, BLP_DISTMULT = 1, BLP_COMPLEX = 2, BLP_SIMPLE = 3 } blp_model;
+/* loss_fn of models.py:31-36 */
+typedef enum blp_loss { BLP_LOSS_MARGIN = 0, BLP_LOSS_NLL = 1 } blp_loss;
+
+typedef struct blp_caps {
+    int compute_units;        /* 256 on MI355X                      */
+    int wavefront_size;       /* 64                                 */
+    int lds_bytes_per_cu;     /* 163840                             */
+    int clock_mhz;            /* max engine clock                   */
+    int64_t hbm_bytes;        /* total device memory                */
+    char arch[32];            /* "gfx950..."                        */
+} blp_caps;
+
+int blp_version(void);
+const char *blp_last_error(void);
+int blp_device_caps(int device, blp_caps *out);
+/* 1 if kernels are compiled for embedding width D of `model` (D % 32 == 0, D <= 256; the
+ * half-width models complex / simple additionally need D % 64 == 0). */
+int blp_dim_supported(int model, int D);
+
+/* --------------------------------------------------------------------------------------------
+ * All-entities ranking  (replaces train.py:146-171 + utils.py:103-105 for one block of queries)
+ *
+ *   heads_predictions = score_fn(ent_emb, tail_embs, rel_embs)      train.py:146
+ *   tails_predictions = score_fn(head_embs, ent_emb, rel_embs)      train.py:147
+ *   pred_ents = cat(heads_predictions, tails_predictions)           train.py:149
+ *   best = (pred > true).sum + 1 ; worst = (pred >= true).sum       utils.py:103-105
+ *   pred_ents[filter_mask] = pred_ents.min() - 1.0 ; get_metrics    train.py:165-167
+ *
+ * One call streams the (N, D) candidate table once and serves Q = q_head + q_tail queries:
+ * queries [0, q_head) replace the HEAD (q_fixed = tail embedding), queries [q_head, Q) replace
+ * the TAIL (q_fixed = head embedding) -- the same "head queries first" order as train.py:149.
+ * The (Q, N) score matrix is never materialised.
+ *
+ *   table      (N, D) f32, row stride ld floats (ld % 4 == 0, 16-byte aligned base)
+ *   q_fixed    (Q, D) f32  the entity kept fixed (tail_embs for head queries, head_embs for tail)
+ *   q_rel      (Q, D) f32  rel_emb(rels)
+ *   true_row   (Q) int64   row of the true entity in `table` (true_ents, train.py:150), or NULL
+ *   q_true     (Q, D) f32  the true entity's vector, used when true_row == NULL (candidate-axis
+ *                          sharding: the true row may live in another shard).  Exactly one of
+ *                          true_row / q_true is non-NULL.
+ *   filt_rowptr (Q+1) int64, filt_col (nnz) int64: CSR of table rows that the filtered setting
+ *                          removes for each query (the True entries of utils.get_triple_filters'
+ *                          mask, utils.py:46-83); NULL/NULL = no filtering (filtered == raw).
+ *   counts     (Q, 4) int32 OUT: {#(pred > true), #(pred >= true), same two over the
+ *                          non-filtered candidates}.  Overwritten.  With the candidate axis
+ *                          sharded, per-shard counts add up to the unsharded ones.
+ *   workspace  caller-owned scratch of >= blp_rank_all_workspace_bytes(...) bytes, 256-B aligned.
+ * -------------------------------------------------------------------------------------------- */
+size_t blp_rank_all_workspace_bytes(int model, int D, int64_t q_head, int64_t q_tail);
+int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
+                 const float *q_fixed, const float *q_rel, const int64_t *true_row,
+                 const float *q_true, int64_t q_head, int64_t q_tail,
+                 const int64_t *filt_rowptr, const int64_t *filt_col, int32_t *counts,
+                 void *workspace, size_t workspace_bytes, int device, void *stream);
+
+/* Measurement aid (bench.py): the NEXT blp_rank_all issued by the calling thread records the two
+ * hipEvent_t (created by the caller with timing enabled) on its stream immediately before and after
+ * the dominant kernel (rank_tiles), so its duration can be read without a profiler.  One-shot;
+ * NULL, NULL cancels.  Has no effect on results. */
+int blp_profile_next_rank_kernel(void *start_event, void *stop_event);
+
+/* utils.py:104-109 on the counts of blp_rank_all: realistic rank = ((gt + 1) + ge) / 2,
+ * rr = 1 / rank (f32), hits = rank <= k.   rr (Q, 2) f32 {raw, filtered};
+ * hits (Q, 2, 3) uint8 for k = k_values[0..2] (train.py:72: 1, 3, 10). */
+int blp_rank_metrics(const int32_t *counts, int64_t Q, const int32_t k_values[3], float *rr,
+                     uint8_t *hits, int device, void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * score_fn(heads, tails, rels)   models.py:222-248, any broadcast the reference uses.
+ *
+ * Output is an (M0, M1) f32 matrix; each operand row is addressed as
+ *     base + i0 * stride0 + i1 * stride1      (strides in floats; 0 broadcasts that axis)
+ * which covers the eval shapes (1,N,D)x(B,1,D) -> (B,N) of train.py:146-147, the training shapes
+ * (B,K,D)x(B,1,D) -> (B,K) of models.py:67 and plain aligned rows (M0 = 1 or M1 = 1).
+ * Scores are bit-identical to the reference's torch-CPU result.
+ * -------------------------------------------------------------------------------------------- */
+int blp_score_fwd(int model, int D, int64_t M0, int64_t M1,
+                  const float *heads, int64_t h_s0, int64_t h_s1,
+                  const float *tails, int64_t t_s0, int64_t t_s1,
+                  const float *rels, int64_t r_s0, int64_t r_s1,
+                  float *out, int device, void *stream);
+/* d score / d operand for every (i0, i1): grad_* are (M0, M1, D) f32 dense (NULL = skip); the
+ * caller reduces over broadcast axes.  grad_out is (M0, M1). */
+int blp_score_bwd(int model, int D, int64_t M0, int64_t M1,
+                  const float *heads, int64_t h_s0, int64_t h_s1,
+                  const float *tails, int64_t t_s0, int64_t t_s1,
+                  const float *rels, int64_t r_s0, int64_t r_s1,
+                  const float *grad_out, float *grad_heads, float *grad_tails, float *grad_rels,
+                  int device, void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * In-batch negatives loss   LinkPrediction.compute_loss, models.py:51-70 (+ :251-266)
+ *
+ *   ent_embs  (B, 2, D) f32 contiguous == (2B, D): row 2b = head of b, 2b+1 = tail of b
+ *   rel_vecs  (B, D)    f32: rel_emb(rels) already gathered (its backward stays in torch)
+ *   neg_idx   (B, K, 2) int64, values in [0, 2B): rows of ent_embs.view(2B, D)  (data.py:35-81)
+ *   regularizer: models.py:59-60, applied iff > 0
+ * fwd: loss (1) f32; pos (B) and neg (B, K) scores are saved for bwd.
+ * bwd: grad_ent (2B, D), grad_rel (B, D), both overwritten, scaled by *grad_loss (device scalar).
+ *      Deterministic (no float atomics).  margin_loss passes gradient where the hinge is
+ *      exactly 0 (models.py:252-253 masks in place).
+ * -------------------------------------------------------------------------------------------- */
+int blp_inbatch_loss_fwd(int model, int loss, const float *ent_embs, const float *rel_vecs,
+                         const int64_t *neg_idx, int B, int K, int D, float regularizer,
+                         float *out_loss, float *save_pos, float *save_neg, int device,
+                         void *stream);
+int blp_inbatch_loss_bwd(int model, int loss, const float *ent_embs, const float *rel_vecs,
+                         const int64_t *neg_idx, int B, int K, int D, float regularizer,
+                         const float *grad_loss, const float *save_pos, const float *save_neg,
+                         float *grad_ent, float *grad_rel, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLP_HIP_H */

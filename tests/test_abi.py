@@ -1,0 +1,50 @@
+"""The C-ABI library builds, loads and exports exactly what include/blp_hip.h declares (no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from blp_amd import build
+    return build.build()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "blp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(blp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_match_binding(built_lib):
+    from blp_amd import _lib
+    assert _declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_loads_and_exports_every_symbol(built_lib):
+    from blp_amd import _lib
+    L = _lib.lib()
+    for name in _declared_symbols():
+        assert hasattr(L, name), name
+    assert L.blp_version() == 100
+    assert L.blp_dim_supported(0, 128) == 1
+    assert L.blp_dim_supported(0, 100) == 0
+    assert L.blp_rank_all_workspace_bytes(0, 128, 64, 64) >= 128 * (256 * 4 + 4 + 16)
+
+
+def test_bad_arguments_return_status_not_crash(built_lib):
+    from blp_amd import _lib
+    L = _lib.lib()
+    # argument validation happens before any device call, so this runs without a GPU
+    rc = L.blp_rank_all(7, None, 0, 128, 128, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    assert rc == -1 and b"unknown model" in L.blp_last_error()
+    rc = L.blp_rank_all(0, None, 0, 100, 100, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    assert rc == -2
+    rc = L.blp_score_fwd(1, 100, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
+    assert rc == -2
+    with pytest.raises(RuntimeError, match="BLP_ERR_BAD_ARG"):
+        _lib.check(-1, "demo")

@@ -1,0 +1,286 @@
+"""GPU parity: the HIP path (through the C-ABI) against the golden vectors and the CPU oracle.
+Bit-exact for scores and rank counts; tolerance (stated per test) for the floating-point loss."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import REL_MODELS, golden, golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    from blp_amd import ops as _ops
+    return _ops
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def random_problem(model, N, D, q_head, q_tail, seed, nrel=11):
+    g = torch.Generator().manual_seed(seed)
+    table = torch.randn(N, D, generator=g)
+    table = torch.nn.functional.normalize(table, dim=-1) if model == "transe" else table * 0.1
+    rel_w = (torch.rand(nrel, D, generator=g) - 0.5) * 0.25
+    Q = q_head + q_tail
+    fixed_row = torch.randint(0, N, (Q,), generator=g)
+    true_row = torch.randint(0, N, (Q,), generator=g)
+    rels = torch.randint(0, nrel, (Q,), generator=g)
+    return table, table[fixed_row].clone(), rel_w[rels].clone(), true_row
+
+
+def oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None, csr=None):
+    t, f, r = table.numpy(), q_fixed.numpy(), q_rel.numpy()
+    parts = []
+    for side, sl in ((oracle.SIDE_HEAD, slice(0, q_head)), (oracle.SIDE_TAIL, slice(q_head, None))):
+        if f[sl].shape[0] == 0:
+            continue
+        kw = {}
+        if true_row is not None:
+            kw["true_row"] = true_row.numpy()[sl]
+        else:
+            kw["q_true"] = q_true.numpy()[sl]
+        if csr is not None:
+            rowptr, col = csr
+            lo, hi = (0, q_head) if side == oracle.SIDE_HEAD else (q_head, len(rowptr) - 1)
+            kw["filt_rowptr"] = rowptr[lo:hi + 1] - rowptr[lo]
+            kw["filt_col"] = col[rowptr[lo]:rowptr[hi]]
+        parts.append(oracle.rank_counts(model, side, t, f[sl], r[sl], **kw))
+    return np.concatenate(parts) if parts else np.zeros((0, 4), np.int32)
+
+
+def random_csr(Q, N, true_row, seed, max_per_row=9):
+    rng = np.random.default_rng(seed)
+    rowptr = [0]
+    cols = []
+    for q in range(Q):
+        k = int(rng.integers(0, max_per_row + 1))
+        if q % 7 == 0:
+            k = 0  # empty rows
+        c = rng.choice(N, size=min(k, N), replace=False)
+        c = c[c != int(true_row[q])]  # the true entity is never filtered (utils.py:71,78)
+        cols.append(np.sort(c))
+        rowptr.append(rowptr[-1] + len(c))
+    return np.asarray(rowptr, np.int64), (np.concatenate(cols) if cols else np.zeros(0)).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("scores_"))
+def test_golden_rank_counts_and_scores(ops, name):
+    g = golden(name)
+    model = name.split("_")[1]
+    table = dev(g["table"])
+    rel_w = dev(g["rel_w"])
+    heads, tails, rels = (dev(g[k])[:, 0] for k in ("heads", "tails", "rels"))
+    B = heads.shape[0]
+    q_fixed = torch.cat((table[tails], table[heads]))
+    q_rel = torch.cat((rel_w[rels], rel_w[rels]))
+    true_row = torch.cat((heads, tails))
+    counts = ops.rank_all(model, table, q_fixed, q_rel, B, true_row=true_row).cpu().numpy()
+    assert np.array_equal(counts[:, 0], g["gt"])
+    assert np.array_equal(counts[:, 1], g["ge"])
+    assert np.array_equal(counts[:, 2:], counts[:, :2])
+    rr, hits = ops.rank_metrics(dev(counts))
+    assert np.array_equal(rr[:, 0].cpu().numpy().view(np.uint32), g["rr"][:, 0].view(np.uint32))
+    assert np.array_equal(hits[:, 0].cpu().numpy(), g["hits"])
+    # score_fn with the reference's own broadcast shapes (train.py:146-147): bit-identical scores
+    ent = table.unsqueeze(0)
+    hp = ops.score(model, ent, table[tails].unsqueeze(1), rel_w[rels].unsqueeze(1)).cpu().numpy()
+    tp = ops.score(model, table[heads].unsqueeze(1), ent, rel_w[rels].unsqueeze(1)).cpu().numpy()
+    assert np.array_equal(hp.view(np.uint32), g["head_pred"].view(np.uint32))
+    assert np.array_equal(tp.view(np.uint32), g["tail_pred"].view(np.uint32))
+
+
+@pytest.mark.parametrize("model", REL_MODELS)
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_random_vs_oracle_ragged(ops, oracle, model, D):
+    """N not a multiple of the 64-row tile, more than one query chunk, both sides, CSR filter."""
+    N, q_head, q_tail = 1000 + D // 64, 300, 41
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=D + len(model))
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("model", REL_MODELS)
+def test_edge_shapes(ops, oracle, model):
+    D = 128
+    for N, q_head, q_tail in ((1, 1, 1), (63, 0, 5), (64, 5, 0), (65, 2, 2), (129, 1, 0)):
+        table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=N)
+        want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
+        got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda())
+        assert np.array_equal(got.cpu().numpy(), want), (N, q_head, q_tail)
+    # empty query block
+    table = torch.randn(10, D).cuda()
+    out = ops.rank_all(model, table, torch.empty(0, D).cuda(), torch.empty(0, D).cuda(), 0,
+                       true_row=torch.empty(0, dtype=torch.int64).cuda())
+    assert out.shape == (0, 4)
+    # strided table rows (ld > D)
+    big = torch.randn(70, D + 4)
+    tab = big[:, :D]
+    if model == "transe":
+        tab = torch.nn.functional.normalize(tab, dim=-1)
+        big[:, :D] = tab
+    q_fixed, q_rel = tab[:6].contiguous(), torch.randn(6, D) * 0.1
+    true_row = torch.arange(6)
+    want = oracle_counts(oracle, model, tab.contiguous(), q_fixed, q_rel, 3, true_row=true_row)
+    got = ops.rank_all(model, big.cuda()[:, :D], q_fixed.cuda(), q_rel.cuda(), 3, true_row=true_row.cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("model", REL_MODELS)
+def test_candidate_shards_add_up(ops, oracle, model):
+    """Candidate-axis sharding: per-shard counts (true entity given as a vector) sum to the unsharded
+    counts, for any split -- the property the multi-GPU ranking relies on."""
+    N, D, q_head, q_tail = 777, 128, 19, 23
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=5)
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=3)
+    t = table.cuda()
+    whole = ops.rank_all(model, t, q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                         filt_rowptr=dev(rowptr), filt_col=dev(col))
+    q_true = table[true_row].cuda()
+    total = torch.zeros_like(whole)
+    for lo, hi in ((0, 100), (100, 101), (101, 640), (640, N)):
+        # CSR columns restricted to the shard and rebased
+        keep = (col >= lo) & (col < hi)
+        rp = np.zeros(len(rowptr), np.int64)
+        for q in range(len(rowptr) - 1):
+            rp[q + 1] = rp[q] + keep[rowptr[q]:rowptr[q + 1]].sum()
+        total += ops.rank_all(model, t[lo:hi], q_fixed.cuda(), q_rel.cuda(), q_head, q_true=q_true,
+                              filt_rowptr=dev(rp), filt_col=dev(col[keep] - lo))
+    assert torch.equal(total, whole)
+    assert np.array_equal(whole.cpu().numpy(),
+                          oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row,
+                                        csr=(rowptr, col)))
+
+
+@pytest.mark.parametrize("model", REL_MODELS)
+def test_fb15k237_shape_vs_oracle(ops, oracle, model):
+    """BASELINE config 2/3 table shape (14 541 x 128), two reference batches worth of queries."""
+    N, D, q_head, q_tail = 14541, 128, 64, 64
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=237, nrel=237)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_wikidata5m_scale_properties(ops, oracle):
+    """BASELINE config 4 scale (4.6 M x 128, reference batch of 2 triples = 4 queries): too big for
+    the oracle to rank in full, so check (a) a 200k-row slab against the oracle, (b) additivity of
+    the slab decomposition against the one-pass result, (c) idempotence."""
+    N, D = 4_600_000, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    table = torch.nn.functional.normalize(torch.randn(N, D, device="cuda", generator=g), dim=-1)
+    rows = torch.tensor([17, N - 1, 2_300_000, 4_599_000], device="cuda")
+    q_fixed = table[rows].clone()
+    q_rel = (torch.rand(4, D, device="cuda", generator=g) - 0.5) * 0.25
+    true_row = torch.tensor([N - 5, 123_456, 0, 3_999_999], device="cuda")
+    whole = ops.rank_all("transe", table, q_fixed, q_rel, 2, true_row=true_row)
+    again = ops.rank_all("transe", table, q_fixed, q_rel, 2, true_row=true_row)
+    assert torch.equal(whole, again)
+    q_true = table[true_row].clone()
+    total = torch.zeros_like(whole)
+    bounds = [0, 200_000, 1_000_003, 2_777_777, N]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        part = ops.rank_all("transe", table[lo:hi], q_fixed, q_rel, 2, q_true=q_true)
+        if lo == 0:
+            slab = table[lo:hi].cpu()
+            want = oracle_counts(oracle, "transe", slab, q_fixed.cpu(), q_rel.cpu(), 2, q_true=q_true.cpu())
+            assert np.array_equal(part.cpu().numpy(), want)
+        total += part
+    assert torch.equal(total, whole)
+    assert int(whole[:, 1].min()) >= 1  # the true entity itself is always >=
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("loss_"))
+def test_golden_inbatch_loss(ops, name):
+    """Loss within 1e-6 relative, gradients within rtol 1e-5 / atol 1e-7 of the reference (f32
+    reductions in a different order; the reference's own CPU/GPU results differ by as much)."""
+    g = golden(name)
+    _, model, loss_fn, _ = name.split("_")
+    ent = dev(g["ent_embs"]).requires_grad_(True)
+    rel_w = dev(g["rel_w"]).requires_grad_(True)
+    rels = dev(g["rels"])
+    neg_idx = dev(g["neg_idx"])
+    loss = ops.inbatch_loss(model, loss_fn, ent, rel_w[rels], neg_idx, float(g["regularizer"]))
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-6, abs=1e-7)
+    np.testing.assert_allclose(ent.grad.cpu().numpy(), g["grad_ent"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rel_w.grad.cpu().numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("model", REL_MODELS)
+@pytest.mark.parametrize("loss_fn", ["margin", "nll"])
+def test_inbatch_loss_training_shape_vs_port(ops, model, loss_fn):
+    """B = 64, K = 64, D = 128 (scripts/blp-*-fb15k237.sh) against the torch port on CPU; backward is
+    deterministic (bitwise equal across runs)."""
+    from oracle import ref_port
+    torch.manual_seed(3)
+    B, K, D = 64, 64, 128
+    ent = torch.randn(B, 2, D) * (1.0 if model == "transe" else 0.4)
+    if model == "transe":
+        ent = torch.nn.functional.normalize(ent, dim=-1)
+    rel = torch.randn(B, 1, D) * 0.3
+    neg_idx = torch.randint(0, 2 * B, (B, K, 2))
+    reg = 1e-3 if model == "complex" else 0.0
+    e_ref, r_ref = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    ref = ref_port.compute_loss(model, loss_fn, e_ref, r_ref, neg_idx, reg)
+    ref.backward()
+    results = []
+    for _ in range(2):
+        e, r = ent.cuda().requires_grad_(True), rel.cuda().requires_grad_(True)
+        loss = ops.inbatch_loss(model, loss_fn, e, r, neg_idx.cuda(), reg)
+        (loss * 2.0).backward()  # upstream gradient is honoured
+        results.append((loss.item(), e.grad.clone(), r.grad.clone()))
+    assert results[0][0] == pytest.approx(ref.item(), rel=2e-6, abs=1e-7)
+    np.testing.assert_allclose(results[0][1].cpu().numpy() / 2.0, e_ref.grad.numpy(), rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(results[0][2].cpu().numpy() / 2.0, r_ref.grad.numpy(), rtol=2e-5, atol=2e-7)
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+
+
+@pytest.mark.parametrize("model", REL_MODELS)
+def test_score_fn_training_broadcast_and_grad(ops, model):
+    """score_fn on (B, K, D) x (B, 1, D) (models.py:67): golden-exact forward, analytic backward vs
+    autograd of the torch port (rtol 1e-5)."""
+    from oracle import ref_port
+    g = golden("score_pairs")
+    h, t, r = (torch.from_numpy(g[f"train_{k}_{model}"]) for k in ("h", "t", "r"))
+    hd, td, rd = (x.cuda().requires_grad_(True) for x in (h, t, r))
+    out = ops.score(model, hd, td, rd)
+    assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), g[f"train_{model}"].view(np.uint32))
+    w = torch.randn(out.shape)
+    (out * w.cuda()).sum().backward()
+    hc, tc, rc = (x.clone().requires_grad_(True) for x in (h, t, r))
+    (ref_port.SCORE_FNS[model](hc, tc, rc) * w).sum().backward()
+    for got, want in ((hd.grad, hc.grad), (td.grad, tc.grad), (rd.grad, rc.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_transe_wide_rows_score_fn(ops):
+    """TransE on BOW widths (300 GloVe / 768 BERT embeddings): runtime-D path, golden-exact."""
+    g = golden("score_pairs")
+    for d in (300, 768):
+        out = ops.score("transe", dev(g[f"h_{d}"]), dev(g[f"t_{d}"]), dev(g[f"r_{d}"]))
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), g[f"transe_{d}"].view(np.uint32))
+
+
+def test_errors_are_loud(ops):
+    table = torch.randn(8, 96).cuda()  # D = 96 is not a compiled ranking width
+    q = torch.randn(2, 96).cuda()
+    with pytest.raises(RuntimeError, match="UNSUPPORTED_DIM"):
+        ops.rank_all("transe", table, q, q, 1, true_row=torch.zeros(2, dtype=torch.int64).cuda())
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        ops.rank_all("transe", torch.randn(8, 128), torch.randn(2, 128), torch.randn(2, 128), 1,
+                     true_row=torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(KeyError):
+        ops.score("rotate", table, table, table)
