@@ -36,8 +36,10 @@ constexpr int kWaves = 4;            // waves per workgroup
 constexpr int kTileRows = 64;        // candidates per wave tile (one per lane)
 constexpr int kSubCols = 32;         // floats per row per LDS pass (128 B = one cache line)
 constexpr int kLdsStride = 36;       // dwords; 36*l mod 64 is conflict-free for ds_read_b128
-constexpr int kQueryChunk = 256;     // queries per wave pass over its tiles
+constexpr int kQueryChunk = 128;     // queries per workgroup pass over its tiles
+constexpr int kQB = 4;               // queries staged per LDS coefficient batch
 constexpr int kSlabFloats = kTileRows * kLdsStride;
+__host__ __device__ constexpr int kMaxCoef(int D) { return 2 * D; }
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave execute in issue order; this only stops the compiler from
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
     float e[D];
     load_row<D>(e, true_row ? table + true_row[q] * ld : q_true + q * D);
     key_true[q] = q < q_head
-        ? Scorer<MODEL, HEAD, D>::template score<false>(e, coef_head + q * Scorer<MODEL, HEAD, D>::C)
-        : Scorer<MODEL, TAIL, D>::template score<false>(e, coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C);
+        ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C})
+        : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -99,42 +101,73 @@ __device__ __forceinline__ void load_tile(float (&e)[D], const float* __restrict
                                           int64_t ld, int64_t row0, float* slab, int lane) {
     const int sub_row = lane >> 3;        // 8 rows per wave instruction
     const int sub_col = (lane & 7) * 4;   // 8 x 16 B = one 128-B line per row
-    const float* src[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    // 1. every global load of the tile up front (D/4 x 1 KiB in flight per wave), landing in e[] in
+    //    the coalesced layout: e[32s + 4i .. +3] = row (row0 + 8i + sub_row), cols 32s + sub_col .. +3
+    static_for<8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
         int64_t row = row0 + 8 * i + sub_row;
         row = row < N ? row : N - 1;
-        src[i] = table + row * ld + sub_col;
-    }
+        const float* src = table + row * ld + sub_col;
+        static_for<D / kSubCols>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            const float4 v = *reinterpret_cast<const float4*>(src + s * kSubCols);
+            e[32 * s + 4 * i] = v.x; e[32 * s + 4 * i + 1] = v.y;
+            e[32 * s + 4 * i + 2] = v.z; e[32 * s + 4 * i + 3] = v.w;
+        });
+    });
+    // 2. transpose 32 columns at a time through the wave's slab, in place in e[]
     float* wr = slab + sub_row * kLdsStride + sub_col;
     const float* rd = slab + lane * kLdsStride;
-#pragma unroll
-    for (int s = 0; s < D / kSubCols; ++s) {
+    static_for<D / kSubCols>([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
         if (s > 0) wave_lds_sync();  // previous pass' reads are done before the slab is rewritten
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(src[i] + s * kSubCols);
-            *reinterpret_cast<float4*>(wr + 8 * i * kLdsStride) = v;
-        }
+        static_for<8>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            *reinterpret_cast<float4*>(wr + 8 * i * kLdsStride) =
+                make_float4(e[32 * s + 4 * i], e[32 * s + 4 * i + 1], e[32 * s + 4 * i + 2], e[32 * s + 4 * i + 3]);
+        });
         wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < kSubCols / 4; ++j) {
+        static_for<8>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
             const float4 w = *reinterpret_cast<const float4*>(rd + 4 * j);
-            e[s * kSubCols + 4 * j] = w.x; e[s * kSubCols + 4 * j + 1] = w.y;
-            e[s * kSubCols + 4 * j + 2] = w.z; e[s * kSubCols + 4 * j + 3] = w.w;
-        }
+            e[32 * s + 4 * j] = w.x; e[32 * s + 4 * j + 1] = w.y;
+            e[32 * s + 4 * j + 2] = w.z; e[32 * s + 4 * j + 3] = w.w;
+        });
+    });
+}
+
+typedef __attribute__((address_space(1))) const void* global_cptr;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// Stage `count` floats (a multiple of 4, at most 2 * 4 * 256) from global memory into LDS with
+// LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS at wave-uniform base + lane * 16,
+// no VGPR round trip).  The copy stays in flight until the caller's `s_waitcnt vmcnt(0)` + barrier.
+__device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* dst, int count, int wave, int lane) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int base = (k * kWaves + wave) * 256;  // floats: 64 lanes x 4 per wave instruction
+        if (base + lane * 4 < count)
+            __builtin_amdgcn_global_load_lds((global_cptr)(src + base + lane * 4), (lds_ptr)(dst + base), 16, 0, 0);
     }
 }
 
-template <int MODEL, int SIDE, int D>
-__device__ __forceinline__ void apply_queries(const float (&e)[D], bool valid, const float* __restrict__ coef,
-                                              const float* __restrict__ key_true, int n_queries,
-                                              unsigned* cnt, int lane) {
+// Score nq queries of one side against the wave's tile and add the two rank counts of each to the
+// wave's LDS counters.  USE_SGPR = false: coefficient rows are staged in LDS at `cur` (DppCoef).
+// USE_SGPR = true: `cur` is the wave-uniform global address of the rows, so the compiler fetches them
+// with scalar loads and they are SGPR operands of full-rate VALU instructions -- the right choice
+// when the whole query block (a few KB) stays resident in the scalar cache (STATIC mode); DPP
+// operands issue at roughly a third of the plain VALU rate on gfx950 (tools/valu_ubench.hip).
+template <int MODEL, int SIDE, int D, bool USE_SGPR>
+__device__ __forceinline__ void score_batch(const float (&e)[D], bool valid, const float* cur, int nq,
+                                            const float* __restrict__ key_true, unsigned* cnt, int lane) {
     using S = Scorer<MODEL, SIDE, D>;
-    // j is wave-uniform, so the coefficient loads below are scalar loads (s_load_dwordx16) and the
-    // coefficients are SGPR operands of the VALU instructions.
-    for (int j = 0; j < n_queries; ++j) {
-        const float key = S::template score<false>(e, coef + (size_t)j * S::C);
+    for (int j = 0; j < nq; ++j) {
+        float key;
+        if constexpr (USE_SGPR) {
+            key = S::template score<false>(e, PtrCoef{cur + (size_t)j * S::C});
+        } else {
+            key = S::template score<false>(e, DppCoef{reinterpret_cast<const float4*>(cur + j * S::C) + (lane & 3)});
+        }
         const float kt = key_true[j];
         const unsigned gt = __popcll(__ballot(valid && key > kt));
         const unsigned ge = __popcll(__ballot(valid && key >= kt));
@@ -145,23 +178,53 @@ __device__ __forceinline__ void apply_queries(const float (&e)[D], bool valid, c
     }
 }
 
-template <int MODEL, int D>
-__global__ __launch_bounds__(kWaves * 64) void rank_tiles_kernel(
+// Apply the n queries of one side (coefficient rows coef[0..n), C floats each, contiguous in global
+// memory) to the wave's tile.  The workgroup stages kQB queries at a time into a double-buffered LDS
+// block shared by its four waves (LDS-DMA, in flight under the previous batch's arithmetic); one
+// barrier per batch.  Every wave of the workgroup calls this with the same n.
+template <int MODEL, int SIDE, int D>
+__device__ __forceinline__ void apply_queries(const float (&e)[D], bool valid, const float* __restrict__ coef,
+                                              const float* __restrict__ key_true, int n, float* cbuf,
+                                              unsigned* cnt, int wave, int lane) {
+    using S = Scorer<MODEL, SIDE, D>;
+    constexpr int C = S::C;
+    static_assert(C % 16 == 0 && kQB * C <= 2 * kWaves * 256, "coefficient batch does not fit the staging plan");
+    if (n <= 0) return;
+    const int nb = (n + kQB - 1) / kQB;
+    stage_dma(coef, cbuf, (n < kQB ? n : kQB) * C, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+        const float* cur = cbuf + (b & 1) * (kQB * kMaxCoef(D));
+        const int nq = n - b * kQB < kQB ? n - b * kQB : kQB;
+        const int next = n - (b + 1) * kQB < kQB ? n - (b + 1) * kQB : kQB;  // <= 0 on the last batch
+        // the other buffer was last read in batch b-1, which every wave left through the barrier below
+        if (next > 0) stage_dma(coef + (size_t)(b + 1) * kQB * C, cbuf + ((b + 1) & 1) * (kQB * kMaxCoef(D)), next * C, wave, lane);
+        score_batch<MODEL, SIDE, D, false>(e, valid, cur, nq, key_true + b * kQB, cnt + 2 * b * kQB, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next batch has landed
+        __syncthreads();
+    }
+}
+
+// STATIC = a handful of queries (<= kQB head- and <= kQB tail-replacing, e.g. the reference's
+// Wikidata5M eval batch of 2 triples): their coefficients (a few KB) stay in the scalar cache and are
+// read as SGPR operands; the waves stream tiles independently, with no workgroup barrier in the loop.
+template <int MODEL, int D, bool STATIC>
+__global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_tiles_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
-    int n_tiles, int n_tile_groups, int n_chunks, unsigned long long* __restrict__ acc) {
+    int n_tiles, int n_quad_groups, int n_chunks, unsigned long long* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     float* slab = smem + wave * kSlabFloats;
-    unsigned* cnt = reinterpret_cast<unsigned*>(smem + kWaves * kSlabFloats) + wave * (2 * kQueryChunk);
+    float* cbuf = smem + kWaves * kSlabFloats;
+    unsigned* cnt = reinterpret_cast<unsigned*>(cbuf + 2 * kQB * kMaxCoef(D)) + wave * (2 * kQueryChunk);
 
-    // wave id -> (query chunk, tile group); the 4 waves of a workgroup share the chunk (same
-    // coefficients in the scalar cache) and take adjacent tile groups.
-    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wave);
-    if (wid >= (unsigned)n_tile_groups * (unsigned)n_chunks) return;
-    const int chunk = __builtin_amdgcn_readfirstlane(wid / (unsigned)n_tile_groups);
-    const int tg = __builtin_amdgcn_readfirstlane(wid % (unsigned)n_tile_groups);
+    // workgroup -> (query chunk, group of tile quads); its four waves take four consecutive tiles
+    const int chunk = blockIdx.x / n_quad_groups;
+    const int qg = blockIdx.x % n_quad_groups;
     const int Q = q_head + q_tail;
     const int qa = chunk * kQueryChunk;
     const int qb = qa + kQueryChunk < Q ? qa + kQueryChunk : Q;
@@ -172,15 +235,22 @@ __global__ __launch_bounds__(kWaves * 64) void rank_tiles_kernel(
     const float* ct = coef_tail + (size_t)(t_lo - q_head) * Scorer<MODEL, TAIL, D>::C;
 
     for (int i = lane; i < 2 * kQueryChunk; i += 64) cnt[i] = 0;
+
     wave_lds_sync();
 
-    for (int tile = tg; tile < n_tiles; tile += n_tile_groups) {
+    const int n_quads = (n_tiles + kWaves - 1) / kWaves;
+    for (int quad = qg; quad < n_quads; quad += n_quad_groups) {
         float e[D];
-        const int64_t row0 = (int64_t)tile * kTileRows;
-        load_tile<D>(e, table, N, ld, row0, slab, lane);
+        const int64_t row0 = ((int64_t)quad * kWaves + wave) * kTileRows;
+        load_tile<D>(e, table, N, ld, row0, slab, lane);  // rows past the end are clamped, then masked
         const bool valid = row0 + lane < N;
-        apply_queries<MODEL, HEAD, D>(e, valid, ch, key_true + h_lo, h_hi - h_lo, cnt + 2 * (h_lo - qa), lane);
-        apply_queries<MODEL, TAIL, D>(e, valid, ct, key_true + t_lo, t_hi - t_lo, cnt + 2 * (t_lo - qa), lane);
+        if (STATIC) {
+            score_batch<MODEL, HEAD, D, true>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), lane);
+            score_batch<MODEL, TAIL, D, true>(e, valid, ct, t_hi - t_lo, key_true + t_lo, cnt + 2 * (t_lo - qa), lane);
+        } else {
+            apply_queries<MODEL, HEAD, D>(e, valid, ch, key_true + h_lo, h_hi - h_lo, cbuf, cnt + 2 * (h_lo - qa), wave, lane);
+            apply_queries<MODEL, TAIL, D>(e, valid, ct, key_true + t_lo, t_hi - t_lo, cbuf, cnt + 2 * (t_lo - qa), wave, lane);
+        }
     }
 
     wave_lds_sync();
@@ -208,8 +278,8 @@ __global__ __launch_bounds__(256) void filt_counts_kernel(
         float e[D];
         load_row<D>(e, table + col[k] * ld);
         const float key = q < q_head
-            ? Scorer<MODEL, HEAD, D>::template score<false>(e, coef_head + q * Scorer<MODEL, HEAD, D>::C)
-            : Scorer<MODEL, TAIL, D>::template score<false>(e, coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C);
+            ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C})
+            : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
         gt += key > kt;
         ge += key >= kt;
     }
@@ -304,24 +374,38 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
 
     if (N > 0) {
         const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
+        const int64_t n_quads = (n_tiles + kWaves - 1) / kWaves;
         const int64_t n_chunks = (Q + kQueryChunk - 1) / kQueryChunk;
-        // Resident waves: 3 per SIMD at ~144 VGPRs.  With plenty of (tile, chunk) pairs give every
-        // wave one tile (many short waves -> no tail); otherwise grid-stride a few thousand waves.
-        const int64_t resident = (int64_t)n_cu * 12;
-        int64_t groups = n_tiles;
-        if (n_tiles * n_chunks > 8 * resident) {
-            groups = n_tiles;
+        // Resident workgroups: 3 per CU (12 waves at <= 168 VGPRs, ~48 KB of LDS each).  With plenty
+        // of (tile quad, chunk) pairs give every workgroup one quad (many short workgroups -> no
+        // tail); otherwise grid-stride ~2 resident sets of workgroups over the quads.
+        const int64_t resident = (int64_t)n_cu * 3;
+        const bool static_mode = q_head <= kQB && q_tail <= kQB;
+        int64_t groups;
+        if (static_mode) {
+            // few queries, long table (HBM-bound): one resident set of persistent workgroups that
+            // grid-stride over the tile quads with no barrier in the loop, so waves drift apart and
+            // one wave's arithmetic overlaps the others' loads.  (One quad per workgroup ran every
+            // wave of the chip in lock-step: load phase, then compute phase, never overlapped.)
+            groups = n_quads < resident ? n_quads : resident;
+        } else if (n_quads * n_chunks > 8 * resident) {
+            groups = n_quads;
         } else {
             const int64_t want = (2 * resident + n_chunks - 1) / n_chunks;
-            groups = n_tiles < want ? n_tiles : want;
+            groups = n_quads < want ? n_quads : want;
         }
-        const int64_t waves = groups * n_chunks;
-        const int64_t blocks = (waves + kWaves - 1) / kWaves;
-        const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)kWaves * 2 * kQueryChunk * 4;
+        const int64_t blocks = groups * n_chunks;
+        const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)2 * kQB * kMaxCoef(D) * 4 +
+                           (size_t)kWaves * 2 * kQueryChunk * 4;
         if (ev_start) (void)hipEventRecord(ev_start, stream);
-        rank_tiles_kernel<MODEL, D><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
-            table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-            (int)groups, (int)n_chunks, w.acc);
+        if (static_mode)
+            rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
+                table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
+                (int)groups, (int)n_chunks, w.acc);
+        else
+            rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
+                table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
+                (int)groups, (int)n_chunks, w.acc);
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
 

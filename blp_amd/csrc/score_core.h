@@ -14,8 +14,14 @@
 // A query is reduced once (prep kernel) to C "coefficients": whatever part of the expression does
 // not involve the candidate (e.g. h + r for TransE tail queries) is hoisted, with the same
 // rounding the reference applies, so the per-candidate work is 2-3 VALU ops per element.
+//
+// All element loops are compile-time (static_for over integral constants), not "#pragma unroll":
+// the candidate row must stay in registers and the DPP lane selectors must be immediates.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
 
 #pragma clang fp contract(off)
 
@@ -24,47 +30,70 @@ namespace blp {
 enum : int { TRANSE = 0, DISTMULT = 1, COMPLEX = 2, SIMPLE = 3 };
 enum : int { HEAD = 0, TAIL = 1 };  // which position the candidates replace
 
+template <int I>
+using ic = std::integral_constant<int, I>;
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(ic<Is>{}), ...);  // comma fold: evaluated left to right
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // torch.sum(dim=-1) order for n = NT terms, NT % 32 == 0, NT < 512 (no cascade level is reached):
 // A[k][l] += p[32c + 8k + l] over c;  V[l] = ((A0+A1)+A2)+A3;  result = ((V0+V1)+...)+V7.
 // LITERAL_ZERO keeps the "0 + first term" additions of the reference (they only matter for the
 // sign of an all-zero sum, i.e. for bitwise score output, never for > / >= comparisons).
+// term(ic<i>) yields the i-th summand.
 template <int NT, bool LITERAL_ZERO, class Term>
 __device__ __forceinline__ float torch_inner_sum(Term term) {
     static_assert(NT % 32 == 0 && NT >= 32 && NT < 512, "unsupported reduction width");
     float A[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) A[i] = LITERAL_ZERO ? 0.0f + term(i) : term(i);
-#pragma unroll
-    for (int c = 1; c < NT / 32; ++c) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) A[i] = A[i] + term(32 * c + i);
-    }
+    static_for<32>([&](auto i) { A[i] = LITERAL_ZERO ? 0.0f + term(i) : term(i); });
+    static_for<NT - 32>([&](auto k) {
+        constexpr int i = decltype(k)::value + 32;
+        A[i % 32] = A[i % 32] + term(ic<i>{});
+    });
     float V[8];
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
+    static_for<8>([&](auto l) {
         float v = A[l] + A[8 + l];
         v = v + A[16 + l];
         V[l] = v + A[24 + l];
-    }
+    });
     float s = LITERAL_ZERO ? 0.0f + V[0] : V[0];
-#pragma unroll
-    for (int l = 1; l < 8; ++l) s = s + V[l];
+    static_for<7>([&](auto l) { s = s + V[l + 1]; });
     return s;
 }
 
 template <int MODEL, int SIDE, int D>
 struct Scorer;
 
+// In every Scorer: e is the candidate row (registers), c(ic<i>) the query's i-th coefficient.
+
 // ---------------------------------------------------------------- TransE (models.py:222-223)
+// The L1 sum is one dependent chain of D adds per (candidate, query); the differences feeding it are
+// independent.  They are computed kPipe elements ahead of the add that consumes them, into a small
+// ring of temporaries, so an add never waits on the subtract issued just before it (and no DPP
+// instruction re-uses a register written two instructions earlier, which costs an s_nop).
+constexpr int kPipe = 4;
+
 template <int D>
 struct Scorer<TRANSE, TAIL, D> {  // candidates are tails: (h + r) - e, h + r hoisted
     static constexpr int C = D;
     __device__ static float coef(const float* f, const float* r, int i) { return f[i] + r[i]; }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
-        float acc = LZ ? 0.0f + fabsf(c[0] - e[0]) : fabsf(c[0] - e[0]);
-#pragma unroll
-        for (int d = 1; d < D; ++d) acc = acc + fabsf(c[d] - e[d]);
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        float x[kPipe];
+        static_for<kPipe>([&](auto k) { x[k] = c(k) - e[k]; });
+        float acc = 0.0f;
+        static_for<D>([&](auto k) {
+            constexpr int d = decltype(k)::value;
+            const float cur = fabsf(x[d % kPipe]);
+            if constexpr (d + kPipe < D) x[d % kPipe] = c(ic<d + kPipe>{}) - e[d + kPipe];
+            acc = (d == 0 && !LZ) ? cur : acc + cur;
+        });
         return -acc;
     }
 };
@@ -72,15 +101,24 @@ template <int D>
 struct Scorer<TRANSE, HEAD, D> {  // candidates are heads: (e + r) - t, nothing hoistable
     static constexpr int C = 2 * D;
     __device__ static float coef(const float* f, const float* r, int i) { return i < D ? r[i] : f[i - D]; }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        float x[kPipe];
+        static_for<kPipe>([&](auto k) {
+            constexpr int d = decltype(k)::value;
+            const float y = e[d] + c(ic<d>{});
+            x[d] = y - c(ic<D + d>{});
+        });
         float acc = 0.0f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float x = e[d] + c[d];
-            x = x - c[D + d];
-            acc = (d == 0 && !LZ) ? fabsf(x) : acc + fabsf(x);
-        }
+        static_for<D>([&](auto k) {
+            constexpr int d = decltype(k)::value;
+            const float cur = fabsf(x[d % kPipe]);
+            if constexpr (d + kPipe < D) {
+                const float y = e[d + kPipe] + c(ic<d + kPipe>{});
+                x[d % kPipe] = y - c(ic<D + d + kPipe>{});
+            }
+            acc = (d == 0 && !LZ) ? cur : acc + cur;
+        });
         return -acc;
     }
 };
@@ -90,20 +128,21 @@ template <int D>
 struct Scorer<DISTMULT, TAIL, D> {  // (h * r) * e
     static constexpr int C = D;
     __device__ static float coef(const float* f, const float* r, int i) { return f[i] * r[i]; }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
-        return torch_inner_sum<D, LZ>([&](int i) { return c[i] * e[i]; });
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        return torch_inner_sum<D, LZ>([&](auto i) { return c(i) * e[i]; });
     }
 };
 template <int D>
 struct Scorer<DISTMULT, HEAD, D> {  // (e * r) * t
     static constexpr int C = 2 * D;
     __device__ static float coef(const float* f, const float* r, int i) { return i < D ? r[i] : f[i - D]; }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
-        return torch_inner_sum<D, LZ>([&](int i) {
-            float x = e[i] * c[i];
-            return x * c[D + i];
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        return torch_inner_sum<D, LZ>([&](auto i) {
+            constexpr int d = decltype(i)::value;
+            float x = e[d] * c(ic<d>{});
+            return x * c(ic<D + d>{});
         });
     }
 };
@@ -123,13 +162,14 @@ struct Scorer<COMPLEX, TAIL, D> {  // e = tail; the four r*h products are hoiste
         default: return r[H + j] * f[H + j];   // ri * hi
         }
     }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
-        return torch_inner_sum<H, LZ>([&](int j) {
-            const float a = c[j] * e[j];
-            const float b = c[H + j] * e[H + j];
-            const float cc = c[2 * H + j] * e[H + j];
-            const float d = c[3 * H + j] * e[j];
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        return torch_inner_sum<H, LZ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            const float a = c(ic<j>{}) * e[j];
+            const float b = c(ic<H + j>{}) * e[H + j];
+            const float cc = c(ic<2 * H + j>{}) * e[H + j];
+            const float d = c(ic<3 * H + j>{}) * e[j];
             float s = a + b;
             s = s + cc;
             return s - d;
@@ -141,13 +181,14 @@ struct Scorer<COMPLEX, HEAD, D> {  // e = head; coefficients are r then t, uncha
     static constexpr int H = D / 2;
     static constexpr int C = 2 * D;
     __device__ static float coef(const float* f, const float* r, int i) { return i < D ? r[i] : f[i - D]; }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
-        return torch_inner_sum<H, LZ>([&](int j) {
-            float a = c[j] * e[j];          a = a * c[D + j];          // (rr*hr)*tr
-            float b = c[j] * e[H + j];      b = b * c[D + H + j];      // (rr*hi)*ti
-            float cc = c[H + j] * e[j];     cc = cc * c[D + H + j];    // (ri*hr)*ti
-            float d = c[H + j] * e[H + j];  d = d * c[D + j];          // (ri*hi)*tr
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        return torch_inner_sum<H, LZ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            float a = c(ic<j>{}) * e[j];          a = a * c(ic<D + j>{});        // (rr*hr)*tr
+            float b = c(ic<j>{}) * e[H + j];      b = b * c(ic<D + H + j>{});    // (rr*hi)*ti
+            float cc = c(ic<H + j>{}) * e[j];     cc = cc * c(ic<D + H + j>{});  // (ri*hr)*ti
+            float d = c(ic<H + j>{}) * e[H + j];  d = d * c(ic<D + j>{});        // (ri*hi)*tr
             float s = a + b;
             s = s + cc;
             return s - d;
@@ -169,12 +210,13 @@ struct Scorer<SIMPLE, TAIL, D> {  // e = tail = [th | tt]
         default: return f[H + j];     // ht
         }
     }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
-        const float s = torch_inner_sum<H, LZ>([&](int j) {
-            const float a = c[j] * e[H + j];
-            float b = e[j] * c[H + j];
-            b = b * c[2 * H + j];
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        const float s = torch_inner_sum<H, LZ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            const float a = c(ic<j>{}) * e[H + j];
+            float b = e[j] * c(ic<H + j>{});
+            b = b * c(ic<2 * H + j>{});
             return a + b;
         });
         return s / 2.0f;
@@ -192,15 +234,48 @@ struct Scorer<SIMPLE, HEAD, D> {  // e = head = [hh | ht]
         default: return f[j] * r[H + j];   // th * rb
         }
     }
-    template <bool LZ>
-    __device__ __forceinline__ static float score(const float (&e)[D], const float* __restrict__ c) {
-        const float s = torch_inner_sum<H, LZ>([&](int j) {
-            float a = e[j] * c[j];
-            a = a * c[H + j];
-            const float b = c[2 * H + j] * e[H + j];
+    template <bool LZ, class CF>
+    __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
+        const float s = torch_inner_sum<H, LZ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            float a = e[j] * c(ic<j>{});
+            a = a * c(ic<H + j>{});
+            const float b = c(ic<2 * H + j>{}) * e[H + j];
             return a + b;
         });
         return s / 2.0f;
+    }
+};
+
+// ---------------------------------------------------------------- coefficient accessors
+// PtrCoef: plain memory (true-score and filter kernels; per-lane pointer).
+struct PtrCoef {
+    const float* __restrict__ p;
+    template <int I>
+    __device__ __forceinline__ float operator()(ic<I>) const { return p[I]; }
+};
+
+template <int K>
+__device__ __forceinline__ float quad_bcast(float x) {  // lane K of each quad -> the whole quad
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true));
+}
+
+// DppCoef: the rank kernel's path.  The query's coefficient row sits in LDS; lane l reads the 16 bytes
+// at float4 index 4*(i/16) + (l & 3), so one conflict-free ds_read_b128 hands every quad 16 consecutive
+// coefficients (a 4-periodic register set), and coefficient i is then the DPP quad_perm broadcast of
+// component i%4 from quad-lane (i/4)%4 -- folded by the compiler into the consuming VALU instruction
+// (v_sub_f32_dpp / v_mul_f32_dpp), so the broadcast costs no instruction and no SGPRs.  LDS returns
+// in order, so the reads can be issued ahead of their use (scalar loads return out of order and can
+// only be waited for all at once, which made the scalar-cache version of this kernel stall).
+struct DppCoef {
+    const float4* p;  // LDS: (const float4*)row + (lane & 3)
+    template <int I>
+    __device__ __forceinline__ float operator()(ic<I>) const {
+        const float4 v = p[(I >> 4) * 4];
+        constexpr int comp = I & 3, src = (I >> 2) & 3;
+        const float x = comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+        return quad_bcast<src>(x);
     }
 };
 

@@ -86,6 +86,8 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
         filt_col = filt_col.to(torch.int64).contiguous()
         if filt_rowptr.shape[0] != Q + 1:
             raise ValueError("filt_rowptr must have Q + 1 entries")
+        if filt_col.numel() == 0:  # empty CSR: keep a non-NULL pointer for the C-ABI
+            filt_col = torch.zeros(1, dtype=torch.int64, device=filt_col.device)
     dev = table.device
     counts = out if out is not None else torch.empty((Q, 4), dtype=torch.int32, device=dev)
     if counts.shape != (Q, 4) or counts.dtype != torch.int32 or not counts.is_contiguous():
