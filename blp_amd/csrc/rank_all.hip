@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "launch.h"
+#include "rank_common.h"
 #include "score_core.h"
 
 #pragma clang fp contract(off)
@@ -40,14 +41,6 @@ constexpr int kQueryChunk = 128;     // queries per workgroup pass over its tile
 constexpr int kQB = 4;               // queries staged per LDS coefficient batch
 constexpr int kSlabFloats = kTileRows * kLdsStride;
 __host__ __device__ constexpr int kMaxCoef(int D) { return 2 * D; }
-
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave execute in issue order; this only stops the compiler from
-    // moving LDS accesses across the hand-off point.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // ------------------------------------------------------------------------------------------------
 template <int MODEL, int D>
@@ -67,15 +60,6 @@ __global__ void prep_coef_kernel(const float* __restrict__ q_fixed, const float*
             const int64_t k = i - n_head, q = k / ST::C;
             coef_tail[k] = ST::coef(q_fixed + (q_head + q) * D, q_rel + (q_head + q) * D, (int)(k % ST::C));
         }
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void load_row(float (&e)[D], const float* __restrict__ row) {
-#pragma unroll
-    for (int d = 0; d < D; d += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(row + d);
-        e[d] = v.x; e[d + 1] = v.y; e[d + 2] = v.z; e[d + 3] = v.w;
     }
 }
 
@@ -135,9 +119,6 @@ __device__ __forceinline__ void load_tile(float (&e)[D], const float* __restrict
         });
     });
 }
-
-typedef __attribute__((address_space(1))) const void* global_cptr;
-typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // Stage `count` floats (a multiple of 4, at most 2 * 4 * 256) from global memory into LDS with
 // LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS at wave-uniform base + lane * 16,
@@ -330,8 +311,6 @@ struct RankWorkspace {
     size_t bytes;
 };
 
-static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
 static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t q_tail) {
     // Both sides are sized for the larger coefficient layout (2 * D floats per query).
     RankWorkspace w;
@@ -348,7 +327,18 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
 }
 
 size_t rank_all_workspace_bytes(int D, int64_t q_head, int64_t q_tail) {
-    return carve_workspace(nullptr, D, q_head, q_tail).bytes;
+    size_t bytes = carve_workspace(nullptr, D, q_head, q_tail).bytes;
+    for (int model = 0; model < 4; ++model) {
+        const size_t m = rank_mfma_workspace_bytes(model, D, q_head, q_tail);
+        bytes = m > bytes ? m : bytes;
+    }
+    return bytes;
+}
+
+hipError_t launch_finalize_counts(const unsigned long long* acc, const unsigned long long* acc_f, int64_t Q,
+                                  int32_t* counts, hipStream_t stream) {
+    finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(acc, acc_f, Q, counts);
+    return hipGetLastError();
 }
 
 template <int MODEL, int D>
@@ -443,6 +433,9 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
                            const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                            hipEvent_t ev_stop) {
+    if (rank_mfma_applicable(model, D, q_head, q_tail))
+        return launch_rank_all_mfma(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
+                                    filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (model) {
     case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);

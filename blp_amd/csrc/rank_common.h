@@ -1,0 +1,47 @@
+// rank_common.h -- helpers shared by the ranking kernels (rank_all.hip: one-lane-per-candidate VALU
+// kernel; rank_mfma.hip: 32x32 MFMA tile kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "score_core.h"
+
+namespace blp {
+
+typedef __attribute__((address_space(1))) const void* global_cptr;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from
+    // moving LDS accesses across the hand-off point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int D>
+__device__ __forceinline__ void load_row(float (&e)[D], const float* __restrict__ row) {
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + d);
+        e[d] = v.x; e[d + 1] = v.y; e[d + 2] = v.z; e[d + 3] = v.w;
+    }
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// counts[q] = {gt, ge, gt - fgt, ge - fge} from the packed 64-bit accumulators (rank_all.hip)
+hipError_t launch_finalize_counts(const unsigned long long* acc, const unsigned long long* acc_f, int64_t Q,
+                                  int32_t* counts, hipStream_t stream);
+
+// rank_mfma.hip: MFMA-tile pipeline for large query blocks; same contract as launch_rank_all.
+bool rank_mfma_applicable(int model, int D, int64_t q_head, int64_t q_tail);
+size_t rank_mfma_workspace_bytes(int model, int D, int64_t q_head, int64_t q_tail);
+hipError_t launch_rank_all_mfma(int model, int D, const float* table, int64_t N, int64_t ld,
+                                const float* q_fixed, const float* q_rel, const int64_t* true_row,
+                                const float* q_true, int64_t q_head, int64_t q_tail,
+                                const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                                hipEvent_t ev_stop);
+
+}  // namespace blp

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <vector>
 
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(err_), __LINE__); return 1; } } while (0)
 
 // PATTERN 0: instruction i of a wave reads 1 KiB contiguous (2 rows of 512 B)
 // PATTERN 1: instruction (s, i) reads 8 rows x 128 B (row stride 512 B)  [the rank kernel's pattern]

@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstring>
 
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(err_), __LINE__); return 1; } } while (0)
 #define R4(x) x x x x
 #define R16(x) R4(R4(x))
 
