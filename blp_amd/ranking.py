@@ -1,0 +1,313 @@
+"""All-entities ranking evaluation: the reference's eval_link_prediction (/root/reference/train.py:57-243)
+restated around the fused HIP ranking, plus candidate-axis sharding across GPUs (new capability).
+
+What changes relative to the reference, and what does not:
+  * same inputs, same metric names, same numbers: raw and filtered MRR / Hits@{1,3,10}, the by-new-
+    position split, the relation-category split, ``(mrr, ent_emb)`` return value;
+  * the (2B, N) score matrix, the dense (2B, N) filter mask and the per-batch ``.item()`` syncs are
+    gone: a block of triples becomes a (2B, 4) int32 count tensor on the device (blp_amd.ops.rank_all
+    with a CSR filter from utils.FilterIndex), metrics are reduced once at the end;
+  * with a process group, every rank keeps rows [lo, hi) of the entity table (and encodes only
+    those), query / true-entity vectors are replicated by one exchange, and the per-shard counts of
+    the whole evaluation are combined by ONE all-gather (RCCL over xGMI on GPUs; gloo in CPU tests).
+
+CPU tensors (the reference's CPU-runnable smoke configuration) take the reference's own dense route
+through score_fn + get_metrics.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import models, ops, utils
+
+HIT_POSITIONS = (1, 3, 10)
+
+
+# ----------------------------------------------------------------------------------- one block
+def _rank_block_dense(score_fn, table, q_fixed, q_rel, q_head, true_scores_from, filt_rowptr, filt_col):
+    """Reference route (train.py:146-171) for CPU tensors: dense scores, then counts.
+    ``true_scores_from`` is either ('row', true_row) or ('vec', q_true)."""
+    ent = table.unsqueeze(0)
+    fixed, rel = q_fixed.unsqueeze(1), q_rel.unsqueeze(1)
+    pred = torch.cat((score_fn(ent, fixed[:q_head], rel[:q_head]), score_fn(fixed[q_head:], ent, rel[q_head:])))
+    kind, value = true_scores_from
+    if kind == "row":
+        true = pred.gather(1, value.reshape(-1, 1))
+    else:
+        tv = value.unsqueeze(1)
+        true = torch.cat((score_fn(tv[:q_head], fixed[:q_head], rel[:q_head]),
+                          score_fn(fixed[q_head:], tv[q_head:], rel[q_head:])))
+    gt_mask, ge_mask = pred > true, pred >= true
+    counts = torch.empty((pred.shape[0], 4), dtype=torch.int32)
+    counts[:, 0] = gt_mask.sum(1)
+    counts[:, 1] = ge_mask.sum(1)
+    if filt_rowptr is not None:
+        keep = torch.ones_like(gt_mask)
+        rows = torch.repeat_interleave(torch.arange(pred.shape[0]), filt_rowptr[1:] - filt_rowptr[:-1])
+        keep[rows, filt_col] = False
+        counts[:, 2] = (gt_mask & keep).sum(1)
+        counts[:, 3] = (ge_mask & keep).sum(1)
+    else:
+        counts[:, 2:] = counts[:, :2]
+    return counts
+
+
+def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None, filt_rowptr=None, filt_col=None):
+    """Counts (Q, 4) int32 {gt, ge, gt_filtered, ge_filtered} for a block of queries against ``table``.
+    Queries [0, q_head) replace the head, the rest replace the tail (train.py:149 order)."""
+    if table.is_cuda:
+        dev = table.device
+        return ops.rank_all(model.rel_model, table, q_fixed, q_rel, q_head,
+                            true_row=None if true_row is None else true_row.to(dev),
+                            q_true=q_true,
+                            filt_rowptr=None if filt_rowptr is None else filt_rowptr.to(dev),
+                            filt_col=None if filt_col is None else filt_col.to(dev))
+    source = ("row", true_row) if true_row is not None else ("vec", q_true)
+    return _rank_block_dense(model.score_fn, table, q_fixed, q_rel, q_head, source, filt_rowptr, filt_col)
+
+
+def metrics_from_counts(counts, k_values=HIT_POSITIONS):
+    """utils.py:104-109 from counts: rr (Q, 2) f32 [raw, filtered], hits (Q, 2, 3) bool."""
+    if counts.is_cuda:
+        return ops.rank_metrics(counts, k_values)
+    c = counts.to(torch.int64)
+    avg = torch.stack((c[:, 0] + 1 + c[:, 1], c[:, 2] + 1 + c[:, 3]), dim=1).float() * 0.5
+    k = torch.tensor(k_values, dtype=torch.float32).view(1, 1, -1)
+    return avg.reciprocal(), avg.unsqueeze(-1) <= k
+
+
+# ----------------------------------------------------------------------------------- sharding
+def shard_bounds(num_rows, world_size, rank):
+    per = (num_rows + world_size - 1) // world_size
+    return min(rank * per, num_rows), min((rank + 1) * per, num_rows)
+
+
+class ShardedRanker:
+    """Candidate-axis sharded ranking.  Rank r owns table rows [lo, hi); the per-shard
+    count tensors add up exactly to the unsharded counts, so one all-gather of int32 counts per
+    evaluation is the only data-path collective."""
+
+    def __init__(self, model, local_table, num_rows, group=None):
+        self.model = model
+        self.table = local_table
+        self.num_rows = int(num_rows)
+        self.group = group
+        self.world = dist.get_world_size(group) if self._distributed() else 1
+        self.rank = dist.get_rank(group) if self._distributed() else 0
+        self.lo, self.hi = shard_bounds(self.num_rows, self.world, self.rank)
+        if local_table.shape[0] != self.hi - self.lo:
+            raise ValueError(f"rank {self.rank} must hold rows [{self.lo}, {self.hi}) of the table, "
+                             f"got {local_table.shape[0]} rows")
+        self._blocks = []
+
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized()
+
+    def gather_rows(self, rows):
+        """Vectors of the given global table rows on every rank: owners fill, one all-reduce (adding
+        exact zeros) replicates.  Called once per evaluation for the entities of the test triples."""
+        rows = rows.to(torch.long)
+        out = torch.zeros((rows.shape[0], self.table.shape[1]), dtype=self.table.dtype, device=self.table.device)
+        mine = (rows >= self.lo) & (rows < self.hi)
+        if mine.any():
+            out[mine.to(out.device)] = self.table[(rows[mine] - self.lo).to(self.table.device)]
+        if self.world > 1:
+            dist.all_reduce(out, group=self.group)
+        return out
+
+    def rank_block(self, q_fixed, q_rel, q_true, q_head, filt_rowptr=None, filt_col=None):
+        """Local counts of one query block against this rank's shard (queued for the final exchange).
+        filt_col are GLOBAL table rows; only the ones this shard owns are kept."""
+        if filt_rowptr is not None:
+            owned = (filt_col >= self.lo) & (filt_col < self.hi)
+            per_row = torch.zeros(filt_rowptr.shape[0] - 1, dtype=torch.long)
+            rows = torch.repeat_interleave(torch.arange(per_row.shape[0]), filt_rowptr[1:] - filt_rowptr[:-1])
+            per_row.index_add_(0, rows[owned], torch.ones(int(owned.sum()), dtype=torch.long))
+            filt_rowptr = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(per_row, 0)))
+            filt_col = filt_col[owned] - self.lo
+        counts = rank_block(self.model, self.table, q_fixed, q_rel, q_head, q_true=q_true,
+                            filt_rowptr=filt_rowptr, filt_col=filt_col)
+        self._blocks.append(counts)
+        return counts
+
+    def finish(self):
+        """Global counts of every queued block: ONE all-gather of the (Q, 4) int32 tensor, then a sum."""
+        local = torch.cat(self._blocks) if self._blocks else torch.zeros((0, 4), dtype=torch.int32, device=self.table.device)
+        self._blocks = []
+        if self.world == 1:
+            return local
+        gathered = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(gathered.view(-1), local.contiguous().view(-1), group=self.group)
+        return gathered.sum(dim=0, dtype=torch.int32)
+
+
+# ----------------------------------------------------------------------------------- evaluation
+def _module(model):
+    return model.module if isinstance(model, torch.nn.DataParallel) else model
+
+
+@torch.no_grad()
+def build_entity_table(model, text_dataset, entities, emb_batch_size, device, log=None, rows=None):
+    """train.py:96-121: encode ``entities`` (or the slice ``rows`` = (lo, hi) of them) in chunks of
+    emb_batch_size into an (n, dim) f32 table, in the order of ``entities``."""
+    lo, hi = rows if rows is not None else (0, entities.shape[0])
+    n = hi - lo
+    table = torch.zeros((n, model.dim), dtype=torch.float, device=device)
+    num_iters = math.ceil(n / emb_batch_size) if n else 0
+    report = max(1, math.ceil(0.2 * num_iters))
+    for it, idx in enumerate(range(0, n, emb_batch_size)):
+        batch_ents = entities[lo + idx: lo + min(idx + emb_batch_size, n)]
+        if isinstance(model, models.InductiveLinkPrediction):
+            text_tok, text_mask, _ = text_dataset.get_entity_description(batch_ents)
+            batch_emb = model(text_tok.unsqueeze(1).to(device), text_mask.unsqueeze(1).to(device))
+        else:
+            batch_emb = model(batch_ents.to(device))
+        table[idx: idx + batch_ents.shape[0]] = batch_emb
+        if log is not None and (it + 1) % report == 0:
+            log.info(f"[{idx + batch_ents.shape[0]:,}/{n:,}]")
+    return table
+
+
+@torch.no_grad()
+def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, emb_batch_size, _run, _log,
+                         prefix="", max_num_batches=None, filtering_graph=None, new_entities=None,
+                         return_embeddings=False, device=None, group=None, block_size=8192):
+    """Drop-in for train.eval_link_prediction (same positional arguments, metric names and return
+    value).  ``device`` defaults to the model's device; ``group`` enables candidate-axis sharding."""
+    model = _module(model)
+    if device is None:
+        device = next(model.parameters()).device
+    compute_filtered = filtering_graph is not None
+    dataset = triples_loader.dataset
+
+    if isinstance(model, models.InductiveLinkPrediction):
+        if compute_filtered:
+            index = filtering_graph if isinstance(filtering_graph, utils.FilterIndex) else utils.FilterIndex(filtering_graph)
+            max_ent_id = max(index.max_node, int(entities.max()))
+        else:
+            index, max_ent_id = None, int(entities.max())
+        ent2idx = utils.make_ent2idx(entities, max_ent_id)
+    else:
+        entities = torch.arange(model.ent_emb.num_embeddings)
+        ent2idx = entities
+        index = None
+        if compute_filtered:
+            index = filtering_graph if isinstance(filtering_graph, utils.FilterIndex) else utils.FilterIndex(filtering_graph)
+    num_entities = entities.shape[0]
+
+    sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    world = dist.get_world_size(group) if sharded else 1
+    rank = dist.get_rank(group) if sharded else 0
+    lo, hi = shard_bounds(num_entities, world, rank)
+    was_training = model.training
+    model.eval()
+    table = build_entity_table(model, text_dataset, entities, emb_batch_size, device, _log, rows=(lo, hi))
+    ranker = ShardedRanker(model, table, num_entities, group) if sharded else None
+
+    # every evaluated triple, in loader order (train.py:128-131)
+    batches = []
+    for i, triples in enumerate(triples_loader):
+        if max_num_batches is not None and i == max_num_batches:
+            break
+        batches.append(triples)
+    triples = torch.cat(batches) if batches else torch.zeros((0, 3), dtype=torch.long)
+    heads = ent2idx[triples[:, 0]]
+    tails = ent2idx[triples[:, 1]]
+    assert triples.shape[0] == 0 or (heads.min() >= 0 and tails.min() >= 0)
+    num_triples = triples.shape[0]
+    _log.info("Computing metrics on set of triples")
+
+    if sharded:  # replicate the vectors of every entity that occurs in a test triple: one exchange
+        uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
+        vectors = ranker.gather_rows(uniq)
+        head_pos, tail_pos = inverse[:num_triples], inverse[num_triples:]
+
+    counts_blocks = []
+    for start in range(0, num_triples, block_size):
+        sl = slice(start, min(start + block_size, num_triples))
+        b = sl.stop - sl.start
+        rel_vecs = model.rel_emb(triples[sl, 2].to(device))
+        filt = index.csr(triples[sl], ent2idx) if compute_filtered else (None, None)
+        if sharded:
+            h_vec, t_vec = vectors[head_pos[sl].to(device)], vectors[tail_pos[sl].to(device)]
+            ranker.rank_block(torch.cat((t_vec, h_vec)), torch.cat((rel_vecs, rel_vecs)), torch.cat((h_vec, t_vec)),
+                              b, filt[0], filt[1])
+        else:
+            h_rows, t_rows = heads[sl].to(device), tails[sl].to(device)
+            counts_blocks.append(rank_block(model, table, torch.cat((table[t_rows], table[h_rows])),
+                                            torch.cat((rel_vecs, rel_vecs)), b,
+                                            true_row=torch.cat((heads[sl], tails[sl])).to(device),
+                                            filt_rowptr=filt[0], filt_col=filt[1]))
+    if sharded:
+        block_counts = ranker.finish()  # ONE all-gather for the whole evaluation
+        counts_blocks, offset = [], 0
+        for start in range(0, num_triples, block_size):
+            b = min(start + block_size, num_triples) - start
+            counts_blocks.append(block_counts[offset: offset + 2 * b])
+            offset += 2 * b
+
+    # per-block layout is [head queries | tail queries]; put every head query first, like one big batch
+    if counts_blocks:
+        sizes = [c.shape[0] // 2 for c in counts_blocks]
+        counts = torch.cat([c[:s] for c, s in zip(counts_blocks, sizes)] + [c[s:] for c, s in zip(counts_blocks, sizes)])
+    else:
+        counts = torch.zeros((0, 4), dtype=torch.int32, device=device)
+    rr, hits = metrics_from_counts(counts)
+    num_predictions = 2 * num_triples
+    _log.info(f"The total number of predictions is {num_predictions:,}")
+    denom = max(num_predictions, 1)
+    sums = rr.double().sum(dim=0).tolist() if num_predictions else [0.0, 0.0]
+    hit_sums = hits.double().sum(dim=0).tolist() if num_predictions else [[0.0] * 3, [0.0] * 3]
+    mrr, mrr_filt = sums[0] / denom, (sums[1] / denom if compute_filtered else 0.0)
+
+    log_str = f"{prefix} mrr: {mrr:.4f}  "
+    _run.log_scalar(f"{prefix}_mrr", mrr, epoch)
+    for j, k in enumerate(HIT_POSITIONS):
+        value = hit_sums[0][j] / denom
+        log_str += f"hits@{k}: {value:.4f}  "
+        _run.log_scalar(f"{prefix}_hits@{k}", value, epoch)
+    if compute_filtered:
+        log_str += f"mrr_filt: {mrr_filt:.4f}  "
+        _run.log_scalar(f"{prefix}_mrr_filt", mrr_filt, epoch)
+        for j, k in enumerate(HIT_POSITIONS):
+            value = hit_sums[1][j] / denom
+            log_str += f"hits@{k}_filt: {value:.4f}  "
+            _run.log_scalar(f"{prefix}_hits@{k}_filt", value, epoch)
+    _log.info(log_str)
+
+    if compute_filtered and new_entities is not None:
+        by_pos, pos_counts = utils.split_by_new_position(triples, rr[:, 1], new_entities)
+        pos_counts[pos_counts < 1.0] = 1.0
+        by_pos = by_pos / pos_counts
+        log_str = ""
+        for i, name in enumerate((f"{prefix}_mrr_filt_both_new", f"{prefix}_mrr_filt_head_new",
+                                  f"{prefix}_mrr_filt_tail_new")):
+            value = by_pos[i].item()
+            log_str += f"{name}: {value:.4f}  "
+            _run.log_scalar(name, value, epoch)
+        _log.info(log_str)
+
+    if compute_filtered and getattr(dataset, "has_rel_categories", False):
+        from .data import CATEGORY_IDS
+        by_cat, cat_count = utils.split_by_category(triples, rr[:, 1], dataset.rel_categories)
+        cat_count[cat_count < 1.0] = 1.0
+        by_cat = by_cat / cat_count
+        for i, case in enumerate(["pred_head", "pred_tail"]):
+            log_str = f"{case} "
+            for cat, cat_id in CATEGORY_IDS.items():
+                log_str += f"{cat}_mrr: {by_cat[i, cat_id]:.4f}  "
+            _log.info(log_str)
+
+    if was_training:
+        model.train()
+    if return_embeddings:
+        if sharded and world > 1:  # the full table only on request: all-gather of the shards
+            per = (num_entities + world - 1) // world
+            padded = torch.zeros((per, table.shape[1]), dtype=table.dtype, device=device)
+            padded[: table.shape[0]] = table
+            full = torch.empty((world * per, table.shape[1]), dtype=table.dtype, device=device)
+            dist.all_gather_into_tensor(full, padded, group=group)
+            table = full[:num_entities]
+        return mrr, table.unsqueeze(0)
+    return mrr, None

@@ -1,0 +1,251 @@
+"""python train.py [link_prediction|node_classification] with key=value ...
+
+The reference's Sacred CLI (/root/reference/train.py) on the MI355X-native hot path: same commands,
+config keys and defaults (train.py:35-54), same outputs (output/model-{id}.pt, ent_emb-{id}.pt,
+ents-{id}.pt) and log-scalar names, with
+  * models from blp_amd.models (fused HIP in-batch loss on a GPU),
+  * evaluation from blp_amd.ranking (fused HIP all-entities ranking, CSR filters, optional
+    candidate-axis sharding when launched under torch.distributed.run),
+  * Sacred itself if installed, otherwise blp_amd.sacred_shim.
+Extra, optional config keys: data_root (default 'data'), seed (default None = unseeded, like the
+reference).
+"""
+import os
+import os.path as osp
+from collections import defaultdict
+
+import numpy as np
+import torch
+from torch.optim import Adam
+from torch.utils.data import DataLoader
+
+try:
+    from sacred import Experiment
+    from sacred.observers import MongoObserver
+except ImportError:  # Sacred is not in this image
+    from blp_amd.sacred_shim import Experiment
+    MongoObserver = None
+
+from blp_amd import utils
+from blp_amd.data import GraphDataset, TextGraphDataset, GloVeTokenizer
+from blp_amd.ranking import eval_link_prediction
+
+OUT_PATH = "output/"
+device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+
+ex = Experiment()
+ex.logger = utils.get_logger()
+if MongoObserver is not None and all([os.environ.get("DB_URI"), os.environ.get("DB_NAME")]):
+    ex.observers.append(MongoObserver(os.environ["DB_URI"], os.environ["DB_NAME"]))
+
+
+@ex.config
+def config():
+    dataset = 'umls'
+    inductive = True
+    dim = 128
+    model = 'blp'
+    rel_model = 'transe'
+    loss_fn = 'margin'
+    encoder_name = 'bert-base-cased'
+    regularizer = 0
+    max_len = 32
+    num_negatives = 64
+    lr = 2e-5
+    use_scheduler = True
+    batch_size = 64
+    emb_batch_size = 512
+    eval_batch_size = 64
+    max_epochs = 40
+    checkpoint = None
+    use_cached_text = False
+    data_root = 'data'
+    seed = None
+
+
+def _linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps):
+    """transformers.get_linear_schedule_with_warmup (train.py:337), restated to avoid the import cost."""
+    def factor(step):
+        if step < num_warmup_steps:
+            return step / max(1, num_warmup_steps)
+        return max(0.0, (num_training_steps - step) / max(1, num_training_steps - num_warmup_steps))
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, factor)
+
+
+def _tokenizer(model, encoder_name, data_root):
+    if model.startswith('bert') or model == 'blp':
+        from transformers import BertTokenizer
+        return BertTokenizer.from_pretrained(encoder_name)
+    return GloVeTokenizer(osp.join(data_root, 'glove', 'glove.6B.300d-maps.pt'))
+
+
+def _get_model(model, dim, rel_model, loss_fn, num_entities, num_relations, encoder_name, regularizer, data_root):
+    if model in ('glove-bow', 'glove-dkrl') and data_root != 'data':
+        from blp_amd import models as m
+        emb = osp.join(data_root, 'glove', 'glove.6B.300d.pt')
+        if model == 'glove-bow':
+            return m.BOW(rel_model, loss_fn, num_relations, regularizer, embeddings=emb)
+        return m.DKRL(dim, rel_model, loss_fn, num_relations, regularizer, embeddings=emb)
+    return utils.get_model(model, dim, rel_model, loss_fn, num_entities, num_relations, encoder_name, regularizer)
+
+
+@ex.command
+def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_name, regularizer, max_len,
+                    num_negatives, lr, use_scheduler, batch_size, emb_batch_size, eval_batch_size, max_epochs,
+                    checkpoint, use_cached_text, data_root, seed, _run, _log):
+    if seed is not None:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+    drop_stopwords = model in {'bert-bow', 'bert-dkrl', 'glove-bow', 'glove-dkrl'}
+    prefix = 'ind-' if inductive and model != 'transductive' else ''
+    triples_file = osp.join(data_root, dataset, f'{prefix}train.tsv')
+
+    if device != torch.device('cpu'):
+        num_devices = torch.cuda.device_count()
+        if batch_size % num_devices != 0:
+            raise ValueError(f'Batch size ({batch_size}) must be a multiple of the number of CUDA devices '
+                             f'({num_devices})')
+        _log.info(f'CUDA devices used: {num_devices}')
+    else:
+        num_devices = 1
+        _log.info('Training on CPU')
+
+    if model == 'transductive':
+        train_data = GraphDataset(triples_file, num_negatives, write_maps_file=True, num_devices=num_devices)
+    else:
+        train_data = TextGraphDataset(triples_file, num_negatives, max_len, _tokenizer(model, encoder_name, data_root),
+                                      drop_stopwords, write_maps_file=True, use_cached_text=use_cached_text,
+                                      num_devices=num_devices)
+    train_loader = DataLoader(train_data, batch_size, shuffle=True, collate_fn=train_data.collate_fn,
+                              num_workers=0, drop_last=True)
+    train_eval_loader = DataLoader(train_data, eval_batch_size)
+    valid_data = GraphDataset(osp.join(data_root, dataset, f'{prefix}dev.tsv'))
+    valid_loader = DataLoader(valid_data, eval_batch_size)
+    test_data = GraphDataset(osp.join(data_root, dataset, f'{prefix}test.tsv'))
+    test_loader = DataLoader(test_data, eval_batch_size)
+
+    # filtering graph over every known triple (train.py:298-302); a sorted index instead of networkx
+    train_ent = set(train_data.entities.tolist())
+    if dataset != 'Wikidata5M':
+        graph = utils.FilterIndex(torch.cat((train_data.triples, valid_data.triples, test_data.triples)))
+        train_val_ent = set(valid_data.entities.tolist()).union(train_ent)
+        train_val_test_ent = set(test_data.entities.tolist()).union(train_val_ent)
+        val_new_ents = train_val_ent.difference(train_ent)
+        test_new_ents = train_val_test_ent.difference(train_val_ent)
+    else:
+        graph = None
+        train_val_ent = set(valid_data.entities.tolist())
+        train_val_test_ent = set(test_data.entities.tolist())
+        val_new_ents = test_new_ents = None
+    _run.log_scalar('num_train_entities', len(train_ent))
+    train_ent = torch.tensor(list(train_ent))
+    train_val_ent = torch.tensor(list(train_val_ent))
+    train_val_test_ent = torch.tensor(list(train_val_test_ent))
+
+    net = _get_model(model, dim, rel_model, loss_fn, len(train_val_test_ent), train_data.num_rels, encoder_name,
+                     regularizer, data_root)
+    if checkpoint is not None:
+        net.load_state_dict(torch.load(checkpoint, map_location='cpu'))
+    if device != torch.device('cpu'):
+        net = torch.nn.DataParallel(net).to(device)
+
+    optimizer = Adam(net.parameters(), lr=lr)
+    total_steps = len(train_loader) * max_epochs
+    scheduler = _linear_schedule_with_warmup(optimizer, int(0.2 * total_steps), total_steps) if use_scheduler else None
+    best_valid_mrr = 0.0
+    os.makedirs(OUT_PATH, exist_ok=True)
+    checkpoint_file = osp.join(OUT_PATH, f'model-{_run._id}.pt')
+    log_every = max(1, int(0.05 * len(train_loader)))
+    for epoch in range(1, max_epochs + 1):
+        train_loss = 0
+        for step, data in enumerate(train_loader):
+            loss = net(*data).mean()
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            if scheduler is not None:
+                scheduler.step()
+            train_loss += loss.item()
+            if step % log_every == 0:
+                _log.info(f'Epoch {epoch}/{max_epochs} [{step}/{len(train_loader)}]: {loss.item():.6f}')
+                _run.log_scalar('batch_loss', loss.item())
+        _run.log_scalar('train_loss', train_loss / len(train_loader), epoch)
+
+        if dataset != 'Wikidata5M':
+            _log.info('Evaluating on sample of training set')
+            eval_link_prediction(net, train_eval_loader, train_data, train_ent, epoch, emb_batch_size, _run, _log,
+                                 prefix='train', max_num_batches=len(valid_loader), device=device)
+        _log.info('Evaluating on validation set')
+        val_mrr, _ = eval_link_prediction(net, valid_loader, train_data, train_val_ent, epoch, emb_batch_size,
+                                          _run, _log, prefix='valid', device=device)
+        if val_mrr > best_valid_mrr:  # best checkpoint by raw validation MRR
+            best_valid_mrr = val_mrr
+            torch.save(net.state_dict(), checkpoint_file)
+
+    if max_epochs > 0 and osp.exists(checkpoint_file):
+        net.load_state_dict(torch.load(checkpoint_file))
+
+    if dataset == 'Wikidata5M':
+        graph = utils.FilterIndex(valid_data.triples)
+    _log.info('Evaluating on validation set (with filtering)')
+    eval_link_prediction(net, valid_loader, train_data, train_val_ent, max_epochs + 1, emb_batch_size, _run, _log,
+                         prefix='valid', filtering_graph=graph, new_entities=val_new_ents, device=device)
+    if dataset == 'Wikidata5M':
+        graph = utils.FilterIndex(test_data.triples)
+    _log.info('Evaluating on test set')
+    _, ent_emb = eval_link_prediction(net, test_loader, train_data, train_val_test_ent, max_epochs + 1,
+                                      emb_batch_size, _run, _log, prefix='test', filtering_graph=graph,
+                                      new_entities=test_new_ents, return_embeddings=True, device=device)
+
+    torch.save(ent_emb, osp.join(OUT_PATH, f'ent_emb-{_run._id}.pt'))
+    torch.save(train_val_test_ent, osp.join(OUT_PATH, f'ents-{_run._id}.pt'))
+    return {name: values[-1][1] for name, values in getattr(_run, 'scalars', {}).items()}
+
+
+@ex.command
+def node_classification(dataset, checkpoint, data_root, _run, _log):
+    """Multinomial logistic regression on the saved entity embeddings (train.py:408-481); CPU sklearn."""
+    import joblib
+    from sklearn.linear_model import LogisticRegression
+    from sklearn.metrics import accuracy_score, balanced_accuracy_score
+
+    ent_emb = torch.load(f'output/ent_emb-{checkpoint}.pt', map_location='cpu')
+    if isinstance(ent_emb, tuple):
+        ent_emb = ent_emb[0]
+    ent_emb = ent_emb.squeeze().numpy()
+    _log.info(f'Loaded {ent_emb.shape[0]} embeddings with dim={ent_emb.shape[1]}')
+    emb_ids = torch.load(f'output/ents-{checkpoint}.pt', map_location='cpu')
+    ent2idx = utils.make_ent2idx(emb_ids, max_ent_id=emb_ids.max()).numpy()
+    ent_ids = torch.load(osp.join(data_root, dataset, 'maps.pt'))['ent_ids']
+    class2label = defaultdict(lambda: len(class2label))
+    data = {}
+    for split in ('train', 'dev', 'test'):
+        idx, labels = [], []
+        with open(osp.join(data_root, dataset, f'{split}-ents-class.txt')) as f:
+            for line in f:
+                entity, ent_class = line.strip().split()
+                idx.append(ent2idx[ent_ids[entity]])
+                labels.append(class2label[ent_class])
+        data[split] = (ent_emb[idx], np.array(labels))
+    (x_train, y_train), (x_dev, y_dev), (x_test, y_test) = data['train'], data['dev'], data['test']
+
+    best_dev_metric, best_c = 0.0, 0
+    for k in range(-4, 2):
+        c = 10 ** -k
+        clf = LogisticRegression(C=c, max_iter=1000).fit(x_train, y_train)
+        dev_acc = accuracy_score(y_dev, clf.predict(x_dev))
+        _log.info(f'{c:.3f} - {dev_acc:.3f}')
+        if dev_acc > best_dev_metric:
+            best_dev_metric, best_c = dev_acc, c
+    _log.info(f'Best regularization coefficient: {best_c:.4f}')
+    x_all, y_all = np.concatenate((x_train, x_dev)), np.concatenate((y_train, y_dev))
+    clf = LogisticRegression(C=best_c, max_iter=1000).fit(x_all, y_all)
+    for metric_fn in (accuracy_score, balanced_accuracy_score):
+        _log.info(f'Train {metric_fn.__name__}: {metric_fn(y_all, clf.predict(x_all)):.3f}')
+        _log.info(f'Test {metric_fn.__name__}: {metric_fn(y_test, clf.predict(x_test)):.3f}')
+    joblib.dump({'model': clf, 'id_to_class': {v: k for k, v in class2label.items()}},
+                osp.join('output', f'classifier-{checkpoint}.joblib'))
+
+
+if __name__ == '__main__':
+    ex.run_commandline()
