@@ -326,11 +326,13 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
     return w;
 }
 
-size_t rank_all_workspace_bytes(int D, int64_t q_head, int64_t q_tail) {
+size_t rank_all_workspace_bytes(int D, int64_t N, int64_t q_head, int64_t q_tail) {
     size_t bytes = carve_workspace(nullptr, D, q_head, q_tail).bytes;
     for (int model = 0; model < 4; ++model) {
         const size_t m = rank_mfma_workspace_bytes(model, D, q_head, q_tail);
         bytes = m > bytes ? m : bytes;
+        const size_t g = rank_gemm_workspace_bytes(model, D, N, q_head, q_tail);
+        bytes = g > bytes ? g : bytes;
     }
     return bytes;
 }
@@ -433,6 +435,9 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
                            const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                            hipEvent_t ev_stop) {
+    if (rank_gemm_applicable(model, D, q_head, q_tail))
+        return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
+                                    filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     if (rank_mfma_applicable(model, D, q_head, q_tail))
         return launch_rank_all_mfma(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
                                     filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
@@ -443,6 +448,56 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
     case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     default:       return hipErrorInvalidValue;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact-path building blocks reused by rank_gemm.hip (row-major coefficients, true keys, CSR filter).
+template <int MODEL, int D>
+static hipError_t exact_prep_impl(const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
+                                  const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
+                                  float* coef_head, float* coef_tail, float* key_true, hipStream_t stream) {
+    const int64_t Q = q_head + q_tail;
+    const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
+    const int64_t blocks = (total + 255) / 256;
+    prep_coef_kernel<MODEL, D><<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, coef_head, coef_tail);
+    true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(table, ld, true_row, q_true, coef_head, coef_tail, q_head, q_tail, key_true);
+    return hipGetLastError();
+}
+
+template <int MODEL, int D>
+static hipError_t exact_filter_impl(const float* table, int64_t ld, const float* coef_head, const float* coef_tail,
+                                    const float* key_true, int64_t q_head, int64_t q_tail, const int64_t* rowptr,
+                                    const int64_t* col, unsigned long long* acc_f, hipStream_t stream) {
+    filt_counts_kernel<MODEL, D><<<(int)((q_head + q_tail + 3) / 4), 256, 0, stream>>>(
+        table, ld, coef_head, coef_tail, key_true, q_head, q_tail, rowptr, col, acc_f);
+    return hipGetLastError();
+}
+
+#define BLP_DISPATCH_MODEL_DIM(FN, ...)                                                     \
+    switch (model * 1000 + D) {                                                             \
+    case DISTMULT * 1000 + 64: return FN<DISTMULT, 64>(__VA_ARGS__);                        \
+    case DISTMULT * 1000 + 128: return FN<DISTMULT, 128>(__VA_ARGS__);                      \
+    case COMPLEX * 1000 + 64: return FN<COMPLEX, 64>(__VA_ARGS__);                          \
+    case COMPLEX * 1000 + 128: return FN<COMPLEX, 128>(__VA_ARGS__);                        \
+    case SIMPLE * 1000 + 64: return FN<SIMPLE, 64>(__VA_ARGS__);                            \
+    case SIMPLE * 1000 + 128: return FN<SIMPLE, 128>(__VA_ARGS__);                          \
+    default: return hipErrorInvalidValue;                                                   \
+    }
+
+hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head,
+                             int64_t q_tail, const float* table, int64_t ld, const int64_t* true_row,
+                             const float* q_true, float* coef_head, float* coef_tail, float* key_true,
+                             hipStream_t stream) {
+    BLP_DISPATCH_MODEL_DIM(exact_prep_impl, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, coef_head,
+                           coef_tail, key_true, stream)
+}
+
+hipError_t launch_exact_filter(int model, int D, const float* table, int64_t ld, const float* coef_head,
+                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+                               const int64_t* rowptr, const int64_t* col, unsigned long long* acc_f,
+                               hipStream_t stream) {
+    BLP_DISPATCH_MODEL_DIM(exact_filter_impl, table, ld, coef_head, coef_tail, key_true, q_head, q_tail, rowptr, col,
+                           acc_f, stream)
 }
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,

@@ -1,0 +1,431 @@
+// rank_gemm.hip -- all-entities ranking for the bilinear models (DistMult / ComplEx / SimplE) as a dense
+// f32 MFMA GEMM with a fused rank-count epilogue, made bit-exact by a rigorous error band and an
+// exact refinement pass.  ("K2".)
+//
+// Scoring every entity against a query block IS a GEMM for these models: score(q, c) = <W_q, e_c> with
+// a query-side vector W_q (DistMult: h*r; ComplEx: the complex product of r with h, or with conj t;
+// SimplE: the two half-products).  But the reference's result is not that dot product rounded once:
+// it rounds every elementwise product and sums in torch's vectorised order, and the ranks must be
+// bit-identical.  So:
+//   pass 1  S~ = W E^T on v_mfma_f32_32x32x2_f32 (64 chained MFMAs per 32 x 32 tile, K = D = 128),
+//           and per pair a three-way decision against the EXACT true-entity score s_true:
+//              S~ > s_true + eps  -> certainly ranked above   (count it)
+//              S~ < s_true - eps  -> certainly below          (ignore it)
+//              otherwise          -> undecided
+//           eps(q, c) = C u ||B_q|| ||e_c|| bounds |S~ - S_ref| for ANY evaluation order: both the GEMM and
+//           the reference are within (n + O(1)) u sum_k B_q[k] |e_c[k]| of the real-number score, where
+//           B_q[k] >= |W_q[k]| is the sum of the absolute values of the products W_q[k] is made of
+//           (Cauchy-Schwarz turns the sum into the two norms).  u = 2^-24, C = 320 for n <= 128 terms.
+//           If any pair of a (query, 32-candidate tile) segment is undecided the segment contributes
+//           nothing and its bit is set in a flag bitmap.
+//   pass 2  every flagged segment is re-scored with the order-exact Scorer<> routine (the same code
+//           that produced s_true) and counted exactly.  Typically ~0.5 % of the segments (the true
+//           entity's own segment plus near-ties); if everything is flagged the result is still exact,
+//           just slower -- there is no capacity to overflow.
+// NaN / Inf anywhere makes a pair undecided (both comparisons are false), so it takes the exact path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch.h"
+#include "rank_common.h"
+#include "score_core.h"
+
+#pragma clang fp contract(off)
+
+namespace blp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGW = 4;              // waves per workgroup (one 32-candidate tile each)
+constexpr int kGQT = 32;            // queries per tile
+constexpr int kGCT = 32;            // candidates per tile
+constexpr int kGTilesPerChunk = 8;  // query tiles per workgroup
+constexpr int kGSlab = 36;          // dwords, transpose slab row stride
+constexpr float kBandC = 320.0f;    // error-band constant (see header)
+
+// LDS floats shared by the two query-tile buffers and (before any staging) the transpose slabs.
+__host__ __device__ constexpr int gemm_buf_floats(int D) {
+    return 2 * (D / 8) * 64 * 4 > kGW * kGCT * kGSlab ? 2 * (D / 8) * 64 * 4 : kGW * kGCT * kGSlab;
+}
+
+// GEMM operand w and its absolute bound b for element k of a query (f = the fixed entity, r = relation).
+template <int MODEL, int SIDE>
+__device__ __forceinline__ void gemm_operand(const float* __restrict__ f, const float* __restrict__ r, int k, int D,
+                                             float& w, float& b) {
+    const int H = D / 2, j = k < H ? k : k - H;
+    if constexpr (MODEL == DISTMULT) {
+        w = f[k] * r[k];
+        b = fabsf(w);
+    } else if constexpr (MODEL == COMPLEX) {
+        const float fr = f[j], fi = f[H + j], rr = r[j], ri = r[H + j];
+        float p, q;
+        if (SIDE == TAIL) {  // f = head:  re: rr*hr - ri*hi ; im: rr*hi + ri*hr
+            if (k < H) { p = rr * fr; q = ri * fi; w = p - q; } else { p = rr * fi; q = ri * fr; w = p + q; }
+        } else {             // f = tail:  re: rr*tr + ri*ti ; im: rr*ti - ri*tr
+            if (k < H) { p = rr * fr; q = ri * fi; w = p + q; } else { p = rr * fi; q = ri * fr; w = p - q; }
+        }
+        b = fabsf(p) + fabsf(q);
+    } else {  // SIMPLE: f = [f_head_role | f_tail_role], r = [ra | rb]
+        if (SIDE == TAIL) w = k < H ? r[H + j] * f[H + j] : f[j] * r[j];      // cand [th | tt]: rb*ht , hh*ra
+        else              w = k < H ? r[j] * f[H + j] : f[j] * r[H + j];      // cand [hh | ht]: ra*tt , th*rb
+        w = w * 0.5f;
+        b = fabsf(w);
+    }
+}
+
+// B-operand image of one 32-query tile: float4 index (g * 64 + l), l = 64-lane id, holds
+// W_{q=l&31}[8g + (l>>5) + 2i], i = 0..3  ->  one linear ds_read_b128 per 4 MFMAs.
+template <int MODEL, int D>
+__global__ void prep_gemm_kernel(const float* __restrict__ q_fixed, const float* __restrict__ q_rel, int64_t q_head,
+                                 int64_t q_tail, float4* __restrict__ img_head, float4* __restrict__ img_tail,
+                                 float* __restrict__ eps_q) {
+    constexpr int F4 = (D / 8) * 64;  // float4 per tile
+    const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
+    const int64_t n_img = (th + tt) * F4, Q = q_head + q_tail;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_img + Q; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_img) {
+            const bool head = i < th * F4;
+            const int64_t ii = head ? i : i - th * F4;
+            const int64_t tile = ii / F4;
+            const int rem = (int)(ii % F4), g = rem / 64, l = rem % 64;
+            const int64_t q_local = tile * kGQT + (l & 31), n_side = head ? q_head : q_tail;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q_local < n_side) {
+                const int64_t q = (head ? 0 : q_head) + q_local;
+                const float* f = q_fixed + q * D;
+                const float* r = q_rel + q * D;
+                for (int c = 0; c < 4; ++c) {
+                    float b;
+                    const int k = 8 * g + (l >> 5) + 2 * c;
+                    if (head) gemm_operand<MODEL, HEAD>(f, r, k, D, v[c], b);
+                    else gemm_operand<MODEL, TAIL>(f, r, k, D, v[c], b);
+                }
+            }
+            (head ? img_head : img_tail)[ii] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {  // per-query band factor: C * u * ||B_q||, rounded up
+            const int64_t q = i - n_img;
+            const float* f = q_fixed + q * D;
+            const float* r = q_rel + q * D;
+            float s = 0.f;
+            for (int k = 0; k < D; ++k) {
+                float w, b;
+                if (q < q_head) gemm_operand<MODEL, HEAD>(f, r, k, D, w, b);
+                else gemm_operand<MODEL, TAIL>(f, r, k, D, w, b);
+                s += b * b;
+            }
+            eps_q[q] = kBandC * 5.9604645e-8f * sqrtf(s) * 1.0001f;
+        }
+    }
+}
+
+// 32 candidate rows -> A operand a[s] (lanes 0-31: e[2s], lanes 32-63: e[2s+1]) + ||e|| of row (lane & 31).
+template <int D>
+__device__ __forceinline__ float load_a_gemm(float (&a)[D / 2], const float* __restrict__ table, int64_t N, int64_t ld,
+                                             int64_t row0, float* slab, int lane) {
+    float e[D];
+    const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
+    static_for<4>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        int64_t row = row0 + 8 * i + sub_row;
+        row = row < N ? row : N - 1;
+        const float* src = table + row * ld + sub_col;
+        static_for<D / 32>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            const float4 v = *reinterpret_cast<const float4*>(src + s * 32);
+            e[32 * s + 4 * i] = v.x; e[32 * s + 4 * i + 1] = v.y; e[32 * s + 4 * i + 2] = v.z; e[32 * s + 4 * i + 3] = v.w;
+        });
+    });
+    float* wr = slab + sub_row * kGSlab + sub_col;
+    const float* rd = slab + (lane & 31) * kGSlab;
+    static_for<D / 32>([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        if (s > 0) wave_lds_sync();
+        static_for<4>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            *reinterpret_cast<float4*>(wr + 8 * i * kGSlab) =
+                make_float4(e[32 * s + 4 * i], e[32 * s + 4 * i + 1], e[32 * s + 4 * i + 2], e[32 * s + 4 * i + 3]);
+        });
+        wave_lds_sync();
+        static_for<8>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            const float4 w = *reinterpret_cast<const float4*>(rd + 4 * j);
+            e[32 * s + 4 * j] = w.x; e[32 * s + 4 * j + 1] = w.y; e[32 * s + 4 * j + 2] = w.z; e[32 * s + 4 * j + 3] = w.w;
+        });
+    });
+    float ss = 0.f;
+    static_for<D>([&](auto d) { ss += e[d] * e[d]; });
+    const bool hi = lane >= 32;
+    static_for<D / 2>([&](auto s) { a[s] = hi ? e[2 * s + 1] : e[2 * s]; });
+    return sqrtf(ss) * 1.0001f;
+}
+
+template <int BYTES>
+__device__ __forceinline__ void stage_gemm_tile(const float4* __restrict__ src, float* dst, int wave, int lane) {
+    constexpr int ROUNDS = (BYTES + kGW * 1024 - 1) / (kGW * 1024);
+    static_for<ROUNDS>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const int seg = (k * kGW + wave) * 1024;
+        if (seg + lane * 16 < BYTES)
+            __builtin_amdgcn_global_load_lds((global_cptr)(reinterpret_cast<const char*>(src) + seg + lane * 16),
+                                             (lds_ptr)(reinterpret_cast<char*>(dst) + seg), 16, 0, 0);
+    });
+}
+
+template <int MODEL, int D>
+__global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const float4* __restrict__ img_head,
+    const float4* __restrict__ img_tail, const float* __restrict__ key_true, const float* __restrict__ eps_q,
+    int q_head, int q_tail, int n_quads, int chunks_head, int words_per_query,
+    unsigned long long* __restrict__ acc, unsigned* __restrict__ flags) {
+    constexpr int TILE_FLOATS = (D / 8) * 64 * 4;  // 16 KB at D = 128
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf0 = smem;
+    float* buf1 = smem + TILE_FLOATS;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem + gemm_buf_floats(D));  // [kGTilesPerChunk * 32]
+    float* nrm = reinterpret_cast<float*>(cnt + kGTilesPerChunk * kGQT);  // [kGW][32] candidate norms
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    const int quad = blockIdx.x % n_quads, chunk = blockIdx.x / n_quads;
+    const bool head = chunk < chunks_head;
+    const int side_chunk = head ? chunk : chunk - chunks_head;
+    const int n_side = head ? q_head : q_tail, q_base = head ? 0 : q_head;
+    const int tile0 = side_chunk * kGTilesPerChunk;
+    const int n_side_tiles = (n_side + kGQT - 1) / kGQT;
+    const int n_tiles = n_side_tiles - tile0 < kGTilesPerChunk ? n_side_tiles - tile0 : kGTilesPerChunk;
+
+    // candidate tile -> A operand + row norms (slabs alias the query buffers)
+    float a[D / 2];
+    const int ctile = quad * kGW + wave;
+    const int64_t row0 = (int64_t)ctile * kGCT;
+    const float my_norm = load_a_gemm<D>(a, table, N, ld, row0, smem + wave * (kGCT * kGSlab), lane);
+    __syncthreads();  // slabs done before anything is staged over them
+    if (lane < 32) nrm[wave * 32 + lane] = my_norm;
+    for (int i = tid; i < kGTilesPerChunk * kGQT; i += kGW * 64) cnt[i] = 0;
+    __syncthreads();
+    float nrow[16];       // ||e|| of the candidate held by accumulator register r of this lane
+    unsigned row_mask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        nrow[r] = nrm[wave * 32 + row];
+        row_mask |= (unsigned)(row0 + row < N) << r;
+    }
+
+    const float4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_FLOATS / 4);
+    stage_gemm_tile<TILE_FLOATS * 4>(img, buf0, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const float* cur = (t & 1) ? buf1 : buf0;
+        if (t + 1 < n_tiles)
+            stage_gemm_tile<TILE_FLOATS * 4>(img + (int64_t)(t + 1) * (TILE_FLOATS / 4), (t & 1) ? buf0 : buf1, wave, lane);
+        const int q_local = (tile0 + t) * kGQT + (lane & 31);
+        const bool q_ok = q_local < n_side;
+        const int q = q_base + (q_ok ? q_local : n_side - 1);
+        const float kt = key_true[q];
+        const float eq = eps_q[q];
+
+        // S~ tile = A (32 candidates x D) . B (D x 32 queries): D/2 MFMAs chained on one accumulator
+        f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float4* bp = reinterpret_cast<const float4*>(cur) + lane;
+        static_for<D / 8>([&](auto gg) {
+            constexpr int g = decltype(gg)::value;
+            const float4 b4 = bp[g * 64];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 0], b4.x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 1], b4.y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 2], b4.z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 3], b4.w, s, 0, 0, 0);
+        });
+
+        // epilogue: three-way decision per pair, per-segment (query, this candidate tile) outcome
+        unsigned above = 0;
+        bool undecided = false;
+        const float guard = fabsf(kt) * 2.4e-7f + 1e-36f;  // rounding of kt +- eps itself, underflow slack
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float eps = eq * nrow[r] + guard;
+            const float v = s[r];
+            const bool gt = v > kt + eps, lt = v < kt - eps, ok = (row_mask >> r) & 1u;
+            above += ok && gt;
+            undecided |= ok && !(gt || lt);
+        }
+        above += __shfl_xor(above, 32);
+        const bool seg_undecided = undecided | (bool)__shfl_xor((int)undecided, 32);
+        if (lane < 32 && q_ok) {
+            if (seg_undecided) atomicOr(flags + (size_t)q * words_per_query + (ctile >> 5), 1u << (ctile & 31));
+            else if (above) atomicAdd(cnt + t * kGQT + lane, above);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int i = tid; i < n_tiles * kGQT; i += kGW * 64) {
+        const int q_local = tile0 * kGQT + i;
+        const unsigned long long c = cnt[i];
+        if (q_local < n_side && c) atomicAdd(acc + q_base + q_local, c | (c << 32));  // certainly above: gt and ge
+    }
+}
+
+// Pass 2: one wave per flag word (32 candidate tiles of one query); each half-wave takes one flagged
+// tile at a time and scores its 32 candidates exactly.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
+                                                     const float* __restrict__ coef_head,
+                                                     const float* __restrict__ coef_tail,
+                                                     const float* __restrict__ key_true, int64_t q_head, int64_t Q,
+                                                     int words_per_query, const unsigned* __restrict__ flags,
+                                                     unsigned long long* __restrict__ acc) {
+    const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= Q * words_per_query) return;
+    unsigned bits = flags[word];
+    if (bits == 0) return;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int64_t q = word / words_per_query;
+    const int tile_base = (int)(word % words_per_query) * 32;
+    const float kt = key_true[q];
+    unsigned gt = 0, ge = 0;
+    while (bits) {  // wave-uniform loop: two flagged tiles per iteration, one per half-wave
+        const int b0 = __builtin_ctz(bits);
+        bits &= bits - 1;
+        int b1 = -1;
+        if (bits) { b1 = __builtin_ctz(bits); bits &= bits - 1; }
+        const int b = half ? b1 : b0;
+        const int64_t row = (int64_t)(tile_base + (b < 0 ? 0 : b)) * kGCT + (lane & 31);
+        const bool ok = b >= 0 && row < N;
+        float e[D];
+        load_row<D>(e, table + (ok ? row : 0) * ld);
+        const float key = q < q_head
+            ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C})
+            : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
+        gt += ok && key > kt;
+        ge += ok && key >= kt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gt += __shfl_down(gt, off);
+        ge += __shfl_down(ge, off);
+    }
+    if (lane == 0 && (gt | ge)) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GemmWorkspace {
+    float* coef_head; float* coef_tail; float* key_true; float* eps_q;
+    float4* img_head; float4* img_tail;
+    unsigned long long* acc; unsigned long long* acc_f; unsigned* flags;
+    size_t flag_bytes, bytes;
+};
+
+// Candidate tiles handled per GEMM + refine pass: the flag bitmap (Q x tiles / 8 bytes) is capped at
+// ~256 MB, larger (Q x N) problems are processed in candidate slabs.
+static int64_t tiles_per_pass(int64_t N, int64_t Q) {
+    const int64_t n_ctiles = (N + kGCT - 1) / kGCT;
+    int64_t words = (n_ctiles + 31) / 32;
+    const int64_t budget_words = ((int64_t)256 << 20) / 4 / (Q > 0 ? Q : 1);
+    if (words > budget_words) words = budget_words < 32 ? 32 : budget_words;
+    return words * 32;
+}
+
+static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, int64_t q_tail) {
+    GemmWorkspace w;
+    const int64_t Q = q_head + q_tail;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    const size_t tile_bytes = (size_t)(D / 8) * 64 * 16;
+    w.coef_head = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_head * max_coef(D) * 4, 256);
+    w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * max_coef(D) * 4, 256);
+    w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
+    w.eps_q = reinterpret_cast<float*>(p + off);     off = align_up(off + (size_t)Q * 4, 256);
+    w.img_head = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_head + kGQT - 1) / kGQT) * tile_bytes, 256);
+    w.img_tail = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_tail + kGQT - 1) / kGQT) * tile_bytes, 256);
+    w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
+    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
+    w.flags = reinterpret_cast<unsigned*>(p + off);
+    int64_t pass_tiles = tiles_per_pass(N, Q);
+    const int64_t n_ctiles = (N + kGCT - 1) / kGCT;
+    if (pass_tiles > n_ctiles) pass_tiles = (n_ctiles + 31) / 32 * 32;
+    w.flag_bytes = (size_t)Q * (size_t)(pass_tiles / 32 > 0 ? pass_tiles / 32 : 1) * 4;
+    off = align_up(off + w.flag_bytes, 256);
+    w.bytes = off;
+    return w;
+}
+
+bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
+    return (model == DISTMULT || model == COMPLEX || model == SIMPLE) && (D == 64 || D == 128) && q_head + q_tail >= 64;
+}
+
+size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
+    if (!rank_gemm_applicable(model, D, q_head, q_tail)) return 0;
+    return carve_gemm(nullptr, D, N, q_head, q_tail).bytes;
+}
+
+template <int MODEL, int D>
+static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
+                                 const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
+                                 const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts, void* workspace,
+                                 hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const int64_t Q = q_head + q_tail;
+    GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
+    const int64_t pass_tiles = tiles_per_pass(N, Q);
+    hipError_t err = hipMemsetAsync(w.acc, 0, (size_t)Q * 8, stream);
+    if (err != hipSuccess) return err;
+    err = launch_exact_prep(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.coef_head,
+                            w.coef_tail, w.key_true, stream);
+    if (err != hipSuccess) return err;
+    const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
+    {
+        const int64_t total = (th + tt) * (D / 8) * 64 + Q;
+        const int64_t blocks = (total + 255) / 256;
+        prep_gemm_kernel<MODEL, D><<<(int)(blocks < 16384 ? blocks : 16384), 256, 0, stream>>>(
+            q_fixed, q_rel, q_head, q_tail, w.img_head, w.img_tail, w.eps_q);
+    }
+    const size_t lds = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4;
+    const int64_t chunks_head = (th + kGTilesPerChunk - 1) / kGTilesPerChunk;
+    const int64_t chunks_tail = (tt + kGTilesPerChunk - 1) / kGTilesPerChunk;
+    if (ev_start) (void)hipEventRecord(ev_start, stream);
+    for (int64_t slab0 = 0; slab0 < N; slab0 += pass_tiles * kGCT) {  // one iteration unless the bitmap is capped
+        const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
+        const int64_t n_ctiles = (n_rows + kGCT - 1) / kGCT;
+        const int64_t n_quads = (n_ctiles + kGW - 1) / kGW;
+        const int words = (int)((n_ctiles + 31) / 32);
+        err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
+        if (err != hipSuccess) return err;
+        const float* slab = table + slab0 * ld;
+        rank_gemm_kernel<MODEL, D><<<dim3((unsigned)(n_quads * (chunks_head + chunks_tail))), kGW * 64, lds, stream>>>(
+            slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_quads,
+            (int)chunks_head, words, w.acc, w.flags);
+        const int64_t n_words = Q * words;
+        refine_kernel<MODEL, D><<<dim3((unsigned)((n_words + 3) / 4)), 256, 0, stream>>>(
+            slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
+    }
+    if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+    const bool filtered = filt_rowptr != nullptr;
+    if (filtered) {
+        err = launch_exact_filter(MODEL, D, table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
+                                  filt_rowptr, filt_col, w.acc_f, stream);
+        if (err != hipSuccess) return err;
+    }
+    err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);
+    return err != hipSuccess ? err : hipGetLastError();
+}
+
+hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,
+                                const float* q_fixed, const float* q_rel, const int64_t* true_row,
+                                const float* q_true, int64_t q_head, int64_t q_tail,
+                                const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                                hipEvent_t ev_stop) {
+    (void)n_cu;
+#define BLP_GEMM_CASE(M, DD)                                                                                    \
+    if (model == M && D == DD)                                                                                  \
+        return rank_gemm_impl<M, DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, \
+                                     filt_col, counts, workspace, stream, ev_start, ev_stop);
+    BLP_GEMM_CASE(DISTMULT, 128) BLP_GEMM_CASE(DISTMULT, 64)
+    BLP_GEMM_CASE(COMPLEX, 128) BLP_GEMM_CASE(COMPLEX, 64)
+    BLP_GEMM_CASE(SIMPLE, 128) BLP_GEMM_CASE(SIMPLE, 64)
+#undef BLP_GEMM_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace blp

@@ -96,7 +96,7 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
         return counts
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
-    ws_bytes = L.blp_rank_all_workspace_bytes(model, D, q_head, Q - q_head)
+    ws_bytes = L.blp_rank_all_workspace_bytes(model, N, D, q_head, Q - q_head)
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     status = L.blp_rank_all(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
                             _ptr(q_rel), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,

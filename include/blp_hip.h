@@ -87,9 +87,10 @@ int blp_dim_supported(int model, int D);
  *   counts     (Q, 4) int32 OUT: {#(pred > true), #(pred >= true), same two over the
  *                          non-filtered candidates}.  Overwritten.  With the candidate axis
  *                          sharded, per-shard counts add up to the unsharded ones.
- *   workspace  caller-owned scratch of >= blp_rank_all_workspace_bytes(...) bytes, 256-B aligned.
+ *   workspace  caller-owned scratch of >= blp_rank_all_workspace_bytes(model, N, D, q_head, q_tail)
+ *              bytes, 256-B aligned.
  * -------------------------------------------------------------------------------------------- */
-size_t blp_rank_all_workspace_bytes(int model, int D, int64_t q_head, int64_t q_tail);
+size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head, int64_t q_tail);
 int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
                  const float *q_fixed, const float *q_rel, const int64_t *true_row,
                  const float *q_true, int64_t q_head, int64_t q_tail,

@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     assert L.blp_version() == 100
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
-    assert L.blp_rank_all_workspace_bytes(0, 128, 64, 64) >= 128 * (256 * 4 + 4 + 16)
+    assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 16)
 
 
 def test_bad_arguments_return_status_not_crash(built_lib):

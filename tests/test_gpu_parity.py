@@ -111,6 +111,47 @@ def test_random_vs_oracle_ragged(ops, oracle, model, D):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
+@pytest.mark.parametrize("D", [64, 128])
+def test_gemm_band_adversarial(ops, oracle, model, D):
+    """The GEMM + error-band path (Q >= 64) on inputs built to land inside the band: duplicated rows
+    (exact ties with the true entity), dyadic values (every order exact), rows scaled by 1 +- 2^-20
+    (near-ties), a huge-norm row and an all-zero row.  Counts must still be bit-exact."""
+    g = torch.Generator().manual_seed(D)
+    N, q_head, q_tail = 700, 50, 46
+    base = torch.randint(-8, 9, (N // 4, D), generator=g).float() / 8.0
+    table = base.repeat(4, 1)[torch.randperm(4 * (N // 4), generator=g)]
+    table[::7] *= (1.0 + 2.0 ** -20)
+    table[3::11] *= (1.0 - 2.0 ** -20)
+    table[5] = 0.0
+    table[6] *= 1e4
+    N = table.shape[0]
+    Q = q_head + q_tail
+    q_fixed = table[torch.randint(0, N, (Q,), generator=g)].clone()
+    q_rel = torch.randint(-16, 17, (Q, D), generator=g).float() / 16.0
+    true_row = torch.randint(0, N, (Q,), generator=g)
+    rowptr, col = random_csr(Q, N, true_row.numpy(), seed=D + 1)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+    # ties make the realistic rank a half-integer for some queries: the >/>= split must survive
+    assert (want[:, 1] - want[:, 0]).max() > 1
+
+
+@pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
+def test_gemm_path_nonfinite_inputs_take_the_exact_path(ops, oracle, model):
+    D, N, q_head, q_tail = 128, 300, 40, 40
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=9)
+    table[17, 3] = float("inf")
+    table[40, 5] = float("nan")
+    q_rel[7, 9] = float("nan")
+    q_fixed[50] = table[17]
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("model", REL_MODELS)
 def test_edge_shapes(ops, oracle, model):
     D = 128
