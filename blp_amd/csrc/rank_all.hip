@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // Fetch rows [row0, row0 + 64) of the table into e[] (lane l <- row row0 + l) through the wave's LDS
 // slab.  Rows past the table end are clamped to the last row (their counts are masked by `valid`).
-template <int D>
+template <int D, bool NT>
 __device__ __forceinline__ void load_tile(float (&e)[D], const float* __restrict__ table, int64_t N,
                                           int64_t ld, int64_t row0, float* slab, int lane) {
     const int sub_row = lane >> 3;        // 8 rows per wave instruction
@@ -94,7 +94,9 @@ __device__ __forceinline__ void load_tile(float (&e)[D], const float* __restrict
         const float* src = table + row * ld + sub_col;
         static_for<D / kSubCols>([&](auto ss) {
             constexpr int s = decltype(ss)::value;
-            const float4 v = *reinterpret_cast<const float4*>(src + s * kSubCols);
+            typedef float floatx4 __attribute__((ext_vector_type(4)));
+            const floatx4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(src + s * kSubCols))
+                                 : *reinterpret_cast<const floatx4*>(src + s * kSubCols);
             e[32 * s + 4 * i] = v.x; e[32 * s + 4 * i + 1] = v.y;
             e[32 * s + 4 * i + 2] = v.z; e[32 * s + 4 * i + 3] = v.w;
         });
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_t
     for (int quad = qg; quad < n_quads; quad += n_quad_groups) {
         float e[D];
         const int64_t row0 = ((int64_t)quad * kWaves + wave) * kTileRows;
-        load_tile<D>(e, table, N, ld, row0, slab, lane);  // rows past the end are clamped, then masked
+        // STATIC streams the table once (non-temporal loads); the many-query mode re-reads it from L2
+        load_tile<D, STATIC>(e, table, N, ld, row0, slab, lane);  // rows past the end are clamped, then masked
         const bool valid = row0 + lane < N;
         if (STATIC) {
             score_batch<MODEL, HEAD, D, true>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), lane);

@@ -267,8 +267,8 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
     }
 }
 
-// Pass 2: one wave per flag word (32 candidate tiles of one query); each half-wave takes one flagged
-// tile at a time and scores its 32 candidates exactly.
+// Pass 2: one wave per query.  The wave sweeps the query's flag words 64 at a time; every flagged
+// (query, 32-candidate tile) segment is re-scored exactly, one segment per half-wave at a time.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
                                                      const float* __restrict__ coef_head,
@@ -276,37 +276,46 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
                                                      const float* __restrict__ key_true, int64_t q_head, int64_t Q,
                                                      int words_per_query, const unsigned* __restrict__ flags,
                                                      unsigned long long* __restrict__ acc) {
-    const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (word >= Q * words_per_query) return;
-    unsigned bits = flags[word];
-    if (bits == 0) return;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
     const int lane = threadIdx.x & 63, half = lane >> 5;
-    const int64_t q = word / words_per_query;
-    const int tile_base = (int)(word % words_per_query) * 32;
+    const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
+    const float* coef = q < q_head ? coef_head + q * Scorer<MODEL, HEAD, D>::C
+                                   : coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C;
     unsigned gt = 0, ge = 0;
-    while (bits) {  // wave-uniform loop: two flagged tiles per iteration, one per half-wave
-        const int b0 = __builtin_ctz(bits);
-        bits &= bits - 1;
-        int b1 = -1;
-        if (bits) { b1 = __builtin_ctz(bits); bits &= bits - 1; }
-        const int b = half ? b1 : b0;
-        const int64_t row = (int64_t)(tile_base + (b < 0 ? 0 : b)) * kGCT + (lane & 31);
-        const bool ok = b >= 0 && row < N;
-        float e[D];
-        load_row<D>(e, table + (ok ? row : 0) * ld);
-        const float key = q < q_head
-            ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C})
-            : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
-        gt += ok && key > kt;
-        ge += ok && key >= kt;
+    for (int w0 = 0; w0 < words_per_query; w0 += 64) {
+        const unsigned mine = w0 + lane < words_per_query ? row[w0 + lane] : 0u;
+        unsigned long long nonzero = __ballot(mine != 0);
+        while (nonzero) {  // wave-uniform: next non-empty flag word
+            const int src = __builtin_ctzll(nonzero);
+            nonzero &= nonzero - 1;
+            unsigned bits = __shfl(mine, src);
+            const int tile_base = (w0 + src) * 32;
+            while (bits) {  // two flagged tiles per iteration, one per half-wave
+                const int b0 = __builtin_ctz(bits);
+                bits &= bits - 1;
+                int b1 = -1;
+                if (bits) { b1 = __builtin_ctz(bits); bits &= bits - 1; }
+                const int b = half ? b1 : b0;
+                const int64_t r = (int64_t)(tile_base + (b < 0 ? 0 : b)) * kGCT + (lane & 31);
+                const bool ok = b >= 0 && r < N;
+                float e[D];
+                load_row<D>(e, table + (ok ? r : 0) * ld);
+                const float key = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef})
+                                             : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef});
+                gt += ok && key > kt;
+                ge += ok && key >= kt;
+            }
+        }
     }
+    if (__ballot(gt | ge) == 0) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         gt += __shfl_down(gt, off);
         ge += __shfl_down(ge, off);
     }
-    if (lane == 0 && (gt | ge)) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+    if (lane == 0) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,8 +404,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         rank_gemm_kernel<MODEL, D><<<dim3((unsigned)(n_quads * (chunks_head + chunks_tail))), kGW * 64, lds, stream>>>(
             slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_quads,
             (int)chunks_head, words, w.acc, w.flags);
-        const int64_t n_words = Q * words;
-        refine_kernel<MODEL, D><<<dim3((unsigned)((n_words + 3) / 4)), 256, 0, stream>>>(
+        refine_kernel<MODEL, D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
