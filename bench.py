@@ -45,8 +45,14 @@ WORKLOADS = {
     "fb15k237-simple": dict(model="simple", N=14541, D=128, R=237, triples=52870, passes=1),
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=2, passes=64),
 }
-# VALU ops per (candidate, query, element): head-side, tail-side (see DESIGN.md "Kernels")
-OPS_PER_ELEM = {"transe": (3, 2), "distmult": (3, 2), "complex": (6.5, 4.5), "simple": (3, 3)}
+# Algorithmic f32 operations per (candidate, query, element), head-side / tail-side:
+# TransE: (e + r) - t, |.| accumulate = 3 ops, with h + r hoisted = 2 ops; bilinear models: the
+# all-entities score is a (Q x D) . (D x N) GEMM = 2 flops per (pair, element).
+OPS_PER_ELEM = {"transe": (3, 2), "distmult": (2, 2), "complex": (2, 2), "simple": (2, 2)}
+DOMINANT_KERNEL = {"transe": "rank_mfma_kernel<TRANSE,128> (f32 MFMA exact subtract + VALU |x| chains)",
+                   "distmult": "rank_gemm_kernel<DISTMULT,128> + refine_kernel (f32 MFMA GEMM + band + exact refinement)",
+                   "complex": "rank_gemm_kernel<COMPLEX,128> + refine_kernel",
+                   "simple": "rank_gemm_kernel<SIMPLE,128> + refine_kernel"}
 
 
 def make_data(cfg, device, seed=1):
@@ -121,6 +127,35 @@ def cpu_baseline(cfg, table, rel_w, heads, tails, rels, budget_s=12.0):
     return {"value": value, "unit": "scored triples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{done} reference batches of {B} triples ({2 * B} queries) x {cfg['N']} candidates, "
                       f"{el:.1f} s of torch-CPU work ({os.cpu_count()} logical CPUs)"}
+
+
+def torch_gpu_baseline(cfg, table, rel_w, heads, tails, rels, budget_s=3.0):
+    """The reference's own expressions (torch broadcasting score_fn + get_metrics, restated in
+    oracle/ref_port.py) on THIS GPU through stock PyTorch-ROCm, reference batch size -- what the
+    unmodified reference does on a MI355X.  Bounded sample; a reported baseline, not the target."""
+    from oracle import ref_port
+    if cfg["N"] > 1_000_000:
+        return None
+    B = 64
+    T = heads.shape[0]
+
+    def batch(i):
+        lo = (i * B) % max(T - B + 1, 1)
+        sl = slice(lo, lo + B)
+        out = ref_port.eval_batch(cfg["model"], table, heads[sl], tails[sl], rel_w[rels[sl]])
+        return out["rr"].sum().item()  # the reference syncs per batch (train.py:154)
+
+    batch(0)
+    torch.cuda.synchronize()
+    done, t0 = 0, time.perf_counter()
+    while True:
+        batch(done + 1)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 400:
+            break
+    return {"value": 2.0 * B * cfg["N"] * done / el, "unit": "scored triples/s", "kind": "reference expressions on "
+            "PyTorch-ROCm (same GPU)", "sample": f"{done} reference batches of {B} triples, {el:.2f} s"}
 
 
 def parity_spot_check(cfg, table, q_fixed, q_rel, true_row, q_head, counts, n=32):
@@ -250,12 +285,15 @@ def main():
         else:
             roofline = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s",
-                        "note": "f32 compute roof: the f32 MFMA peak equals the f32 vector-FMA peak (157.3 TF). "
-                                "The order-exact L1/sum chains are plain f32 add/sub/mul VALU ops (no FMA, no MFMA "
-                                "form), which top out at half of it (78.6 Tops/s)."}
+                        "note": ("f32 compute roof: 157.3 TF is both the f32 MFMA peak and the f32 vector-FMA peak; "
+                                 "they share the SIMD's FP32 units (measured: no MFMA/VALU overlap). TransE's exact L1 "
+                                 "is add/sub/|.| work with no multiply to fuse, so its ceiling is half of it (78.6 Tops/s)."
+                                 if model == "transe" else
+                                 "f32 MFMA GEMM (exact f32 fma chain) + error band; refinement of undecided "
+                                 "(query, 32-candidate) segments is included in the kernel time.")}
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["traffic"] = load_pmc_traffic(args.workload)
-        roofline["kernel"] = "rank_tiles_kernel"
+        roofline["kernel"] = (DOMINANT_KERNEL[model] if Q >= 64 else "rank_tiles_kernel<STATIC> (lane-per-candidate VALU)")
         roofline["kernel_ms"] = kernel_ms
         roofline["algorithmic_bytes_per_launch"] = alg_bytes
         roofline["algorithmic_flops_per_launch"] = alg_flops
@@ -282,6 +320,7 @@ def main():
         result["parity_check"] = parity_spot_check(cfg, table, q_fixed, q_rel, true_row, q_head, counts)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, table, rel_w, heads, tails, rels)
+            result["torch_gpu_baseline"] = torch_gpu_baseline(cfg, table, rel_w, heads, tails, rels)
         if world == 1 and not args.no_hbm_probe and args.workload != "wikidata5m-transe":
             result["hbm_probe"] = hbm_probe(device, events)
         print(json.dumps(result), flush=True)

@@ -91,7 +91,7 @@ def rank_metrics(pred, true_idx, k_values=(1, 3, 10)):
     gt = (pred > true).sum(dim=1)
     ge = (pred >= true).sum(dim=1)
     avg = (gt + 1 + ge).float() * 0.5
-    k = torch.tensor([list(k_values)], dtype=torch.float32)
+    k = torch.tensor([list(k_values)], dtype=torch.float32, device=pred.device)
     return gt, ge, avg.reciprocal(), avg.unsqueeze(1) <= k
 
 
