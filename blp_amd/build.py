@@ -39,7 +39,8 @@ def build(force=False, verbose=False):
         src_path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ, src + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src_path), dep_time):
-            cmd = [cc, *FLAGS, "-x", "hip", "-c", src_path, "-o", obj]
+            extra = os.environ.get("BLP_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
+            cmd = [cc, *FLAGS, *extra, "-x", "hip", "-c", src_path, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

@@ -24,6 +24,8 @@
 //     is f32-VALU-bound; parallelism comes from (tile x query chunk).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "launch.h"
 #include "rank_common.h"
@@ -33,6 +35,9 @@
 
 namespace blp {
 
+#ifndef BLP_TRANSE_WAVES
+#define BLP_TRANSE_WAVES 3           // waves per SIMD the TransE lane-per-candidate kernel is compiled for
+#endif
 constexpr int kWaves = 4;            // waves per workgroup
 constexpr int kTileRows = 64;        // candidates per wave tile (one per lane)
 constexpr int kSubCols = 32;         // floats per row per LDS pass (128 B = one cache line)
@@ -134,6 +139,119 @@ __device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TransE with scalar-cache coefficients, hand-pipelined (many-query mode).  Scalar loads return out of
+// order, so every s_waitcnt on them is a full drain; the compiler issues the next chunk's load in the
+// middle of a chunk and waits a few instructions later, exposing the scalar-cache latency 8-16 times
+// per query.  Here the 64-byte chunk k+1 (and, on the last chunk, chunk 0 of the NEXT query) is
+// requested before chunk k's 32-48 VALU instructions and drained after them, and one dword of every
+// line of the query after next is touched once per query so that those requests hit the scalar cache.
+typedef float sf16 __attribute__((ext_vector_type(16)));
+
+template <int OFF>
+__device__ __forceinline__ sf16 sload16(const float* base) {
+    sf16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "i"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void sdrain(sf16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory"); }
+__device__ __forceinline__ void sdrain(sf16& a, sf16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : : "memory"); }
+
+template <int OFF>
+__device__ __forceinline__ void stouch_line(const float* row) {
+    float sink;
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(sink) : "s"(row), "i"(OFF) : "memory");
+}
+template <int... Ls>
+__device__ __forceinline__ void stouch_lines(const float* row, std::integer_sequence<int, Ls...>) {
+    (stouch_line<Ls * 64>(row), ...);
+}
+template <int BYTES>
+__device__ __forceinline__ void stouch(const float* row) {  // one dword per 64-B line, result discarded
+    stouch_lines(row, std::make_integer_sequence<int, BYTES / 64>{});
+}
+
+template <int D, int CHUNK0, class Get>
+__device__ __forceinline__ void l1_chunk(const float (&e)[D], float& acc, bool first, Get x_of) {
+    // 16 elements starting at CHUNK0: differences kPipe ahead of the dependent |x| adds
+    float x[kPipe];
+    static_for<kPipe>([&](auto k) { x[k] = x_of(k); });
+    static_for<16>([&](auto k) {
+        constexpr int i = decltype(k)::value;
+        const float cur = fabsf(x[i % kPipe]);
+        if constexpr (i + kPipe < 16) x[i % kPipe] = x_of(ic<i + kPipe>{});
+        acc = (first && i == 0) ? cur : acc + cur;
+    });
+}
+
+// tail-replacing query: coefficient row = h + r (D floats).  `cur` holds chunk 0 on entry and chunk 0
+// of `next_row` on exit.
+template <int D>
+__device__ __forceinline__ float transe_tail_sgpr(const float (&e)[D], sf16& cur, const float* row,
+                                                  const float* next_row, const float* touch_row) {
+    float acc = 0.f;
+    static_for<D / 16>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        sf16 nxt;
+        if constexpr (k + 1 < D / 16) nxt = sload16<(k + 1) * 64>(row); else nxt = sload16<0>(next_row);
+        if constexpr (k == 0) stouch<D * 4>(touch_row);
+        l1_chunk<D, 16 * k>(e, acc, k == 0, [&](auto ii) { return cur[decltype(ii)::value] - e[16 * k + decltype(ii)::value]; });
+        sdrain(nxt);
+        cur = nxt;
+    });
+    return -acc;
+}
+
+// head-replacing query: coefficient row = r (D floats) then t (D floats): (e + r) - t
+template <int D>
+__device__ __forceinline__ float transe_head_sgpr(const float (&e)[D], sf16& cur_r, sf16& cur_t, const float* row,
+                                                  const float* next_row, const float* touch_row) {
+    float acc = 0.f;
+    static_for<D / 16>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        sf16 nr, nt;
+        if constexpr (k + 1 < D / 16) { nr = sload16<(k + 1) * 64>(row); nt = sload16<D * 4 + (k + 1) * 64>(row); }
+        else { nr = sload16<0>(next_row); nt = sload16<D * 4>(next_row); }
+        if constexpr (k == 0) stouch<2 * D * 4>(touch_row);
+        l1_chunk<D, 16 * k>(e, acc, k == 0, [&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const float y = e[16 * k + i] + cur_r[i];
+            return y - cur_t[i];
+        });
+        sdrain(nr, nt);
+        cur_r = nr;
+        cur_t = nt;
+    });
+    return -acc;
+}
+
+template <int SIDE, int D>
+__device__ __forceinline__ void score_batch_transe_sgpr(const float (&e)[D], bool valid, const float* rows, int nq,
+                                                        const float* __restrict__ key_true, unsigned* cnt, int wave,
+                                                        int lane) {
+    constexpr int C = Scorer<TRANSE, SIDE, D>::C;
+    if (nq <= 0) return;
+    sf16 a = sload16<0>(rows), b = a;
+    if constexpr (SIDE == HEAD) b = sload16<D * 4>(rows);
+    sdrain(a, b);
+    for (int j = 0; j < nq; ++j) {
+        const float* row = rows + (size_t)j * C;
+        const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * C;
+        // the four waves of a workgroup walk the same rows: they take turns touching the lines of the
+        // query three ahead, so each wave pays the scalar-cache miss drain once every four queries
+        const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * C : row;
+        const float key = SIDE == HEAD ? transe_head_sgpr<D>(e, a, b, row, next_row, touch_row)
+                                       : transe_tail_sgpr<D>(e, a, row, next_row, touch_row);
+        const float kt = key_true[j];
+        const unsigned gt = __popcll(__ballot(valid && key > kt));
+        const unsigned ge = __popcll(__ballot(valid && key >= kt));
+        if (lane == 0) {
+            __hip_atomic_fetch_add(cnt + 2 * j, gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(cnt + 2 * j + 1, ge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+}
+
 // Score nq queries of one side against the wave's tile and add the two rank counts of each to the
 // wave's LDS counters.  USE_SGPR = false: coefficient rows are staged in LDS at `cur` (DppCoef).
 // USE_SGPR = true: `cur` is the wave-uniform global address of the rows, so the compiler fetches them
@@ -193,7 +311,7 @@ __device__ __forceinline__ void apply_queries(const float (&e)[D], bool valid, c
 // Wikidata5M eval batch of 2 triples): their coefficients (a few KB) stay in the scalar cache and are
 // read as SGPR operands; the waves stream tiles independently, with no workgroup barrier in the loop.
 template <int MODEL, int D, bool STATIC>
-__global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_tiles_kernel(
+__global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE && BLP_TRANSE_WAVES == 3 ? 3 : 2)) void rank_tiles_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
     int n_tiles, int n_quad_groups, int n_chunks, unsigned long long* __restrict__ acc) {
@@ -232,8 +350,13 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_t
             score_batch<MODEL, HEAD, D, true>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), lane);
             score_batch<MODEL, TAIL, D, true>(e, valid, ct, t_hi - t_lo, key_true + t_lo, cnt + 2 * (t_lo - qa), lane);
         } else {
-            apply_queries<MODEL, HEAD, D>(e, valid, ch, key_true + h_lo, h_hi - h_lo, cbuf, cnt + 2 * (h_lo - qa), wave, lane);
-            apply_queries<MODEL, TAIL, D>(e, valid, ct, key_true + t_lo, t_hi - t_lo, cbuf, cnt + 2 * (t_lo - qa), wave, lane);
+            if constexpr (MODEL == TRANSE) {  // scalar-cache coefficients, hand-pipelined (no barriers)
+                score_batch_transe_sgpr<HEAD, D>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), wave, lane);
+                score_batch_transe_sgpr<TAIL, D>(e, valid, ct, t_hi - t_lo, key_true + t_lo, cnt + 2 * (t_lo - qa), wave, lane);
+            } else {                          // LDS-staged coefficients + DPP broadcast
+                apply_queries<MODEL, HEAD, D>(e, valid, ch, key_true + h_lo, h_hi - h_lo, cbuf, cnt + 2 * (h_lo - qa), wave, lane);
+                apply_queries<MODEL, TAIL, D>(e, valid, ct, key_true + t_lo, t_hi - t_lo, cbuf, cnt + 2 * (t_lo - qa), wave, lane);
+            }
         }
     }
 
@@ -391,7 +514,8 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         }
         const int64_t blocks = groups * n_chunks;
         const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)2 * kQB * kMaxCoef(D) * 4 +
-                           (size_t)kWaves * 2 * kQueryChunk * 4;
+                     (size_t)kWaves * 2 * kQueryChunk * 4;
+
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         if (static_mode)
             rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
@@ -441,7 +565,10 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
     if (rank_gemm_applicable(model, D, q_head, q_tail))
         return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
                                     filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    if (rank_mfma_applicable(model, D, q_head, q_tail))
+    // TransE with many queries: the hand-pipelined scalar-cache VALU kernel below is the default
+    // (9.9 ms per FB15k-237 pass vs 11.2 ms); BLP_RANK_KERNEL=mfma selects the matrix-core variant.
+    const char* pick = getenv("BLP_RANK_KERNEL");
+    if (pick && strcmp(pick, "mfma") == 0 && rank_mfma_applicable(model, D, q_head, q_tail))
         return launch_rank_all_mfma(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
                                     filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (model) {
