@@ -67,7 +67,7 @@ def lib():
     L.blp_rank_all_workspace_bytes.restype = _sz
     L.blp_rank_all_workspace_bytes.argtypes = [_i, _i64, _i, _i64, _i64]
     L.blp_rank_all.restype = _i
-    L.blp_rank_all.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
+    L.blp_rank_all.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
                                _vp, _sz, _i, _vp]
     L.blp_profile_next_rank_kernel.restype = _i
     L.blp_profile_next_rank_kernel.argtypes = [_vp, _vp]

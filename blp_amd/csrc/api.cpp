@@ -117,7 +117,7 @@ size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head,
 }
 
 int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
-                 const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                 const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true, int64_t q_head,
                  int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
                  void* workspace, size_t workspace_bytes, int device, void* stream) {
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
@@ -148,7 +148,7 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
     if (int rc = compute_units(device, &cu)) return rc;
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
-    hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
+    hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail,
                                           filt_rowptr, filt_col, counts, workspace, cu,
                                           static_cast<hipStream_t>(stream), ev0, ev1);
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all launch");

@@ -9,8 +9,8 @@ namespace blp {
 size_t rank_all_workspace_bytes(int D, int64_t N, int64_t q_head, int64_t q_tail);
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
-                           const float* q_fixed, const float* q_rel, const int64_t* true_row,
-                           const float* q_true, int64_t q_head, int64_t q_tail,
+                           const float* q_fixed, const float* q_rel, const int64_t* q_rel_id,
+                           const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
                            const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
                            hipEvent_t ev_stop = nullptr);

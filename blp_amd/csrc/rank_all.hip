@@ -252,6 +252,51 @@ __device__ __forceinline__ void score_batch_transe_sgpr(const float (&e)[D], boo
     }
 }
 
+// Head-replacing TransE queries whose relation ids are known: x = (e + r) - t, and e + r depends only on
+// (candidate, relation).  Whenever the relation id changes the wave re-fetches its tile and adds r in
+// place (exactly the reference's first rounding), after which every query of that relation costs the
+// two instructions per element of the tail side (|t - (e + r)| == |(e + r) - t| bit for bit) instead of
+// three.  Callers sort the block by relation (blp_amd.ranking does) so changes are rare; correctness
+// does not depend on the order.  Must run AFTER the tail queries of the tile (e is overwritten).
+template <int D>
+__device__ __forceinline__ void score_batch_transe_head_grouped(float (&e)[D], bool valid, const float* rows, int nq,
+                                                               const float* __restrict__ key_true,
+                                                               const int64_t* __restrict__ rel_id, unsigned* cnt,
+                                                               const float* __restrict__ table, int64_t N, int64_t ld,
+                                                               int64_t row0, float* slab, int wave, int lane) {
+    constexpr int C = 2 * D;  // coefficient row: r (D floats) then t (D floats)
+    if (nq <= 0) return;
+    int64_t cur_rel = rel_id[0] - 1;  // != rel_id[0]
+    bool pristine = true;
+    sf16 a = sload16<D * 4>(rows);    // chunk 0 of t of query 0
+    sdrain(a);
+    for (int j = 0; j < nq; ++j) {
+        const float* row = rows + (size_t)j * C;
+        const int64_t rid = rel_id[j];
+        if (rid != cur_rel) {
+            if (!pristine) load_tile<D, false>(e, table, N, ld, row0, slab, lane);
+            static_for<D / 16>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                sf16 r = sload16<k * 64>(row);
+                sdrain(r);
+                static_for<16>([&](auto ii) { e[16 * k + decltype(ii)::value] = e[16 * k + decltype(ii)::value] + r[decltype(ii)::value]; });
+            });
+            cur_rel = rid;
+            pristine = false;
+        }
+        const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * C;
+        const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * C : row;
+        const float key = transe_tail_sgpr<D>(e, a, row + D, next_row + D, touch_row + D);
+        const float kt = key_true[j];
+        const unsigned gt = __popcll(__ballot(valid && key > kt));
+        const unsigned ge = __popcll(__ballot(valid && key >= kt));
+        if (lane == 0) {
+            __hip_atomic_fetch_add(cnt + 2 * j, gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(cnt + 2 * j + 1, ge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+}
+
 // Score nq queries of one side against the wave's tile and add the two rank counts of each to the
 // wave's LDS counters.  USE_SGPR = false: coefficient rows are staged in LDS at `cur` (DppCoef).
 // USE_SGPR = true: `cur` is the wave-uniform global address of the rows, so the compiler fetches them
@@ -314,7 +359,8 @@ template <int MODEL, int D, bool STATIC>
 __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE && BLP_TRANSE_WAVES == 3 ? 3 : 2)) void rank_tiles_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
-    int n_tiles, int n_quad_groups, int n_chunks, unsigned long long* __restrict__ acc) {
+    int n_tiles, int n_quad_groups, int n_chunks, const int64_t* __restrict__ q_rel_id,
+    unsigned long long* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -351,8 +397,12 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE && BLP_TRANSE_WAVES =
             score_batch<MODEL, TAIL, D, true>(e, valid, ct, t_hi - t_lo, key_true + t_lo, cnt + 2 * (t_lo - qa), lane);
         } else {
             if constexpr (MODEL == TRANSE) {  // scalar-cache coefficients, hand-pipelined (no barriers)
-                score_batch_transe_sgpr<HEAD, D>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), wave, lane);
                 score_batch_transe_sgpr<TAIL, D>(e, valid, ct, t_hi - t_lo, key_true + t_lo, cnt + 2 * (t_lo - qa), wave, lane);
+                if (q_rel_id)  // relation ids known: e + r once per (tile, relation); overwrites e
+                    score_batch_transe_head_grouped<D>(e, valid, ch, h_hi - h_lo, key_true + h_lo, q_rel_id + h_lo,
+                                                       cnt + 2 * (h_lo - qa), table, N, ld, row0, slab, wave, lane);
+                else
+                    score_batch_transe_sgpr<HEAD, D>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), wave, lane);
             } else {                          // LDS-staged coefficients + DPP broadcast
                 apply_queries<MODEL, HEAD, D>(e, valid, ch, key_true + h_lo, h_hi - h_lo, cbuf, cnt + 2 * (h_lo - qa), wave, lane);
                 apply_queries<MODEL, TAIL, D>(e, valid, ct, key_true + t_lo, t_hi - t_lo, cbuf, cnt + 2 * (t_lo - qa), wave, lane);
@@ -471,7 +521,7 @@ hipError_t launch_finalize_counts(const unsigned long long* acc, const unsigned 
 
 template <int MODEL, int D>
 static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                                const float* q_rel, const int64_t* true_row, const float* q_true,
+                                const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
                                 int64_t q_head, int64_t q_tail, const int64_t* filt_rowptr,
                                 const int64_t* filt_col, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -520,11 +570,11 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         if (static_mode)
             rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-                (int)groups, (int)n_chunks, w.acc);
+                (int)groups, (int)n_chunks, q_rel_id, w.acc);
         else
             rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-                (int)groups, (int)n_chunks, w.acc);
+                (int)groups, (int)n_chunks, q_rel_id, w.acc);
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
 
@@ -538,13 +588,13 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
 
 template <int MODEL>
 static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                               const float* q_rel, const int64_t* true_row, const float* q_true,
+                               const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
                                int64_t q_head, int64_t q_tail, const int64_t* filt_rowptr,
                                const int64_t* filt_col, int32_t* counts, void* workspace, int n_cu,
                                hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define BLP_RANK_CASE(DD)                                                                              \
     case DD:                                                                                           \
-        return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, \
+        return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, \
                                         filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (D) {
         BLP_RANK_CASE(64)
@@ -557,8 +607,8 @@ static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld,
 }
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
-                           const float* q_fixed, const float* q_rel, const int64_t* true_row,
-                           const float* q_true, int64_t q_head, int64_t q_tail,
+                           const float* q_fixed, const float* q_rel, const int64_t* q_rel_id,
+                           const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
                            const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                            hipEvent_t ev_stop) {
@@ -572,10 +622,10 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
         return launch_rank_all_mfma(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
                                     filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (model) {
-    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     default:       return hipErrorInvalidValue;
     }
 }

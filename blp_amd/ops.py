@@ -48,16 +48,18 @@ def dim_supported(rel_model, dim):
 
 
 def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
-             filt_rowptr=None, filt_col=None, out=None):
+             filt_rowptr=None, filt_col=None, out=None, rel_ids=None):
     """Rank-count every query against every row of ``table`` in one pass over the table.
 
     table (N, D) f32; q_fixed, q_rel (Q, D) f32; queries [0, q_head) replace the head (q_fixed is the
     tail embedding), queries [q_head, Q) replace the tail (q_fixed is the head embedding).
     true_row (Q,) int64 rows of the true entities in ``table``  -- or -- q_true (Q, D) their vectors
     (sharded ranking).  filt_rowptr (Q+1,), filt_col (nnz,) int64: CSR of filtered rows per query.
+    rel_ids (Q,) int64, optional: the relation id of each query (equal id => identical q_rel row); a
+    performance hint for TransE (sort the block by relation to benefit), never changes a result.
     Returns counts (Q, 4) int32: gt, ge, gt_filtered, ge_filtered.
     """
-    _require_device(table, q_fixed, q_rel, true_row, q_true, filt_rowptr, filt_col)
+    _require_device(table, q_fixed, q_rel, true_row, q_true, filt_rowptr, filt_col, rel_ids)
     table = _f32_rows(table, "table")
     if table.dim() != 2:
         raise ValueError(f"table must be (N, D), got {tuple(table.shape)}")
@@ -79,6 +81,10 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
         q_true = _f32_rows(q_true, "q_true").reshape(-1, D).contiguous()
         if q_true.shape[0] != Q:
             raise ValueError("q_true must have one row per query")
+    if rel_ids is not None:
+        rel_ids = rel_ids.reshape(-1).to(torch.int64).contiguous()
+        if rel_ids.shape[0] != Q:
+            raise ValueError("rel_ids must have one entry per query")
     if (filt_rowptr is None) != (filt_col is None):
         raise ValueError("filt_rowptr and filt_col go together")
     if filt_rowptr is not None:
@@ -99,7 +105,7 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     ws_bytes = L.blp_rank_all_workspace_bytes(model, N, D, q_head, Q - q_head)
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     status = L.blp_rank_all(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
-                            _ptr(q_rel), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
+                            _ptr(q_rel), _ptr(rel_ids), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
                             _ptr(filt_rowptr), _ptr(filt_col), _ptr(counts), _ptr(workspace), ws_bytes,
                             dev.index, _stream(dev))
     _lib.check(status, "blp_rank_all")

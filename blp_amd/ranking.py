@@ -53,7 +53,8 @@ def _rank_block_dense(score_fn, table, q_fixed, q_rel, q_head, true_scores_from,
     return counts
 
 
-def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None, filt_rowptr=None, filt_col=None):
+def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None, filt_rowptr=None, filt_col=None,
+               rel_ids=None):
     """Counts (Q, 4) int32 {gt, ge, gt_filtered, ge_filtered} for a block of queries against ``table``.
     Queries [0, q_head) replace the head, the rest replace the tail (train.py:149 order)."""
     if table.is_cuda:
@@ -62,7 +63,8 @@ def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
                             true_row=None if true_row is None else true_row.to(dev),
                             q_true=q_true,
                             filt_rowptr=None if filt_rowptr is None else filt_rowptr.to(dev),
-                            filt_col=None if filt_col is None else filt_col.to(dev))
+                            filt_col=None if filt_col is None else filt_col.to(dev),
+                            rel_ids=None if rel_ids is None else rel_ids.to(dev))
     source = ("row", true_row) if true_row is not None else ("vec", q_true)
     return _rank_block_dense(model.score_fn, table, q_fixed, q_rel, q_head, source, filt_rowptr, filt_col)
 
@@ -116,7 +118,7 @@ class ShardedRanker:
             dist.all_reduce(out, group=self.group)
         return out
 
-    def rank_block(self, q_fixed, q_rel, q_true, q_head, filt_rowptr=None, filt_col=None):
+    def rank_block(self, q_fixed, q_rel, q_true, q_head, filt_rowptr=None, filt_col=None, rel_ids=None):
         """Local counts of one query block against this rank's shard (queued for the final exchange).
         filt_col are GLOBAL table rows; only the ones this shard owns are kept."""
         if filt_rowptr is not None:
@@ -127,7 +129,7 @@ class ShardedRanker:
             filt_rowptr = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(per_row, 0)))
             filt_col = filt_col[owned] - self.lo
         counts = rank_block(self.model, self.table, q_fixed, q_rel, q_head, q_true=q_true,
-                            filt_rowptr=filt_rowptr, filt_col=filt_col)
+                            filt_rowptr=filt_rowptr, filt_col=filt_col, rel_ids=rel_ids)
         self._blocks.append(counts)
         return counts
 
@@ -212,6 +214,9 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
             break
         batches.append(triples)
     triples = torch.cat(batches) if batches else torch.zeros((0, 3), dtype=torch.long)
+    # The metrics are sums over triples, so the evaluation order is free: group by relation, which lets
+    # the TransE kernel share e + r among the head-replacing queries of a relation.
+    triples = triples[torch.argsort(triples[:, 2], stable=True)]
     heads = ent2idx[triples[:, 0]]
     tails = ent2idx[triples[:, 1]]
     assert triples.shape[0] == 0 or (heads.min() >= 0 and tails.min() >= 0)
@@ -228,17 +233,18 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
         sl = slice(start, min(start + block_size, num_triples))
         b = sl.stop - sl.start
         rel_vecs = model.rel_emb(triples[sl, 2].to(device))
+        rel_ids = torch.cat((triples[sl, 2], triples[sl, 2]))
         filt = index.csr(triples[sl], ent2idx) if compute_filtered else (None, None)
         if sharded:
             h_vec, t_vec = vectors[head_pos[sl].to(device)], vectors[tail_pos[sl].to(device)]
             ranker.rank_block(torch.cat((t_vec, h_vec)), torch.cat((rel_vecs, rel_vecs)), torch.cat((h_vec, t_vec)),
-                              b, filt[0], filt[1])
+                              b, filt[0], filt[1], rel_ids=rel_ids)
         else:
             h_rows, t_rows = heads[sl].to(device), tails[sl].to(device)
             counts_blocks.append(rank_block(model, table, torch.cat((table[t_rows], table[h_rows])),
                                             torch.cat((rel_vecs, rel_vecs)), b,
                                             true_row=torch.cat((heads[sl], tails[sl])).to(device),
-                                            filt_rowptr=filt[0], filt_col=filt[1]))
+                                            filt_rowptr=filt[0], filt_col=filt[1], rel_ids=rel_ids))
     if sharded:
         block_counts = ranker.finish()  # ONE all-gather for the whole evaluation
         counts_blocks, offset = [], 0

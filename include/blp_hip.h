@@ -77,6 +77,11 @@ int blp_dim_supported(int model, int D);
  *   table      (N, D) f32, row stride ld floats (ld % 4 == 0, 16-byte aligned base)
  *   q_fixed    (Q, D) f32  the entity kept fixed (tail_embs for head queries, head_embs for tail)
  *   q_rel      (Q, D) f32  rel_emb(rels)
+ *   q_rel_id   (Q) int64   OPTIONAL (may be NULL) relation id of each query (`rels`, train.py:132).
+ *                          Contract: queries with equal ids have identical q_rel rows.  Lets the
+ *                          head-replacing TransE queries of one relation share e + r (2 instead of 3
+ *                          VALU ops per element); sort the block by relation to benefit.  Never
+ *                          changes a result.
  *   true_row   (Q) int64   row of the true entity in `table` (true_ents, train.py:150), or NULL
  *   q_true     (Q, D) f32  the true entity's vector, used when true_row == NULL (candidate-axis
  *                          sharding: the true row may live in another shard).  Exactly one of
@@ -92,7 +97,7 @@ int blp_dim_supported(int model, int D);
  * -------------------------------------------------------------------------------------------- */
 size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head, int64_t q_tail);
 int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
-                 const float *q_fixed, const float *q_rel, const int64_t *true_row,
+                 const float *q_fixed, const float *q_rel, const int64_t *q_rel_id, const int64_t *true_row,
                  const float *q_true, int64_t q_head, int64_t q_tail,
                  const int64_t *filt_rowptr, const int64_t *filt_col, int32_t *counts,
                  void *workspace, size_t workspace_bytes, int device, void *stream);

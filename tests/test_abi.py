@@ -40,9 +40,9 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     from blp_amd import _lib
     L = _lib.lib()
     # argument validation happens before any device call, so this runs without a GPU
-    rc = L.blp_rank_all(7, None, 0, 128, 128, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    rc = L.blp_rank_all(7, None, 0, 128, 128, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
     assert rc == -1 and b"unknown model" in L.blp_last_error()
-    rc = L.blp_rank_all(0, None, 0, 100, 100, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    rc = L.blp_rank_all(0, None, 0, 100, 100, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
     assert rc == -2
     rc = L.blp_score_fwd(1, 100, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
     assert rc == -2

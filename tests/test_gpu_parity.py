@@ -152,6 +152,32 @@ def test_gemm_path_nonfinite_inputs_take_the_exact_path(ops, oracle, model):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("sort", [False, True])
+def test_transe_relation_id_hint(ops, oracle, D, sort):
+    """rel_ids only changes HOW head-replacing TransE queries are scored (e + r shared per relation),
+    never the counts -- in any order of the block, with a CSR filter, more than one query chunk."""
+    g = torch.Generator().manual_seed(17 + D)
+    N, q_head, q_tail, nrel = 1000, 300, 70, 7
+    table = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=-1)
+    rel_w = (torch.rand(nrel, D, generator=g) - 0.5) * 0.25
+    rels = torch.randint(0, nrel, (q_head,), generator=g)
+    if sort:
+        rels = torch.sort(rels).values
+    rels_t = torch.randint(0, nrel, (q_tail,), generator=g)
+    fixed_row = torch.randint(0, N, (q_head + q_tail,), generator=g)
+    true_row = torch.randint(0, N, (q_head + q_tail,), generator=g)
+    q_fixed = table[fixed_row].clone()
+    q_rel = torch.cat((rel_w[rels], rel_w[rels_t]))
+    rel_ids = torch.cat((rels, rels_t))
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    for ids in (None, rel_ids.cuda()):
+        got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                           filt_rowptr=dev(rowptr), filt_col=dev(col), rel_ids=ids)
+        assert np.array_equal(got.cpu().numpy(), want), ("with ids" if ids is not None else "without ids")
+
+
 @pytest.mark.parametrize("model", REL_MODELS)
 def test_edge_shapes(ops, oracle, model):
     D = 128
