@@ -46,10 +46,11 @@ WORKLOADS = {
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=2, passes=64),
 }
 # Algorithmic f32 operations per (candidate, query, element), head-side / tail-side:
-# TransE: (e + r) - t, |.| accumulate = 3 ops, with h + r hoisted = 2 ops; bilinear models: the
-# all-entities score is a (Q x D) . (D x N) GEMM = 2 flops per (pair, element).
-OPS_PER_ELEM = {"transe": (3, 2), "distmult": (2, 2), "complex": (2, 2), "simple": (2, 2)}
-DOMINANT_KERNEL = {"transe": "rank_mfma_kernel<TRANSE,128> (f32 MFMA exact subtract + VALU |x| chains)",
+# TransE: one subtract and one |.|-accumulate once the query-only part is hoisted (h + r per query on
+# the tail side, e + r per (candidate, relation) on the head side); bilinear models: the all-entities
+# score is a (Q x D) . (D x N) GEMM = 2 flops per (pair, element).
+OPS_PER_ELEM = {"transe": (2, 2), "distmult": (2, 2), "complex": (2, 2), "simple": (2, 2)}
+DOMINANT_KERNEL = {"transe": "rank_tiles_kernel<TRANSE,128,many-query> (lane-per-candidate VALU, scalar-cache coefficients)",
                    "distmult": "rank_gemm_kernel<DISTMULT,128> + refine_kernel (f32 MFMA GEMM + band + exact refinement)",
                    "complex": "rank_gemm_kernel<COMPLEX,128> + refine_kernel",
                    "simple": "rank_gemm_kernel<SIMPLE,128> + refine_kernel"}
@@ -206,11 +207,18 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the measured path)")
+    # BLP_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks
+    # (ranks share devices, counts are exchanged through host memory).  Timings are then meaningless.
+    backend = os.environ.get("BLP_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count() if backend == "gloo" else max(local_rank + 1, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from blp_amd import _lib, ops
 
@@ -233,7 +241,12 @@ def main():
         for _ in range(passes):
             if world > 1:
                 local = ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids)
-                dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+                if backend == "gloo":
+                    parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
+                    dist.all_gather(parts, local.cpu())
+                    gathered.copy_(torch.stack(parts))
+                else:
+                    dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
                 counts = gathered.sum(dim=0, dtype=torch.int32)
             else:
                 counts = ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids)
@@ -255,7 +268,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 

@@ -81,3 +81,28 @@ def test_link_prediction_module_on_gpu_uses_fused_loss(name):
     assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-6, abs=1e-7)
     np.testing.assert_allclose(ent.grad.cpu().numpy(), g["grad_ent"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(model.rel_emb.weight.grad.cpu().numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
+
+
+def test_bench_two_ranks_share_one_gpu_functional():
+    """bench.py's N > 1 path (candidate shards, replicated true-entity vectors, count exchange, max-over-
+    ranks timing) run as 2 ranks on this one GPU with the gloo backend: the sharded MRR / Hits must
+    equal the single-rank ones exactly (integer counts add up)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--workload", "fb15k237-transe", "--no-cpu-baseline", "--no-hbm-probe"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, BLP_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", *common], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    assert a["mrr"] == b["mrr"] and a["hits@1,3,10"] == b["hits@1,3,10"]
+    assert b["parity_check"].endswith("identical counts")
