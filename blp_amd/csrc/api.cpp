@@ -163,6 +163,25 @@ int blp_profile_next_rank_kernel(void* start_event, void* stop_event) {
     return BLP_OK;
 }
 
+int blp_rank_from_scores(const float* scores, int64_t Q, int64_t N, int64_t ld, const int64_t* true_idx,
+                         const float* true_score, const int64_t* filt_rowptr, const int64_t* filt_col,
+                         int32_t* counts, int device, void* stream) {
+    if (Q < 0 || N < 0 || ld < N) return fail(BLP_ERR_BAD_ARG, "blp_rank_from_scores: negative size or ld < N");
+    if (Q == 0) return BLP_OK;
+    if (!scores || !counts) return fail(BLP_ERR_BAD_ARG, "blp_rank_from_scores: NULL scores / counts");
+    if ((true_idx == nullptr) == (true_score == nullptr))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_from_scores: exactly one of true_idx / true_score must be given");
+    if ((filt_rowptr == nullptr) != (filt_col == nullptr))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_from_scores: filt_rowptr and filt_col go together");
+    if (!aligned16(counts)) return fail(BLP_ERR_BAD_ARG, "blp_rank_from_scores: counts must be 16-byte aligned");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_rank_from_scores(scores, Q, N, ld, true_idx, true_score, filt_rowptr, filt_col, counts,
+                                                  static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_from_scores launch");
+    return BLP_OK;
+}
+
 int blp_rank_metrics(const int32_t* counts, int64_t Q, const int32_t k_values[3], float* rr, uint8_t* hits,
                      int device, void* stream) {
     if (Q < 0 || (Q > 0 && (!counts || !rr || !hits || !k_values)))

@@ -18,6 +18,10 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,
                                uint8_t* hits, hipStream_t stream);
 
+hipError_t launch_rank_from_scores(const float* scores, int64_t Q, int64_t N, int64_t ld, const int64_t* true_idx,
+                                   const float* true_score, const int64_t* rowptr, const int64_t* col,
+                                   int32_t* counts, hipStream_t stream);
+
 struct StridedRows {  // row(i0, i1) = base + i0 * s0 + i1 * s1   (strides in floats)
     const float* base;
     int64_t s0, s1;

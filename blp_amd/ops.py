@@ -112,6 +112,35 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     return counts
 
 
+def rank_from_scores(scores, true_idx=None, true_score=None, filt_rowptr=None, filt_col=None):
+    """Counts (Q, 4) int32 from a dense (Q, N) score matrix on the device (utils.py:103-105 +
+    train.py:159-167): the true entity as column index ``true_idx`` (Q,) or as score ``true_score`` (Q,)."""
+    _require_device(scores, true_idx, true_score, filt_rowptr, filt_col)
+    if scores.dtype != torch.float32 or scores.dim() != 2:
+        raise TypeError("scores must be a 2-D float32 tensor")
+    if scores.stride(1) != 1:
+        scores = scores.contiguous()
+    if (true_idx is None) == (true_score is None):
+        raise ValueError("give exactly one of true_idx / true_score")
+    Q, N = scores.shape
+    dev = scores.device
+    if true_idx is not None:
+        true_idx = true_idx.reshape(-1).to(torch.int64).contiguous()
+    else:
+        true_score = true_score.reshape(-1).to(torch.float32).contiguous()
+    if filt_rowptr is not None:
+        filt_rowptr = filt_rowptr.to(torch.int64).contiguous()
+        filt_col = filt_col.to(torch.int64).contiguous()
+        if filt_col.numel() == 0:
+            filt_col = torch.zeros(1, dtype=torch.int64, device=dev)
+    counts = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+    status = _lib.lib().blp_rank_from_scores(_ptr(scores), Q, N, scores.stride(0) if Q else N, _ptr(true_idx),
+                                             _ptr(true_score), _ptr(filt_rowptr), _ptr(filt_col), _ptr(counts),
+                                             dev.index, _stream(dev))
+    _lib.check(status, "blp_rank_from_scores")
+    return counts
+
+
 def rank_metrics(counts, k_values=(1, 3, 10)):
     """counts (Q, 4) int32 -> rr (Q, 2) f32 [raw, filtered], hits (Q, 2, 3) bool."""
     _require_device(counts)

@@ -57,6 +57,8 @@ def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
                rel_ids=None):
     """Counts (Q, 4) int32 {gt, ge, gt_filtered, ge_filtered} for a block of queries against ``table``.
     Queries [0, q_head) replace the head, the rest replace the tail (train.py:149 order)."""
+    if table.is_cuda and not ops.dim_supported(model.rel_model, table.shape[1]):
+        return _rank_block_generic_width(model, table, q_fixed, q_rel, q_head, true_row, q_true, filt_rowptr, filt_col)
     if table.is_cuda:
         dev = table.device
         return ops.rank_all(model.rel_model, table, q_fixed, q_rel, q_head,
@@ -67,6 +69,42 @@ def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
                             rel_ids=None if rel_ids is None else rel_ids.to(dev))
     source = ("row", true_row) if true_row is not None else ("vec", q_true)
     return _rank_block_dense(model.score_fn, table, q_fixed, q_rel, q_head, source, filt_rowptr, filt_col)
+
+
+def _rank_block_generic_width(model, table, q_fixed, q_rel, q_head, true_row, q_true, filt_rowptr, filt_col,
+                              max_matrix_bytes=1 << 30):
+    """HIP route for embedding widths the fused ranking kernels are not compiled for (300 / 768-wide
+    bag-of-words encoders): order-exact dense scores from blp_score_fwd in query slabs of bounded size,
+    then blp_rank_from_scores.  Same counts; the (Q, N) slab does go through HBM here."""
+    dev = table.device
+    n = table.shape[0]
+    q_total = q_fixed.shape[0]
+    slab = max(1, min(q_total, max_matrix_bytes // max(4 * n, 1)))
+    ent = table.unsqueeze(0)
+    out = torch.empty((q_total, 4), dtype=torch.int32, device=dev)
+    if filt_rowptr is not None:
+        filt_rowptr, filt_col = filt_rowptr.to(dev), filt_col.to(dev)
+    for lo in range(0, q_total, slab):
+        hi = min(lo + slab, q_total)
+        parts = []
+        for a, b, head in ((lo, min(hi, q_head), True), (max(lo, q_head), hi, False)):
+            if a < b:
+                fixed, rel = q_fixed[a:b].unsqueeze(1), q_rel[a:b].unsqueeze(1)
+                parts.append(model.score_fn(ent, fixed, rel) if head else model.score_fn(fixed, ent, rel))
+        scores = torch.cat(parts) if len(parts) > 1 else parts[0]
+        kw = {}
+        if true_row is not None:
+            kw["true_idx"] = true_row[lo:hi].to(dev)
+        else:
+            tv = q_true[lo:hi]
+            h_end = max(min(hi, q_head) - lo, 0)
+            kw["true_score"] = torch.cat((model.score_fn(tv[:h_end], q_fixed[lo:lo + h_end], q_rel[lo:lo + h_end]),
+                                          model.score_fn(q_fixed[lo + h_end:hi], tv[h_end:], q_rel[lo + h_end:hi])))
+        if filt_rowptr is not None:
+            kw["filt_rowptr"] = filt_rowptr[lo:hi + 1] - filt_rowptr[lo]
+            kw["filt_col"] = filt_col[filt_rowptr[lo]:filt_rowptr[hi]]
+        out[lo:hi] = ops.rank_from_scores(scores, **kw)
+    return out
 
 
 def metrics_from_counts(counts, k_values=HIT_POSITIONS):

@@ -108,6 +108,15 @@ int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
  * NULL, NULL cancels.  Has no effect on results. */
 int blp_profile_next_rank_kernel(void *start_event, void *stop_event);
 
+/* The same counts from a DENSE score matrix already in HBM: scores (Q, N) f32 with row stride ld, the
+ * true entity given per query as a column index (true_idx, the reference's `true_ents`,
+ * utils.py:102) or as a score (true_score); exactly one of the two.  Replaces utils.py:103-105 and the
+ * filtered overwrite train.py:159-167 for callers that materialise pred_ents, and serves embedding
+ * widths the fused kernels are not compiled for (the matrix then comes from blp_score_fwd). */
+int blp_rank_from_scores(const float *scores, int64_t Q, int64_t N, int64_t ld, const int64_t *true_idx,
+                         const float *true_score, const int64_t *filt_rowptr, const int64_t *filt_col,
+                         int32_t *counts, int device, void *stream);
+
 /* utils.py:104-109 on the counts of blp_rank_all: realistic rank = ((gt + 1) + ge) / 2,
  * rr = 1 / rank (f32), hits = rank <= k.   rr (Q, 2) f32 {raw, filtered};
  * hits (Q, 2, 3) uint8 for k = k_values[0..2] (train.py:72: 1, 3, 10). */

@@ -106,3 +106,25 @@ def test_bench_two_ranks_share_one_gpu_functional():
     assert b["n_gpus"] == 2 and a["n_gpus"] == 1
     assert a["mrr"] == b["mrr"] and a["hits@1,3,10"] == b["hits@1,3,10"]
     assert b["parity_check"].endswith("identical counts")
+
+
+@pytest.mark.parametrize("rel_model,D", [("transe", 300), ("transe", 768), ("distmult", 96), ("complex", 192)])
+def test_generic_width_route_matches_oracle(rel_model, D, oracle):
+    """Widths without a fused ranking kernel (GloVe 300, BERT-embedding 768, ...): dense order-exact
+    scores (blp_score_fwd) + blp_rank_from_scores, in query slabs; counts identical to the oracle, with
+    row-index and vector forms of the true entity, with a CSR filter."""
+    from blp_amd import models, ops, ranking
+    from test_gpu_parity import oracle_counts, random_csr, random_problem
+    assert not ops.dim_supported(rel_model, D)
+    N, q_head, q_tail = 523, 21, 18
+    table, q_fixed, q_rel, true_row = random_problem(rel_model, N, D, q_head, q_tail, seed=D)
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D)
+    want = oracle_counts(oracle, rel_model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    model = models.LinkPrediction(D, rel_model, "margin", 3, 0)
+    t, f, r = table.cuda(), q_fixed.cuda(), q_rel.cuda()
+    rp, cl = torch.from_numpy(rowptr), torch.from_numpy(col)
+    got = ranking.rank_block(model, t, f, r, q_head, true_row=true_row.cuda(), filt_rowptr=rp, filt_col=cl)
+    assert np.array_equal(got.cpu().numpy(), want)
+    got = ranking._rank_block_generic_width(model, t, f, r, q_head, None, t[true_row.cuda()], rp.cuda(), cl.cuda(),
+                                            max_matrix_bytes=4 * N * 7)  # 7-query slabs
+    assert np.array_equal(got.cpu().numpy(), want)
