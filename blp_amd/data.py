@@ -72,6 +72,23 @@ def get_negative_sampling_indices(batch_size, num_negatives, repeats=1):
     return neg_idx.transpose_(0, 1)
 
 
+def get_negative_sampling_indices_on_device(batch_size, num_negatives, device, generator=None):
+    """Same distribution as get_negative_sampling_indices (repeats = 1), drawn directly on ``device``
+    with two randint calls -- no (B, 2B) weight matrix, no host-to-device copy per step (SURVEY.md 8f,
+    next-row 4).  The torch CUDA/HIP generator is a different stream than the CPU one, so the values
+    differ from the reference's for a given seed; the law is identical: for row b one of the two slots
+    is kept and the other is replaced by a slot drawn uniformly from the 2B - 2 slots of the other rows."""
+    b, k = batch_size, num_negatives
+    own = torch.arange(b, device=device).view(b, 1)
+    # uniform over the 2B - 2 slots not in row b: draw in [0, 2B - 2), skip the own pair {2b, 2b + 1}
+    draw = torch.randint(0, 2 * b - 2, (b, k), device=device, generator=generator)
+    replacement = draw + 2 * (draw >= 2 * own).long()
+    which = torch.randint(0, 2, (b, k), device=device, generator=generator)
+    pairs = torch.stack((2 * own, 2 * own + 1), dim=-1).expand(b, k, 2).clone()
+    pairs.scatter_(2, which.unsqueeze(-1), replacement.unsqueeze(-1))
+    return pairs
+
+
 class GraphDataset(Dataset):
     """Triples of a knowledge graph as a (num_triples, 3) tensor of (head, tail, rel) ids."""
 

@@ -43,6 +43,26 @@ def test_negative_sampling_properties(b, k, rep):
     assert torch.all(replaced // 2 != (torch.arange(b * rep) % b).unsqueeze(1))  # never the own row
 
 
+def test_device_sampler_has_the_reference_law():
+    """The on-device sampler keeps one slot, replaces the other from another row, uniformly."""
+    g = torch.Generator().manual_seed(3)
+    b, k = 6, 4000
+    idx = data.get_negative_sampling_indices_on_device(b, k, "cpu", generator=g)
+    assert idx.shape == (b, k, 2) and idx.dtype == torch.int64
+    own = torch.arange(2 * b).reshape(b, 1, 2).expand(-1, k, -1)
+    kept = idx == own
+    assert torch.all(kept.sum(-1) == 1)
+    replaced = idx[~kept].reshape(b, k)
+    assert torch.all(replaced // 2 != torch.arange(b).unsqueeze(1))
+    # uniform over the 2B - 2 foreign slots and over the two columns (chi-square-ish bounds)
+    for row in range(b):
+        hist = torch.bincount(replaced[row], minlength=2 * b).float()
+        assert hist[2 * row] == 0 and hist[2 * row + 1] == 0
+        expected = k / (2 * b - 2)
+        assert (hist[hist > 0] - expected).abs().max() < 6 * expected ** 0.5
+    assert abs(float((~kept)[..., 0].float().mean()) - 0.5) < 0.02
+
+
 def test_filter_index_matches_reference_masks():
     g = golden("filters_toy")
     triples = torch.from_numpy(g["triples"])
