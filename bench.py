@@ -210,7 +210,8 @@ def main():
     # BLP_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks
     # (ranks share devices, counts are exchanged through host memory).  Timings are then meaningless.
     backend = os.environ.get("BLP_BENCH_BACKEND", "nccl")
-    local_rank %= torch.cuda.device_count() if backend == "gloo" else max(local_rank + 1, 1)
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

@@ -35,9 +35,6 @@
 
 namespace blp {
 
-#ifndef BLP_TRANSE_WAVES
-#define BLP_TRANSE_WAVES 3           // waves per SIMD the TransE lane-per-candidate kernel is compiled for
-#endif
 constexpr int kWaves = 4;            // waves per workgroup
 constexpr int kTileRows = 64;        // candidates per wave tile (one per lane)
 constexpr int kSubCols = 32;         // floats per row per LDS pass (128 B = one cache line)
@@ -356,7 +353,9 @@ __device__ __forceinline__ void apply_queries(const float (&e)[D], bool valid, c
 // Wikidata5M eval batch of 2 triples): their coefficients (a few KB) stay in the scalar cache and are
 // read as SGPR operands; the waves stream tiles independently, with no workgroup barrier in the loop.
 template <int MODEL, int D, bool STATIC>
-__global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE && BLP_TRANSE_WAVES == 3 ? 3 : 2)) void rank_tiles_kernel(
+// TransE keeps D + ~35 VGPRs -> 3 waves/SIMD (fewer waves measured slower: 12.2 vs 9.9 ms); the bilinear
+// fallback needs 32 more accumulators -> 2 waves/SIMD.
+__global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_tiles_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
     int n_tiles, int n_quad_groups, int n_chunks, const int64_t* __restrict__ q_rel_id,
