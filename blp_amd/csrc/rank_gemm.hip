@@ -16,15 +16,17 @@
 //           the reference are within (n + O(1)) u sum_k B_q[k] |e_c[k]| of the real-number score, where
 //           B_q[k] >= |W_q[k]| is the sum of the absolute values of the products W_q[k] is made of
 //           (Cauchy-Schwarz turns the sum into the two norms).  u = 2^-24, C = 320 for n <= 128 terms.
-//           If any pair of a (query, 32-candidate tile) segment is undecided the segment contributes
-//           nothing and its bit is set in a flag bitmap.
-//   pass 2  every flagged segment is re-scored with the order-exact Scorer<> routine (the same code
-//           that produced s_true) and counted exactly.  Typically ~0.5 % of the segments (the true
-//           entity's own segment plus near-ties); if everything is flagged the result is still exact,
-//           just slower -- there is no capacity to overflow.
+//           Undecided pairs (the true entity itself plus near-ties, ~3 per query on FB15k-237) go to a
+//           per-workgroup pair list (kPairQuota entries, a fixed region per workgroup: no global
+//           atomics, nothing to overflow).  When a workgroup's quota is used up, the lane's whole
+//           (query, 16-candidate) half-segment contributes nothing and its bit is set in a flag bitmap.
+//   pass 2  a) every listed pair and b) every flagged half-segment is re-scored with the order-exact
+//           Scorer<> routine (the same code that produced s_true) and counted exactly.  If everything
+//           is flagged the result is still exact, just slower.
 // NaN / Inf anywhere makes a pair undecided (both comparisons are false), so it takes the exact path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "launch.h"
 #include "rank_common.h"
@@ -42,6 +44,11 @@ constexpr int kGCT = 32;            // candidates per tile
 constexpr int kGTilesPerChunk = 8;  // query tiles per workgroup
 constexpr int kGSlab = 36;          // dwords, transpose slab row stride
 constexpr float kBandC = 320.0f;    // error-band constant (see header)
+constexpr int kPairQuota = 32;      // undecided (query, candidate) pairs a workgroup can list
+constexpr unsigned kNoPair = 0xFFFFFFFFu;
+
+// candidate row (within its 32-row tile) held by accumulator register r of a lane in half `half`
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // LDS floats shared by the two query-tile buffers and (before any staging) the transpose slabs.
 __host__ __device__ constexpr int gemm_buf_floats(int D) {
@@ -75,46 +82,47 @@ __device__ __forceinline__ void gemm_operand(const float* __restrict__ f, const 
 
 // B-operand image of one 32-query tile: float4 index (g * 64 + l), l = 64-lane id, holds
 // W_{q=l&31}[8g + (l>>5) + 2i], i = 0..3  ->  one linear ds_read_b128 per 4 MFMAs.
+// One workgroup per query tile: 8 threads per query build W (and the band factor C u ||B_q||, rounded
+// up) from coalesced reads, the image goes out through LDS so that the stores are linear too.
 template <int MODEL, int D>
-__global__ void prep_gemm_kernel(const float* __restrict__ q_fixed, const float* __restrict__ q_rel, int64_t q_head,
-                                 int64_t q_tail, float4* __restrict__ img_head, float4* __restrict__ img_tail,
-                                 float* __restrict__ eps_q) {
+__global__ __launch_bounds__(256) void prep_gemm_kernel(const float* __restrict__ q_fixed,
+                                                        const float* __restrict__ q_rel, int64_t q_head,
+                                                        int64_t q_tail, float4* __restrict__ img_head,
+                                                        float4* __restrict__ img_tail, float* __restrict__ eps_q) {
     constexpr int F4 = (D / 8) * 64;  // float4 per tile
-    const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
-    const int64_t n_img = (th + tt) * F4, Q = q_head + q_tail;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_img + Q; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < n_img) {
-            const bool head = i < th * F4;
-            const int64_t ii = head ? i : i - th * F4;
-            const int64_t tile = ii / F4;
-            const int rem = (int)(ii % F4), g = rem / 64, l = rem % 64;
-            const int64_t q_local = tile * kGQT + (l & 31), n_side = head ? q_head : q_tail;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (q_local < n_side) {
-                const int64_t q = (head ? 0 : q_head) + q_local;
-                const float* f = q_fixed + q * D;
-                const float* r = q_rel + q * D;
-                for (int c = 0; c < 4; ++c) {
-                    float b;
-                    const int k = 8 * g + (l >> 5) + 2 * c;
-                    if (head) gemm_operand<MODEL, HEAD>(f, r, k, D, v[c], b);
-                    else gemm_operand<MODEL, TAIL>(f, r, k, D, v[c], b);
-                }
-            }
-            (head ? img_head : img_tail)[ii] = make_float4(v[0], v[1], v[2], v[3]);
-        } else {  // per-query band factor: C * u * ||B_q||, rounded up
-            const int64_t q = i - n_img;
-            const float* f = q_fixed + q * D;
-            const float* r = q_rel + q * D;
-            float s = 0.f;
-            for (int k = 0; k < D; ++k) {
-                float w, b;
-                if (q < q_head) gemm_operand<MODEL, HEAD>(f, r, k, D, w, b);
-                else gemm_operand<MODEL, TAIL>(f, r, k, D, w, b);
-                s += b * b;
-            }
-            eps_q[q] = kBandC * 5.9604645e-8f * sqrtf(s) * 1.0001f;
+    __shared__ float w_s[kGQT][D + 1];
+    const int64_t th = (q_head + kGQT - 1) / kGQT;
+    const bool head = blockIdx.x < th;
+    const int64_t tile = head ? blockIdx.x : blockIdx.x - th;
+    const int64_t n_side = head ? q_head : q_tail;
+    const int ql = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int64_t q_local = tile * kGQT + ql;
+    const bool q_ok = q_local < n_side;
+    const int64_t q = (head ? 0 : q_head) + (q_ok ? q_local : n_side - 1);
+    const float* f = q_fixed + q * D;
+    const float* r = q_rel + q * D;
+    float bsq = 0.f;
+    for (int i = 0; i < D / 32; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 32 * i + 4 * sub + c;
+            float w, b;
+            if (head) gemm_operand<MODEL, HEAD>(f, r, k, D, w, b);
+            else gemm_operand<MODEL, TAIL>(f, r, k, D, w, b);
+            w_s[ql][k] = q_ok ? w : 0.f;
+            bsq += b * b;
         }
+    }
+    bsq += __shfl_xor(bsq, 1);
+    bsq += __shfl_xor(bsq, 2);
+    bsq += __shfl_xor(bsq, 4);
+    if (sub == 0 && q_ok) eps_q[q] = kBandC * 5.9604645e-8f * sqrtf(bsq) * 1.0001f;
+    __syncthreads();
+    float4* out = (head ? img_head : img_tail) + tile * F4;
+    for (int idx = threadIdx.x; idx < F4; idx += 256) {
+        const int g = idx >> 6, l = idx & 63;
+        const float* w = &w_s[l & 31][8 * g + (l >> 5)];
+        out[idx] = make_float4(w[0], w[2], w[4], w[6]);
     }
 }
 
@@ -176,13 +184,15 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float4* __restrict__ img_head,
     const float4* __restrict__ img_tail, const float* __restrict__ key_true, const float* __restrict__ eps_q,
     int q_head, int q_tail, int n_quads, int chunks_head, int words_per_query,
-    unsigned long long* __restrict__ acc, unsigned* __restrict__ flags) {
+    unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs) {
     constexpr int TILE_FLOATS = (D / 8) * 64 * 4;  // 16 KB at D = 128
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf0 = smem;
     float* buf1 = smem + TILE_FLOATS;
     unsigned* cnt = reinterpret_cast<unsigned*>(smem + gemm_buf_floats(D));  // [kGTilesPerChunk * 32]
     float* nrm = reinterpret_cast<float*>(cnt + kGTilesPerChunk * kGQT);  // [kGW][32] candidate norms
+    uint2* pair_s = reinterpret_cast<uint2*>(nrm + kGW * 32);             // [kPairQuota] (query, row)
+    unsigned* pair_n = reinterpret_cast<unsigned*>(pair_s + kPairQuota);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -203,12 +213,14 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
     __syncthreads();  // slabs done before anything is staged over them
     if (lane < 32) nrm[wave * 32 + lane] = my_norm;
     for (int i = tid; i < kGTilesPerChunk * kGQT; i += kGW * 64) cnt[i] = 0;
+    if (tid < kPairQuota) pair_s[tid] = make_uint2(kNoPair, 0u);
+    if (tid == 0) *pair_n = 0;
     __syncthreads();
     float nrow[16];       // ||e|| of the candidate held by accumulator register r of this lane
     unsigned row_mask = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = acc_row(r, lane >> 5);
         nrow[r] = nrm[wave * 32 + row];
         row_mask |= (unsigned)(row0 + row < N) << r;
     }
@@ -239,9 +251,8 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 3], b4.w, s, 0, 0, 0);
         });
 
-        // epilogue: three-way decision per pair, per-segment (query, this candidate tile) outcome
-        unsigned above = 0;
-        bool undecided = false;
+        // epilogue: three-way decision per pair; each lane owns a (query, 16-candidate) half-segment
+        unsigned above = 0, und = 0;
         const float guard = fabsf(kt) * 2.4e-7f + 1e-36f;  // rounding of kt +- eps itself, underflow slack
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -249,13 +260,23 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
             const float v = s[r];
             const bool gt = v > kt + eps, lt = v < kt - eps, ok = (row_mask >> r) & 1u;
             above += ok && gt;
-            undecided |= ok && !(gt || lt);
+            und |= (unsigned)(ok && !(gt || lt)) << r;
         }
-        above += __shfl_xor(above, 32);
-        const bool seg_undecided = undecided | (bool)__shfl_xor((int)undecided, 32);
-        if (lane < 32 && q_ok) {
-            if (seg_undecided) atomicOr(flags + (size_t)q * words_per_query + (ctile >> 5), 1u << (ctile & 31));
-            else if (above) atomicAdd(cnt + t * kGQT + lane, above);
+        if (q_ok) {
+            bool listed = true;
+            if (und) {
+                const unsigned n_und = __popc(und);
+                unsigned slot = atomicAdd(pair_n, n_und);
+                listed = slot + n_und <= kPairQuota;
+                if (listed) {
+                    for (unsigned m = und; m; m &= m - 1)
+                        pair_s[slot++] = make_uint2((unsigned)q, (unsigned)(row0 + acc_row(__builtin_ctz(m), lane >> 5)));
+                } else {
+                    const int hseg = ctile * 2 + (lane >> 5);
+                    atomicOr(flags + (size_t)q * words_per_query + (hseg >> 5), 1u << (hseg & 31));
+                }
+            }
+            if (listed && above) atomicAdd(cnt + t * kGQT + (lane & 31), above);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -265,10 +286,34 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
         const unsigned long long c = cnt[i];
         if (q_local < n_side && c) atomicAdd(acc + q_base + q_local, c | (c << 32));  // certainly above: gt and ge
     }
+    if (tid < kPairQuota) pairs[(size_t)blockIdx.x * kPairQuota + tid] = pair_s[tid];
 }
 
-// Pass 2: one wave per query.  The wave sweeps the query's flag words 64 at a time; every flagged
-// (query, 32-candidate tile) segment is re-scored exactly, one segment per half-wave at a time.
+// Pass 2a: one lane per listed pair.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
+                                                           const float* __restrict__ coef_head,
+                                                           const float* __restrict__ coef_tail,
+                                                           const float* __restrict__ key_true, int64_t q_head,
+                                                           const uint2* __restrict__ pairs, int64_t n_entries,
+                                                           unsigned long long* __restrict__ acc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    const uint2 p = pairs[i];
+    if (p.x == kNoPair) return;
+    const int64_t q = p.x;
+    float e[D];
+    load_row<D>(e, table + (int64_t)p.y * ld);
+    float key;
+    if (q < q_head) key = Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C});
+    else key = Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
+    const float kt = key_true[q];
+    const unsigned long long gt = key > kt, ge = key >= kt;
+    if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
+}
+
+// Pass 2b: one wave per query.  The wave sweeps the query's flag words 64 at a time; every flagged
+// (query, 16-candidate) half-segment is re-scored exactly, four half-segments per iteration.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
                                                      const float* __restrict__ coef_head,
@@ -278,7 +323,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
                                                      unsigned long long* __restrict__ acc) {
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
-    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int lane = threadIdx.x & 63, part = lane >> 4;
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
     const float* coef = q < q_head ? coef_head + q * Scorer<MODEL, HEAD, D>::C
@@ -291,14 +336,17 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
             const int src = __builtin_ctzll(nonzero);
             nonzero &= nonzero - 1;
             unsigned bits = __shfl(mine, src);
-            const int tile_base = (w0 + src) * 32;
-            while (bits) {  // two flagged tiles per iteration, one per half-wave
-                const int b0 = __builtin_ctz(bits);
-                bits &= bits - 1;
-                int b1 = -1;
-                if (bits) { b1 = __builtin_ctz(bits); bits &= bits - 1; }
-                const int b = half ? b1 : b0;
-                const int64_t r = (int64_t)(tile_base + (b < 0 ? 0 : b)) * kGCT + (lane & 31);
+            const int hseg_base = (w0 + src) * 32;
+            while (bits) {
+                int b = -1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // k-th set bit -> 16-lane group k
+                    const int bk = bits ? __builtin_ctz(bits) : -1;
+                    bits &= bits - 1;  // 0 stays 0
+                    b = part == k ? bk : b;
+                }
+                const int hseg = hseg_base + (b < 0 ? 0 : b);
+                const int64_t r = (int64_t)(hseg >> 1) * kGCT + acc_row(lane & 15, hseg & 1);
                 const bool ok = b >= 0 && r < N;
                 float e[D];
                 load_row<D>(e, table + (ok ? r : 0) * ld);
@@ -322,18 +370,32 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
 struct GemmWorkspace {
     float* coef_head; float* coef_tail; float* key_true; float* eps_q;
     float4* img_head; float4* img_tail;
-    unsigned long long* acc; unsigned long long* acc_f; unsigned* flags;
-    size_t flag_bytes, bytes;
+    unsigned long long* acc; unsigned long long* acc_f; unsigned* flags; uint2* pairs;
+    int64_t pass_ctiles;  // candidate tiles per GEMM + refine pass
+    size_t bytes;
 };
 
-// Candidate tiles handled per GEMM + refine pass: the flag bitmap (Q x tiles / 8 bytes) is capped at
-// ~256 MB, larger (Q x N) problems are processed in candidate slabs.
-static int64_t tiles_per_pass(int64_t N, int64_t Q) {
-    const int64_t n_ctiles = (N + kGCT - 1) / kGCT;
-    int64_t words = (n_ctiles + 31) / 32;
-    const int64_t budget_words = ((int64_t)256 << 20) / 4 / (Q > 0 ? Q : 1);
-    if (words > budget_words) words = budget_words < 32 ? 32 : budget_words;
-    return words * 32;
+static int64_t query_chunks(int64_t q_head, int64_t q_tail) {
+    const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
+    return (th + kGTilesPerChunk - 1) / kGTilesPerChunk + (tt + kGTilesPerChunk - 1) / kGTilesPerChunk;
+}
+
+// Candidate tiles handled per GEMM + refine pass (a multiple of 16 = one flag word per query): the flag
+// bitmap (2 bits per (query, tile)) and the pair regions (kPairQuota entries per workgroup) are each
+// capped at ~256 MB; larger (Q x N) problems are processed in candidate slabs.
+static int64_t tiles_per_pass(int64_t N, int64_t q_head, int64_t q_tail) {
+    const int64_t Q = q_head + q_tail > 0 ? q_head + q_tail : 1;
+    const int64_t cap = (int64_t)256 << 20;
+    int64_t words = ((N + kGCT - 1) / kGCT + 15) / 16;
+    const int64_t by_flags = cap / 4 / Q;
+    const int64_t by_pairs = cap / (kPairQuota * 8) / query_chunks(q_head, q_tail) * kGW / 16;
+    if (words > by_flags) words = by_flags;
+    if (words > by_pairs) words = by_pairs;
+    if (const char* env = getenv("BLP_GEMM_PASS_WORDS")) {  // test knob: force the multi-slab path
+        const int64_t forced = atoll(env);
+        if (forced > 0 && forced < words) words = forced;
+    }
+    return (words < 1 ? 1 : words) * 16;
 }
 
 static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, int64_t q_tail) {
@@ -350,12 +412,11 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     w.img_tail = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_tail + kGQT - 1) / kGQT) * tile_bytes, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
     w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
+    w.pass_ctiles = tiles_per_pass(N, q_head, q_tail);
     w.flags = reinterpret_cast<unsigned*>(p + off);
-    int64_t pass_tiles = tiles_per_pass(N, Q);
-    const int64_t n_ctiles = (N + kGCT - 1) / kGCT;
-    if (pass_tiles > n_ctiles) pass_tiles = (n_ctiles + 31) / 32 * 32;
-    w.flag_bytes = (size_t)Q * (size_t)(pass_tiles / 32 > 0 ? pass_tiles / 32 : 1) * 4;
-    off = align_up(off + w.flag_bytes, 256);
+    off = align_up(off + (size_t)Q * (size_t)(w.pass_ctiles / 16) * 4, 256);
+    w.pairs = reinterpret_cast<uint2*>(p + off);
+    off = align_up(off + (size_t)((w.pass_ctiles + kGW - 1) / kGW) * query_chunks(q_head, q_tail) * kPairQuota * 8, 256);
     w.bytes = off;
     return w;
 }
@@ -376,20 +437,17 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                                  hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
     GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
-    const int64_t pass_tiles = tiles_per_pass(N, Q);
+    const int64_t pass_tiles = w.pass_ctiles;
     hipError_t err = hipMemsetAsync(w.acc, 0, (size_t)Q * 8, stream);
     if (err != hipSuccess) return err;
     err = launch_exact_prep(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.coef_head,
                             w.coef_tail, w.key_true, stream);
     if (err != hipSuccess) return err;
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
-    {
-        const int64_t total = (th + tt) * (D / 8) * 64 + Q;
-        const int64_t blocks = (total + 255) / 256;
-        prep_gemm_kernel<MODEL, D><<<(int)(blocks < 16384 ? blocks : 16384), 256, 0, stream>>>(
-            q_fixed, q_rel, q_head, q_tail, w.img_head, w.img_tail, w.eps_q);
-    }
-    const size_t lds = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4;
+    prep_gemm_kernel<MODEL, D><<<dim3((unsigned)(th + tt)), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.img_head,
+                                                                             w.img_tail, w.eps_q);
+    const size_t lds = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
+                       (size_t)kPairQuota * 8 + 16;
     const int64_t chunks_head = (th + kGTilesPerChunk - 1) / kGTilesPerChunk;
     const int64_t chunks_tail = (tt + kGTilesPerChunk - 1) / kGTilesPerChunk;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
@@ -397,13 +455,16 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
         const int64_t n_ctiles = (n_rows + kGCT - 1) / kGCT;
         const int64_t n_quads = (n_ctiles + kGW - 1) / kGW;
-        const int words = (int)((n_ctiles + 31) / 32);
+        const int words = (int)((n_ctiles + 15) / 16);
+        const int64_t n_blocks = n_quads * (chunks_head + chunks_tail);
         err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
         if (err != hipSuccess) return err;
         const float* slab = table + slab0 * ld;
-        rank_gemm_kernel<MODEL, D><<<dim3((unsigned)(n_quads * (chunks_head + chunks_tail))), kGW * 64, lds, stream>>>(
+        rank_gemm_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kGW * 64, lds, stream>>>(
             slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_quads,
-            (int)chunks_head, words, w.acc, w.flags);
+            (int)chunks_head, words, w.acc, w.flags, w.pairs);
+        refine_pairs_kernel<MODEL, D><<<dim3((unsigned)((n_blocks * kPairQuota + 255) / 256)), 256, 0, stream>>>(
+            slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_blocks * kPairQuota, w.acc);
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
     }

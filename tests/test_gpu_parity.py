@@ -140,6 +140,37 @@ def test_gemm_band_adversarial(ops, oracle, model, D):
 
 
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
+def test_gemm_candidate_slabs(ops, oracle, model, monkeypatch):
+    """When the flag bitmap / pair regions would exceed their cap the candidate axis is processed in
+    slabs.  BLP_GEMM_PASS_WORDS=1 forces 512-candidate slabs: counts must equal the one-pass result
+    and the oracle's (ragged last slab, true entities in every slab)."""
+    D, N, q_head, q_tail = 128, 2000 + 37, 70, 90
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=23)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
+    args = (model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+    one_pass = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+    monkeypatch.setenv("BLP_GEMM_PASS_WORDS", "1")
+    slabs = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+    assert np.array_equal(one_pass, want)
+    assert np.array_equal(slabs, want)
+
+
+def test_gemm_pair_quota_overflow_falls_back_to_flags(ops, oracle):
+    """Every candidate ties with the true entity (constant table): far more undecided pairs than a
+    workgroup can list, so almost everything takes the flagged half-segment path."""
+    D, N, Q = 128, 1000, 128
+    table = torch.full((N, D), 0.25)
+    q_fixed = torch.full((Q, D), 0.5)
+    q_rel = torch.full((Q, D), -0.125)
+    true_row = torch.arange(Q) * 7 % N
+    for model in ("distmult", "complex", "simple"):
+        want = oracle_counts(oracle, model, table, q_fixed, q_rel, Q // 2, true_row=true_row)
+        got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), Q // 2, true_row=true_row.cuda())
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert (want[:, 1] == N).all() and (want[:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
 def test_gemm_path_nonfinite_inputs_take_the_exact_path(ops, oracle, model):
     D, N, q_head, q_tail = 128, 300, 40, 40
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=9)
