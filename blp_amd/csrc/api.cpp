@@ -111,9 +111,8 @@ int blp_dim_supported(int model, int D) {
 }
 
 size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head, int64_t q_tail) {
-    (void)model;
     if (D <= 0 || N < 0 || q_head < 0 || q_tail < 0) return 0;
-    return blp::rank_all_workspace_bytes(D, N, q_head, q_tail);
+    return blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
 }
 
 int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
@@ -138,7 +137,7 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filt_rowptr and filt_col must both be given or both NULL");
     if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: table / q_true / counts must be 16-byte aligned and ld %% 4 == 0");
-    const size_t need = blp::rank_all_workspace_bytes(D, N, q_head, q_tail);
+    const size_t need = blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail(BLP_ERR_WORKSPACE, "blp_rank_all: workspace must be 256-byte aligned and >= %zu bytes (got %zu)",
                     need, workspace_bytes);

@@ -143,31 +143,6 @@ __device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* 
 // per query.  Here the 64-byte chunk k+1 (and, on the last chunk, chunk 0 of the NEXT query) is
 // requested before chunk k's 32-48 VALU instructions and drained after them, and one dword of every
 // line of the query after next is touched once per query so that those requests hit the scalar cache.
-typedef float sf16 __attribute__((ext_vector_type(16)));
-
-template <int OFF>
-__device__ __forceinline__ sf16 sload16(const float* base) {
-    sf16 v;
-    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "i"(OFF) : "memory");
-    return v;
-}
-__device__ __forceinline__ void sdrain(sf16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory"); }
-__device__ __forceinline__ void sdrain(sf16& a, sf16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : : "memory"); }
-
-template <int OFF>
-__device__ __forceinline__ void stouch_line(const float* row) {
-    float sink;
-    asm volatile("s_load_dword %0, %1, %2" : "=s"(sink) : "s"(row), "i"(OFF) : "memory");
-}
-template <int... Ls>
-__device__ __forceinline__ void stouch_lines(const float* row, std::integer_sequence<int, Ls...>) {
-    (stouch_line<Ls * 64>(row), ...);
-}
-template <int BYTES>
-__device__ __forceinline__ void stouch(const float* row) {  // one dword per 64-B line, result discarded
-    stouch_lines(row, std::make_integer_sequence<int, BYTES / 64>{});
-}
-
 template <int D, int CHUNK0, class Get>
 __device__ __forceinline__ void l1_chunk(const float (&e)[D], float& acc, bool first, Get x_of) {
     // 16 elements starting at CHUNK0: differences kPipe ahead of the dependent |x| adds
@@ -501,14 +476,12 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
     return w;
 }
 
-size_t rank_all_workspace_bytes(int D, int64_t N, int64_t q_head, int64_t q_tail) {
+size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
     size_t bytes = carve_workspace(nullptr, D, q_head, q_tail).bytes;
-    for (int model = 0; model < 4; ++model) {
-        const size_t m = rank_mfma_workspace_bytes(model, D, q_head, q_tail);
-        bytes = m > bytes ? m : bytes;
-        const size_t g = rank_gemm_workspace_bytes(model, D, N, q_head, q_tail);
-        bytes = g > bytes ? g : bytes;
-    }
+    const size_t alt[3] = {rank_mfma_workspace_bytes(model, D, q_head, q_tail),
+                           rank_gemm_workspace_bytes(model, D, N, q_head, q_tail),
+                           rank_sad_workspace_bytes(model, D, N, q_head, q_tail)};
+    for (size_t a : alt) bytes = a > bytes ? a : bytes;
     return bytes;
 }
 
@@ -614,8 +587,11 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
     if (rank_gemm_applicable(model, D, q_head, q_tail))
         return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
                                     filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    // TransE with many queries: the hand-pipelined scalar-cache VALU kernel below is the default
-    // (9.9 ms per FB15k-237 pass vs 11.2 ms); BLP_RANK_KERNEL=mfma selects the matrix-core variant.
+    if (rank_sad_applicable(model, D, q_head, q_tail))
+        return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,
+                                   filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    // TransE, exact f32 kernels (few queries, or BLP_RANK_KERNEL=valu|mfma): the hand-pipelined
+    // scalar-cache VALU kernel below is the default, "mfma" selects the matrix-core variant.
     const char* pick = getenv("BLP_RANK_KERNEL");
     if (pick && strcmp(pick, "mfma") == 0 && rank_mfma_applicable(model, D, q_head, q_tail))
         return launch_rank_all_mfma(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
@@ -630,7 +606,7 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exact-path building blocks reused by rank_gemm.hip (row-major coefficients, true keys, CSR filter).
+// Exact-path building blocks reused by rank_gemm.hip and rank_sad.hip (row-major coefficients, true keys, CSR filter).
 template <int MODEL, int D>
 static hipError_t exact_prep_impl(const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
                                   const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
@@ -654,6 +630,9 @@ static hipError_t exact_filter_impl(const float* table, int64_t ld, const float*
 
 #define BLP_DISPATCH_MODEL_DIM(FN, ...)                                                     \
     switch (model * 1000 + D) {                                                             \
+    case TRANSE * 1000 + 64: return FN<TRANSE, 64>(__VA_ARGS__);                            \
+    case TRANSE * 1000 + 128: return FN<TRANSE, 128>(__VA_ARGS__);                          \
+    case TRANSE * 1000 + 256: return FN<TRANSE, 256>(__VA_ARGS__);                          \
     case DISTMULT * 1000 + 64: return FN<DISTMULT, 64>(__VA_ARGS__);                        \
     case DISTMULT * 1000 + 128: return FN<DISTMULT, 128>(__VA_ARGS__);                      \
     case COMPLEX * 1000 + 64: return FN<COMPLEX, 64>(__VA_ARGS__);                          \

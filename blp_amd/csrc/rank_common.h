@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "score_core.h"
 
 namespace blp {
@@ -26,6 +28,35 @@ __device__ __forceinline__ void load_row(float (&e)[D], const float* __restrict_
         const float4 v = *reinterpret_cast<const float4*>(row + d);
         e[d] = v.x; e[d + 1] = v.y; e[d + 2] = v.z; e[d + 3] = v.w;
     }
+}
+
+// Hand-issued scalar loads (wave-uniform data straight into SGPRs).  Scalar loads return out of order,
+// so every wait on them is a full drain: callers request the next 64-byte chunk before a block of VALU
+// work and drain after it.  stouch<> reads one dword per 64-byte line (result discarded) to pull lines
+// into the scalar cache ahead of use.
+typedef float sf16 __attribute__((ext_vector_type(16)));
+
+template <int OFF>
+__device__ __forceinline__ sf16 sload16(const float* base) {
+    sf16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "i"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void sdrain(sf16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory"); }
+__device__ __forceinline__ void sdrain(sf16& a, sf16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : : "memory"); }
+
+template <int OFF>
+__device__ __forceinline__ void stouch_line(const float* row) {
+    float sink;
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(sink) : "s"(row), "i"(OFF) : "memory");
+}
+template <int... Ls>
+__device__ __forceinline__ void stouch_lines(const float* row, std::integer_sequence<int, Ls...>) {
+    (stouch_line<Ls * 64>(row), ...);
+}
+template <int BYTES>
+__device__ __forceinline__ void stouch(const float* row) {  // one dword per 64-B line, result discarded
+    stouch_lines(row, std::make_integer_sequence<int, BYTES / 64>{});
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -63,5 +94,15 @@ hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N,
                                 const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop);
+
+// rank_sad.hip: TransE with many queries as a 16-bit fixed-point v_sad_u16 pre-pass + error band +
+// exact refinement.
+bool rank_sad_applicable(int model, int D, int64_t q_head, int64_t q_tail);
+size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
+hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                               const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                               int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                               void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                               hipEvent_t ev_stop);
 
 }  // namespace blp

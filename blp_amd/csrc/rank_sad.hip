@@ -1,0 +1,522 @@
+// rank_sad.hip -- all-entities ranking for TransE with many queries: a 16-bit fixed-point pre-pass on
+// v_sad_u16 with a rigorous error band, then exact refinement of the undecided pairs.
+// (SURVEY.md 8a "K1"; replaces train.py:146-171 + utils.py:103-105 of the reference for rel_model=transe.)
+//
+// The exact TransE key costs two f32 VALU instructions per element (subtract, |x| accumulate) and the
+// f32 VALU pipe is the roof of the exact kernel (rank_all.hip: 61 % of it at FB15k-237).  There is no
+// matrix-core form of an L1 norm, but gfx950 has v_sad_u16: D = S2 + |S0.lo - S1.lo| + |S0.hi - S1.hi|,
+// two elements per instruction at 4.2 cycles (tools/sad_ubench.hip) against 2 x 2 x 2.43 for the f32
+// pair: 2.3x fewer VALU cycles per element.  So, as for the bilinear models (rank_gemm.hip):
+//   prep    one affine map x^ = rint((x - lo) s) in [0, 65535] for the whole call (lo, hi = range of the
+//           table and of the query coefficients c = h + r | t - r); candidate rows are packed two
+//           elements per dword into a lane-major tile image, query coefficients into 2-byte rows.
+//   pass 1  SAD(q, c) = sum_k |c^_k - e^_k| (exact integer), so |SAD - s X| <= 1.02 D for the real-number
+//           distance X = sum_k |c_k - e_k|.  The reference score S_ref is -X up to f32 rounding:
+//           |S_ref + X| <= gamma X + rho (gamma = (D+2) u, rho = 6 D u M, M = max |value|; the head side's
+//           extra rounding of e + r and of t - r is inside rho).  Against the EXACT true-entity key
+//           s_true = -d_t this gives two integer thresholds per query:
+//              SAD < T_lo  -> certainly ranked above (count it)
+//              SAD > T_hi  -> certainly below        (ignore it)
+//              otherwise   -> undecided: listed as a (query, row) pair
+//           Undecided pairs are ~0.2 % for FB15k-237-like data.  A workgroup lists up to kSQuota pairs;
+//           beyond that the (query, 64-candidate tile) segment contributes nothing and its bit is set in
+//           a flag bitmap.
+//   pass 2  listed pairs and flagged segments are re-scored with the order-exact Scorer<TRANSE> (the
+//           code that produced s_true) and counted exactly.
+// Non-finite values anywhere, or a degenerate range, make every kernel of the pre-pass a no-op and the
+// segment refinement sweep all tiles: the result is exact in every case, just slower.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "launch.h"
+#include "rank_common.h"
+#include "score_core.h"
+
+#pragma clang fp contract(off)
+
+namespace blp {
+
+constexpr int kSW = 4;                       // waves per workgroup
+constexpr int kSChunk = 128;                 // queries per workgroup
+constexpr int kSQuota = 512;                 // undecided pairs a workgroup can list
+constexpr unsigned kSInvalid = 0x40000000u;  // accumulator bias of padding rows: beyond every T_hi
+constexpr unsigned kSThrMax = 0x3fffffffu;
+constexpr unsigned kSNoPair = 0xFFFFFFFFu;
+
+struct SadParams {
+    int lo_ord, hi_ord;     // range of table + coefficients, as order-preserving ints
+    unsigned maxabs_bits;   // max |value| over table, q_fixed, q_rel (bits of a non-negative float)
+    unsigned nonfinite;
+    unsigned n_pairs;       // pairs listed in the current pass
+    unsigned pad[3];
+};
+
+__device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
+
+struct SadScale { float lo, scale; bool ok; };
+
+__device__ __forceinline__ SadScale sad_scale(const SadParams* __restrict__ p) {
+    SadScale s;
+    const int lo_ord = p->lo_ord, hi_ord = p->hi_ord;
+    s.lo = ord2f(lo_ord);
+    const float range = ord2f(hi_ord) - s.lo;
+    s.scale = 65535.0f / range;
+    s.ok = !p->nonfinite && lo_ord <= hi_ord && range > 0.f && range < 3.0e38f && s.scale > 0.f && s.scale < 3.0e38f;
+    return s;
+}
+
+// |x^ - (x - lo) s| <= 0.5 + 65535 (2u + u^2) < 0.508 for every x in [lo, hi]
+__device__ __forceinline__ unsigned sad_quant(float x, const SadScale& s) {
+    const float v = rintf((x - s.lo) * s.scale);
+    return (unsigned)fminf(fmaxf(v, 0.f), 65535.f);
+}
+
+__device__ __forceinline__ float sad_coef(float fixed, float rel, bool head) { return head ? fixed - rel : fixed + rel; }
+
+__global__ void sad_init_kernel(SadParams* p) {
+    p->lo_ord = 0x7fffffff;
+    p->hi_ord = (int)0x80000000;
+    p->maxabs_bits = 0;
+    p->nonfinite = 0;
+    p->n_pairs = 0;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
+                                                        const float* __restrict__ q_fixed,
+                                                        const float* __restrict__ q_rel, int64_t q_head, int64_t Q,
+                                                        SadParams* __restrict__ p) {
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    float maxabs = 0.f;
+    bool bad = false;
+    auto see = [&](float x) {
+        const float ax = fabsf(x);
+        if (!(ax < 3.0e38f)) { bad = true; return; }  // NaN, Inf or too close to overflow
+        const int o = f2ord(x);
+        lo = o < lo ? o : lo;
+        hi = o > hi ? o : hi;
+        maxabs = ax > maxabs ? ax : maxabs;
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < N * (D / 4); i += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(table + (i / (D / 4)) * ld + (i % (D / 4)) * 4);
+        see(v.x); see(v.y); see(v.z); see(v.w);
+    }
+    for (int64_t i = t0; i < Q * D; i += stride) {
+        const float f = q_fixed[i], r = q_rel[i];
+        const int lo_keep = lo, hi_keep = hi;
+        see(f); see(r);  // for max |value| only: the range is that of the coefficient
+        lo = lo_keep; hi = hi_keep;
+        see(sad_coef(f, r, i / D < q_head));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        const float m2 = __shfl_xor(maxabs, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        maxabs = m2 > maxabs ? m2 : maxabs;
+    }
+    const bool any_bad = __any(bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (lo <= hi) { atomicMin(&p->lo_ord, lo); atomicMax(&p->hi_ord, hi); }
+        atomicMax(&p->maxabs_bits, __float_as_uint(maxabs));
+        if (any_bad) atomicOr(&p->nonfinite, 1u);
+    }
+}
+
+// Candidate tile image: 64 rows per tile, uint4 index ((tile * D/8 + j4) * 64 + lane) holds dwords
+// 4 j4 .. 4 j4 + 3 of row (tile * 64 + lane); dword j packs elements 2j (low half) and 2j + 1.
+template <int D>
+__global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __restrict__ table, int64_t N,
+                                                                 int64_t ld, const SadParams* __restrict__ p,
+                                                                 uint4* __restrict__ cimg) {
+    const SadScale sc = sad_scale(p);
+    if (!sc.ok) return;
+    const int64_t tile = blockIdx.x;
+    const int row_in = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int64_t row = tile * 64 + row_in;
+    constexpr int F = D / 4;  // floats per thread
+    unsigned w[F / 2];
+    if (row < N) {
+        const float* src = table + row * ld + part * F;
+#pragma unroll
+        for (int i = 0; i < F / 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
+            w[2 * i] = sad_quant(v.x, sc) | (sad_quant(v.y, sc) << 16);
+            w[2 * i + 1] = sad_quant(v.z, sc) | (sad_quant(v.w, sc) << 16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < F / 2; ++i) w[i] = 0;
+    }
+    uint4* dst = cimg + (tile * (D / 8) + part * (F / 8)) * 64 + row_in;
+#pragma unroll
+    for (int i = 0; i < F / 8; ++i) dst[i * 64] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// Query image (D/2 dwords per query, same packing) and the two thresholds {T_lo, T_hi - T_lo}.
+template <int D>
+__global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const float* __restrict__ q_fixed,
+                                                                   const float* __restrict__ q_rel, int64_t q_head,
+                                                                   int64_t Q, const float* __restrict__ key_true,
+                                                                   const SadParams* __restrict__ p,
+                                                                   unsigned* __restrict__ qimg,
+                                                                   uint2* __restrict__ thr) {
+    const SadScale sc = sad_scale(p);
+    if (!sc.ok) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q * (D / 2)) return;
+    const int64_t q = i / (D / 2);
+    const bool head = q < q_head;
+    const float2 f = *reinterpret_cast<const float2*>(q_fixed + 2 * i);
+    const float2 r = *reinterpret_cast<const float2*>(q_rel + 2 * i);
+    qimg[i] = sad_quant(sad_coef(f.x, r.x, head), sc) | (sad_quant(sad_coef(f.y, r.y, head), sc) << 16);
+    if (i % (D / 2) == 0) {
+        const double u = 5.9604644775390625e-8;
+        const double dt = -(double)key_true[q], s = (double)sc.scale, M = (double)__uint_as_float(p->maxabs_bits);
+        const double band = 1.03 * D, gamma = 1.05 * (D + 2) * u, rho = 6.0 * D * u * M;
+        unsigned t_lo = 0, t_hi = kSThrMax;
+        if (dt >= 0.0 && dt < 1.0e300) {  // false for NaN
+            const double lo_v = s * (dt - rho) / (1.0 + gamma) - band;   // SAD below this: certainly above
+            const double hi_v = s * (dt + rho) / (1.0 - gamma) + band;   // SAD above this: certainly below
+            if (lo_v > 2.0) t_lo = lo_v - 1.0 < (double)kSThrMax ? (unsigned)(lo_v - 1.0) : kSThrMax;
+            if (hi_v + 2.0 < (double)kSThrMax) t_hi = (unsigned)(hi_v + 2.0);
+        }
+        thr[q] = make_uint2(t_lo, t_hi - t_lo);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D, int TPW>
+struct SadTiles {
+    unsigned v[TPW][D / 2];
+    unsigned bias[TPW];
+};
+
+template <int D, int TPW>
+__global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 128 ? 3 : 2)) void rank_sad_kernel(
+    const uint4* __restrict__ cimg, int64_t n_rows, int n_groups, const unsigned* __restrict__ qimg,
+    const uint2* __restrict__ thr, int64_t Q, int words_per_query, unsigned long long* __restrict__ acc,
+    unsigned* __restrict__ flags, uint2* __restrict__ pairs, SadParams* __restrict__ params) {
+    if (!sad_scale(params).ok) return;
+    __shared__ uint2 thr_s[kSChunk];
+    __shared__ unsigned cnt[kSChunk];
+    __shared__ uint2 pair_s[kSQuota];
+    __shared__ unsigned pair_n, pair_base;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int group = blockIdx.x % n_groups;
+    const int64_t q0 = (int64_t)(blockIdx.x / n_groups) * kSChunk;
+    const int nq = (int)(Q - q0 < kSChunk ? Q - q0 : kSChunk);
+
+    for (int i = tid; i < kSChunk; i += kSW * 64) {
+        thr_s[i] = i < nq ? thr[q0 + i] : make_uint2(0u, 0u);
+        cnt[i] = 0;
+    }
+    for (int i = tid; i < kSQuota; i += kSW * 64) pair_s[i] = make_uint2(kSNoPair, 0u);
+    if (tid == 0) pair_n = 0;
+
+    // this wave's TPW candidate tiles: one row per lane, D/2 packed dwords each
+    SadTiles<D, TPW> c;
+    const int64_t n_tiles = (n_rows + 63) / 64;
+    const int64_t tile0 = ((int64_t)group * kSW + wave) * TPW;
+    static_for<TPW>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        int64_t tile = tile0 + t;
+        c.bias[t] = tile * 64 + lane < n_rows ? 0u : kSInvalid;
+        tile = tile < n_tiles ? tile : n_tiles - 1;
+        const uint4* src = cimg + tile * (D / 8) * 64 + lane;
+        static_for<D / 8>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            const uint4 x = src[j * 64];
+            c.v[t][4 * j] = x.x; c.v[t][4 * j + 1] = x.y; c.v[t][4 * j + 2] = x.z; c.v[t][4 * j + 3] = x.w;
+        });
+    });
+    __syncthreads();
+
+    const float* rows = reinterpret_cast<const float*>(qimg + q0 * (D / 2));
+    sf16 cur = sload16<0>(rows);
+    sdrain(cur);
+    for (int j = 0; j < nq; ++j) {
+        const float* row = rows + (size_t)j * (D / 2);
+        const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * (D / 2);
+        // the four waves walk the same rows: they take turns touching the lines of the query three ahead
+        const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * (D / 2) : row;
+        const uint2 th = thr_s[j];
+        unsigned sad[TPW];
+        static_for<TPW>([&](auto tt) { sad[decltype(tt)::value] = c.bias[decltype(tt)::value]; });
+        static_for<D / 32>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            sf16 nxt;
+            if constexpr (k + 1 < D / 32) nxt = sload16<(k + 1) * 64>(row); else nxt = sload16<0>(next_row);
+            if constexpr (k == 0) stouch<D * 2>(touch_row);
+            static_for<16>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const float qf = cur[i];  // (bit_cast straight from the vector element reads element 0)
+                const unsigned qv = __float_as_uint(qf);
+                static_for<TPW>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+                    sad[t] = __builtin_amdgcn_sad_u16(qv, c.v[t][16 * k + i], sad[t]);
+                });
+            });
+            sdrain(nxt);
+            cur = nxt;
+        });
+        unsigned n_above = 0;
+        static_for<TPW>([&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            const unsigned long long und = __ballot(sad[t] - th.x <= th.y);
+            unsigned n_t = __popcll(__ballot(sad[t] < th.x));
+            if (und) {  // wave-uniform
+                const unsigned n = __popcll(und);
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(&pair_n, n);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                if (slot + n <= kSQuota) {
+                    if ((und >> lane) & 1ull)
+                        pair_s[slot + __popcll(und & ((1ull << lane) - 1ull))] =
+                            make_uint2((unsigned)(q0 + j), (unsigned)((tile0 + t) * 64 + lane));
+                } else {
+                    const int64_t tile = tile0 + t;
+                    if (lane == 0) atomicOr(flags + (size_t)(q0 + j) * words_per_query + (tile >> 5), 1u << (tile & 31));
+                    n_t = 0;
+                }
+            }
+            n_above += n_t;
+        });
+        if (lane == 0 && n_above) atomicAdd(&cnt[j], n_above);
+    }
+    __syncthreads();
+    for (int i = tid; i < nq; i += kSW * 64) {
+        const unsigned long long v = cnt[i];
+        if (v) atomicAdd(acc + q0 + i, v | (v << 32));  // certainly above: gt and ge
+    }
+    const unsigned used = pair_n < (unsigned)kSQuota ? pair_n : (unsigned)kSQuota;
+    if (tid == 0 && used) pair_base = atomicAdd(&params->n_pairs, used);
+    __syncthreads();
+    for (unsigned i = tid; i < used; i += kSW * 64) pairs[pair_base + i] = pair_s[i];
+}
+
+// Pass 2a: one lane per listed pair.
+template <int D>
+__global__ __launch_bounds__(256) void sad_refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
+                                                               const float* __restrict__ coef_head,
+                                                               const float* __restrict__ coef_tail,
+                                                               const float* __restrict__ key_true, int64_t q_head,
+                                                               const uint2* __restrict__ pairs,
+                                                               const SadParams* __restrict__ params,
+                                                               unsigned long long* __restrict__ acc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= params->n_pairs) return;
+    const uint2 p = pairs[i];
+    if (p.x == kSNoPair) return;
+    const int64_t q = p.x;
+    float e[D];
+    load_row<D>(e, table + (int64_t)p.y * ld);
+    float key;
+    if (q < q_head) key = Scorer<TRANSE, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<TRANSE, HEAD, D>::C});
+    else key = Scorer<TRANSE, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<TRANSE, TAIL, D>::C});
+    const float kt = key_true[q];
+    const unsigned long long gt = key > kt, ge = key >= kt;
+    if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
+}
+
+// Pass 2b: one wave per query sweeps the query's flag words; every flagged 64-candidate tile is
+// re-scored exactly.  When the pre-pass did not run (non-finite input, degenerate range) all tiles are.
+template <int D>
+__global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __restrict__ table, int64_t n_rows,
+                                                               int64_t ld, const float* __restrict__ coef_head,
+                                                               const float* __restrict__ coef_tail,
+                                                               const float* __restrict__ key_true, int64_t q_head,
+                                                               int64_t Q, int words_per_query,
+                                                               const unsigned* __restrict__ flags,
+                                                               const SadParams* __restrict__ params,
+                                                               unsigned long long* __restrict__ acc) {
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const bool all = !sad_scale(params).ok;
+    const int lane = threadIdx.x & 63;
+    const unsigned* row = flags + q * words_per_query;
+    const float kt = key_true[q];
+    const float* coef = q < q_head ? coef_head + q * Scorer<TRANSE, HEAD, D>::C
+                                   : coef_tail + (q - q_head) * Scorer<TRANSE, TAIL, D>::C;
+    unsigned gt = 0, ge = 0;
+    for (int w0 = 0; w0 < words_per_query; w0 += 64) {
+        const unsigned mine = w0 + lane < words_per_query ? (all ? 0xFFFFFFFFu : row[w0 + lane]) : 0u;
+        unsigned long long nonzero = __ballot(mine != 0);
+        while (nonzero) {  // wave-uniform: next non-empty flag word
+            const int src = __builtin_ctzll(nonzero);
+            nonzero &= nonzero - 1;
+            unsigned bits = __shfl(mine, src);
+            const int64_t tile_base = (int64_t)(w0 + src) * 32;
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int64_t r = (tile_base + b) * 64 + lane;
+                const bool ok = r < n_rows;
+                if (__ballot(ok) == 0) continue;
+                float e[D];
+                load_row<D>(e, table + (ok ? r : 0) * ld);
+                const float key = q < q_head ? Scorer<TRANSE, HEAD, D>::template score<false>(e, PtrCoef{coef})
+                                             : Scorer<TRANSE, TAIL, D>::template score<false>(e, PtrCoef{coef});
+                gt += ok && key > kt;
+                ge += ok && key >= kt;
+            }
+        }
+    }
+    if (__ballot(gt | ge) == 0) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gt += __shfl_down(gt, off);
+        ge += __shfl_down(ge, off);
+    }
+    if (lane == 0) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+}
+
+// ------------------------------------------------------------------------------------------------
+static constexpr int sad_tiles_per_wave(int D) { return D <= 128 ? 2 : 1; }
+
+struct SadWorkspace {
+    float* coef_head; float* coef_tail; float* key_true;
+    unsigned long long* acc; unsigned long long* acc_f;
+    SadParams* params; uint2* thr; unsigned* qimg; uint4* cimg; unsigned* flags; uint2* pairs;
+    int64_t pass_groups;  // candidate groups (kSW * TPW tiles) per pre-pass + refine pass
+    size_t bytes;
+};
+
+// Candidate groups per pass: the flag bitmap (one bit per (query, tile)) and the pair list (kSQuota
+// entries per workgroup, worst case) are each capped at ~256 MB; larger (Q x N) problems are
+// processed in candidate slabs.
+static int64_t sad_groups_per_pass(int D, int64_t N, int64_t Q) {
+    const int64_t tiles_per_group = kSW * sad_tiles_per_wave(D);
+    const int64_t n_groups = ((N + 63) / 64 + tiles_per_group - 1) / tiles_per_group;
+    const int64_t n_chunks = (Q + kSChunk - 1) / kSChunk;
+    const int64_t cap = (int64_t)256 << 20;
+    int64_t by_pairs = cap / (kSQuota * 8) / (n_chunks > 0 ? n_chunks : 1);
+    int64_t by_flags = cap / 4 / (Q > 0 ? Q : 1) * 32 / tiles_per_group;
+    int64_t g = n_groups;
+    if (g > by_pairs) g = by_pairs;
+    if (g > by_flags) g = by_flags;
+    if (const char* env = getenv("BLP_SAD_PASS_GROUPS")) {  // test knob: force the multi-slab path
+        const int64_t forced = atoll(env);
+        if (forced > 0 && forced < g) g = forced;
+    }
+    return g < 1 ? 1 : g;
+}
+
+static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int64_t q_tail) {
+    SadWorkspace w;
+    const int64_t Q = q_head + q_tail;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    w.coef_head = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_head * 2 * D * 4, 256);
+    w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * 2 * D * 4, 256);
+    w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
+    w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
+    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
+    w.params = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams), 256);
+    w.thr = reinterpret_cast<uint2*>(p + off);        off = align_up(off + (size_t)Q * 8, 256);
+    w.qimg = reinterpret_cast<unsigned*>(p + off);    off = align_up(off + (size_t)Q * (D / 2) * 4 + 64, 256);
+    w.cimg = reinterpret_cast<uint4*>(p + off);       off = align_up(off + (size_t)((N + 63) / 64) * 64 * (D / 2) * 4, 256);
+    w.pass_groups = sad_groups_per_pass(D, N, Q);
+    const int64_t tiles_per_group = kSW * sad_tiles_per_wave(D);
+    const int64_t words = (w.pass_groups * tiles_per_group + 31) / 32;
+    w.flags = reinterpret_cast<unsigned*>(p + off); off = align_up(off + (size_t)Q * words * 4, 256);
+    w.pairs = reinterpret_cast<uint2*>(p + off);
+    off = align_up(off + (size_t)w.pass_groups * ((Q + kSChunk - 1) / kSChunk) * kSQuota * 8, 256);
+    w.bytes = off;
+    return w;
+}
+
+// Worth it once the quantisation passes over the table (~2.5 table reads) are amortised.
+bool rank_sad_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
+    if (const char* pick = getenv("BLP_RANK_KERNEL"))
+        if (pick[0] == 'v' || pick[0] == 'm') return false;  // "valu" / "mfma": the exact f32 kernels
+    return model == TRANSE && (D == 64 || D == 128 || D == 256) && q_head + q_tail >= 256;
+}
+
+size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
+    if (!rank_sad_applicable(model, D, q_head, q_tail)) return 0;
+    return carve_sad(nullptr, D, N, q_head, q_tail).bytes;
+}
+
+template <int D>
+static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
+                                const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
+                                const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts, void* workspace,
+                                int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    constexpr int TPW = sad_tiles_per_wave(D);
+    const int64_t Q = q_head + q_tail;
+    SadWorkspace w = carve_sad(workspace, D, N, q_head, q_tail);
+    hipError_t err = hipMemsetAsync(w.acc, 0, (size_t)Q * 8, stream);
+    if (err != hipSuccess) return err;
+    err = launch_exact_prep(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.coef_head,
+                            w.coef_tail, w.key_true, stream);
+    if (err != hipSuccess) return err;
+    if (ev_start) (void)hipEventRecord(ev_start, stream);
+    const int64_t n_tiles = (N + 63) / 64;
+    sad_init_kernel<<<1, 1, 0, stream>>>(w.params);
+    {
+        const int64_t items = N * (D / 4) > Q * D ? N * (D / 4) : Q * D;
+        int64_t blocks = (items + 255) / 256;
+        blocks = blocks < (int64_t)n_cu * 8 ? blocks : (int64_t)n_cu * 8;
+        sad_range_kernel<D><<<dim3((unsigned)(blocks > 0 ? blocks : 1)), 256, 0, stream>>>(table, N, ld, q_fixed, q_rel,
+                                                                                           q_head, Q, w.params);
+    }
+    if (n_tiles > 0)
+        sad_quantize_table_kernel<D><<<dim3((unsigned)n_tiles), 256, 0, stream>>>(table, N, ld, w.params, w.cimg);
+    sad_quantize_queries_kernel<D><<<dim3((unsigned)((Q * (D / 2) + 255) / 256)), 256, 0, stream>>>(
+        q_fixed, q_rel, q_head, Q, w.key_true, w.params, w.qimg, w.thr);
+
+    const int64_t tiles_per_group = kSW * TPW;
+    const int64_t n_chunks = (Q + kSChunk - 1) / kSChunk;
+    const int64_t pass_rows = w.pass_groups * tiles_per_group * 64;
+    for (int64_t slab0 = 0; slab0 < N; slab0 += pass_rows) {  // one iteration unless the caps bind
+        const int64_t n_rows = N - slab0 < pass_rows ? N - slab0 : pass_rows;
+        const int64_t slab_tiles = (n_rows + 63) / 64;
+        const int64_t n_groups = (slab_tiles + tiles_per_group - 1) / tiles_per_group;
+        const int words = (int)((n_groups * tiles_per_group + 31) / 32);
+        const int64_t n_blocks = n_groups * n_chunks;
+        err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
+        if (err != hipSuccess) return err;
+        err = hipMemsetAsync(&w.params->n_pairs, 0, 4, stream);
+        if (err != hipSuccess) return err;
+        const float* slab = table + slab0 * ld;
+        rank_sad_kernel<D, TPW><<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
+            w.cimg + (slab0 / 64) * (D / 8) * 64, n_rows, (int)n_groups, w.qimg, w.thr, Q, words, w.acc, w.flags,
+            w.pairs, w.params);
+        sad_refine_pairs_kernel<D><<<dim3((unsigned)((n_blocks * kSQuota + 255) / 256)), 256, 0, stream>>>(
+            slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, w.params, w.acc);
+        sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
+            slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
+    }
+    if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+    const bool filtered = filt_rowptr != nullptr;
+    if (filtered) {
+        err = launch_exact_filter(TRANSE, D, table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
+                                  filt_rowptr, filt_col, w.acc_f, stream);
+        if (err != hipSuccess) return err;
+    }
+    err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);
+    return err != hipSuccess ? err : hipGetLastError();
+}
+
+hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                               const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                               int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                               void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                               hipEvent_t ev_stop) {
+#define BLP_SAD_CASE(DD)                                                                                          \
+    if (D == DD)                                                                                                  \
+        return rank_sad_impl<DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,     \
+                                 filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    BLP_SAD_CASE(64) BLP_SAD_CASE(128) BLP_SAD_CASE(256)
+#undef BLP_SAD_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace blp

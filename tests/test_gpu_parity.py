@@ -111,6 +111,84 @@ def test_random_vs_oracle_ragged(ops, oracle, model, D):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+def test_transe_exact_kernels_many_queries(ops, oracle, D, kernel, monkeypatch):
+    """Q >= 256 TransE normally takes the fixed-point pre-pass; BLP_RANK_KERNEL selects the exact f32
+    kernels (hand-pipelined VALU, MFMA) for the same block.  Same counts."""
+    monkeypatch.setenv("BLP_RANK_KERNEL", kernel)
+    N, q_head, q_tail = 1000 + D // 64, 300, 41
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=D + 3)
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_sad_band_adversarial(ops, oracle, D):
+    """The fixed-point pre-pass (TransE, Q >= 256) on inputs built to land inside its band: duplicated
+    rows (exact ties with the true entity), dyadic values, rows nudged by 2^-20 (near-ties far below
+    the 16-bit resolution), an all-zero row and an outlier row that stretches the quantisation range."""
+    g = torch.Generator().manual_seed(D)
+    N, q_head, q_tail = 900, 150, 170
+    base = torch.randint(-8, 9, (N // 4, D), generator=g).float() / 8.0
+    table = base.repeat(4, 1)[torch.randperm(4 * (N // 4), generator=g)]
+    table[::7] *= (1.0 + 2.0 ** -20)
+    table[3::11] *= (1.0 - 2.0 ** -20)
+    table[5] = 0.0
+    table[6] *= 40.0
+    N = table.shape[0]
+    Q = q_head + q_tail
+    q_fixed = table[torch.randint(0, N, (Q,), generator=g)].clone()
+    q_rel = torch.randint(-16, 17, (Q, D), generator=g).float() / 16.0
+    true_row = torch.randint(0, N, (Q,), generator=g)
+    rowptr, col = random_csr(Q, N, true_row.numpy(), seed=D + 1)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert (want[:, 1] - want[:, 0]).max() > 1  # real ties: the > / >= split must survive
+
+
+@pytest.mark.parametrize("case", ["nan", "inf", "constant", "huge", "all_ties"])
+def test_sad_degenerate_inputs_stay_exact(ops, oracle, case):
+    """Non-finite values or a zero-width range switch the pre-pass off (every tile is refined exactly);
+    values near FLT_MAX and an all-ties table go through it.  Counts equal the oracle's in all cases."""
+    D, N, q_head, q_tail = 128, 700, 130, 140
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=31)
+    if case == "nan":
+        table[17, 3] = float("nan"); q_rel[7, 9] = float("nan")
+    elif case == "inf":
+        table[40, 5] = float("inf"); q_fixed[50] = table[40]
+    elif case == "constant":
+        table[:] = 0.25; q_fixed[:] = 0.25; q_rel[:] = 0.0
+    elif case == "huge":
+        table[11] = 1e37; table[12] = -1e37
+    elif case == "all_ties":
+        table[:] = table[0]
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row)
+    got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_sad_candidate_slabs_and_shard_vectors(ops, oracle, monkeypatch):
+    """BLP_SAD_PASS_GROUPS=1 forces 512-candidate slabs (ragged last slab); q_true instead of true_row
+    (the form a candidate shard sees) gives the same counts."""
+    D, N, q_head, q_tail = 128, 2000 + 37, 170, 190
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=29)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row)
+    args = ("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+    one_pass = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+    by_vector = ops.rank_all(*args, q_true=table[true_row].cuda()).cpu().numpy()
+    monkeypatch.setenv("BLP_SAD_PASS_GROUPS", "1")
+    slabs = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+    assert np.array_equal(one_pass, want)
+    assert np.array_equal(by_vector, want)
+    assert np.array_equal(slabs, want)
+
+
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
 @pytest.mark.parametrize("D", [64, 128])
 def test_gemm_band_adversarial(ops, oracle, model, D):
