@@ -10,13 +10,16 @@
 //   prep    one affine map x^ = rint((x - lo) s) in [0, 65535] for the whole call (lo, hi = range of the
 //           table and of the query coefficients c = h + r | t - r); candidate rows are packed two
 //           elements per dword into a lane-major tile image, query coefficients into 2-byte rows.
-//   pass 1  SAD(q, c) = sum_k |c^_k - e^_k| (exact integer), so |SAD - s X| <= 1.02 D for the real-number
-//           distance X = sum_k |c_k - e_k|.  The reference score S_ref is -X up to f32 rounding:
+//   pass 1  SAD(q, c) = sum_k |c^_k - e^_k| (exact integer), so |SAD - s X| <= E_q + E_c for the real-number
+//           distance X = sum_k |c_k - e_k|, where E_row = sum_k |x^_k - (x_k - lo) s| is the row's own
+//           rounding residual (~D/4, at most 0.508 D; measured while quantising, rounded up, kept per
+//           candidate row and folded into the thresholds per query).  The reference score S_ref is -X
+//           up to f32 rounding:
 //           |S_ref + X| <= gamma X + rho (gamma = (D+2) u, rho = 6 D u M, M = max |value|; the head side's
 //           extra rounding of e + r and of t - r is inside rho).  Against the EXACT true-entity key
 //           s_true = -d_t this gives two integer thresholds per query:
-//              SAD < T_lo  -> certainly ranked above (count it)
-//              SAD > T_hi  -> certainly below        (ignore it)
+//              SAD + E_c < T_lo  -> certainly ranked above (count it)
+//              SAD - E_c > T_hi  -> certainly below        (ignore it)
 //              otherwise   -> undecided: listed as a (query, row) pair
 //           Undecided pairs are ~0.2 % for FB15k-237-like data.  A workgroup lists up to kSQuota pairs;
 //           beyond that the (query, 64-candidate tile) segment contributes nothing and its bit is set in
@@ -40,7 +43,7 @@ namespace blp {
 constexpr int kSW = 4;                       // waves per workgroup
 constexpr int kSChunk = 128;                 // queries per workgroup
 constexpr int kSQuota = 512;                 // undecided pairs a workgroup can list
-constexpr unsigned kSInvalid = 0x40000000u;  // accumulator bias of padding rows: beyond every T_hi
+constexpr unsigned kSInvalid = 0x40001000u;  // accumulator bias of padding rows: beyond every T_hi + E_c
 constexpr unsigned kSThrMax = 0x3fffffffu;
 constexpr unsigned kSNoPair = 0xFFFFFFFFu;
 
@@ -51,6 +54,7 @@ struct SadParams {
     unsigned n_pairs;       // pairs listed in the current pass
     unsigned pad[3];
 };
+constexpr int kSRangeBlocks = 1024;  // partial results of the range pass
 
 __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
@@ -67,27 +71,23 @@ __device__ __forceinline__ SadScale sad_scale(const SadParams* __restrict__ p) {
     return s;
 }
 
-// |x^ - (x - lo) s| <= 0.5 + 65535 (2u + u^2) < 0.508 for every x in [lo, hi]
-__device__ __forceinline__ unsigned sad_quant(float x, const SadScale& s) {
-    const float v = rintf((x - s.lo) * s.scale);
-    return (unsigned)fminf(fmaxf(v, 0.f), 65535.f);
+// x^ = rint(v), v = fl(fl(x - lo) s): |v - (x - lo) s| <= 65535 (2u + u^2) < 0.0079 for every x in
+// [lo, hi], and v - x^ is exact in f32, so |x^ - (x - lo) s| <= resid + 0.0079 with resid += |v - x^|.
+__device__ __forceinline__ unsigned sad_quant(float x, const SadScale& s, float& resid) {
+    const float v = fminf(fmaxf((x - s.lo) * s.scale, 0.f), 65535.f);
+    const float r = rintf(v);
+    resid += fabsf(v - r);
+    return (unsigned)r;
 }
+constexpr float kSResidSlack = 0.0079f;  // per element, see sad_quant
 
 __device__ __forceinline__ float sad_coef(float fixed, float rel, bool head) { return head ? fixed - rel : fixed + rel; }
-
-__global__ void sad_init_kernel(SadParams* p) {
-    p->lo_ord = 0x7fffffff;
-    p->hi_ord = (int)0x80000000;
-    p->maxabs_bits = 0;
-    p->nonfinite = 0;
-    p->n_pairs = 0;
-}
 
 template <int D>
 __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
                                                         const float* __restrict__ q_fixed,
                                                         const float* __restrict__ q_rel, int64_t q_head, int64_t Q,
-                                                        SadParams* __restrict__ p) {
+                                                        SadParams* __restrict__ partial) {
     int lo = 0x7fffffff, hi = (int)0x80000000;
     float maxabs = 0.f;
     bool bad = false;
@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict_
         lo = lo_keep; hi = hi_keep;
         see(sad_coef(f, r, i / D < q_head));
     }
+    __shared__ int s_lo[4], s_hi[4];
+    __shared__ float s_max[4];
+    __shared__ int s_bad[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
@@ -120,19 +123,59 @@ __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict_
         maxabs = m2 > maxabs ? m2 : maxabs;
     }
     const bool any_bad = __any(bad);
-    if ((threadIdx.x & 63) == 0) {
-        if (lo <= hi) { atomicMin(&p->lo_ord, lo); atomicMax(&p->hi_ord, hi); }
-        atomicMax(&p->maxabs_bits, __float_as_uint(maxabs));
-        if (any_bad) atomicOr(&p->nonfinite, 1u);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_max[wave] = maxabs; s_bad[wave] = any_bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SadParams p = {};
+        p.lo_ord = 0x7fffffff; p.hi_ord = (int)0x80000000;
+        float m = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            p.lo_ord = s_lo[w] < p.lo_ord ? s_lo[w] : p.lo_ord;
+            p.hi_ord = s_hi[w] > p.hi_ord ? s_hi[w] : p.hi_ord;
+            m = s_max[w] > m ? s_max[w] : m;
+            p.nonfinite |= (unsigned)s_bad[w];
+        }
+        p.maxabs_bits = __float_as_uint(m);
+        partial[blockIdx.x] = p;
+    }
+}
+
+__global__ __launch_bounds__(64) void sad_range_finish_kernel(const SadParams* __restrict__ partial, int n,
+                                                              SadParams* __restrict__ out) {
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    unsigned m = 0, bad = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const SadParams p = partial[i];
+        lo = p.lo_ord < lo ? p.lo_ord : lo;
+        hi = p.hi_ord > hi ? p.hi_ord : hi;
+        m = p.maxabs_bits > m ? p.maxabs_bits : m;  // non-negative floats order like their bits
+        bad |= p.nonfinite;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        const unsigned m2 = __shfl_xor(m, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        m = m2 > m ? m2 : m;
+        bad |= __shfl_xor(bad, off);
+    }
+    if (threadIdx.x == 0) {
+        SadParams p = {};
+        p.lo_ord = lo; p.hi_ord = hi; p.maxabs_bits = m; p.nonfinite = bad;
+        *out = p;
     }
 }
 
 // Candidate tile image: 64 rows per tile, uint4 index ((tile * D/8 + j4) * 64 + lane) holds dwords
 // 4 j4 .. 4 j4 + 3 of row (tile * 64 + lane); dword j packs elements 2j (low half) and 2j + 1.
+// resid[row] = the row's rounding residual E_c, rounded up to an integer.
 template <int D>
 __global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __restrict__ table, int64_t N,
                                                                  int64_t ld, const SadParams* __restrict__ p,
-                                                                 uint4* __restrict__ cimg) {
+                                                                 uint4* __restrict__ cimg,
+                                                                 unsigned* __restrict__ resid) {
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
     const int64_t tile = blockIdx.x;
@@ -140,52 +183,73 @@ __global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __
     const int64_t row = tile * 64 + row_in;
     constexpr int F = D / 4;  // floats per thread
     unsigned w[F / 2];
+    float res = 0.f;
     if (row < N) {
         const float* src = table + row * ld + part * F;
 #pragma unroll
         for (int i = 0; i < F / 4; ++i) {
             const float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
-            w[2 * i] = sad_quant(v.x, sc) | (sad_quant(v.y, sc) << 16);
-            w[2 * i + 1] = sad_quant(v.z, sc) | (sad_quant(v.w, sc) << 16);
+            w[2 * i] = sad_quant(v.x, sc, res);
+            w[2 * i] |= sad_quant(v.y, sc, res) << 16;
+            w[2 * i + 1] = sad_quant(v.z, sc, res);
+            w[2 * i + 1] |= sad_quant(v.w, sc, res) << 16;
         }
     } else {
 #pragma unroll
         for (int i = 0; i < F / 2; ++i) w[i] = 0;
     }
+    res += __shfl_xor(res, 1);
+    res += __shfl_xor(res, 2);
+    if (part == 0) resid[row] = (unsigned)(res * 1.0001f + kSResidSlack * D) + 1u;  // image is padded to whole tiles
     uint4* dst = cimg + (tile * (D / 8) + part * (F / 8)) * 64 + row_in;
 #pragma unroll
     for (int i = 0; i < F / 8; ++i) dst[i * 64] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
-// Query image (D/2 dwords per query, same packing) and the two thresholds {T_lo, T_hi - T_lo}.
+// Query image (D/2 dwords per query, same packing) and the two signed thresholds {T_lo, T_hi}.
+// D/2 consecutive threads per query (32, 64 or 128: whole waves or half-waves).
 template <int D>
 __global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const float* __restrict__ q_fixed,
                                                                    const float* __restrict__ q_rel, int64_t q_head,
                                                                    int64_t Q, const float* __restrict__ key_true,
                                                                    const SadParams* __restrict__ p,
                                                                    unsigned* __restrict__ qimg,
-                                                                   uint2* __restrict__ thr) {
+                                                                   int2* __restrict__ thr) {
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
+    __shared__ float part_res[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Q * (D / 2)) return;
-    const int64_t q = i / (D / 2);
+    const bool live = i < Q * (D / 2);
+    const int64_t q = live ? i / (D / 2) : Q - 1;
     const bool head = q < q_head;
-    const float2 f = *reinterpret_cast<const float2*>(q_fixed + 2 * i);
-    const float2 r = *reinterpret_cast<const float2*>(q_rel + 2 * i);
-    qimg[i] = sad_quant(sad_coef(f.x, r.x, head), sc) | (sad_quant(sad_coef(f.y, r.y, head), sc) << 16);
-    if (i % (D / 2) == 0) {
+    float res = 0.f;
+    if (live) {
+        const float2 f = *reinterpret_cast<const float2*>(q_fixed + 2 * i);
+        const float2 r = *reinterpret_cast<const float2*>(q_rel + 2 * i);
+        unsigned w = sad_quant(sad_coef(f.x, r.x, head), sc, res);
+        w |= sad_quant(sad_coef(f.y, r.y, head), sc, res) << 16;
+        qimg[i] = w;
+    }
+#pragma unroll
+    for (int off = 1; off < (D / 2 < 64 ? D / 2 : 64); off <<= 1) res += __shfl_xor(res, off);
+    if constexpr (D / 2 > 64) {  // D = 256: two waves per query
+        if ((threadIdx.x & 63) == 0) part_res[threadIdx.x >> 6] = res;
+        __syncthreads();
+        res = part_res[(threadIdx.x >> 6) & ~1] + part_res[(threadIdx.x >> 6) | 1];
+    }
+    if (live && i % (D / 2) == 0) {
         const double u = 5.9604644775390625e-8;
         const double dt = -(double)key_true[q], s = (double)sc.scale, M = (double)__uint_as_float(p->maxabs_bits);
-        const double band = 1.03 * D, gamma = 1.05 * (D + 2) * u, rho = 6.0 * D * u * M;
-        unsigned t_lo = 0, t_hi = kSThrMax;
+        const double band = (double)res * 1.0001 + 2.0 * kSResidSlack * D + 1.0;  // E_q + both sides' slack
+        const double gamma = 1.05 * (D + 2) * u, rho = 6.0 * D * u * M;
+        int t_lo = -1, t_hi = (int)kSThrMax;  // nothing decided
         if (dt >= 0.0 && dt < 1.0e300) {  // false for NaN
-            const double lo_v = s * (dt - rho) / (1.0 + gamma) - band;   // SAD below this: certainly above
-            const double hi_v = s * (dt + rho) / (1.0 - gamma) + band;   // SAD above this: certainly below
-            if (lo_v > 2.0) t_lo = lo_v - 1.0 < (double)kSThrMax ? (unsigned)(lo_v - 1.0) : kSThrMax;
-            if (hi_v + 2.0 < (double)kSThrMax) t_hi = (unsigned)(hi_v + 2.0);
+            const double lo_v = s * (dt - rho) / (1.0 + gamma) - band;   // SAD + E_c below this: certainly above
+            const double hi_v = s * (dt + rho) / (1.0 - gamma) + band;   // SAD - E_c above this: certainly below
+            if (lo_v > 2.0) t_lo = lo_v - 1.0 < (double)kSThrMax ? (int)(lo_v - 1.0) : (int)kSThrMax;
+            if (hi_v + 2.0 < (double)kSThrMax) t_hi = (int)(hi_v + 2.0);
         }
-        thr[q] = make_uint2(t_lo, t_hi - t_lo);
+        thr[q] = make_int2(t_lo, t_hi);
     }
 }
 
@@ -193,16 +257,18 @@ __global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const float* 
 template <int D, int TPW>
 struct SadTiles {
     unsigned v[TPW][D / 2];
-    unsigned bias[TPW];
+    unsigned bias[TPW];  // accumulator start: 0, or kSInvalid for padding rows
+    unsigned ec[TPW];    // the row's rounding residual E_c
 };
 
 template <int D, int TPW>
-__global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 128 ? 3 : 2)) void rank_sad_kernel(
-    const uint4* __restrict__ cimg, int64_t n_rows, int n_groups, const unsigned* __restrict__ qimg,
-    const uint2* __restrict__ thr, int64_t Q, int words_per_query, unsigned long long* __restrict__ acc,
+__global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 128 ? 3 : 2)) void rank_sad_kernel(
+    const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups,
+    const unsigned* __restrict__ qimg, const int2* __restrict__ thr, int64_t Q, int words_per_query,
+    unsigned long long* __restrict__ acc,
     unsigned* __restrict__ flags, uint2* __restrict__ pairs, SadParams* __restrict__ params) {
     if (!sad_scale(params).ok) return;
-    __shared__ uint2 thr_s[kSChunk];
+    __shared__ int2 thr_s[kSChunk];
     __shared__ unsigned cnt[kSChunk];
     __shared__ uint2 pair_s[kSQuota];
     __shared__ unsigned pair_n, pair_base;
@@ -214,7 +280,7 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 128 ? 3 : 2)) void rank_s
     const int nq = (int)(Q - q0 < kSChunk ? Q - q0 : kSChunk);
 
     for (int i = tid; i < kSChunk; i += kSW * 64) {
-        thr_s[i] = i < nq ? thr[q0 + i] : make_uint2(0u, 0u);
+        thr_s[i] = i < nq ? thr[q0 + i] : make_int2(0, 0);
         cnt[i] = 0;
     }
     for (int i = tid; i < kSQuota; i += kSW * 64) pair_s[i] = make_uint2(kSNoPair, 0u);
@@ -229,6 +295,7 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 128 ? 3 : 2)) void rank_s
         int64_t tile = tile0 + t;
         c.bias[t] = tile * 64 + lane < n_rows ? 0u : kSInvalid;
         tile = tile < n_tiles ? tile : n_tiles - 1;
+        c.ec[t] = resid[tile * 64 + lane];
         const uint4* src = cimg + tile * (D / 8) * 64 + lane;
         static_for<D / 8>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -246,7 +313,7 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 128 ? 3 : 2)) void rank_s
         const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * (D / 2);
         // the four waves walk the same rows: they take turns touching the lines of the query three ahead
         const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * (D / 2) : row;
-        const uint2 th = thr_s[j];
+        const int2 th = thr_s[j];
         unsigned sad[TPW];
         static_for<TPW>([&](auto tt) { sad[decltype(tt)::value] = c.bias[decltype(tt)::value]; });
         static_for<D / 32>([&](auto kk) {
@@ -269,8 +336,9 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 128 ? 3 : 2)) void rank_s
         unsigned n_above = 0;
         static_for<TPW>([&](auto tt) {
             constexpr int t = decltype(tt)::value;
-            const unsigned long long und = __ballot(sad[t] - th.x <= th.y);
-            unsigned n_t = __popcll(__ballot(sad[t] < th.x));
+            const unsigned long long above = __ballot((int)(sad[t] + c.ec[t]) < th.x);
+            const unsigned long long und = __ballot((int)(sad[t] - c.ec[t]) <= th.y) & ~above;
+            unsigned n_t = __popcll(above);
             if (und) {  // wave-uniform
                 const unsigned n = __popcll(und);
                 unsigned slot = 0;
@@ -378,12 +446,13 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-static constexpr int sad_tiles_per_wave(int D) { return D <= 128 ? 2 : 1; }
+static constexpr int sad_tiles_per_wave(int D) { return D <= 64 ? 2 : 1; }
 
 struct SadWorkspace {
     float* coef_head; float* coef_tail; float* key_true;
     unsigned long long* acc; unsigned long long* acc_f;
-    SadParams* params; uint2* thr; unsigned* qimg; uint4* cimg; unsigned* flags; uint2* pairs;
+    SadParams* params; SadParams* partial; int2* thr; unsigned* qimg; uint4* cimg; unsigned* resid; unsigned* flags;
+    uint2* pairs;
     int64_t pass_groups;  // candidate groups (kSW * TPW tiles) per pre-pass + refine pass
     size_t bytes;
 };
@@ -419,9 +488,11 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
     w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
     w.params = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams), 256);
-    w.thr = reinterpret_cast<uint2*>(p + off);        off = align_up(off + (size_t)Q * 8, 256);
+    w.partial = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams) * kSRangeBlocks, 256);
+    w.thr = reinterpret_cast<int2*>(p + off);         off = align_up(off + (size_t)Q * 8, 256);
     w.qimg = reinterpret_cast<unsigned*>(p + off);    off = align_up(off + (size_t)Q * (D / 2) * 4 + 64, 256);
     w.cimg = reinterpret_cast<uint4*>(p + off);       off = align_up(off + (size_t)((N + 63) / 64) * 64 * (D / 2) * 4, 256);
+    w.resid = reinterpret_cast<unsigned*>(p + off);   off = align_up(off + (size_t)((N + 63) / 64) * 64 * 4, 256);
     w.pass_groups = sad_groups_per_pass(D, N, Q);
     const int64_t tiles_per_group = kSW * sad_tiles_per_wave(D);
     const int64_t words = (w.pass_groups * tiles_per_group + 31) / 32;
@@ -459,16 +530,15 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     if (err != hipSuccess) return err;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     const int64_t n_tiles = (N + 63) / 64;
-    sad_init_kernel<<<1, 1, 0, stream>>>(w.params);
     {
         const int64_t items = N * (D / 4) > Q * D ? N * (D / 4) : Q * D;
         int64_t blocks = (items + 255) / 256;
-        blocks = blocks < (int64_t)n_cu * 8 ? blocks : (int64_t)n_cu * 8;
-        sad_range_kernel<D><<<dim3((unsigned)(blocks > 0 ? blocks : 1)), 256, 0, stream>>>(table, N, ld, q_fixed, q_rel,
-                                                                                           q_head, Q, w.params);
+        blocks = blocks < kSRangeBlocks ? (blocks > 0 ? blocks : 1) : kSRangeBlocks;
+        sad_range_kernel<D><<<dim3((unsigned)blocks), 256, 0, stream>>>(table, N, ld, q_fixed, q_rel, q_head, Q, w.partial);
+        sad_range_finish_kernel<<<1, 64, 0, stream>>>(w.partial, (int)blocks, w.params);
     }
     if (n_tiles > 0)
-        sad_quantize_table_kernel<D><<<dim3((unsigned)n_tiles), 256, 0, stream>>>(table, N, ld, w.params, w.cimg);
+        sad_quantize_table_kernel<D><<<dim3((unsigned)n_tiles), 256, 0, stream>>>(table, N, ld, w.params, w.cimg, w.resid);
     sad_quantize_queries_kernel<D><<<dim3((unsigned)((Q * (D / 2) + 255) / 256)), 256, 0, stream>>>(
         q_fixed, q_rel, q_head, Q, w.key_true, w.params, w.qimg, w.thr);
 
@@ -487,8 +557,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         if (err != hipSuccess) return err;
         const float* slab = table + slab0 * ld;
         rank_sad_kernel<D, TPW><<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
-            w.cimg + (slab0 / 64) * (D / 8) * 64, n_rows, (int)n_groups, w.qimg, w.thr, Q, words, w.acc, w.flags,
-            w.pairs, w.params);
+            w.cimg + (slab0 / 64) * (D / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, words, w.acc,
+            w.flags, w.pairs, w.params);
         sad_refine_pairs_kernel<D><<<dim3((unsigned)((n_blocks * kSQuota + 255) / 256)), 256, 0, stream>>>(
             slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, w.params, w.acc);
         sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
