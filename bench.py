@@ -46,11 +46,11 @@ WORKLOADS = {
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=2, passes=64),
 }
 # Algorithmic f32 operations per (candidate, query, element), head-side / tail-side:
-# TransE: one subtract and one |.|-accumulate once the query-only part is hoisted (h + r per query on
-# the tail side, e + r per (candidate, relation) on the head side); bilinear models: the all-entities
+# TransE: one subtract and one |.|-accumulate once the query-only part is hoisted (h + r | t - r per
+# query); bilinear models: the all-entities
 # score is a (Q x D) . (D x N) GEMM = 2 flops per (pair, element).
 OPS_PER_ELEM = {"transe": (2, 2), "distmult": (2, 2), "complex": (2, 2), "simple": (2, 2)}
-DOMINANT_KERNEL = {"transe": "rank_tiles_kernel<TRANSE,128,many-query> (lane-per-candidate VALU, scalar-cache coefficients)",
+DOMINANT_KERNEL = {"transe": "rank_sad_kernel<128> + sad_refine_* (u16 fixed-point v_sad_u16 pre-pass + band + exact f32 refinement; prep kernels included)",
                    "distmult": "rank_gemm_kernel<DISTMULT,128> + refine_kernel (f32 MFMA GEMM + band + exact refinement)",
                    "complex": "rank_gemm_kernel<COMPLEX,128> + refine_kernel",
                    "simple": "rank_gemm_kernel<SIMPLE,128> + refine_kernel"}
@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--workload", default="fb15k237-transe", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
+    ap.add_argument("--shard-axis", default="auto", choices=["auto", "candidate", "query"],
+                    help="N > 1: which axis to shard (default: what blp_amd.ranking.choose_shard_axis picks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,7 +223,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    from blp_amd import _lib, ops
+    from blp_amd import _lib, ops, ranking
 
     cfg = WORKLOADS[args.workload]
     model, N, D = cfg["model"], cfg["N"], cfg["D"]
@@ -229,18 +231,35 @@ def main():
     q_fixed, q_rel, true_row = build_queries(table, rel_w, heads, tails, rels)
     q_head = heads.shape[0]
     Q = q_fixed.shape[0]
-    q_true = table[true_row].contiguous() if world > 1 else None
     rel_ids = torch.cat((rels, rels)).contiguous()
-    per = (N + world - 1) // world
-    lo, hi = min(rank * per, N), min((rank + 1) * per, N)
-    shard = table[lo:hi]
-    gathered = torch.empty((world, Q, 4), dtype=torch.int32, device=device) if world > 1 else None
     passes = cfg["passes"]
+    # N > 1: shard along the axis blp_amd.ranking would pick for this shape (see choose_shard_axis).
+    #   "candidate": rank r ranks every query against table rows [lo, hi); ONE all-gather of the int32
+    #                counts + a sum per pass.  Right when the table pass dominates (Wikidata5M).
+    #   "query":     the table is replicated (inputs resident: like the table build itself, its one
+    #                all-gather per evaluation happens before the hot path), rank r ranks its slice of
+    #                the test triples against the whole table; the only collective is the all-reduce
+    #                of four metric sums.  Right when per-query work dominates (FB15k-237).
+    axis = ranking.choose_shard_axis(N, D, Q, world)
+    if args.shard_axis != "auto" and world > 1:
+        axis = args.shard_axis
+    lo, hi = ranking.shard_bounds(N, world, rank) if axis == "candidate" else (0, N)
+    shard = table[lo:hi]
+    if world > 1 and axis == "query":
+        t_lo, t_hi = ranking.shard_bounds(q_head, world, rank)
+        pick = torch.cat((torch.arange(t_lo, t_hi), torch.arange(q_head + t_lo, q_head + t_hi))).to(device)
+        q_fixed, q_rel, true_row, rel_ids = q_fixed[pick].contiguous(), q_rel[pick].contiguous(), true_row[pick], rel_ids[pick]
+        Q_global, q_head = Q, t_hi - t_lo
+        Q = q_fixed.shape[0]
+    else:
+        Q_global = Q
+    q_true = table[true_row].contiguous() if (world > 1 and axis == "candidate") else None
+    gathered = torch.empty((world, Q, 4), dtype=torch.int32, device=device) if q_true is not None else None
 
     def step():
         out = None
         for _ in range(passes):
-            if world > 1:
+            if q_true is not None:
                 local = ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids)
                 if backend == "gloo":
                     parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
@@ -252,7 +271,15 @@ def main():
             else:
                 counts = ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids)
             rr, hits = ops.rank_metrics(counts)
-            out = (counts, rr[:, 0].double().mean(), hits[:, 0].double().mean(dim=0))
+            sums = torch.cat((rr[:, :1].double().sum(dim=0), hits[:, 0].double().sum(dim=0)))
+            if world > 1 and axis == "query":
+                if backend == "gloo":
+                    host = sums.cpu()
+                    dist.all_reduce(host)
+                    sums = host.to(device)
+                else:
+                    dist.all_reduce(sums)
+            out = (counts, sums[0] / Q_global, sums[1:] / Q_global)
         return out
 
     def fence():
@@ -280,7 +307,7 @@ def main():
     for _ in range(max(1, min(args.steps, 10)) * passes):
         a, b = events.pair()
         _lib.check(_lib.lib().blp_profile_next_rank_kernel(a, b), "blp_profile_next_rank_kernel")
-        if world > 1:
+        if q_true is not None:
             ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids)
         else:
             ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids)
@@ -290,7 +317,7 @@ def main():
 
     if rank == 0:
         n_local = hi - lo
-        scored = float(Q) * N * passes
+        scored = float(Q_global) * N * passes
         ops_h, ops_t = OPS_PER_ELEM[model]
         alg_flops = n_local * D * (q_head * ops_h + (Q - q_head) * ops_t)
         alg_bytes = n_local * D * 4 + Q * (2 * D * 4 + 24)
@@ -301,9 +328,11 @@ def main():
         else:
             roofline = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s",
-                        "note": ("f32 compute roof: 157.3 TF is both the f32 MFMA peak and the f32 vector-FMA peak; "
-                                 "they share the SIMD's FP32 units (measured: no MFMA/VALU overlap). TransE's exact L1 "
-                                 "is add/sub/|.| work with no multiply to fuse, so its ceiling is half of it (78.6 Tops/s)."
+                        "note": ("VALU roof, not MFMA (an L1 norm has no matrix-core form): 157.3 Tops/s is the f32 vector-FMA "
+                                 "peak and also what v_sad_u16 delivers at its 4 cycles/instruction (2 elements x "
+                                 "(subtract + |.|-accumulate) x 64 lanes); the exact f32 add/sub kernel tops out at half "
+                                 "of it. achieved = 2 ops x D x Q x N / time of the whole rank pass (range + quantise + "
+                                 "SAD pre-pass + exact refinement of the undecided pairs)."
                                  if model == "transe" else
                                  "f32 MFMA GEMM (exact f32 fma chain) + error band; refinement of undecided "
                                  "(query, 32-candidate) segments is included in the kernel time.")}
@@ -327,8 +356,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic (seeded randn table, Xavier rel_emb, uniform random test triples)",
             "config": {"workload": args.workload, "rel_model": model, "entities": N, "dim": D,
-                       "queries_per_step": Q * passes, "table_passes_per_step": passes,
-                       "parallelism": f"candidate-axis shards x{world}" if world > 1 else "single GPU"},
+                       "queries_per_step": Q_global * passes, "table_passes_per_step": passes,
+                       "parallelism": f"{axis}-axis shards x{world}" if world > 1 else "single GPU"},
             "mrr": mrr.item(),
             "hits@1,3,10": [x.item() for x in hits],
             "roofline": roofline,

@@ -378,19 +378,20 @@ __global__ __launch_bounds__(256) void sad_refine_pairs_kernel(const float* __re
                                                                const uint2* __restrict__ pairs,
                                                                const SadParams* __restrict__ params,
                                                                unsigned long long* __restrict__ acc) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= params->n_pairs) return;
-    const uint2 p = pairs[i];
-    if (p.x == kSNoPair) return;
-    const int64_t q = p.x;
-    float e[D];
-    load_row<D>(e, table + (int64_t)p.y * ld);
-    float key;
-    if (q < q_head) key = Scorer<TRANSE, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<TRANSE, HEAD, D>::C});
-    else key = Scorer<TRANSE, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<TRANSE, TAIL, D>::C});
-    const float kt = key_true[q];
-    const unsigned long long gt = key > kt, ge = key >= kt;
-    if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
+    const int64_t n = params->n_pairs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 p = pairs[i];
+        if (p.x == kSNoPair) continue;
+        const int64_t q = p.x;
+        float e[D];
+        load_row<D>(e, table + (int64_t)p.y * ld);
+        float key;
+        if (q < q_head) key = Scorer<TRANSE, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<TRANSE, HEAD, D>::C});
+        else key = Scorer<TRANSE, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<TRANSE, TAIL, D>::C});
+        const float kt = key_true[q];
+        const unsigned long long gt = key > kt, ge = key >= kt;
+        if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
+    }
 }
 
 // Pass 2b: one wave per query sweeps the query's flag words; every flagged 64-candidate tile is
@@ -559,7 +560,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         rank_sad_kernel<D, TPW><<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
             w.cimg + (slab0 / 64) * (D / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, words, w.acc,
             w.flags, w.pairs, w.params);
-        sad_refine_pairs_kernel<D><<<dim3((unsigned)((n_blocks * kSQuota + 255) / 256)), 256, 0, stream>>>(
+        const int64_t pair_blocks = (n_blocks * kSQuota + 255) / 256;
+        sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 16 ? pair_blocks : (int64_t)n_cu * 16)), 256, 0, stream>>>(
             slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, w.params, w.acc);
         sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);

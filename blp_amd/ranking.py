@@ -7,9 +7,15 @@ What changes relative to the reference, and what does not:
   * the (2B, N) score matrix, the dense (2B, N) filter mask and the per-batch ``.item()`` syncs are
     gone: a block of triples becomes a (2B, 4) int32 count tensor on the device (blp_amd.ops.rank_all
     with a CSR filter from utils.FilterIndex), metrics are reduced once at the end;
-  * with a process group, every rank keeps rows [lo, hi) of the entity table (and encodes only
-    those), query / true-entity vectors are replicated by one exchange, and the per-shard counts of
-    the whole evaluation are combined by ONE all-gather (RCCL over xGMI on GPUs; gloo in CPU tests).
+  * with a process group, every rank encodes only rows [lo, hi) of the entity table; the ranking is
+    then sharded along one of two axes (choose_shard_axis):
+      - "candidate" (big tables, e.g. Wikidata5M): every rank keeps its rows, query / true-entity
+        vectors are replicated by one exchange, and the per-shard counts of the whole evaluation
+        are combined by ONE all-gather + sum;
+      - "query" (small tables, many test triples, e.g. FB15k-237): the table shards are all-gathered
+        once, every rank ranks its slice of the test triples against the full table, and the
+        per-triple counts are all-gathered (no sum).  Per-query costs shrink with the world size too.
+    RCCL over xGMI on GPUs; gloo in the CPU tests.
 
 CPU tensors (the reference's CPU-runnable smoke configuration) take the reference's own dense route
 through score_fn + get_metrics.
@@ -123,6 +129,31 @@ def shard_bounds(num_rows, world_size, rank):
     return min(rank * per, num_rows), min((rank + 1) * per, num_rows)
 
 
+QUERY_AXIS_MAX_TABLE_BYTES = 256 << 20   # replicate the table only if it is this small ...
+QUERY_AXIS_MIN_QUERIES = 256             # ... and every rank still gets a many-query block
+
+
+def choose_shard_axis(num_rows, dim, num_queries, world_size):
+    """"query" when replicating the table is cheap and each rank keeps >= 256 queries (the regime
+    where per-query costs, not the table pass, dominate a candidate shard); else "candidate"."""
+    if world_size <= 1:
+        return "candidate"
+    small_table = num_rows * dim * 4 <= QUERY_AXIS_MAX_TABLE_BYTES
+    return "query" if small_table and num_queries // world_size >= QUERY_AXIS_MIN_QUERIES else "candidate"
+
+
+def all_gather_rows(local, num_rows, world_size, group=None):
+    """Row shards (shard_bounds layout) -> the full (num_rows, ...) tensor on every rank: ONE all-gather."""
+    if world_size == 1:
+        return local
+    per = (num_rows + world_size - 1) // world_size
+    padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    full = torch.empty((world_size * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, padded, group=group)
+    return full[:num_rows]
+
+
 class ShardedRanker:
     """Candidate-axis sharded ranking.  Rank r owns table rows [lo, hi); the per-shard
     count tensors add up exactly to the unsharded counts, so one all-gather of int32 counts per
@@ -212,9 +243,10 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
 @torch.no_grad()
 def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, emb_batch_size, _run, _log,
                          prefix="", max_num_batches=None, filtering_graph=None, new_entities=None,
-                         return_embeddings=False, device=None, group=None, block_size=8192):
+                         return_embeddings=False, device=None, group=None, block_size=8192, shard_axis="auto"):
     """Drop-in for train.eval_link_prediction (same positional arguments, metric names and return
-    value).  ``device`` defaults to the model's device; ``group`` enables candidate-axis sharding."""
+    value).  ``device`` defaults to the model's device; ``group`` (or an initialised default process
+    group) shards the evaluation, along ``shard_axis`` = "candidate" | "query" | "auto"."""
     model = _module(model)
     if device is None:
         device = next(model.parameters()).device
@@ -243,7 +275,6 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     was_training = model.training
     model.eval()
     table = build_entity_table(model, text_dataset, entities, emb_batch_size, device, _log, rows=(lo, hi))
-    ranker = ShardedRanker(model, table, num_entities, group) if sharded else None
 
     # every evaluated triple, in loader order (train.py:128-131)
     batches = []
@@ -261,14 +292,24 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     num_triples = triples.shape[0]
     _log.info("Computing metrics on set of triples")
 
+    axis = shard_axis if shard_axis != "auto" else choose_shard_axis(num_entities, table.shape[1], 2 * num_triples, world)
+    by_query = sharded and world > 1 and axis == "query"
+    if by_query:  # full table everywhere, this rank's slice of the triples
+        table = all_gather_rows(table, num_entities, world, group)
+        t_lo, t_hi = shard_bounds(num_triples, world, rank)
+        sharded = False
+    else:
+        t_lo, t_hi = 0, num_triples
+    ranker = ShardedRanker(model, table, num_entities, group) if sharded else None
+
     if sharded:  # replicate the vectors of every entity that occurs in a test triple: one exchange
         uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
         vectors = ranker.gather_rows(uniq)
         head_pos, tail_pos = inverse[:num_triples], inverse[num_triples:]
 
     counts_blocks = []
-    for start in range(0, num_triples, block_size):
-        sl = slice(start, min(start + block_size, num_triples))
+    for start in range(t_lo, t_hi, block_size):
+        sl = slice(start, min(start + block_size, t_hi))
         b = sl.stop - sl.start
         rel_vecs = model.rel_emb(triples[sl, 2].to(device))
         rel_ids = torch.cat((triples[sl, 2], triples[sl, 2]))
@@ -292,11 +333,14 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
             offset += 2 * b
 
     # per-block layout is [head queries | tail queries]; put every head query first, like one big batch
-    if counts_blocks:
-        sizes = [c.shape[0] // 2 for c in counts_blocks]
-        counts = torch.cat([c[:s] for c, s in zip(counts_blocks, sizes)] + [c[s:] for c, s in zip(counts_blocks, sizes)])
-    else:
-        counts = torch.zeros((0, 4), dtype=torch.int32, device=device)
+    sizes = [c.shape[0] // 2 for c in counts_blocks]
+    empty = [torch.zeros((0, 4), dtype=torch.int32, device=device)]
+    head_counts = torch.cat(empty + [c[:s] for c, s in zip(counts_blocks, sizes)])
+    tail_counts = torch.cat(empty + [c[s:] for c, s in zip(counts_blocks, sizes)])
+    if by_query:  # per-triple counts of every rank's slice: ONE all-gather for the whole evaluation
+        both = all_gather_rows(torch.cat((head_counts, tail_counts), dim=1), num_triples, world, group)
+        head_counts, tail_counts = both[:, :4], both[:, 4:]
+    counts = torch.cat((head_counts, tail_counts)).contiguous()
     rr, hits = metrics_from_counts(counts)
     num_predictions = 2 * num_triples
     _log.info(f"The total number of predictions is {num_predictions:,}")
@@ -347,11 +391,6 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
         model.train()
     if return_embeddings:
         if sharded and world > 1:  # the full table only on request: all-gather of the shards
-            per = (num_entities + world - 1) // world
-            padded = torch.zeros((per, table.shape[1]), dtype=table.dtype, device=device)
-            padded[: table.shape[0]] = table
-            full = torch.empty((world * per, table.shape[1]), dtype=table.dtype, device=device)
-            dist.all_gather_into_tensor(full, padded, group=group)
-            table = full[:num_entities]
+            table = all_gather_rows(table, num_entities, world, group)
         return mrr, table.unsqueeze(0)
     return mrr, None

@@ -83,10 +83,12 @@ def test_link_prediction_module_on_gpu_uses_fused_loss(name):
     np.testing.assert_allclose(model.rel_emb.weight.grad.cpu().numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
 
 
-def test_bench_two_ranks_share_one_gpu_functional():
-    """bench.py's N > 1 path (candidate shards, replicated true-entity vectors, count exchange, max-over-
-    ranks timing) run as 2 ranks on this one GPU with the gloo backend: the sharded MRR / Hits must
-    equal the single-rank ones exactly (integer counts add up)."""
+@pytest.mark.parametrize("axis", ["candidate", "query"])
+def test_bench_two_ranks_share_one_gpu_functional(axis):
+    """bench.py's N > 1 paths run as 2 ranks on this one GPU with the gloo backend.  Candidate shards:
+    replicated true-entity vectors, count exchange + sum.  Query shards: each rank ranks its slice of
+    the triples against the whole table, metric sums are all-reduced.  Either way the MRR / Hits must
+    equal the single-rank ones (integer counts; the f64 sum of the reciprocal ranks may reassociate)."""
     import json
     import os
     import subprocess
@@ -99,12 +101,14 @@ def test_bench_two_ranks_share_one_gpu_functional():
     env = dict(os.environ, BLP_BENCH_BACKEND="gloo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", *common], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+                          "--gpus", "2", "--shard-axis", axis, *common],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
     b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == 2 and a["n_gpus"] == 1
-    assert a["mrr"] == b["mrr"] and a["hits@1,3,10"] == b["hits@1,3,10"]
+    assert b["config"]["parallelism"] == f"{axis}-axis shards x2"
+    assert abs(a["mrr"] - b["mrr"]) < 1e-12 and a["hits@1,3,10"] == pytest.approx(b["hits@1,3,10"], abs=1e-12)
     assert b["parity_check"].endswith("identical counts")
 
 

@@ -65,6 +65,17 @@ def _worker(rank, world, port, rel_model, out_dir):
         for name, value in want.items():
             assert abs(run.scalars[name] - value) <= (0.0 if "hits" in name else 1e-6), (name, run.scalars[name], value)
         assert np.array_equal(ent_emb[0].numpy(), g["ent_emb"])
+        # the other axis: table replicated by one all-gather, the test triples sharded across ranks
+        run_q = _Run()
+        mrr_q, ent_emb_q = ranking.eval_link_prediction(emodel, loader, text, entities, 3, int(g["emb_batch_size"]),
+                                                        run_q, logging.getLogger("t"), prefix="test",
+                                                        filtering_graph=index, new_entities=new_ents,
+                                                        return_embeddings=True, block_size=5, shard_axis="query")
+        assert run_q.scalars == run.scalars and mrr_q == mrr
+        assert np.array_equal(ent_emb_q[0].numpy(), g["ent_emb"])
+        assert ranking.choose_shard_axis(14541, 128, 105740, 8) == "query"        # FB15k-237 test set
+        assert ranking.choose_shard_axis(4_600_000, 128, 10266, 8) == "candidate"  # Wikidata5M
+        assert ranking.choose_shard_axis(14541, 128, 128, 8) == "candidate"        # one reference batch
         np.save(os.path.join(out_dir, f"counts_{rank}.npy"), total.numpy())
     finally:
         dist.destroy_process_group()
