@@ -289,6 +289,269 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
     if (tid < kPairQuota) pairs[(size_t)blockIdx.x * kPairQuota + tid] = pair_s[tid];
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 x 3 variant of pass 1 (default): every f32 operand x is split into x = hi + lo + r with
+// hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|, and W . e is taken as w_hi e_hi + w_hi e_lo + w_lo e_hi
+// on v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in f32, the accumulator is f32).  Three
+// bf16 MFMAs of K = 16 replace eight f32 MFMAs of K = 2: 5.3x less matrix-pipe time per tile.  The price
+// is a wider band (kBandCBf16): dropped terms 3.02 * 2^-18 = 194 u, accumulation of 3 D products at one
+// ulp each (the matrix pipe's internal rounding is not documented; one ulp = 2 u per addition covers
+// round-to-nearest and truncation) 775 u, reference side (n + 2) u = 130 u  ->  1100 u, taken as 1150 u.
+// Operands whose magnitudes would break the relative bounds (bf16 denormal flush below 1e-18, bf16
+// overflow above 3e38, non-finite) get an infinite band factor and so take the exact path.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kBandCBf16 = 1150.0f;
+constexpr int kBfTPW = 2;        // candidate tiles per wave
+constexpr int kBfQuota = 128;    // undecided pairs a workgroup can list
+
+// band factor of a row from its norm / largest magnitude (see above); exact zero rows need no band
+__device__ __forceinline__ float band_norm(float sumsq, float maxabs) {
+    if (maxabs == 0.f) return 0.f;
+    if (!(maxabs >= 1e-18f && maxabs <= 3.0e38f)) return __builtin_inff();  // also NaN
+    return sqrtf(sumsq) * 1.0001f;  // overflow of sumsq gives inf: conservative
+}
+
+// (x0, x1) -> packed bf16 pairs hi, lo (x0 in the low half)
+__device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 x = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(x, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2 rest = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    const bf16x2 l = __builtin_convertvector(rest, bf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// Query tile image for the bf16 kernel: uint4 index (s * 64 + l) of the hi part, then of the lo part,
+// holds W_{q = l & 31}[16 s + 8 (l >> 5) + j], j = 0..7, as four packed bf16 pairs.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const float* __restrict__ q_fixed,
+                                                             const float* __restrict__ q_rel, int64_t q_head,
+                                                             int64_t q_tail, uint4* __restrict__ img_head,
+                                                             uint4* __restrict__ img_tail, float* __restrict__ eps_q) {
+    constexpr int STEPS = D / 16, U4 = STEPS * 64;  // uint4 per part
+    __shared__ float w_s[kGQT][D + 1];
+    const int64_t th = (q_head + kGQT - 1) / kGQT;
+    const bool head = blockIdx.x < th;
+    const int64_t tile = head ? blockIdx.x : blockIdx.x - th;
+    const int64_t n_side = head ? q_head : q_tail;
+    const int ql = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int64_t q_local = tile * kGQT + ql;
+    const bool q_ok = q_local < n_side;
+    const int64_t q = (head ? 0 : q_head) + (q_ok ? q_local : n_side - 1);
+    const float* f = q_fixed + q * D;
+    const float* r = q_rel + q * D;
+    float bsq = 0.f, bmax = 0.f;
+    bool bad = false;
+    for (int i = 0; i < D / 32; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 32 * i + 4 * sub + c;
+            float w, b;
+            if (head) gemm_operand<MODEL, HEAD>(f, r, k, D, w, b);
+            else gemm_operand<MODEL, TAIL>(f, r, k, D, w, b);
+            w_s[ql][k] = q_ok ? w : 0.f;
+            bsq += b * b;
+            bad |= !(b <= 3.0e38f);  // NaN too
+            bmax = b > bmax ? b : bmax;
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        bsq += __shfl_xor(bsq, off);
+        const float m2 = __shfl_xor(bmax, off);
+        bmax = m2 > bmax ? m2 : bmax;
+        bad |= (bool)__shfl_xor((int)bad, off);
+    }
+    if (sub == 0 && q_ok) eps_q[q] = kBandCBf16 * 5.9604645e-8f * band_norm(bsq, bad ? __builtin_inff() : bmax);
+    __syncthreads();
+    uint4* out = (head ? img_head : img_tail) + tile * (2 * U4);
+    for (int idx = threadIdx.x; idx < U4; idx += 256) {
+        const int st = idx >> 6, l = idx & 63;
+        const float* w = &w_s[l & 31][16 * st + 8 * (l >> 5)];
+        uint4 hi, lo;
+        split_bf16(w[0], w[1], hi.x, lo.x);
+        split_bf16(w[2], w[3], hi.y, lo.y);
+        split_bf16(w[4], w[5], hi.z, lo.z);
+        split_bf16(w[6], w[7], hi.w, lo.w);
+        out[idx] = hi;
+        out[U4 + idx] = lo;
+    }
+}
+
+template <int D>
+struct BfTile {
+    uint4 hi[D / 16], lo[D / 16];  // A operands of the D/16 K-steps
+    float nrow[16];                // band factor of the candidate held by accumulator register r
+    unsigned row_mask;             // bit r: that candidate exists (row < N)
+};
+
+template <int MODEL, int D>
+__global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_bf16_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const uint4* __restrict__ img_head,
+    const uint4* __restrict__ img_tail, const float* __restrict__ key_true, const float* __restrict__ eps_q,
+    int q_head, int q_tail, int n_groups, int chunks_head, int words_per_query,
+    unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs) {
+    constexpr int STEPS = D / 16;
+    constexpr int TILE_BYTES = 2 * STEPS * 64 * 16;  // hi + lo parts: 16 KB at D = 128
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf0 = smem;
+    float* buf1 = smem + TILE_BYTES / 4;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * (TILE_BYTES / 4));   // [kGTilesPerChunk * 32]
+    float* nrm = reinterpret_cast<float*>(cnt + kGTilesPerChunk * kGQT);        // [kGW][kBfTPW][32]
+    uint2* pair_s = reinterpret_cast<uint2*>(nrm + kGW * kBfTPW * 32);          // [kBfQuota]
+    unsigned* pair_n = reinterpret_cast<unsigned*>(pair_s + kBfQuota);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, half = lane >> 5;
+
+    const int group = blockIdx.x % n_groups, chunk = blockIdx.x / n_groups;
+    const bool head = chunk < chunks_head;
+    const int side_chunk = head ? chunk : chunk - chunks_head;
+    const int n_side = head ? q_head : q_tail, q_base = head ? 0 : q_head;
+    const int tile0 = side_chunk * kGTilesPerChunk;
+    const int n_side_tiles = (n_side + kGQT - 1) / kGQT;
+    const int n_tiles = n_side_tiles - tile0 < kGTilesPerChunk ? n_side_tiles - tile0 : kGTilesPerChunk;
+
+    for (int i = tid; i < kGTilesPerChunk * kGQT; i += kGW * 64) cnt[i] = 0;
+    if (tid < kBfQuota) pair_s[tid] = make_uint2(kNoPair, 0u);
+    if (tid == 0) *pair_n = 0;
+
+    // this wave's candidate tiles: lane (row l & 31, K-half l >> 5) reads its 8 floats of every K-step
+    // straight from the table, splits them, and keeps them as MFMA A operands
+    BfTile<D> c[kBfTPW];
+    const int ctile0 = (group * kGW + wave) * kBfTPW;
+    static_for<kBfTPW>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
+        int64_t row = row0 + (lane & 31);
+        row = row < N ? row : N - 1;
+        const float* src = table + row * ld + 8 * half;
+        float ss = 0.f, mx = 0.f;
+        bool bad = false;
+        static_for<STEPS>([&](auto kk) {
+            constexpr int st = decltype(kk)::value;
+            const float4 x = *reinterpret_cast<const float4*>(src + 16 * st);
+            const float4 y = *reinterpret_cast<const float4*>(src + 16 * st + 4);
+            split_bf16(x.x, x.y, c[t].hi[st].x, c[t].lo[st].x);
+            split_bf16(x.z, x.w, c[t].hi[st].y, c[t].lo[st].y);
+            split_bf16(y.x, y.y, c[t].hi[st].z, c[t].lo[st].z);
+            split_bf16(y.z, y.w, c[t].hi[st].w, c[t].lo[st].w);
+            const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ss += v[j] * v[j];
+                const float a = fabsf(v[j]);
+                bad |= !(a <= 3.0e38f);  // NaN too
+                mx = a > mx ? a : mx;
+            }
+        });
+        ss += __shfl_xor(ss, 32);
+        const float m2 = __shfl_xor(mx, 32);
+        mx = m2 > mx ? m2 : mx;
+        bad |= (bool)__shfl_xor((int)bad, 32);
+        if (lane < 32) nrm[(wave * kBfTPW + t) * 32 + lane] = band_norm(ss, bad ? __builtin_inff() : mx);
+    });
+    __syncthreads();
+    static_for<kBfTPW>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
+        c[t].row_mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, half);
+            c[t].nrow[r] = nrm[(wave * kBfTPW + t) * 32 + row];
+            c[t].row_mask |= (unsigned)(row0 + row < N) << r;
+        }
+    });
+
+    const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
+    stage_gemm_tile<TILE_BYTES>(reinterpret_cast<const float4*>(img), buf0, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const float* cur = (t & 1) ? buf1 : buf0;
+        if (t + 1 < n_tiles)
+            stage_gemm_tile<TILE_BYTES>(reinterpret_cast<const float4*>(img + (int64_t)(t + 1) * (TILE_BYTES / 16)),
+                                        (t & 1) ? buf0 : buf1, wave, lane);
+        const int q_local = (tile0 + t) * kGQT + (lane & 31);
+        const bool q_ok = q_local < n_side;
+        const int q = q_base + (q_ok ? q_local : n_side - 1);
+        const float kt = key_true[q];
+        const float eq = eps_q[q];
+
+        f32x16 s[kBfTPW];
+        static_for<kBfTPW>([&](auto tt) {
+            s[decltype(tt)::value] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        });
+        const uint4* bp = reinterpret_cast<const uint4*>(cur) + lane;
+        static_for<STEPS>([&](auto kk) {
+            constexpr int st = decltype(kk)::value;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[st * 64]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, bp[(STEPS + st) * 64]);
+            static_for<kBfTPW>([&](auto tt) {
+                constexpr int ti = decltype(tt)::value;
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, c[ti].hi[st]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, c[ti].lo[st]);
+                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, s[ti], 0, 0, 0);
+                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, s[ti], 0, 0, 0);
+                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, s[ti], 0, 0, 0);
+            });
+        });
+
+        // epilogue: decided iff |S~ - s_true| - eps_q * ||e|| > guard; each lane owns (query, 16 candidates)
+        const float guard = fabsf(kt) * 2.4e-7f + 1e-35f;  // rounding of the test itself, product underflow
+        static_for<kBfTPW>([&](auto tt) {
+            constexpr int ti = decltype(tt)::value;
+            const unsigned row_mask = c[ti].row_mask;
+            unsigned above = 0;
+            bool any_und = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = s[ti][r] - kt;
+                const float m = __builtin_fmaf(-eq, c[ti].nrow[r], fabsf(d));
+                const bool ok = (row_mask >> r) & 1u, dec = m > guard;  // NaN / Inf anywhere: not decided
+                above += ok && dec && d > 0.f;
+                any_und |= ok && !dec;
+            }
+            if (q_ok) {
+                bool listed = true;
+                if (any_und) {
+                    unsigned und = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = s[ti][r] - kt;
+                        const float m = __builtin_fmaf(-eq, c[ti].nrow[r], fabsf(d));
+                        und |= (unsigned)(((row_mask >> r) & 1u) && !(m > guard)) << r;
+                    }
+                    const unsigned n_und = __popc(und);
+                    unsigned slot = atomicAdd(pair_n, n_und);
+                    listed = slot + n_und <= kBfQuota;
+                    const int ctile = ctile0 + ti;
+                    if (listed) {
+                        for (unsigned mm = und; mm; mm &= mm - 1)
+                            pair_s[slot++] = make_uint2((unsigned)q, (unsigned)(ctile * kGCT + acc_row(__builtin_ctz(mm), half)));
+                    } else {
+                        const int hseg = ctile * 2 + half;
+                        atomicOr(flags + (size_t)q * words_per_query + (hseg >> 5), 1u << (hseg & 31));
+                    }
+                }
+                if (listed && above) atomicAdd(cnt + t * kGQT + (lane & 31), above);
+            }
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int i = tid; i < n_tiles * kGQT; i += kGW * 64) {
+        const int q_local = tile0 * kGQT + i;
+        const unsigned long long v = cnt[i];
+        if (q_local < n_side && v) atomicAdd(acc + q_base + q_local, v | (v << 32));  // certainly above: gt and ge
+    }
+    if (tid < kBfQuota) pairs[(size_t)blockIdx.x * kBfQuota + tid] = pair_s[tid];
+}
+
 // Pass 2a: one lane per listed pair.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
@@ -375,6 +638,18 @@ struct GemmWorkspace {
     size_t bytes;
 };
 
+// pair-list entries needed for T candidate tiles x one query chunk: the larger of the two pass-1 kernels
+static int64_t pair_entries_per_chunk(int64_t T) {
+    const int64_t f32_kernel = (T + kGW - 1) / kGW * kPairQuota;
+    const int64_t bf16_kernel = (T + kGW * kBfTPW - 1) / (kGW * kBfTPW) * kBfQuota;
+    return f32_kernel > bf16_kernel ? f32_kernel : bf16_kernel;
+}
+
+static bool gemm_use_f32() {  // BLP_GEMM_KERNEL=f32: the exact-f32-chain MFMA kernel instead of bf16 x 3
+    const char* pick = getenv("BLP_GEMM_KERNEL");
+    return pick && pick[0] == 'f';
+}
+
 static int64_t query_chunks(int64_t q_head, int64_t q_tail) {
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
     return (th + kGTilesPerChunk - 1) / kGTilesPerChunk + (tt + kGTilesPerChunk - 1) / kGTilesPerChunk;
@@ -388,7 +663,7 @@ static int64_t tiles_per_pass(int64_t N, int64_t q_head, int64_t q_tail) {
     const int64_t cap = (int64_t)256 << 20;
     int64_t words = ((N + kGCT - 1) / kGCT + 15) / 16;
     const int64_t by_flags = cap / 4 / Q;
-    const int64_t by_pairs = cap / (kPairQuota * 8) / query_chunks(q_head, q_tail) * kGW / 16;
+    const int64_t by_pairs = cap / 8 / query_chunks(q_head, q_tail) / pair_entries_per_chunk(16);
     if (words > by_flags) words = by_flags;
     if (words > by_pairs) words = by_pairs;
     if (const char* env = getenv("BLP_GEMM_PASS_WORDS")) {  // test knob: force the multi-slab path
@@ -416,7 +691,7 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     w.flags = reinterpret_cast<unsigned*>(p + off);
     off = align_up(off + (size_t)Q * (size_t)(w.pass_ctiles / 16) * 4, 256);
     w.pairs = reinterpret_cast<uint2*>(p + off);
-    off = align_up(off + (size_t)((w.pass_ctiles + kGW - 1) / kGW) * query_chunks(q_head, q_tail) * kPairQuota * 8, 256);
+    off = align_up(off + (size_t)pair_entries_per_chunk(w.pass_ctiles) * query_chunks(q_head, q_tail) * 8, 256);
     w.bytes = off;
     return w;
 }
@@ -444,27 +719,43 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                             w.coef_tail, w.key_true, stream);
     if (err != hipSuccess) return err;
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
-    prep_gemm_kernel<MODEL, D><<<dim3((unsigned)(th + tt)), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.img_head,
-                                                                             w.img_tail, w.eps_q);
-    const size_t lds = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
-                       (size_t)kPairQuota * 8 + 16;
+    const bool f32_kernel = gemm_use_f32();
+    if (f32_kernel)
+        prep_gemm_kernel<MODEL, D><<<dim3((unsigned)(th + tt)), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail,
+                                                                                 w.img_head, w.img_tail, w.eps_q);
+    else
+        prep_gemm_bf16_kernel<MODEL, D><<<dim3((unsigned)(th + tt)), 256, 0, stream>>>(
+            q_fixed, q_rel, q_head, q_tail, reinterpret_cast<uint4*>(w.img_head), reinterpret_cast<uint4*>(w.img_tail),
+            w.eps_q);
+    const size_t lds_f32 = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
+                           (size_t)kPairQuota * 8 + 16;
+    const size_t lds_bf16 = (size_t)2 * (2 * (D / 16) * 64 * 16) + (size_t)kGTilesPerChunk * kGQT * 4 +
+                            (size_t)kGW * kBfTPW * 32 * 4 + (size_t)kBfQuota * 8 + 16;
     const int64_t chunks_head = (th + kGTilesPerChunk - 1) / kGTilesPerChunk;
     const int64_t chunks_tail = (tt + kGTilesPerChunk - 1) / kGTilesPerChunk;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_tiles * kGCT) {  // one iteration unless the bitmap is capped
         const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
         const int64_t n_ctiles = (n_rows + kGCT - 1) / kGCT;
-        const int64_t n_quads = (n_ctiles + kGW - 1) / kGW;
+        const int tiles_per_group = f32_kernel ? kGW : kGW * kBfTPW;
+        const int64_t n_groups = (n_ctiles + tiles_per_group - 1) / tiles_per_group;
         const int words = (int)((n_ctiles + 15) / 16);
-        const int64_t n_blocks = n_quads * (chunks_head + chunks_tail);
+        const int64_t n_blocks = n_groups * (chunks_head + chunks_tail);
+        const int64_t n_entries = n_blocks * (f32_kernel ? kPairQuota : kBfQuota);
         err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
         if (err != hipSuccess) return err;
         const float* slab = table + slab0 * ld;
-        rank_gemm_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kGW * 64, lds, stream>>>(
-            slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_quads,
-            (int)chunks_head, words, w.acc, w.flags, w.pairs);
-        refine_pairs_kernel<MODEL, D><<<dim3((unsigned)((n_blocks * kPairQuota + 255) / 256)), 256, 0, stream>>>(
-            slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_blocks * kPairQuota, w.acc);
+        if (f32_kernel)
+            rank_gemm_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kGW * 64, lds_f32, stream>>>(
+                slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups,
+                (int)chunks_head, words, w.acc, w.flags, w.pairs);
+        else
+            rank_gemm_bf16_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kGW * 64, lds_bf16, stream>>>(
+                slab, n_rows, ld, reinterpret_cast<const uint4*>(w.img_head), reinterpret_cast<const uint4*>(w.img_tail),
+                w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head, words, w.acc, w.flags,
+                w.pairs);
+        refine_pairs_kernel<MODEL, D><<<dim3((unsigned)((n_entries + 255) / 256)), 256, 0, stream>>>(
+            slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_entries, w.acc);
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
     }
