@@ -167,12 +167,12 @@ __device__ __forceinline__ float load_a_gemm(float (&a)[D / 2], const float* __r
     return sqrtf(ss) * 1.0001f;
 }
 
-template <int BYTES>
+template <int BYTES, int WAVES = kGW>
 __device__ __forceinline__ void stage_gemm_tile(const float4* __restrict__ src, float* dst, int wave, int lane) {
-    constexpr int ROUNDS = (BYTES + kGW * 1024 - 1) / (kGW * 1024);
+    constexpr int ROUNDS = (BYTES + WAVES * 1024 - 1) / (WAVES * 1024);
     static_for<ROUNDS>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
-        const int seg = (k * kGW + wave) * 1024;
+        const int seg = (k * WAVES + wave) * 1024;
         if (seg + lane * 16 < BYTES)
             __builtin_amdgcn_global_load_lds((global_cptr)(reinterpret_cast<const char*>(src) + seg + lane * 16),
                                              (lds_ptr)(reinterpret_cast<char*>(dst) + seg), 16, 0, 0);
@@ -304,8 +304,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kBandCBf16 = 1150.0f;
+constexpr int kBfW = 4;          // waves per workgroup
 constexpr int kBfTPW = 2;        // candidate tiles per wave
-constexpr int kBfQuota = 128;    // undecided pairs a workgroup can list
+constexpr int kBfWavesPerSimd = 2;  // launch bound: <= 256 VGPRs (128 of them hold the A operands)
+constexpr int kBfTilesPerChunk = 16;             // query tiles per workgroup (a multiple of kGTilesPerChunk)
+constexpr int kBfQuota = 16 * kBfTilesPerChunk;  // undecided pairs a workgroup can list
 
 // band factor of a row from its norm / largest magnitude (see above); exact zero rows need no band
 __device__ __forceinline__ float band_norm(float sumsq, float maxabs) {
@@ -384,12 +387,11 @@ __global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const float* __rest
 template <int D>
 struct BfTile {
     uint4 hi[D / 16], lo[D / 16];  // A operands of the D/16 K-steps
-    float nrow[16];                // band factor of the candidate held by accumulator register r
-    unsigned row_mask;             // bit r: that candidate exists (row < N)
+    unsigned row_mask;             // bit r: the candidate of accumulator register r exists (row < N)
 };
 
 template <int MODEL, int D>
-__global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_bf16_kernel(
+__global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const uint4* __restrict__ img_head,
     const uint4* __restrict__ img_tail, const float* __restrict__ key_true, const float* __restrict__ eps_q,
     int q_head, int q_tail, int n_groups, int chunks_head, int words_per_query,
@@ -399,10 +401,11 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_bf16_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf0 = smem;
     float* buf1 = smem + TILE_BYTES / 4;
-    unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * (TILE_BYTES / 4));   // [kGTilesPerChunk * 32]
-    float* nrm = reinterpret_cast<float*>(cnt + kGTilesPerChunk * kGQT);        // [kGW][kBfTPW][32]
-    uint2* pair_s = reinterpret_cast<uint2*>(nrm + kGW * kBfTPW * 32);          // [kBfQuota]
-    unsigned* pair_n = reinterpret_cast<unsigned*>(pair_s + kBfQuota);
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * (TILE_BYTES / 4));   // [kBfTilesPerChunk * 32]
+    float* nrm = reinterpret_cast<float*>(cnt + kBfTilesPerChunk * kGQT);        // [kBfW][kBfTPW][32]
+    uint2* pair_s = reinterpret_cast<uint2*>(nrm + kBfW * kBfTPW * 32);          // [kBfQuota]
+    float2* kq_s = reinterpret_cast<float2*>(pair_s + kBfQuota);                 // [kBfTilesPerChunk * 32] {s_true, eps_q}
+    unsigned* pair_n = reinterpret_cast<unsigned*>(kq_s + kBfTilesPerChunk * kGQT);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, half = lane >> 5;
@@ -411,18 +414,23 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_bf16_kernel(
     const bool head = chunk < chunks_head;
     const int side_chunk = head ? chunk : chunk - chunks_head;
     const int n_side = head ? q_head : q_tail, q_base = head ? 0 : q_head;
-    const int tile0 = side_chunk * kGTilesPerChunk;
+    const int tile0 = side_chunk * kBfTilesPerChunk;
     const int n_side_tiles = (n_side + kGQT - 1) / kGQT;
-    const int n_tiles = n_side_tiles - tile0 < kGTilesPerChunk ? n_side_tiles - tile0 : kGTilesPerChunk;
+    const int n_tiles = n_side_tiles - tile0 < kBfTilesPerChunk ? n_side_tiles - tile0 : kBfTilesPerChunk;
 
-    for (int i = tid; i < kGTilesPerChunk * kGQT; i += kGW * 64) cnt[i] = 0;
-    if (tid < kBfQuota) pair_s[tid] = make_uint2(kNoPair, 0u);
+    for (int i = tid; i < kBfTilesPerChunk * kGQT; i += kBfW * 64) {
+        cnt[i] = 0;
+        const int q_local = tile0 * kGQT + i;
+        const int q = q_base + (q_local < n_side ? q_local : n_side - 1);
+        kq_s[i] = make_float2(key_true[q], eps_q[q]);
+    }
+    for (int i = tid; i < kBfQuota; i += kBfW * 64) pair_s[i] = make_uint2(kNoPair, 0u);
     if (tid == 0) *pair_n = 0;
 
     // this wave's candidate tiles: lane (row l & 31, K-half l >> 5) reads its 8 floats of every K-step
     // straight from the table, splits them, and keeps them as MFMA A operands
     BfTile<D> c[kBfTPW];
-    const int ctile0 = (group * kGW + wave) * kBfTPW;
+    const int ctile0 = (group * kBfW + wave) * kBfTPW;
     static_for<kBfTPW>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
         const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
@@ -452,7 +460,9 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_bf16_kernel(
         const float m2 = __shfl_xor(mx, 32);
         mx = m2 > mx ? m2 : mx;
         bad |= (bool)__shfl_xor((int)bad, 32);
-        if (lane < 32) nrm[(wave * kBfTPW + t) * 32 + lane] = band_norm(ss, bad ? __builtin_inff() : mx);
+        // a row that does not exist gets a NaN band factor: never decided, never listed (row_mask)
+        if (lane < 32)
+            nrm[(wave * kBfTPW + t) * 32 + lane] = row0 + lane < N ? band_norm(ss, bad ? __builtin_inff() : mx) : __builtin_nanf("");
     });
     __syncthreads();
     static_for<kBfTPW>([&](auto tt) {
@@ -462,74 +472,72 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, half);
-            c[t].nrow[r] = nrm[(wave * kBfTPW + t) * 32 + row];
             c[t].row_mask |= (unsigned)(row0 + row < N) << r;
         }
     });
 
     const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
-    stage_gemm_tile<TILE_BYTES>(reinterpret_cast<const float4*>(img), buf0, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        const float* cur = (t & 1) ? buf1 : buf0;
-        if (t + 1 < n_tiles)
-            stage_gemm_tile<TILE_BYTES>(reinterpret_cast<const float4*>(img + (int64_t)(t + 1) * (TILE_BYTES / 16)),
-                                        (t & 1) ? buf0 : buf1, wave, lane);
-        const int q_local = (tile0 + t) * kGQT + (lane & 31);
-        const bool q_ok = q_local < n_side;
-        const int q = q_base + (q_ok ? q_local : n_side - 1);
-        const float kt = key_true[q];
-        const float eq = eps_q[q];
-
-        f32x16 s[kBfTPW];
-        static_for<kBfTPW>([&](auto tt) {
-            s[decltype(tt)::value] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        });
-        const uint4* bp = reinterpret_cast<const uint4*>(cur) + lane;
-        static_for<STEPS>([&](auto kk) {
-            constexpr int st = decltype(kk)::value;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[st * 64]);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, bp[(STEPS + st) * 64]);
-            static_for<kBfTPW>([&](auto tt) {
-                constexpr int ti = decltype(tt)::value;
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, c[ti].hi[st]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, c[ti].lo[st]);
-                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, s[ti], 0, 0, 0);
-                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, s[ti], 0, 0, 0);
-                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, s[ti], 0, 0, 0);
-            });
-        });
-
-        // epilogue: decided iff |S~ - s_true| - eps_q * ||e|| > guard; each lane owns (query, 16 candidates)
-        const float guard = fabsf(kt) * 2.4e-7f + 1e-35f;  // rounding of the test itself, product underflow
+    // K-step st of query tile `buf` against both candidate tiles; the two accumulator chains are
+    // interleaved so that no MFMA reads the accumulator the previous one writes
+    auto mfma_step = [&](auto kk, f32x16 (&s)[kBfTPW], const float* buf) {
+        constexpr int st = decltype(kk)::value;
+        const uint4* bp = reinterpret_cast<const uint4*>(buf) + lane;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[st * 64]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, bp[(STEPS + st) * 64]);
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            const unsigned row_mask = c[ti].row_mask;
-            unsigned above = 0;
-            bool any_und = false;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].lo[st]), bh, s[ti], 0, 0, 0);
+        });
+        static_for<kBfTPW>([&](auto tt) {
+            constexpr int ti = decltype(tt)::value;
+            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bl, s[ti], 0, 0, 0);
+        });
+
+        static_for<kBfTPW>([&](auto tt) {
+            constexpr int ti = decltype(tt)::value;
+            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bh, s[ti], 0, 0, 0);
+        });
+    };
+    // Decision for accumulator registers [R0, R0 + NR) of both tiles: decided iff
+    // |S~ - s_true| - eps_q ||e|| > guard (NaN / Inf anywhere, or a row that does not exist: not decided)
+    auto decide_chunk = [&](auto r0, auto nr, const f32x16 (&s)[kBfTPW], float kt, float eq, float guard,
+                            unsigned (&above)[kBfTPW], bool (&any_und)[kBfTPW]) {
+        constexpr int R0 = decltype(r0)::value, NR = decltype(nr)::value;
+        static_for<kBfTPW>([&](auto tt) {
+            constexpr int ti = decltype(tt)::value;
+            const float* nr_lds = nrm + (wave * kBfTPW + ti) * 32 + 4 * half;
+            static_for<NR>([&](auto jj) {
+                constexpr int r = R0 + decltype(jj)::value;
                 const float d = s[ti][r] - kt;
-                const float m = __builtin_fmaf(-eq, c[ti].nrow[r], fabsf(d));
-                const bool ok = (row_mask >> r) & 1u, dec = m > guard;  // NaN / Inf anywhere: not decided
-                above += ok && dec && d > 0.f;
-                any_und |= ok && !dec;
-            }
-            if (q_ok) {
-                bool listed = true;
-                if (any_und) {
-                    unsigned und = 0;
+                const float m = __builtin_fmaf(-eq, nr_lds[8 * (r >> 2) + (r & 3)], fabsf(d));
+                const bool dec = m > guard;
+                above[ti] += dec && d > 0.f;
+                any_und[ti] |= !dec;
+            });
+        });
+    };
+    // Rare per lane: which registers are undecided; list them, or flag the half-segment when the
+    // workgroup's quota is used up.  Adds the decided-above count to the query's LDS counter.
+    auto settle = [&](int t, int q, bool q_ok, const f32x16 (&s)[kBfTPW], float kt, float eq, float guard,
+                      const unsigned (&above)[kBfTPW], const bool (&any_und)[kBfTPW]) {
+        static_for<kBfTPW>([&](auto tt) {
+            constexpr int ti = decltype(tt)::value;
+            if (!q_ok) return;
+            bool listed = true;
+            if (any_und[ti]) {
+                const float* nr_lds = nrm + (wave * kBfTPW + ti) * 32 + 4 * half;
+                unsigned und = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float d = s[ti][r] - kt;
-                        const float m = __builtin_fmaf(-eq, c[ti].nrow[r], fabsf(d));
-                        und |= (unsigned)(((row_mask >> r) & 1u) && !(m > guard)) << r;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const float m = __builtin_fmaf(-eq, nr_lds[8 * (r >> 2) + (r & 3)], fabsf(s[ti][r] - kt));
+                    und |= (unsigned)!(m > guard) << r;
+                }
+                und &= c[ti].row_mask;
+                if (und) {
+                    const int ctile = ctile0 + ti;
                     const unsigned n_und = __popc(und);
                     unsigned slot = atomicAdd(pair_n, n_und);
                     listed = slot + n_und <= kBfQuota;
-                    const int ctile = ctile0 + ti;
                     if (listed) {
                         for (unsigned mm = und; mm; mm &= mm - 1)
                             pair_s[slot++] = make_uint2((unsigned)q, (unsigned)(ctile * kGCT + acc_row(__builtin_ctz(mm), half)));
@@ -538,18 +546,66 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_bf16_kernel(
                         atomicOr(flags + (size_t)q * words_per_query + (hseg >> 5), 1u << (hseg & 31));
                     }
                 }
-                if (listed && above) atomicAdd(cnt + t * kGQT + (lane & 31), above);
             }
+            if (listed && above[ti]) atomicAdd(cnt + t * kGQT + (lane & 31), above[ti]);
         });
+    };
+    auto zero_acc = [&](f32x16 (&s)[kBfTPW]) {
+        static_for<kBfTPW>([&](auto tt) {
+            s[decltype(tt)::value] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        });
+    };
+    // One pipeline stage: the MFMAs of query tile t + 1 (into `nxt`) are issued between the chunks of
+    // tile t's decision arithmetic (on `cur`), so the vector ALU works in the matrix pipe's shadow.
+    auto stage = [&](int t, f32x16 (&cur)[kBfTPW], f32x16 (&nxt)[kBfTPW]) {
+        const bool more = t + 1 < n_tiles;
+        if (t + 2 < n_tiles)  // buf[t & 1] was last read by the MFMAs of tile t, one barrier ago
+            stage_gemm_tile<TILE_BYTES, kBfW>(reinterpret_cast<const float4*>(img + (int64_t)(t + 2) * (TILE_BYTES / 16)),
+                                              (t & 1) ? buf1 : buf0, wave, lane);
+        const int q_local = (tile0 + t) * kGQT + (lane & 31);
+        const bool q_ok = q_local < n_side;
+        const int q = q_base + (q_ok ? q_local : n_side - 1);
+        const float2 kq = kq_s[t * kGQT + (lane & 31)];
+        const float kt = kq.x, eq = kq.y;
+        const float guard = fabsf(kt) * 2.4e-7f + 1e-35f;  // rounding of the test itself, product underflow
+        unsigned above[kBfTPW];
+        bool any_und[kBfTPW];
+        static_for<kBfTPW>([&](auto tt) { above[decltype(tt)::value] = 0; any_und[decltype(tt)::value] = false; });
+        if (more) {
+            const float* nbuf = ((t + 1) & 1) ? buf1 : buf0;
+            zero_acc(nxt);
+            static_for<STEPS>([&](auto kk) {
+                constexpr int st = decltype(kk)::value;
+                mfma_step(kk, nxt, nbuf);
+                decide_chunk(ic<st * (16 / STEPS)>{}, ic<16 / STEPS>{}, cur, kt, eq, guard, above, any_und);
+            });
+        } else {
+            decide_chunk(ic<0>{}, ic<16>{}, cur, kt, eq, guard, above, any_und);
+        }
+        settle(t, q, q_ok, cur, kt, eq, guard, above, any_und);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    };
+
+    stage_gemm_tile<TILE_BYTES, kBfW>(reinterpret_cast<const float4*>(img), buf0, wave, lane);
+    if (n_tiles > 1)
+        stage_gemm_tile<TILE_BYTES, kBfW>(reinterpret_cast<const float4*>(img + TILE_BYTES / 16), buf1, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc_a[kBfTPW], acc_b[kBfTPW];
+    zero_acc(acc_a);
+    static_for<STEPS>([&](auto kk) { mfma_step(kk, acc_a, buf0); });
+    __syncthreads();  // buf0 is read: stage(0) may overwrite it with tile 2
+    for (int t = 0; t < n_tiles; t += 2) {
+        stage(t, acc_a, acc_b);
+        if (t + 1 < n_tiles) stage(t + 1, acc_b, acc_a);
     }
-    for (int i = tid; i < n_tiles * kGQT; i += kGW * 64) {
+    for (int i = tid; i < n_tiles * kGQT; i += kBfW * 64) {
         const int q_local = tile0 * kGQT + i;
         const unsigned long long v = cnt[i];
         if (q_local < n_side && v) atomicAdd(acc + q_base + q_local, v | (v << 32));  // certainly above: gt and ge
     }
-    if (tid < kBfQuota) pairs[(size_t)blockIdx.x * kBfQuota + tid] = pair_s[tid];
+    for (int i = tid; i < kBfQuota; i += kBfW * 64) pairs[(size_t)blockIdx.x * kBfQuota + i] = pair_s[i];
 }
 
 // Pass 2a: one lane per listed pair.
@@ -641,7 +697,7 @@ struct GemmWorkspace {
 // pair-list entries needed for T candidate tiles x one query chunk: the larger of the two pass-1 kernels
 static int64_t pair_entries_per_chunk(int64_t T) {
     const int64_t f32_kernel = (T + kGW - 1) / kGW * kPairQuota;
-    const int64_t bf16_kernel = (T + kGW * kBfTPW - 1) / (kGW * kBfTPW) * kBfQuota;
+    const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * (16 * kGTilesPerChunk);  // per 8 query tiles
     return f32_kernel > bf16_kernel ? f32_kernel : bf16_kernel;
 }
 
@@ -729,15 +785,16 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             w.eps_q);
     const size_t lds_f32 = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
                            (size_t)kPairQuota * 8 + 16;
-    const size_t lds_bf16 = (size_t)2 * (2 * (D / 16) * 64 * 16) + (size_t)kGTilesPerChunk * kGQT * 4 +
-                            (size_t)kGW * kBfTPW * 32 * 4 + (size_t)kBfQuota * 8 + 16;
-    const int64_t chunks_head = (th + kGTilesPerChunk - 1) / kGTilesPerChunk;
-    const int64_t chunks_tail = (tt + kGTilesPerChunk - 1) / kGTilesPerChunk;
+    const size_t lds_bf16 = (size_t)2 * (2 * (D / 16) * 64 * 16) + (size_t)kBfTilesPerChunk * kGQT * 4 +
+                            (size_t)kBfW * kBfTPW * 32 * 4 + (size_t)kBfQuota * 8 + (size_t)kBfTilesPerChunk * kGQT * 8 + 16;
+    const int tiles_per_chunk = f32_kernel ? kGTilesPerChunk : kBfTilesPerChunk;
+    const int64_t chunks_head = (th + tiles_per_chunk - 1) / tiles_per_chunk;
+    const int64_t chunks_tail = (tt + tiles_per_chunk - 1) / tiles_per_chunk;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_tiles * kGCT) {  // one iteration unless the bitmap is capped
         const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
         const int64_t n_ctiles = (n_rows + kGCT - 1) / kGCT;
-        const int tiles_per_group = f32_kernel ? kGW : kGW * kBfTPW;
+        const int tiles_per_group = f32_kernel ? kGW : kBfW * kBfTPW;
         const int64_t n_groups = (n_ctiles + tiles_per_group - 1) / tiles_per_group;
         const int words = (int)((n_ctiles + 15) / 16);
         const int64_t n_blocks = n_groups * (chunks_head + chunks_tail);
@@ -750,7 +807,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                 slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups,
                 (int)chunks_head, words, w.acc, w.flags, w.pairs);
         else
-            rank_gemm_bf16_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kGW * 64, lds_bf16, stream>>>(
+            rank_gemm_bf16_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kBfW * 64, lds_bf16, stream>>>(
                 slab, n_rows, ld, reinterpret_cast<const uint4*>(w.img_head), reinterpret_cast<const uint4*>(w.img_tail),
                 w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head, words, w.acc, w.flags,
                 w.pairs);
