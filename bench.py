@@ -37,6 +37,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_PEAK_TFLOPS = 157.3         # f32 MFMA peak == f32 vector (FMA) peak; plain add/sub ops reach half
+BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md); the bilinear pre-pass spends 3 bf16
+BF16X3_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3   # products per f32-equivalent product, so its roof is a third of it
 
 WORKLOADS = {
     "fb15k237-transe": dict(model="transe", N=14541, D=128, R=237, triples=52870, passes=1),
@@ -51,9 +53,9 @@ WORKLOADS = {
 # score is a (Q x D) . (D x N) GEMM = 2 flops per (pair, element).
 OPS_PER_ELEM = {"transe": (2, 2), "distmult": (2, 2), "complex": (2, 2), "simple": (2, 2)}
 DOMINANT_KERNEL = {"transe": "rank_sad_kernel<128> + sad_refine_* (u16 fixed-point v_sad_u16 pre-pass + band + exact f32 refinement; prep kernels included)",
-                   "distmult": "rank_gemm_kernel<DISTMULT,128> + refine_kernel (f32 MFMA GEMM + band + exact refinement)",
-                   "complex": "rank_gemm_kernel<COMPLEX,128> + refine_kernel",
-                   "simple": "rank_gemm_kernel<SIMPLE,128> + refine_kernel"}
+                   "distmult": "rank_gemm_bf16_kernel<DISTMULT,128> + refine_pairs/refine (bf16 x 3 split MFMA GEMM + band + exact f32 refinement)",
+                   "complex": "rank_gemm_bf16_kernel<COMPLEX,128> + refine_pairs/refine",
+                   "simple": "rank_gemm_bf16_kernel<SIMPLE,128> + refine_pairs/refine"}
 
 
 def make_data(cfg, device, seed=1):
@@ -322,20 +324,25 @@ def main():
         alg_flops = n_local * D * (q_head * ops_h + (Q - q_head) * ops_t)
         alg_bytes = n_local * D * 4 + Q * (2 * D * 4 + 24)
         t_k = kernel_ms * 1e-3
-        hbm_time, cmp_time = alg_bytes / (HBM_PEAK_GBPS * 1e9), alg_flops / (F32_PEAK_TFLOPS * 1e12)
+        sad_path = model == "transe"
+        peak_tf = F32_PEAK_TFLOPS if sad_path else BF16X3_PEAK_TFLOPS
+        hbm_time, cmp_time = alg_bytes / (HBM_PEAK_GBPS * 1e9), alg_flops / (peak_tf * 1e12)
         if hbm_time >= cmp_time:
             roofline = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
         else:
-            roofline = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS,
+            roofline = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf,
                         "unit": "TFLOP/s",
                         "note": ("VALU roof, not MFMA (an L1 norm has no matrix-core form): 157.3 Tops/s is the f32 vector-FMA "
                                  "peak and also what v_sad_u16 delivers at its 4 cycles/instruction (2 elements x "
                                  "(subtract + |.|-accumulate) x 64 lanes); the exact f32 add/sub kernel tops out at half "
                                  "of it. achieved = 2 ops x D x Q x N / time of the whole rank pass (range + quantise + "
                                  "SAD pre-pass + exact refinement of the undecided pairs)."
-                                 if model == "transe" else
-                                 "f32 MFMA GEMM (exact f32 fma chain) + error band; refinement of undecided "
-                                 "(query, 32-candidate) segments is included in the kernel time.")}
+                                 if sad_path else
+                                 "achieved = 2 flops x D x Q x N (the f32 GEMM the reference's scores amount to) / time of "
+                                 "GEMM pre-pass + exact refinement.  Every f32 product is three bf16 MFMA products "
+                                 "(hi*hi + hi*lo + lo*hi), so the roof is the dense bf16 MFMA peak / 3 = 833 TF "
+                                 "(5.3x the f32 MFMA peak of 157.3 TF, which the f32-chain variant BLP_GEMM_KERNEL=f32 "
+                                 "is bounded by).")}
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["traffic"] = load_pmc_traffic(args.workload)
         roofline["kernel"] = (DOMINANT_KERNEL[model] if Q >= 64 else "rank_tiles_kernel<STATIC> (lane-per-candidate VALU)")
