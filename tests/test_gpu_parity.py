@@ -377,6 +377,53 @@ def test_wikidata5m_scale_properties(ops, oracle):
     assert int(whole[:, 1].min()) >= 1  # the true entity itself is always >=
 
 
+def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, monkeypatch):
+    """4.6 M x 128 with enough queries for the pre-pass paths (TransE: fixed-point SAD, Q = 512;
+    DistMult: bf16 x 3 GEMM, Q = 128).  Their counts must equal (a) the exact f32 kernels' on the whole
+    table and (b) the oracle's on a 100k-row slab (true entities as vectors, the sharded form)."""
+    N, D = 4_600_000, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    table = torch.nn.functional.normalize(torch.randn(N, D, device="cuda", generator=g), dim=-1)
+    for model, q_half in (("transe", 256), ("distmult", 64)):
+        Q = 2 * q_half
+        fixed_row = torch.randint(0, N, (Q,), device="cuda", generator=g)
+        true_row = torch.randint(0, N, (Q,), device="cuda", generator=g)
+        q_fixed = table[fixed_row].clone()
+        q_rel = (torch.rand(Q, D, device="cuda", generator=g) - 0.5) * (0.25 if model == "transe" else 2.0)
+        fast = ops.rank_all(model, table, q_fixed, q_rel, q_half, true_row=true_row)
+        if model == "transe":
+            monkeypatch.setenv("BLP_RANK_KERNEL", "valu")
+            exact = ops.rank_all(model, table, q_fixed, q_rel, q_half, true_row=true_row)
+            monkeypatch.delenv("BLP_RANK_KERNEL")
+        else:  # blocks of < 64 queries take the exact VALU kernel
+            parts_h = [ops.rank_all(model, table, q_fixed[a:a + 32], q_rel[a:a + 32], 32, true_row=true_row[a:a + 32])
+                       for a in range(0, q_half, 32)]
+            parts_t = [ops.rank_all(model, table, q_fixed[a:a + 32], q_rel[a:a + 32], 0, true_row=true_row[a:a + 32])
+                       for a in range(q_half, Q, 32)]
+            exact = torch.cat(parts_h + parts_t)
+        assert torch.equal(fast, exact), model
+        assert int(fast[:, 1].min()) >= 1
+        q_true = table[true_row].clone()
+        slab = table[:100_000]
+        part = ops.rank_all(model, slab, q_fixed, q_rel, q_half, q_true=q_true)
+        want = oracle_counts(oracle, model, slab.cpu(), q_fixed.cpu(), q_rel.cpu(), q_half, q_true=q_true.cpu())
+        assert np.array_equal(part.cpu().numpy(), want), model
+
+
+@pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
+def test_gemm_f32_chain_variant(ops, oracle, model, monkeypatch):
+    """BLP_GEMM_KERNEL=f32 selects the f32 MFMA chain pre-pass (band constant 320) instead of bf16 x 3."""
+    monkeypatch.setenv("BLP_GEMM_KERNEL", "f32")
+    D, N, q_head, q_tail = 128, 1000 + 9, 150, 141
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=41)
+    table[::5] = table[1::5]  # exact ties
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=3)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", golden_names("loss_"))
 def test_golden_inbatch_loss(ops, name):
