@@ -477,13 +477,16 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     });
 
     const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
-    // K-step st of query tile `buf` against both candidate tiles; the two accumulator chains are
-    // interleaved so that no MFMA reads the accumulator the previous one writes
-    auto mfma_step = [&](auto kk, f32x16 (&s)[kBfTPW], const float* buf) {
+    // K-step st of a query tile against both candidate tiles (bh / bl = its hi / lo B operands); the two
+    // accumulator chains are interleaved so that no MFMA reads the accumulator the previous one writes
+    auto load_b = [&](auto kk, const float* buf, bf16x8& bh, bf16x8& bl) {
         constexpr int st = decltype(kk)::value;
         const uint4* bp = reinterpret_cast<const uint4*>(buf) + lane;
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[st * 64]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, bp[(STEPS + st) * 64]);
+        bh = __builtin_bit_cast(bf16x8, bp[st * 64]);
+        bl = __builtin_bit_cast(bf16x8, bp[(STEPS + st) * 64]);
+    };
+    auto mfma_step = [&](auto kk, f32x16 (&s)[kBfTPW], const bf16x8& bh, const bf16x8& bl) {
+        constexpr int st = decltype(kk)::value;
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
             s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].lo[st]), bh, s[ti], 0, 0, 0);
@@ -492,10 +495,20 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
             constexpr int ti = decltype(tt)::value;
             s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bl, s[ti], 0, 0, 0);
         });
-
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
             s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bh, s[ti], 0, 0, 0);
+        });
+    };
+    // all K-steps of one query tile; the B operands of step st + 1 are requested before step st's MFMAs
+    auto mfma_tile = [&](f32x16 (&s)[kBfTPW], const float* buf, auto&& between) {
+        bf16x8 bh[2], bl[2];
+        load_b(ic<0>{}, buf, bh[0], bl[0]);
+        static_for<STEPS>([&](auto kk) {
+            constexpr int st = decltype(kk)::value;
+            if constexpr (st + 1 < STEPS) load_b(ic<st + 1>{}, buf, bh[(st + 1) & 1], bl[(st + 1) & 1]);
+            mfma_step(kk, s, bh[st & 1], bl[st & 1]);
+            between(kk);
         });
     };
     // Decision for accumulator registers [R0, R0 + NR) of both tiles: decided iff
@@ -574,9 +587,8 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         if (more) {
             const float* nbuf = ((t + 1) & 1) ? buf1 : buf0;
             zero_acc(nxt);
-            static_for<STEPS>([&](auto kk) {
+            mfma_tile(nxt, nbuf, [&](auto kk) {
                 constexpr int st = decltype(kk)::value;
-                mfma_step(kk, nxt, nbuf);
                 decide_chunk(ic<st * (16 / STEPS)>{}, ic<16 / STEPS>{}, cur, kt, eq, guard, above, any_und);
             });
         } else {
@@ -594,7 +606,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     __syncthreads();
     f32x16 acc_a[kBfTPW], acc_b[kBfTPW];
     zero_acc(acc_a);
-    static_for<STEPS>([&](auto kk) { mfma_step(kk, acc_a, buf0); });
+    mfma_tile(acc_a, buf0, [](auto) {});
     __syncthreads();  // buf0 is read: stage(0) may overwrite it with tile 2
     for (int t = 0; t < n_tiles; t += 2) {
         stage(t, acc_a, acc_b);
