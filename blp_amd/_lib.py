@@ -21,7 +21,11 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 # every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
            "blp_rank_all_workspace_bytes", "blp_rank_all", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_score_fwd",
-           "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd")
+           "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
+           "blp_inbatch_loss_bwd_t")
+
+
+DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h
 
 
 class HipLibraryError(RuntimeError):
@@ -86,6 +90,11 @@ def lib():
     L.blp_inbatch_loss_bwd.restype = _i
     L.blp_inbatch_loss_bwd.argtypes = [_i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                        _i, _vp]
+    L.blp_inbatch_loss_fwd_t.restype = _i
+    L.blp_inbatch_loss_fwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]
+    L.blp_inbatch_loss_bwd_t.restype = _i
+    L.blp_inbatch_loss_bwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
+                                         _i, _vp]
     _lib = L
     return L
 

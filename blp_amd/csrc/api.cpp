@@ -238,32 +238,58 @@ static int check_inbatch(const char* who, int model, int loss, const void* ent, 
     return BLP_OK;
 }
 
-int blp_inbatch_loss_fwd(int model, int loss, const float* ent_embs, const float* rel_vecs, const int64_t* neg_idx,
-                         int B, int K, int D, float regularizer, float* out_loss, float* save_pos, float* save_neg,
-                         int device, void* stream) {
+static int check_dtypes(const char* who, int ent_dtype, int rel_dtype) {
+    const bool known = ent_dtype >= BLP_DTYPE_F32 && ent_dtype <= BLP_DTYPE_BF16;
+    if (!known || (rel_dtype != ent_dtype && rel_dtype != BLP_DTYPE_F32))
+        return fail(BLP_ERR_BAD_ARG, "%s: ent_dtype %d / rel_dtype %d (rel must have ent's type or be f32)", who,
+                    ent_dtype, rel_dtype);
+    return BLP_OK;
+}
+
+int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void* ent_embs,
+                           const void* rel_vecs, const int64_t* neg_idx, int B, int K, int D, float regularizer,
+                           float* out_loss, float* save_pos, float* save_neg, int device, void* stream) {
     if (int rc = check_inbatch("blp_inbatch_loss_fwd", model, loss, ent_embs, rel_vecs, neg_idx, B, K, D)) return rc;
+    if (int rc = check_dtypes("blp_inbatch_loss_fwd", ent_dtype, rel_dtype)) return rc;
     if (!out_loss || !save_pos || !save_neg) return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_fwd: NULL output");
     DeviceGuard guard(device);
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
-    hipError_t err = blp::launch_inbatch_loss_fwd(model, loss, ent_embs, rel_vecs, neg_idx, B, K, D, regularizer,
-                                                  out_loss, save_pos, save_neg, static_cast<hipStream_t>(stream));
+    hipError_t err = blp::launch_inbatch_loss_fwd(model, loss, ent_dtype, rel_dtype, ent_embs, rel_vecs, neg_idx, B, K, D,
+                                                  regularizer, out_loss, save_pos, save_neg,
+                                                  static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_inbatch_loss_fwd launch");
     return BLP_OK;
+}
+
+int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void* ent_embs,
+                           const void* rel_vecs, const int64_t* neg_idx, int B, int K, int D, float regularizer,
+                           const float* grad_loss, const float* save_pos, const float* save_neg, void* grad_ent,
+                           void* grad_rel, int device, void* stream) {
+    if (int rc = check_inbatch("blp_inbatch_loss_bwd", model, loss, ent_embs, rel_vecs, neg_idx, B, K, D)) return rc;
+    if (int rc = check_dtypes("blp_inbatch_loss_bwd", ent_dtype, rel_dtype)) return rc;
+    if (!grad_loss || !save_pos || !save_neg || !grad_ent || !grad_rel)
+        return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_bwd: NULL pointer");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_inbatch_loss_bwd(model, loss, ent_dtype, rel_dtype, ent_embs, rel_vecs, neg_idx, B, K, D,
+                                                  regularizer, grad_loss, save_pos, save_neg, grad_ent, grad_rel,
+                                                  static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_inbatch_loss_bwd launch");
+    return BLP_OK;
+}
+
+int blp_inbatch_loss_fwd(int model, int loss, const float* ent_embs, const float* rel_vecs, const int64_t* neg_idx,
+                         int B, int K, int D, float regularizer, float* out_loss, float* save_pos, float* save_neg,
+                         int device, void* stream) {
+    return blp_inbatch_loss_fwd_t(model, loss, BLP_DTYPE_F32, BLP_DTYPE_F32, ent_embs, rel_vecs, neg_idx, B, K, D,
+                                  regularizer, out_loss, save_pos, save_neg, device, stream);
 }
 
 int blp_inbatch_loss_bwd(int model, int loss, const float* ent_embs, const float* rel_vecs, const int64_t* neg_idx,
                          int B, int K, int D, float regularizer, const float* grad_loss, const float* save_pos,
                          const float* save_neg, float* grad_ent, float* grad_rel, int device, void* stream) {
-    if (int rc = check_inbatch("blp_inbatch_loss_bwd", model, loss, ent_embs, rel_vecs, neg_idx, B, K, D)) return rc;
-    if (!grad_loss || !save_pos || !save_neg || !grad_ent || !grad_rel)
-        return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_bwd: NULL pointer");
-    DeviceGuard guard(device);
-    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
-    hipError_t err = blp::launch_inbatch_loss_bwd(model, loss, ent_embs, rel_vecs, neg_idx, B, K, D, regularizer,
-                                                  grad_loss, save_pos, save_neg, grad_ent, grad_rel,
-                                                  static_cast<hipStream_t>(stream));
-    if (err != hipSuccess) return hip_fail(err, "blp_inbatch_loss_bwd launch");
-    return BLP_OK;
+    return blp_inbatch_loss_bwd_t(model, loss, BLP_DTYPE_F32, BLP_DTYPE_F32, ent_embs, rel_vecs, neg_idx, B, K, D,
+                                  regularizer, grad_loss, save_pos, save_neg, grad_ent, grad_rel, device, stream);
 }
 
 }  // extern "C"

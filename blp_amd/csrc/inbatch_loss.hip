@@ -6,6 +6,9 @@
 //   fwd: pair scores (one lane per pair)  ->  one-block deterministic reduction
 //   bwd: one wave per entity row / relation row, gathering its contributions in a fixed order
 // so gradients are bit-reproducible run to run (no float atomics).
+// Storage types: ent_embs / grad_ent in TE, rel_vecs / grad_rel in TR, each f32, f16 or bf16 (TR = TE or
+// f32: under autocast the encoder output is half while nn.Embedding rows stay f32).  Half operands are
+// widened exactly and every operation is the f32 one of the reference; gradients are rounded once on store.
 // This path is launch/latency-bound (tens of KB of data): no roofline applies; see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,21 +23,21 @@ namespace blp {
 enum : int { LOSS_MARGIN = 0, LOSS_NLL = 1 };
 
 // ---------------------------------------------------------------- forward
-template <int MODEL>
-__global__ __launch_bounds__(64) void inbatch_scores_kernel(const float* __restrict__ ent,
-                                                           const float* __restrict__ rel,
+template <int MODEL, class TE, class TR>
+__global__ __launch_bounds__(64) void inbatch_scores_kernel(const TE* __restrict__ ent,
+                                                           const TR* __restrict__ rel,
                                                            const int64_t* __restrict__ neg_idx, int B, int K,
                                                            int D, float* __restrict__ pos,
                                                            float* __restrict__ neg) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B * (K + 1)
     if (idx >= B * (K + 1)) return;
     const int b = idx / (K + 1), k = idx % (K + 1);
-    const float* r = rel + (size_t)b * D;
+    const RowF<TR> r{rel + (size_t)b * D};
     if (k == K) {  // positive pair: models.py:56-57
-        pos[b] = score_direct<MODEL>(ent + (size_t)(2 * b) * D, ent + (size_t)(2 * b + 1) * D, r, D);
+        pos[b] = score_direct<MODEL>(RowF<TE>{ent + (size_t)(2 * b) * D}, RowF<TE>{ent + (size_t)(2 * b + 1) * D}, r, D);
     } else {       // negative pair: models.py:65-67
         const int64_t ih = neg_idx[((size_t)b * K + k) * 2], it = neg_idx[((size_t)b * K + k) * 2 + 1];
-        neg[(size_t)b * K + k] = score_direct<MODEL>(ent + ih * D, ent + it * D, r, D);
+        neg[(size_t)b * K + k] = score_direct<MODEL>(RowF<TE>{ent + ih * D}, RowF<TE>{ent + it * D}, r, D);
     }
 }
 
@@ -54,8 +57,9 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return total;
 }
 
-__global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, const float* __restrict__ ent,
-                                                             const float* __restrict__ rel,
+template <class TE, class TR>
+__global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, const TE* __restrict__ ent,
+                                                             const TR* __restrict__ rel,
                                                              const float* __restrict__ pos,
                                                              const float* __restrict__ neg, int B, int K, int D,
                                                              float regularizer, float* __restrict__ out) {
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, const fl
     double reg = 0.0;
     if (regularizer > 0.0f) {  // models.py:59-60, 261-266: mean(h^2) + mean(t^2) + mean(r^2) over positives
         double s = 0.0;
-        for (int i = tid; i < 2 * B * D; i += nt) s += (double)ent[i] * ent[i];
-        for (int i = tid; i < B * D; i += nt) s += (double)rel[i] * rel[i];
+        for (int i = tid; i < 2 * B * D; i += nt) s += (double)(float)ent[i] * (double)(float)ent[i];
+        for (int i = tid; i < B * D; i += nt) s += (double)(float)rel[i] * (double)(float)rel[i];
         reg = (double)regularizer * block_sum(s, sh) / ((double)B * D) / 3.0;
     }
     if (tid == 0) out[0] = (float)(model_loss + reg);
@@ -116,11 +120,11 @@ __device__ __forceinline__ float dloss_dpos(int loss, float pos_b, const float* 
 
 // One wave per row j of ent_embs.view(2B, D): positive-pair term, then every negative pair that
 // references row j, found by scanning neg_idx in order (8 KB of int64 per K = 64 row -- L2 hits).
-template <int MODEL>
+template <int MODEL, class TE, class TR>
 __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
-    int loss, const float* __restrict__ ent, const float* __restrict__ rel, const int64_t* __restrict__ neg_idx,
+    int loss, const TE* __restrict__ ent, const TR* __restrict__ rel, const int64_t* __restrict__ neg_idx,
     int B, int K, int D, float regularizer, const float* __restrict__ grad_loss,
-    const float* __restrict__ pos, const float* __restrict__ neg, float* __restrict__ grad_ent) {
+    const float* __restrict__ pos, const float* __restrict__ neg, TE* __restrict__ grad_ent) {
     const int j = blockIdx.x, lane = threadIdx.x;
     const int b = j >> 1, slot = j & 1;
     const float gl = grad_loss[0];
@@ -131,9 +135,8 @@ __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
 
     {   // positive pair (2b, 2b+1, rel b)
         const float gp = dloss_dpos(loss, pos[b], neg + (size_t)b * K, B, K);
-        const float* h = ent + (size_t)(2 * b) * D;
-        const float* t = h + D;
-        const float* r = rel + (size_t)b * D;
+        const RowF<TE> h{ent + (size_t)(2 * b) * D}, t{ent + (size_t)(2 * b + 1) * D};
+        const RowF<TR> r{rel + (size_t)b * D};
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
             const int d = lane + 64 * i;
@@ -151,9 +154,8 @@ __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
             const int e = base + bit, pair = e >> 1, s = e & 1, pb = pair / K;
             const float gn = dloss_dneg(loss, pos[pb], neg[pair], B, K);
             if (gn != 0.0f) {
-                const float* h = ent + neg_idx[2 * (size_t)pair] * D;
-                const float* t = ent + neg_idx[2 * (size_t)pair + 1] * D;
-                const float* r = rel + (size_t)pb * D;
+                const RowF<TE> h{ent + neg_idx[2 * (size_t)pair] * D}, t{ent + neg_idx[2 * (size_t)pair + 1] * D};
+                const RowF<TR> r{rel + (size_t)pb * D};
 #pragma unroll
                 for (int q = 0; q < MAXR; ++q) {
                     const int d = lane + 64 * q;
@@ -166,30 +168,30 @@ __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const int d = lane + 64 * i;
-        if (d < D) grad_ent[(size_t)j * D + d] = gl * (g[i] + reg_scale * ent[(size_t)j * D + d]);
+        if (d < D) grad_ent[(size_t)j * D + d] = (TE)(gl * (g[i] + reg_scale * (float)ent[(size_t)j * D + d]));
     }
 }
 
 // One wave per relation row b: positive pair + its K negatives (rels broadcast over K, models.py:67).
-template <int MODEL>
+template <int MODEL, class TE, class TR>
 __global__ __launch_bounds__(64) void inbatch_grad_rel_kernel(
-    int loss, const float* __restrict__ ent, const float* __restrict__ rel, const int64_t* __restrict__ neg_idx,
+    int loss, const TE* __restrict__ ent, const TR* __restrict__ rel, const int64_t* __restrict__ neg_idx,
     int B, int K, int D, float regularizer, const float* __restrict__ grad_loss,
-    const float* __restrict__ pos, const float* __restrict__ neg, float* __restrict__ grad_rel) {
+    const float* __restrict__ pos, const float* __restrict__ neg, TR* __restrict__ grad_rel) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float gl = grad_loss[0];
-    const float* r = rel + (size_t)b * D;
+    const RowF<TR> r{rel + (size_t)b * D};
     const float gp = dloss_dpos(loss, pos[b], neg + (size_t)b * K, B, K);
     const float reg_scale = regularizer > 0.0f ? regularizer * 2.0f / (3.0f * B * D) : 0.0f;
     for (int d = lane; d < D; d += 64) {
-        float g = gp * dscore<MODEL>(2, ent + (size_t)(2 * b) * D, ent + (size_t)(2 * b + 1) * D, r, d, D);
+        float g = gp * dscore<MODEL>(2, RowF<TE>{ent + (size_t)(2 * b) * D}, RowF<TE>{ent + (size_t)(2 * b + 1) * D}, r, d, D);
         for (int k = 0; k < K; ++k) {
             const size_t pair = (size_t)b * K + k;
             const float gn = dloss_dneg(loss, pos[b], neg[pair], B, K);
             if (gn != 0.0f)
-                g += gn * dscore<MODEL>(2, ent + neg_idx[2 * pair] * D, ent + neg_idx[2 * pair + 1] * D, r, d, D);
+                g += gn * dscore<MODEL>(2, RowF<TE>{ent + neg_idx[2 * pair] * D}, RowF<TE>{ent + neg_idx[2 * pair + 1] * D}, r, d, D);
         }
-        grad_rel[(size_t)b * D + d] = gl * (g + reg_scale * r[d]);
+        grad_rel[(size_t)b * D + d] = (TR)(gl * (g + reg_scale * r[d]));
     }
 }
 
@@ -205,27 +207,52 @@ static hipError_t dispatch_model(int model, F f) {
     }
 }
 
-hipError_t launch_inbatch_loss_fwd(int model, int loss, const float* ent, const float* rel,
+template <class T> struct TypeTag { using type = T; };
+
+// (ent dtype, rel dtype) with 0 = f32, 1 = f16, 2 = bf16; rel is either ent's type or f32
+template <class F>
+static hipError_t dispatch_types(int ent_dtype, int rel_dtype, F f) {
+    if (ent_dtype == 0 && rel_dtype == 0) return f(TypeTag<float>{}, TypeTag<float>{});
+    if (ent_dtype == 1 && rel_dtype == 1) return f(TypeTag<_Float16>{}, TypeTag<_Float16>{});
+    if (ent_dtype == 1 && rel_dtype == 0) return f(TypeTag<_Float16>{}, TypeTag<float>{});
+    if (ent_dtype == 2 && rel_dtype == 2) return f(TypeTag<__bf16>{}, TypeTag<__bf16>{});
+    if (ent_dtype == 2 && rel_dtype == 0) return f(TypeTag<__bf16>{}, TypeTag<float>{});
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_inbatch_loss_fwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent, const void* rel,
                                    const int64_t* neg_idx, int B, int K, int D, float regularizer,
                                    float* out_loss, float* save_pos, float* save_neg, hipStream_t stream) {
     return dispatch_model(model, [&](auto m) {
-        const int pairs = B * (K + 1);
-        inbatch_scores_kernel<decltype(m)::value><<<(pairs + 63) / 64, 64, 0, stream>>>(ent, rel, neg_idx, B, K, D, save_pos, save_neg);
-        inbatch_reduce_kernel<<<1, 1024, 0, stream>>>(loss, ent, rel, save_pos, save_neg, B, K, D, regularizer, out_loss);
-        return hipGetLastError();
+        return dispatch_types(ent_dtype, rel_dtype, [&](auto te, auto tr) {
+            using TE = typename decltype(te)::type;
+            using TR = typename decltype(tr)::type;
+            const TE* e = static_cast<const TE*>(ent);
+            const TR* r = static_cast<const TR*>(rel);
+            const int pairs = B * (K + 1);
+            inbatch_scores_kernel<decltype(m)::value, TE, TR><<<(pairs + 63) / 64, 64, 0, stream>>>(e, r, neg_idx, B, K, D, save_pos, save_neg);
+            inbatch_reduce_kernel<TE, TR><<<1, 1024, 0, stream>>>(loss, e, r, save_pos, save_neg, B, K, D, regularizer, out_loss);
+            return hipGetLastError();
+        });
     });
 }
 
-hipError_t launch_inbatch_loss_bwd(int model, int loss, const float* ent, const float* rel,
+hipError_t launch_inbatch_loss_bwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent, const void* rel,
                                    const int64_t* neg_idx, int B, int K, int D, float regularizer,
                                    const float* grad_loss, const float* save_pos, const float* save_neg,
-                                   float* grad_ent, float* grad_rel, hipStream_t stream) {
+                                   void* grad_ent, void* grad_rel, hipStream_t stream) {
     return dispatch_model(model, [&](auto m) {
-        inbatch_grad_ent_kernel<decltype(m)::value><<<2 * B, 64, 0, stream>>>(
-            loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, save_pos, save_neg, grad_ent);
-        inbatch_grad_rel_kernel<decltype(m)::value><<<B, 64, 0, stream>>>(
-            loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, save_pos, save_neg, grad_rel);
-        return hipGetLastError();
+        return dispatch_types(ent_dtype, rel_dtype, [&](auto te, auto tr) {
+            using TE = typename decltype(te)::type;
+            using TR = typename decltype(tr)::type;
+            const TE* e = static_cast<const TE*>(ent);
+            const TR* r = static_cast<const TR*>(rel);
+            inbatch_grad_ent_kernel<decltype(m)::value, TE, TR><<<2 * B, 64, 0, stream>>>(
+                loss, e, r, neg_idx, B, K, D, regularizer, grad_loss, save_pos, save_neg, static_cast<TE*>(grad_ent));
+            inbatch_grad_rel_kernel<decltype(m)::value, TE, TR><<<B, 64, 0, stream>>>(
+                loss, e, r, neg_idx, B, K, D, regularizer, grad_loss, save_pos, save_neg, static_cast<TR*>(grad_rel));
+            return hipGetLastError();
+        });
     });
 }
 

@@ -33,14 +33,12 @@ hipError_t launch_score_bwd(int model, int D, int64_t M0, int64_t M1, StridedRow
                             StridedRows r, const float* grad_out, float* grad_h, float* grad_t,
                             float* grad_r, hipStream_t stream);
 
-hipError_t launch_inbatch_loss_fwd(int model, int loss, const float* ent, const float* rel,
+hipError_t launch_inbatch_loss_fwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent, const void* rel,
                                    const int64_t* neg_idx, int B, int K, int D, float regularizer,
-                                   float* out_loss, float* save_pos, float* save_neg,
-                                   hipStream_t stream);
-hipError_t launch_inbatch_loss_bwd(int model, int loss, const float* ent, const float* rel,
+                                   float* out_loss, float* save_pos, float* save_neg, hipStream_t stream);
+hipError_t launch_inbatch_loss_bwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent, const void* rel,
                                    const int64_t* neg_idx, int B, int K, int D, float regularizer,
-                                   const float* grad_loss, const float* save_pos,
-                                   const float* save_neg, float* grad_ent, float* grad_rel,
-                                   hipStream_t stream);
+                                   const float* grad_loss, const float* save_pos, const float* save_neg,
+                                   void* grad_ent, void* grad_rel, hipStream_t stream);
 
 }  // namespace blp

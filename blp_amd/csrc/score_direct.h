@@ -33,9 +33,16 @@ __device__ __forceinline__ float torch_inner_sum_rt(int n, Term term) {
     return s;
 }
 
-template <int MODEL>
-__device__ __forceinline__ float score_direct(const float* __restrict__ h, const float* __restrict__ t,
-                                              const float* __restrict__ r, int D) {
+// A row of storage type T read as f32 (f16 / bf16 -> f32 is exact): lets the routines below take
+// half-precision operands while every operation stays the reference's f32 one.
+template <class T>
+struct RowF {
+    const T* p;
+    __device__ __forceinline__ float operator[](int i) const { return (float)p[i]; }
+};
+
+template <int MODEL, class PH, class PT, class PR>
+__device__ __forceinline__ float score_direct(PH h, PT t, PR r, int D) {
     if constexpr (MODEL == TRANSE) {
         float acc = 0.0f;
         for (int d = 0; d < D; ++d) {
@@ -74,9 +81,8 @@ __device__ __forceinline__ float score_direct(const float* __restrict__ h, const
 __device__ __forceinline__ float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
 // d score / d operand[d] for operand in {0: heads, 1: tails, 2: rels}.
-template <int MODEL>
-__device__ __forceinline__ float dscore(int operand, const float* __restrict__ h, const float* __restrict__ t,
-                                        const float* __restrict__ r, int d, int D) {
+template <int MODEL, class PH, class PT, class PR>
+__device__ __forceinline__ float dscore(int operand, PH h, PT t, PR r, int d, int D) {
     if constexpr (MODEL == TRANSE) {
         const float sg = sign0(h[d] + r[d] - t[d]);  // -|x|' = -sign(x); sign(0) = 0 like torch
         return operand == 1 ? sg : -sg;

@@ -156,7 +156,10 @@ class LinkPrediction(nn.Module):
         reference's gather temporary and ~40 small kernels; on CPU it is the reference's expression.
         """
         rel_vecs = self.rel_emb(rels)
-        if ent_embs.is_cuda and ent_embs.dtype == torch.float32 and ent_embs.dim() == 3 and neg_idx.dim() == 3:
+        fused_dtype = ent_embs.dtype in (torch.float32, torch.float16, torch.bfloat16)
+        if ent_embs.is_cuda and fused_dtype and ent_embs.dim() == 3 and neg_idx.dim() == 3:
+            if rel_vecs.dtype not in (ent_embs.dtype, torch.float32):
+                rel_vecs = rel_vecs.float()
             return ops.inbatch_loss(self.rel_model, self.loss_name, ent_embs, rel_vecs, neg_idx, self.regularizer)
         return self._compute_loss_torch(ent_embs, rel_vecs, neg_idx)
 

@@ -259,8 +259,11 @@ class _InBatchLoss(torch.autograd.Function):
         if neg_idx.dim() != 3 or neg_idx.shape[0] != B or neg_idx.shape[2] != 2:
             raise ValueError(f"neg_idx must be (B, K, 2), got {tuple(neg_idx.shape)}")
         K = neg_idx.shape[1]
-        if ent_embs.dtype != torch.float32 or rel_vecs.dtype != torch.float32:
-            raise TypeError("ent_embs and rel_vecs must be float32")
+        names = {getattr(torch, n): i for i, n in enumerate(_lib.DTYPE_NAMES)}
+        if ent_embs.dtype not in names or rel_vecs.dtype not in (ent_embs.dtype, torch.float32):
+            raise TypeError("ent_embs must be float32 / float16 / bfloat16 and rel_vecs of the same dtype or float32 "
+                            f"(got {ent_embs.dtype}, {rel_vecs.dtype})")
+        dtypes = (names[ent_embs.dtype], names[rel_vecs.dtype])
         ent = ent_embs.contiguous()
         rel = rel_vecs.reshape(B, D).contiguous()
         idx = neg_idx.to(torch.int64).contiguous()
@@ -268,26 +271,26 @@ class _InBatchLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         pos = torch.empty(B, dtype=torch.float32, device=dev)
         neg = torch.empty((B, K), dtype=torch.float32, device=dev)
-        status = _lib.lib().blp_inbatch_loss_fwd(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], _ptr(ent),
-                                                 _ptr(rel), _ptr(idx), B, K, D, float(regularizer),
-                                                 _ptr(loss), _ptr(pos), _ptr(neg), dev.index, _stream(dev))
+        status = _lib.lib().blp_inbatch_loss_fwd_t(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
+                                                   _ptr(ent), _ptr(rel), _ptr(idx), B, K, D, float(regularizer),
+                                                   _ptr(loss), _ptr(pos), _ptr(neg), dev.index, _stream(dev))
         _lib.check(status, "blp_inbatch_loss_fwd")
-        ctx.meta = (rel_model, loss_fn, float(regularizer), B, K, D, rel_vecs.shape)
+        ctx.meta = (rel_model, loss_fn, float(regularizer), B, K, D, rel_vecs.shape, dtypes)
         ctx.save_for_backward(ent, rel, idx, pos, neg)
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         ent, rel, idx, pos, neg = ctx.saved_tensors
-        rel_model, loss_fn, regularizer, B, K, D, rel_shape = ctx.meta
+        rel_model, loss_fn, regularizer, B, K, D, rel_shape, dtypes = ctx.meta
         dev = ent.device
         grad_loss = grad_loss.to(torch.float32).contiguous()
-        grad_ent = torch.empty((B, 2, D), dtype=torch.float32, device=dev)
-        grad_rel = torch.empty((B, D), dtype=torch.float32, device=dev)
-        status = _lib.lib().blp_inbatch_loss_bwd(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], _ptr(ent),
-                                                 _ptr(rel), _ptr(idx), B, K, D, regularizer, _ptr(grad_loss),
-                                                 _ptr(pos), _ptr(neg), _ptr(grad_ent), _ptr(grad_rel),
-                                                 dev.index, _stream(dev))
+        grad_ent = torch.empty((B, 2, D), dtype=ent.dtype, device=dev)
+        grad_rel = torch.empty((B, D), dtype=rel.dtype, device=dev)
+        status = _lib.lib().blp_inbatch_loss_bwd_t(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
+                                                   _ptr(ent), _ptr(rel), _ptr(idx), B, K, D, regularizer,
+                                                   _ptr(grad_loss), _ptr(pos), _ptr(neg), _ptr(grad_ent),
+                                                   _ptr(grad_rel), dev.index, _stream(dev))
         _lib.check(status, "blp_inbatch_loss_bwd")
         return None, None, None, grad_ent, grad_rel.reshape(rel_shape), None
 

@@ -167,6 +167,24 @@ int blp_inbatch_loss_bwd(int model, int loss, const float *ent_embs, const float
                          const float *grad_loss, const float *save_pos, const float *save_neg,
                          float *grad_ent, float *grad_rel, int device, void *stream);
 
+
+/* Storage-typed variants (BASELINE config 5: half-precision embeddings under autocast).  ent_embs and
+ * grad_ent are ent_dtype, rel_vecs and grad_rel are rel_dtype (= ent_dtype, or f32: nn.Embedding rows
+ * stay f32 under autocast).  Half operands are widened exactly and every operation is the f32 one of
+ * the reference (f32 accumulate); loss and the saved scores stay f32; gradients are rounded once on
+ * store.  The reference has no half path: parity is a tolerance against the f32 oracle on the
+ * widened inputs (tests/test_gpu_parity.py::test_inbatch_loss_half_*). */
+enum { BLP_DTYPE_F32 = 0, BLP_DTYPE_F16 = 1, BLP_DTYPE_BF16 = 2 };
+int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
+                           const void *rel_vecs, const int64_t *neg_idx, int B, int K, int D,
+                           float regularizer, float *out_loss, float *save_pos, float *save_neg,
+                           int device, void *stream);
+int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
+                           const void *rel_vecs, const int64_t *neg_idx, int B, int K, int D,
+                           float regularizer, const float *grad_loss, const float *save_pos,
+                           const float *save_neg, void *grad_ent, void *grad_rel, int device,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

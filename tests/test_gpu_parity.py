@@ -472,6 +472,58 @@ def test_inbatch_loss_training_shape_vs_port(ops, model, loss_fn):
 
 
 @pytest.mark.parametrize("model", REL_MODELS)
+@pytest.mark.parametrize("loss_fn", ["margin", "nll"])
+@pytest.mark.parametrize("dtype,rel_f32", [(torch.float16, False), (torch.float16, True), (torch.bfloat16, False),
+                                            (torch.bfloat16, True)])
+def test_inbatch_loss_half_storage(ops, model, loss_fn, dtype, rel_f32):
+    """BASELINE config 5 shape per GPU (B = 128, K = 64, D = 128) with half-precision embeddings (what
+    the encoder emits under autocast; relation rows optionally still f32).  The reference has no half
+    path: the oracle is the f32 torch port on the SAME values widened to f32.  Operands are widened
+    exactly and accumulated in f32, so the loss matches like the f32 path (rel 2e-6); gradients are f32
+    values rounded once to the storage type: rtol 2^-10 (f16) / 2^-7 (bf16)."""
+    from oracle import ref_port
+    torch.manual_seed(5)
+    B, K, D = 128, 64, 128
+    ent = torch.randn(B, 2, D) * (1.0 if model == "transe" else 0.4)
+    if model == "transe":
+        ent = torch.nn.functional.normalize(ent, dim=-1)
+    ent = ent.to(dtype)
+    rel = torch.randn(B, 1, D) * 0.3
+    rel = rel if rel_f32 else rel.to(dtype)
+    neg_idx = torch.randint(0, 2 * B, (B, K, 2))
+    reg = 1e-3 if model == "complex" else 0.0
+    e_ref, r_ref = ent.float().clone().requires_grad_(True), rel.float().clone().requires_grad_(True)
+    ref = ref_port.compute_loss(model, loss_fn, e_ref, r_ref, neg_idx, reg)
+    ref.backward()
+    e, r = ent.cuda().requires_grad_(True), rel.cuda().requires_grad_(True)
+    loss = ops.inbatch_loss(model, loss_fn, e, r, neg_idx.cuda(), reg)
+    loss.backward()
+    assert loss.dtype == torch.float32 and e.grad.dtype == dtype and r.grad.dtype == rel.dtype
+    assert loss.item() == pytest.approx(ref.item(), rel=2e-6, abs=1e-7)
+    def tol(t):
+        return {torch.float32: 2e-5, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[t]
+    np.testing.assert_allclose(e.grad.float().cpu().numpy(), e_ref.grad.numpy(), rtol=tol(dtype), atol=1e-7)
+    np.testing.assert_allclose(r.grad.float().cpu().numpy(), r_ref.grad.numpy(), rtol=tol(rel.dtype), atol=1e-7)
+
+
+def test_compute_loss_under_autocast(ops):
+    """LinkPrediction.compute_loss with f16 embeddings and f32 relation rows (the autocast mix) takes the
+    fused path and matches its own f32 evaluation of the widened inputs."""
+    from blp_amd import models
+    torch.manual_seed(9)
+    B, K, D = 64, 64, 128
+    model = models.LinkPrediction(D, "complex", "margin", 11, 1e-3).cuda()
+    ent = (torch.randn(B, 2, D, device="cuda") * 0.4).half()
+    rels = torch.randint(0, 11, (B, 1), device="cuda")
+    neg_idx = torch.randint(0, 2 * B, (B, K, 2), device="cuda")
+    with torch.autocast("cuda", dtype=torch.float16):
+        half_loss = model.compute_loss(ent, rels, neg_idx)
+    full_loss = model.compute_loss(ent.float(), rels, neg_idx)
+    assert half_loss.dtype == torch.float32
+    assert half_loss.item() == pytest.approx(full_loss.item(), rel=1e-6)
+
+
+@pytest.mark.parametrize("model", REL_MODELS)
 def test_score_fn_training_broadcast_and_grad(ops, model):
     """score_fn on (B, K, D) x (B, 1, D) (models.py:67): golden-exact forward, analytic backward vs
     autograd of the torch port (rtol 1e-5)."""

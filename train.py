@@ -61,6 +61,7 @@ def config():
     use_cached_text = False
     data_root = 'data'
     seed = None
+    amp = None  # None | 'fp16' | 'bf16': autocast the training step (BASELINE config 5; not in the reference)
 
 
 def _linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps):
@@ -92,7 +93,9 @@ def _get_model(model, dim, rel_model, loss_fn, num_entities, num_relations, enco
 @ex.command
 def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_name, regularizer, max_len,
                     num_negatives, lr, use_scheduler, batch_size, emb_batch_size, eval_batch_size, max_epochs,
-                    checkpoint, use_cached_text, data_root, seed, _run, _log):
+                    checkpoint, use_cached_text, data_root, seed, amp, _run, _log):
+    if amp not in (None, 'fp16', 'bf16'):
+        raise ValueError(f'Unknown amp mode {amp}')
     if seed is not None:
         torch.manual_seed(seed)
         np.random.seed(seed)
@@ -156,13 +159,20 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
     os.makedirs(OUT_PATH, exist_ok=True)
     checkpoint_file = osp.join(OUT_PATH, f'model-{_run._id}.pt')
     log_every = max(1, int(0.05 * len(train_loader)))
+    # amp: the encoder runs under autocast and hands half-precision embeddings to the fused loss, which
+    # widens them exactly and accumulates in f32 (blp_inbatch_loss_*_t); fp16 needs loss scaling
+    use_amp = amp is not None and device != torch.device('cpu')
+    amp_dtype = torch.float16 if amp == 'fp16' else torch.bfloat16
+    scaler = torch.amp.GradScaler('cuda', enabled=use_amp and amp == 'fp16')
     for epoch in range(1, max_epochs + 1):
         train_loss = 0
         for step, data in enumerate(train_loader):
-            loss = net(*data).mean()
+            with torch.autocast('cuda', dtype=amp_dtype, enabled=use_amp):
+                loss = net(*data).mean()
             optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scaler.update()
             if scheduler is not None:
                 scheduler.step()
             train_loss += loss.item()
