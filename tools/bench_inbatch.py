@@ -49,6 +49,24 @@ def main():
 
                 a, b = timeit(fused), timeit(stock)
                 print(f"{model:9s} {loss_fn:7s} {B:4d} | {a:16.1f} | {b:16.1f} | {b / a:5.2f}x")
+    # BASELINE config 5: ComplEx, margin, 128 triples per GPU, half-precision embeddings (autocast mix:
+    # f16 / bf16 encoder output, f32 relation rows); torch leg = the reference expressions on the same tensors
+    B, K, D, model, loss_fn, reg = 128, 64, 128, "complex", "margin", 1e-3
+    for dtype in (torch.float16, torch.bfloat16):
+        ent = (torch.randn(B, 2, D, device="cuda") * 0.4).to(dtype)
+        rel = torch.randn(B, 1, D, device="cuda") * 0.3
+        neg_idx = torch.randint(0, 2 * B, (B, K, 2), device="cuda")
+
+        def fused():
+            e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+            ops.inbatch_loss(model, loss_fn, e, r, neg_idx, reg).backward()
+
+        def stock():
+            e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+            ref_port.compute_loss(model, loss_fn, e, r, neg_idx, reg).backward()
+
+        a, b = timeit(fused), timeit(stock)
+        print(f"{model:9s} {loss_fn:7s} {B:4d} | {a:16.1f} | {b:16.1f} | {b / a:5.2f}x   ({str(dtype)[6:]} embeddings)")
 
 
 if __name__ == "__main__":

@@ -16,7 +16,8 @@ find /tmp/rp/trace -name "*kernel_trace.csv" -exec sh -c 'head -400 "$1" > '$OUT
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
-           "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+           "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/rp/pmc$i -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline $@ > $OUT/pmc$i.log 2>&1
   echo "pmc$i ($grp) rc=$?"
