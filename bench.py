@@ -256,33 +256,35 @@ def main():
     else:
         Q_global = Q
     q_true = table[true_row].contiguous() if (world > 1 and axis == "candidate") else None
-    gathered = torch.empty((world, Q, 4), dtype=torch.int32, device=device) if q_true is not None else None
+    # one step = `passes` table passes (reference batches); their counts are exchanged ONCE per step
+    local_all = torch.empty((passes, Q, 4), dtype=torch.int32, device=device)
+    gathered = torch.empty((world, passes * Q, 4), dtype=torch.int32, device=device) if q_true is not None else None
 
     def step():
-        out = None
-        for _ in range(passes):
+        for i in range(passes):
             if q_true is not None:
-                local = ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids)
-                if backend == "gloo":
-                    parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
-                    dist.all_gather(parts, local.cpu())
-                    gathered.copy_(torch.stack(parts))
-                else:
-                    dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
-                counts = gathered.sum(dim=0, dtype=torch.int32)
+                ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids, out=local_all[i])
             else:
-                counts = ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids)
-            rr, hits = ops.rank_metrics(counts)
-            sums = torch.cat((rr[:, :1].double().sum(dim=0), hits[:, 0].double().sum(dim=0)))
-            if world > 1 and axis == "query":
-                if backend == "gloo":
-                    host = sums.cpu()
-                    dist.all_reduce(host)
-                    sums = host.to(device)
-                else:
-                    dist.all_reduce(sums)
-            out = (counts, sums[0] / Q_global, sums[1:] / Q_global)
-        return out
+                ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids, out=local_all[i])
+        counts = local_all.view(passes * Q, 4)
+        if q_true is not None:  # candidate shards: per-shard counts add up
+            if backend == "gloo":
+                parts = [torch.empty(counts.shape, dtype=counts.dtype) for _ in range(world)]
+                dist.all_gather(parts, counts.cpu())
+                gathered.copy_(torch.stack(parts))
+            else:
+                dist.all_gather_into_tensor(gathered.view(-1), counts.reshape(-1))
+            counts = gathered.sum(dim=0, dtype=torch.int32)
+        rr, hits = ops.rank_metrics(counts)
+        sums = torch.cat((rr[:, :1].double().sum(dim=0), hits[:, 0].double().sum(dim=0)))
+        if world > 1 and axis == "query":  # query shards: only the metric sums travel
+            if backend == "gloo":
+                host = sums.cpu()
+                dist.all_reduce(host)
+                sums = host.to(device)
+            else:
+                dist.all_reduce(sums)
+        return counts[-Q:], sums[0] / (Q_global * passes), sums[1:] / (Q_global * passes)
 
     def fence():
         if world > 1:
