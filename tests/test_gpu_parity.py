@@ -311,6 +311,12 @@ def test_edge_shapes(ops, oracle, model):
     want = oracle_counts(oracle, model, tab.contiguous(), q_fixed, q_rel, 3, true_row=true_row)
     got = ops.rank_all(model, big.cuda()[:, :D], q_fixed.cuda(), q_rel.cuda(), 3, true_row=true_row.cuda())
     assert np.array_equal(got.cpu().numpy(), want)
+    # ... and with enough queries for the pre-pass paths (their own table readers honour ld too)
+    idx = torch.arange(300) % 70
+    q_fixed, q_rel, true_row = tab[idx].contiguous(), torch.randn(300, D) * 0.1, (idx * 7 + 3) % 70
+    want = oracle_counts(oracle, model, tab.contiguous(), q_fixed, q_rel, 140, true_row=true_row)
+    got = ops.rank_all(model, big.cuda()[:, :D], q_fixed.cuda(), q_rel.cuda(), 140, true_row=true_row.cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("model", REL_MODELS)
