@@ -218,6 +218,33 @@ def _module(model):
     return model.module if isinstance(model, torch.nn.DataParallel) else model
 
 
+def _loader_triples(loader, max_num_batches):
+    """Every triple the reference's loop ``for i, triples in enumerate(loader)`` would see before
+    ``i == max_num_batches``.  A sequential default-collate DataLoader over a dataset that holds its
+    triples as one tensor (data.GraphDataset and subclasses: the reference's eval loaders,
+    train.py:124-128) is read as a slice instead of 800+ Python-level batches."""
+    from torch.utils.data import SequentialSampler
+    from torch.utils.data.dataloader import default_collate
+    dataset = getattr(loader, "dataset", None)
+    stored = getattr(dataset, "triples", None)
+    batch_size = getattr(loader, "batch_size", None)
+    if (isinstance(stored, torch.Tensor) and stored.dim() == 2 and batch_size
+            and isinstance(getattr(loader, "sampler", None), SequentialSampler)
+            and getattr(loader, "collate_fn", None) is default_collate and len(dataset) == stored.shape[0]):
+        n = stored.shape[0]
+        if getattr(loader, "drop_last", False):
+            n = n // batch_size * batch_size
+        if max_num_batches is not None:
+            n = min(n, max_num_batches * batch_size)
+        return stored[:n]
+    batches = []
+    for i, triples in enumerate(loader):
+        if max_num_batches is not None and i == max_num_batches:
+            break
+        batches.append(triples)
+    return torch.cat(batches) if batches else torch.zeros((0, 3), dtype=torch.long)
+
+
 @torch.no_grad()
 def build_entity_table(model, text_dataset, entities, emb_batch_size, device, log=None, rows=None):
     """train.py:96-121: encode ``entities`` (or the slice ``rows`` = (lo, hi) of them) in chunks of
@@ -243,7 +270,7 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
 @torch.no_grad()
 def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, emb_batch_size, _run, _log,
                          prefix="", max_num_batches=None, filtering_graph=None, new_entities=None,
-                         return_embeddings=False, device=None, group=None, block_size=8192, shard_axis="auto"):
+                         return_embeddings=False, device=None, group=None, block_size=65536, shard_axis="auto"):
     """Drop-in for train.eval_link_prediction (same positional arguments, metric names and return
     value).  ``device`` defaults to the model's device; ``group`` (or an initialised default process
     group) shards the evaluation, along ``shard_axis`` = "candidate" | "query" | "auto"."""
@@ -276,13 +303,7 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     model.eval()
     table = build_entity_table(model, text_dataset, entities, emb_batch_size, device, _log, rows=(lo, hi))
 
-    # every evaluated triple, in loader order (train.py:128-131)
-    batches = []
-    for i, triples in enumerate(triples_loader):
-        if max_num_batches is not None and i == max_num_batches:
-            break
-        batches.append(triples)
-    triples = torch.cat(batches) if batches else torch.zeros((0, 3), dtype=torch.long)
+    triples = _loader_triples(triples_loader, max_num_batches)  # in loader order (train.py:128-131)
     # The metrics are sums over triples, so the evaluation order is free: group by relation, which lets
     # the TransE kernel share e + r among the head-replacing queries of a relation.
     triples = triples[torch.argsort(triples[:, 2], stable=True)]
@@ -313,7 +334,7 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
         b = sl.stop - sl.start
         rel_vecs = model.rel_emb(triples[sl, 2].to(device))
         rel_ids = torch.cat((triples[sl, 2], triples[sl, 2]))
-        filt = index.csr(triples[sl], ent2idx) if compute_filtered else (None, None)
+        filt = index.csr(triples[sl], ent2idx, device if not sharded else "cpu") if compute_filtered else (None, None)
         if sharded:
             h_vec, t_vec = vectors[head_pos[sl].to(device)], vectors[tail_pos[sl].to(device)]
             ranker.rank_block(torch.cat((t_vec, h_vec)), torch.cat((rel_vecs, rel_vecs)), torch.cat((h_vec, t_vec)),

@@ -81,36 +81,47 @@ class FilterIndex:
     @staticmethod
     def _lookup(sorted_key, sorted_val, key, exclude, ent2idx):
         """For each query key: the values under it, minus `exclude`, mapped through ent2idx, minus -1.
-        Returns (counts per query, flat mapped values)."""
+        Returns (counts per query, flat mapped values).  Device-agnostic: all tensors on one device."""
+        dev = key.device
         lo = torch.searchsorted(sorted_key, key, right=False)
         hi = torch.searchsorted(sorted_key, key, right=True)
         n = hi - lo
         total = int(n.sum())
         if total == 0:
-            return torch.zeros_like(n), torch.empty(0, dtype=torch.long)
-        owner = torch.repeat_interleave(torch.arange(key.shape[0]), n)
-        start = torch.repeat_interleave(lo, n)
-        first = torch.repeat_interleave(torch.cumsum(n, 0) - n, n)
-        pos = start + (torch.arange(total) - first)
+            return torch.zeros_like(n), torch.empty(0, dtype=torch.long, device=dev)
+        owner = torch.repeat_interleave(torch.arange(key.shape[0], device=dev), n, output_size=total)
+        first = torch.cumsum(n, 0) - n
+        pos = (lo - first)[owner] + torch.arange(total, device=dev)
         vals = sorted_val[pos]
-        keep = vals != exclude[owner]
         in_range = vals < ent2idx.shape[0]
-        mapped = torch.full_like(vals, -1)
-        mapped[in_range] = ent2idx[vals[in_range]]
-        keep &= mapped >= 0
+        mapped = torch.where(in_range, ent2idx[torch.where(in_range, vals, torch.zeros_like(vals))],
+                             torch.full_like(vals, -1))
+        keep = (vals != exclude[owner]) & (mapped >= 0)
         owner, mapped = owner[keep], mapped[keep]
         counts = torch.bincount(owner, minlength=key.shape[0])
         return counts, mapped
 
-    def csr(self, triples, ent2idx):
+    def _on(self, device):
+        """The four sorted arrays on ``device`` (moved once, cached)."""
+        device = torch.device(device)
+        if device.type == "cpu":
+            return self.heads_key, self.heads_val, self.tails_key, self.tails_val
+        cache = self.__dict__.setdefault("_device_cache", {})
+        if device not in cache:
+            cache[device] = tuple(x.to(device) for x in (self.heads_key, self.heads_val, self.tails_key, self.tails_val))
+        return cache[device]
+
+    def csr(self, triples, ent2idx, device="cpu"):
         """CSR over 2B queries in the ranking order (B head-replacing queries, then B tail-replacing):
-        rowptr (2B + 1,), cols (nnz,) = table rows removed by the filtered setting for each query."""
-        triples = triples.to(torch.long).cpu()
-        ent2idx = ent2idx.cpu()
+        rowptr (2B + 1,), cols (nnz,) = table rows removed by the filtered setting for each query.
+        With a HIP ``device`` the lookup (searchsorted + gathers) runs there and the CSR stays there."""
+        heads_key, heads_val, tails_key, tails_val = self._on(device)
+        triples = triples.to(device=device, dtype=torch.long)
+        ent2idx = ent2idx.to(device)
         h, t, r = triples[:, 0], triples[:, 1], triples[:, 2]
-        n_head, col_head = self._lookup(self.heads_key, self.heads_val, t * self.R + r, h, ent2idx)
-        n_tail, col_tail = self._lookup(self.tails_key, self.tails_val, h * self.R + r, t, ent2idx)
-        rowptr = torch.zeros(2 * triples.shape[0] + 1, dtype=torch.long)
+        n_head, col_head = self._lookup(heads_key, heads_val, t * self.R + r, h, ent2idx)
+        n_tail, col_tail = self._lookup(tails_key, tails_val, h * self.R + r, t, ent2idx)
+        rowptr = torch.zeros(2 * triples.shape[0] + 1, dtype=torch.long, device=triples.device)
         rowptr[1:] = torch.cumsum(torch.cat((n_head, n_tail)), 0)
         return rowptr, torch.cat((col_head, col_tail))
 
