@@ -275,8 +275,7 @@ def main():
             else:
                 dist.all_gather_into_tensor(gathered.view(-1), counts.reshape(-1))
             counts = gathered.sum(dim=0, dtype=torch.int32)
-        rr, hits = ops.rank_metrics(counts)
-        sums = torch.cat((rr[:, :1].double().sum(dim=0), hits[:, 0].double().sum(dim=0)))
+        sums = ops.rank_metric_sums(counts)[[0, 2, 3, 4]]  # raw: sum of reciprocal ranks, hits@1/3/10
         if world > 1 and axis == "query":  # query shards: only the metric sums travel
             if backend == "gloo":
                 host = sums.cpu()

@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 
 # every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
-           "blp_rank_all_workspace_bytes", "blp_rank_all", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_score_fwd",
+           "blp_rank_all_workspace_bytes", "blp_rank_all", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t")
 
@@ -79,6 +79,8 @@ def lib():
     L.blp_rank_from_scores.argtypes = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]
     L.blp_rank_metrics.restype = _i
     L.blp_rank_metrics.argtypes = [_vp, _i64, ctypes.POINTER(ctypes.c_int32), _vp, _vp, _i, _vp]
+    L.blp_rank_metric_sums.restype = _i
+    L.blp_rank_metric_sums.argtypes = [_vp, _i64, ctypes.POINTER(ctypes.c_int32), _vp, _i, _vp]
     L.blp_score_fwd.restype = _i
     L.blp_score_fwd.argtypes = [_i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
                                 _vp, _i, _vp]

@@ -193,6 +193,18 @@ int blp_rank_metrics(const int32_t* counts, int64_t Q, const int32_t k_values[3]
     return BLP_OK;
 }
 
+int blp_rank_metric_sums(const int32_t* counts, int64_t Q, const int32_t k_values[3], double* sums, int device,
+                         void* stream) {
+    if (Q < 0 || !k_values || !sums || (Q > 0 && !counts))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_metric_sums: NULL pointer or negative Q");
+    if (!aligned16(counts)) return fail(BLP_ERR_BAD_ARG, "blp_rank_metric_sums: counts must be 16-byte aligned");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_rank_metric_sums(counts, Q, k_values, sums, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_metric_sums launch");
+    return BLP_OK;
+}
+
 int blp_score_fwd(int model, int D, int64_t M0, int64_t M1, const float* heads, int64_t h_s0, int64_t h_s1,
                   const float* tails, int64_t t_s0, int64_t t_s1, const float* rels, int64_t r_s0, int64_t r_s1,
                   float* out, int device, void* stream) {

@@ -27,6 +27,9 @@ struct StridedRows {  // row(i0, i1) = base + i0 * s0 + i1 * s1   (strides in fl
     int64_t s0, s1;
 };
 
+hipError_t launch_rank_metric_sums(const int32_t* counts, int64_t Q, const int32_t* k, double* sums,
+                                   hipStream_t stream);
+
 hipError_t launch_score_fwd(int model, int D, int64_t M0, int64_t M1, StridedRows h, StridedRows t,
                             StridedRows r, float* out, hipStream_t stream);
 hipError_t launch_score_bwd(int model, int D, int64_t M0, int64_t M1, StridedRows h, StridedRows t,

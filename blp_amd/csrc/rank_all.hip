@@ -451,6 +451,40 @@ __global__ void rank_metrics_kernel(const int32_t* __restrict__ counts, int64_t 
     }
 }
 
+// train.py:152-157 from the counts: sums[0..1] = sum of reciprocal ranks (raw, filtered), sums[2 + 3 v + j]
+// = number of queries with avg rank <= k_j (v: raw, filtered), as f64.  One block, fixed order: the
+// result is reproducible run to run.
+__global__ __launch_bounds__(1024) void rank_metric_sums_kernel(const int32_t* __restrict__ counts, int64_t Q,
+                                                               int k0, int k1, int k2, double* __restrict__ sums) {
+    __shared__ double sh[16][8];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t q = threadIdx.x; q < Q; q += blockDim.x) {
+        const int4 c = reinterpret_cast<const int4*>(counts)[q];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int64_t best = (int64_t)(v ? c.z : c.x) + 1, worst = v ? c.w : c.y;
+            const float avg = (float)(best + worst) * 0.5f;
+            acc[v] += (double)__fdiv_rn(1.0f, avg);
+            acc[2 + 3 * v + 0] += avg <= (float)k0;
+            acc[2 + 3 * v + 1] += avg <= (float)k1;
+            acc[2 + 3 * v + 2] += avg <= (float)k2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) sh[wave][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double total = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += sh[w][threadIdx.x];
+        sums[threadIdx.x] = total;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct RankWorkspace {
     float* coef_head;
@@ -662,6 +696,12 @@ hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* 
                                uint8_t* hits, hipStream_t stream) {
     if (Q == 0) return hipSuccess;
     rank_metrics_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(counts, Q, k[0], k[1], k[2], rr, hits);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_metric_sums(const int32_t* counts, int64_t Q, const int32_t* k, double* sums,
+                                   hipStream_t stream) {
+    rank_metric_sums_kernel<<<1, 1024, 0, stream>>>(counts, Q, k[0], k[1], k[2], sums);
     return hipGetLastError();
 }
 

@@ -155,6 +155,17 @@ def rank_metrics(counts, k_values=(1, 3, 10)):
     return rr, hits.bool()
 
 
+def rank_metric_sums(counts, k_values=(1, 3, 10)):
+    """counts (Q, 4) int32 -> (8,) f64: [sum rr raw, sum rr filtered, hits@k raw x 3, hits@k filtered x 3]
+    (train.py:152-157 accumulated on the device in one launch, fixed summation order)."""
+    _require_device(counts)
+    sums = torch.empty(8, dtype=torch.float64, device=counts.device)
+    status = _lib.lib().blp_rank_metric_sums(_ptr(counts.contiguous()), counts.shape[0], _K_VALUES(*k_values),
+                                             _ptr(sums), counts.device.index, _stream(counts.device))
+    _lib.check(status, "blp_rank_metric_sums")
+    return sums
+
+
 # ------------------------------------------------------------------------------------- score_fn
 def _collapse(sizes, strides):
     """Collapse a group of dims into (size, stride) or None if not expressible with one stride."""

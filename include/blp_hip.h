@@ -123,6 +123,12 @@ int blp_rank_from_scores(const float *scores, int64_t Q, int64_t N, int64_t ld, 
 int blp_rank_metrics(const int32_t *counts, int64_t Q, const int32_t k_values[3], float *rr,
                      uint8_t *hits, int device, void *stream);
 
+/* The accumulation of train.py:152-157 on the device: sums[0..1] = sum over queries of the reciprocal
+ * rank (raw, filtered), sums[2 + 3 v + j] = number of queries with avg rank <= k_values[j] (v = 0 raw,
+ * 1 filtered), all f64, summed in a fixed order (reproducible).  Divide by Q for MRR / Hits@k. */
+int blp_rank_metric_sums(const int32_t *counts, int64_t Q, const int32_t k_values[3], double *sums,
+                         int device, void *stream);
+
 /* --------------------------------------------------------------------------------------------
  * score_fn(heads, tails, rels)   models.py:222-248, any broadcast the reference uses.
  *

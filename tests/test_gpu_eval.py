@@ -83,6 +83,22 @@ def test_link_prediction_module_on_gpu_uses_fused_loss(name):
     np.testing.assert_allclose(model.rel_emb.weight.grad.cpu().numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
 
 
+def test_rank_metric_sums_equals_reduced_rank_metrics():
+    """blp_rank_metric_sums = get_metrics + the accumulation of train.py:152-157 in one launch."""
+    from blp_amd import ops
+    g = torch.Generator().manual_seed(3)
+    gt = torch.randint(0, 5000, (10_007,), generator=g)
+    ties = torch.randint(1, 4, (10_007,), generator=g)
+    f_gt = (gt.float() * torch.rand(10_007, generator=g)).long()
+    counts = torch.stack((gt, gt + ties, f_gt, f_gt + ties), dim=1).int().cuda()
+    rr, hits = ops.rank_metrics(counts)
+    sums = ops.rank_metric_sums(counts).cpu()
+    assert sums[:2].tolist() == pytest.approx(rr.double().sum(dim=0).tolist(), rel=1e-12)
+    assert sums[2:].tolist() == hits.double().sum(dim=0).reshape(-1).tolist()
+    assert torch.equal(ops.rank_metric_sums(counts).cpu(), sums)  # fixed summation order
+    assert ops.rank_metric_sums(counts[:0]).tolist() == [0.0] * 8
+
+
 @pytest.mark.parametrize("axis", ["candidate", "query"])
 def test_bench_two_ranks_share_one_gpu_functional(axis):
     """bench.py's N > 1 paths run as 2 ranks on this one GPU with the gloo backend.  Candidate shards:
