@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const float* __rest
 
 template <int D>
 struct BfTile {
-    uint4 hi[D / 16], lo[D / 16];  // A operands of the D/16 K-steps
+    uint4 hi[D / 16], lo[D / 16];  // A operands of the D/16 K-steps (rows that do not exist: NaN)
+    float nmax;                    // largest band factor among the 16 candidates this lane's accumulators hold
     unsigned row_mask;             // bit r: the candidate of accumulator register r exists (row < N)
 };
 
@@ -460,18 +461,27 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         const float m2 = __shfl_xor(mx, 32);
         mx = m2 > mx ? m2 : mx;
         bad |= (bool)__shfl_xor((int)bad, 32);
-        // a row that does not exist gets a NaN band factor: never decided, never listed (row_mask)
-        if (lane < 32)
-            nrm[(wave * kBfTPW + t) * 32 + lane] = row0 + lane < N ? band_norm(ss, bad ? __builtin_inff() : mx) : __builtin_nanf("");
+        const bool exists = row0 + (lane & 31) < N;
+        if (!exists) {  // S~ = NaN for a row that does not exist: never decided, dropped by row_mask
+            static_for<STEPS>([&](auto kk) {
+                constexpr int st = decltype(kk)::value;
+                c[t].hi[st] = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
+                c[t].lo[st] = make_uint4(0u, 0u, 0u, 0u);
+            });
+        }
+        if (lane < 32) nrm[(wave * kBfTPW + t) * 32 + lane] = exists ? band_norm(ss, bad ? __builtin_inff() : mx) : 0.f;
     });
     __syncthreads();
     static_for<kBfTPW>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
         const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
         c[t].row_mask = 0;
+        c[t].nmax = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, half);
+            const float nr = nrm[(wave * kBfTPW + t) * 32 + row];
+            c[t].nmax = nr > c[t].nmax ? nr : c[t].nmax;
             c[t].row_mask |= (unsigned)(row0 + row < N) << r;
         }
     });
@@ -511,40 +521,35 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
             between(kk);
         });
     };
-    // Decision for accumulator registers [R0, R0 + NR) of both tiles: decided iff
-    // |S~ - s_true| - eps_q ||e|| > guard (NaN / Inf anywhere, or a row that does not exist: not decided)
-    auto decide_chunk = [&](auto r0, auto nr, const f32x16 (&s)[kBfTPW], float kt, float eq, float guard,
-                            unsigned (&above)[kBfTPW], bool (&any_und)[kBfTPW]) {
+    // Decision for accumulator registers [R0, R0 + NR) of both tiles against the two thresholds of this
+    // (query, 16-candidate half-tile): s_true +- (eps_q * max ||e|| + guard).  Using the half-tile's largest
+    // band factor for all of its rows only widens the band; it makes the decision two compares and an
+    // add-with-carry per accumulator register.  NaN anywhere: neither compare holds -> undecided.
+    auto decide_chunk = [&](auto r0, auto nr, const f32x16 (&s)[kBfTPW], const float (&thr_hi)[kBfTPW],
+                            const float (&thr_lo)[kBfTPW], unsigned (&above)[kBfTPW], bool (&any_und)[kBfTPW]) {
         constexpr int R0 = decltype(r0)::value, NR = decltype(nr)::value;
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            const float* nr_lds = nrm + (wave * kBfTPW + ti) * 32 + 4 * half;
             static_for<NR>([&](auto jj) {
                 constexpr int r = R0 + decltype(jj)::value;
-                const float d = s[ti][r] - kt;
-                const float m = __builtin_fmaf(-eq, nr_lds[8 * (r >> 2) + (r & 3)], fabsf(d));
-                const bool dec = m > guard;
-                above[ti] += dec && d > 0.f;
-                any_und[ti] |= !dec;
+                const bool ab = s[ti][r] > thr_hi[ti];
+                above[ti] += ab;
+                any_und[ti] |= !(ab || s[ti][r] < thr_lo[ti]);
             });
         });
     };
     // Rare per lane: which registers are undecided; list them, or flag the half-segment when the
     // workgroup's quota is used up.  Adds the decided-above count to the query's LDS counter.
-    auto settle = [&](int t, int q, bool q_ok, const f32x16 (&s)[kBfTPW], float kt, float eq, float guard,
-                      const unsigned (&above)[kBfTPW], const bool (&any_und)[kBfTPW]) {
+    auto settle = [&](int t, int q, bool q_ok, const f32x16 (&s)[kBfTPW], const float (&thr_hi)[kBfTPW],
+                      const float (&thr_lo)[kBfTPW], const unsigned (&above)[kBfTPW], const bool (&any_und)[kBfTPW]) {
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
             if (!q_ok) return;
             bool listed = true;
             if (any_und[ti]) {
-                const float* nr_lds = nrm + (wave * kBfTPW + ti) * 32 + 4 * half;
                 unsigned und = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float m = __builtin_fmaf(-eq, nr_lds[8 * (r >> 2) + (r & 3)], fabsf(s[ti][r] - kt));
-                    und |= (unsigned)!(m > guard) << r;
-                }
+                for (int r = 0; r < 16; ++r) und |= (unsigned)!(s[ti][r] > thr_hi[ti] || s[ti][r] < thr_lo[ti]) << r;
                 und &= c[ti].row_mask;
                 if (und) {
                     const int ctile = ctile0 + ti;
@@ -580,21 +585,29 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         const int q = q_base + (q_ok ? q_local : n_side - 1);
         const float2 kq = kq_s[t * kGQT + (lane & 31)];
         const float kt = kq.x, eq = kq.y;
-        const float guard = fabsf(kt) * 2.4e-7f + 1e-35f;  // rounding of the test itself, product underflow
+        const float guard = fabsf(kt) * 2.4e-7f + 1e-35f;  // rounding of the thresholds themselves, product underflow
         unsigned above[kBfTPW];
         bool any_und[kBfTPW];
-        static_for<kBfTPW>([&](auto tt) { above[decltype(tt)::value] = 0; any_und[decltype(tt)::value] = false; });
+        float thr_hi[kBfTPW], thr_lo[kBfTPW];
+        static_for<kBfTPW>([&](auto tt) {
+            constexpr int ti = decltype(tt)::value;
+            const float eps = __builtin_fmaf(eq, c[ti].nmax, guard);
+            thr_hi[ti] = kt + eps;
+            thr_lo[ti] = kt - eps;
+            above[ti] = 0;
+            any_und[ti] = false;
+        });
         if (more) {
             const float* nbuf = ((t + 1) & 1) ? buf1 : buf0;
             zero_acc(nxt);
             mfma_tile(nxt, nbuf, [&](auto kk) {
                 constexpr int st = decltype(kk)::value;
-                decide_chunk(ic<st * (16 / STEPS)>{}, ic<16 / STEPS>{}, cur, kt, eq, guard, above, any_und);
+                decide_chunk(ic<st * (16 / STEPS)>{}, ic<16 / STEPS>{}, cur, thr_hi, thr_lo, above, any_und);
             });
         } else {
-            decide_chunk(ic<0>{}, ic<16>{}, cur, kt, eq, guard, above, any_und);
+            decide_chunk(ic<0>{}, ic<16>{}, cur, thr_hi, thr_lo, above, any_und);
         }
-        settle(t, q, q_ok, cur, kt, eq, guard, above, any_und);
+        settle(t, q, q_ok, cur, thr_hi, thr_lo, above, any_und);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
