@@ -305,10 +305,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kBandCBf16 = 1150.0f;
 constexpr int kBfW = 4;          // waves per workgroup
-constexpr int kBfTPW = 2;        // candidate tiles per wave
+constexpr int kBfTPW = 2;        // candidate tiles per wave (4 at one wave/SIMD spills and runs 1.8x slower)
 constexpr int kBfWavesPerSimd = 2;  // launch bound: <= 256 VGPRs (128 of them hold the A operands)
 constexpr int kBfTilesPerChunk = 16;             // query tiles per workgroup (a multiple of kGTilesPerChunk)
-constexpr int kBfQuota = 16 * kBfTilesPerChunk;  // undecided pairs a workgroup can list
+constexpr int kBfQuota = 8 * kBfTPW * kBfTilesPerChunk;  // undecided pairs a workgroup can list
 
 // band factor of a row from its norm / largest magnitude (see above); exact zero rows need no band
 __device__ __forceinline__ float band_norm(float sumsq, float maxabs) {
@@ -722,7 +722,7 @@ struct GemmWorkspace {
 // pair-list entries needed for T candidate tiles x one query chunk: the larger of the two pass-1 kernels
 static int64_t pair_entries_per_chunk(int64_t T) {
     const int64_t f32_kernel = (T + kGW - 1) / kGW * kPairQuota;
-    const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * (16 * kGTilesPerChunk);  // per 8 query tiles
+    const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * (8 * kBfTPW * kGTilesPerChunk);  // per 8 query tiles
     return f32_kernel > bf16_kernel ? f32_kernel : bf16_kernel;
 }
 
