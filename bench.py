@@ -181,11 +181,12 @@ def parity_spot_check(cfg, table, q_fixed, q_rel, true_row, q_head, counts, n=32
     return f"{idx_h.numel() + idx_t.numel()} queries vs CPU oracle: " + ("identical counts" if ok else "MISMATCH")
 
 
-def load_pmc_traffic(workload):
-    """HBM bytes per rank_tiles launch from the committed rocprofv3 PMC pass (profiles/), or None."""
+def load_pmc(workload, key="hbm_bytes_per_launch"):
+    """A figure of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json):
+    HBM bytes per launch (FETCH_SIZE) or the matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES); else None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(path)).get(workload, {}).get("hbm_bytes_per_launch")
+        return json.load(open(path)).get(workload, {}).get(key)
     except (OSError, ValueError):
         return None
 
@@ -345,7 +346,9 @@ def main():
                                  "(5.3x the f32 MFMA peak of 157.3 TF, which the f32-chain variant BLP_GEMM_KERNEL=f32 "
                                  "is bounded by).")}
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
-        roofline["traffic"] = load_pmc_traffic(args.workload)
+        roofline["traffic"] = load_pmc(args.workload)
+        if not sad_path and roofline["bound"] == "mfma":
+            roofline["mfma_busy"] = load_pmc(args.workload, "mfma_busy_frac_at_2.4GHz")
         roofline["kernel"] = (DOMINANT_KERNEL[model] if Q >= 64 else "rank_tiles_kernel<STATIC> (lane-per-candidate VALU)")
         roofline["kernel_ms"] = kernel_ms
         roofline["algorithmic_bytes_per_launch"] = alg_bytes
