@@ -412,7 +412,7 @@ def hbm_probe(device, events, reps=10):
     return {"workload": "wikidata5m-transe, 4 queries per table pass", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "kernel_ms": ms,
             "whole_call_ms": call_ms, "scored_triples_per_s": 4.0 * cfg["N"] / (call_ms * 1e-3),
-            "traffic": load_pmc_traffic("wikidata5m-transe")}
+            "traffic": load_pmc("wikidata5m-transe")}
 
 
 if __name__ == "__main__":
