@@ -391,6 +391,14 @@ struct BfTile {
     unsigned row_mask;             // bit r: the candidate of accumulator register r exists (row < N)
 };
 
+// -DBLP_TIMING: per-phase cycle counts of the kernel below, summed over waves (tools/gemm_phase_timing.py)
+#ifdef BLP_TIMING
+__device__ unsigned long long g_bf16_timing[8];
+#define BLP_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define BLP_T(i) do { } while (0)
+#endif
+
 template <int MODEL, int D>
 __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const uint4* __restrict__ img_head,
@@ -575,8 +583,12 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     };
     // One pipeline stage: the MFMAs of query tile t + 1 (into `nxt`) are issued between the chunks of
     // tile t's decision arithmetic (on `cur`), so the vector ALU works in the matrix pipe's shadow.
+#ifdef BLP_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     auto stage = [&](int t, f32x16 (&cur)[kBfTPW], f32x16 (&nxt)[kBfTPW]) {
         const bool more = t + 1 < n_tiles;
+        BLP_T(0);
         if (t + 2 < n_tiles)  // buf[t & 1] was last read by the MFMAs of tile t, one barrier ago
             stage_gemm_tile<TILE_BYTES, kBfW>(reinterpret_cast<const float4*>(img + (int64_t)(t + 2) * (TILE_BYTES / 16)),
                                               (t & 1) ? buf1 : buf0, wave, lane);
@@ -607,9 +619,13 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         } else {
             decide_chunk(ic<0>{}, ic<16>{}, cur, thr_hi, thr_lo, above, any_und);
         }
+        BLP_T(1);
         settle(t, q, q_ok, cur, thr_hi, thr_lo, above, any_und);
+        BLP_T(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BLP_T(3);
         __syncthreads();
+        BLP_T(4);
     };
 
     stage_gemm_tile<TILE_BYTES, kBfW>(reinterpret_cast<const float4*>(img), buf0, wave, lane);
@@ -631,6 +647,13 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         if (q_local < n_side && v) atomicAdd(acc + q_base + q_local, v | (v << 32));  // certainly above: gt and ge
     }
     for (int i = tid; i < kBfQuota; i += kBfW * 64) pairs[(size_t)blockIdx.x * kBfQuota + i] = pair_s[i];
+#ifdef BLP_TIMING
+    BLP_T(5);
+    if (lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_bf16_timing[i], tacc[i]);
+        atomicAdd(&g_bf16_timing[7], 1ull);
+    }
+#endif
 }
 
 // Pass 2a: one lane per listed pair.
@@ -869,5 +892,14 @@ hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N,
 #undef BLP_GEMM_CASE
     return hipErrorInvalidValue;
 }
+
+#ifdef BLP_TIMING
+extern "C" int blp_debug_read_timing(unsigned long long* out) {
+    hipError_t err = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_timing), sizeof(g_bf16_timing));
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (err == hipSuccess) err = hipMemcpyToSymbol(HIP_SYMBOL(g_bf16_timing), zero, sizeof(zero));
+    return (int)err;
+}
+#endif
 
 }  // namespace blp
