@@ -48,13 +48,14 @@ __host__ __device__ constexpr int kMaxCoef(int D) { return 2 * D; }
 template <int MODEL, int D>
 __global__ void prep_coef_kernel(const float* __restrict__ q_fixed, const float* __restrict__ q_rel,
                                  int64_t q_head, int64_t q_tail, float* __restrict__ coef_head,
-                                 float* __restrict__ coef_tail) {
+                                 float* __restrict__ coef_tail, unsigned long long* __restrict__ acc) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
     const int64_t n_head = q_head * SH::C;
     const int64_t total = n_head + q_tail * ST::C;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < q_head + q_tail) acc[i] = 0;  // the rank-count accumulators start here (total >= Q)
         if (i < n_head) {
             const int64_t q = i / SH::C;
             coef_head[i] = SH::coef(q_fixed + q * D, q_rel + q * D, (int)(i % SH::C));
@@ -534,14 +535,11 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
     const int64_t Q = q_head + q_tail;
     if (Q == 0) return hipSuccess;
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
-    hipError_t err = hipMemsetAsync(w.acc, 0, (size_t)Q * 8, stream);
-    if (err != hipSuccess) return err;
-
     {
         const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
         const int64_t blocks = (total + 255) / 256;
         const int grid = (int)(blocks < 8192 ? blocks : 8192);
-        prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail);
+        prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail, w.acc);
         true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(
             table, ld, true_row, q_true, w.coef_head, w.coef_tail, q_head, q_tail, w.key_true);
     }
@@ -644,11 +642,12 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 template <int MODEL, int D>
 static hipError_t exact_prep_impl(const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
                                   const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
-                                  float* coef_head, float* coef_tail, float* key_true, hipStream_t stream) {
+                                  float* coef_head, float* coef_tail, float* key_true, unsigned long long* acc,
+                                  hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
     const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
     const int64_t blocks = (total + 255) / 256;
-    prep_coef_kernel<MODEL, D><<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, coef_head, coef_tail);
+    prep_coef_kernel<MODEL, D><<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, coef_head, coef_tail, acc);
     true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(table, ld, true_row, q_true, coef_head, coef_tail, q_head, q_tail, key_true);
     return hipGetLastError();
 }
@@ -679,9 +678,9 @@ static hipError_t exact_filter_impl(const float* table, int64_t ld, const float*
 hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head,
                              int64_t q_tail, const float* table, int64_t ld, const int64_t* true_row,
                              const float* q_true, float* coef_head, float* coef_tail, float* key_true,
-                             hipStream_t stream) {
+                             unsigned long long* acc, hipStream_t stream) {
     BLP_DISPATCH_MODEL_DIM(exact_prep_impl, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, coef_head,
-                           coef_tail, key_true, stream)
+                           coef_tail, key_true, acc, stream)
 }
 
 hipError_t launch_exact_filter(int model, int D, const float* table, int64_t ld, const float* coef_head,

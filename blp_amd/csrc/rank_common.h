@@ -75,11 +75,12 @@ hipError_t launch_rank_all_mfma(int model, int D, const float* table, int64_t N,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop);
 
-// rank_all.hip: exact-path building blocks (row-major coefficients + true keys; CSR filter counts)
+// rank_all.hip: exact-path building blocks (row-major coefficients + true keys, the Q rank-count
+// accumulators `acc` zeroed on the way; CSR filter counts)
 hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head,
                              int64_t q_tail, const float* table, int64_t ld, const int64_t* true_row,
                              const float* q_true, float* coef_head, float* coef_tail, float* key_true,
-                             hipStream_t stream);
+                             unsigned long long* acc, hipStream_t stream);
 hipError_t launch_exact_filter(int model, int D, const float* table, int64_t ld, const float* coef_head,
                                const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
                                const int64_t* rowptr, const int64_t* col, unsigned long long* acc_f,

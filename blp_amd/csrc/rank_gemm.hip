@@ -817,10 +817,8 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     const int64_t Q = q_head + q_tail;
     GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
     const int64_t pass_tiles = w.pass_ctiles;
-    hipError_t err = hipMemsetAsync(w.acc, 0, (size_t)Q * 8, stream);
-    if (err != hipSuccess) return err;
-    err = launch_exact_prep(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.coef_head,
-                            w.coef_tail, w.key_true, stream);
+    hipError_t err = launch_exact_prep(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.coef_head,
+                                       w.coef_tail, w.key_true, w.acc, stream);
     if (err != hipSuccess) return err;
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
     const bool f32_kernel = gemm_use_f32();

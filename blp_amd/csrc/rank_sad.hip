@@ -214,11 +214,13 @@ __global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const float* 
                                                                    int64_t Q, const float* __restrict__ key_true,
                                                                    const SadParams* __restrict__ p,
                                                                    unsigned* __restrict__ qimg,
-                                                                   int2* __restrict__ thr) {
+                                                                   int2* __restrict__ thr, unsigned* __restrict__ flags,
+                                                                   int64_t n_flag_words) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t j = i; j < n_flag_words; j += (int64_t)gridDim.x * blockDim.x) flags[j] = 0;  // first slab's bitmap
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
     __shared__ float part_res[4];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < Q * (D / 2);
     const int64_t q = live ? i / (D / 2) : Q - 1;
     const bool head = q < q_head;
@@ -524,10 +526,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     constexpr int TPW = sad_tiles_per_wave(D);
     const int64_t Q = q_head + q_tail;
     SadWorkspace w = carve_sad(workspace, D, N, q_head, q_tail);
-    hipError_t err = hipMemsetAsync(w.acc, 0, (size_t)Q * 8, stream);
-    if (err != hipSuccess) return err;
-    err = launch_exact_prep(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.coef_head,
-                            w.coef_tail, w.key_true, stream);
+    hipError_t err = launch_exact_prep(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true,
+                                       w.coef_head, w.coef_tail, w.key_true, w.acc, stream);
     if (err != hipSuccess) return err;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     const int64_t n_tiles = (N + 63) / 64;
@@ -538,10 +538,14 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         sad_range_kernel<D><<<dim3((unsigned)blocks), 256, 0, stream>>>(table, N, ld, q_fixed, q_rel, q_head, Q, w.partial);
         sad_range_finish_kernel<<<1, 64, 0, stream>>>(w.partial, (int)blocks, w.params);
     }
+    // the first slab's flag bitmap and pair counter are zeroed by the prep kernels (later slabs: memsets)
+    const int64_t first_rows = N < w.pass_groups * kSW * TPW * 64 ? N : w.pass_groups * kSW * TPW * 64;
+    const int64_t first_groups = ((first_rows + 63) / 64 + kSW * TPW - 1) / (kSW * TPW);
+    const int64_t first_words = (first_groups * kSW * TPW + 31) / 32;
     if (n_tiles > 0)
         sad_quantize_table_kernel<D><<<dim3((unsigned)n_tiles), 256, 0, stream>>>(table, N, ld, w.params, w.cimg, w.resid);
     sad_quantize_queries_kernel<D><<<dim3((unsigned)((Q * (D / 2) + 255) / 256)), 256, 0, stream>>>(
-        q_fixed, q_rel, q_head, Q, w.key_true, w.params, w.qimg, w.thr);
+        q_fixed, q_rel, q_head, Q, w.key_true, w.params, w.qimg, w.thr, w.flags, first_words * Q);
 
     const int64_t tiles_per_group = kSW * TPW;
     const int64_t n_chunks = (Q + kSChunk - 1) / kSChunk;
@@ -552,10 +556,12 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         const int64_t n_groups = (slab_tiles + tiles_per_group - 1) / tiles_per_group;
         const int words = (int)((n_groups * tiles_per_group + 31) / 32);
         const int64_t n_blocks = n_groups * n_chunks;
-        err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
-        if (err != hipSuccess) return err;
-        err = hipMemsetAsync(&w.params->n_pairs, 0, 4, stream);
-        if (err != hipSuccess) return err;
+        if (slab0 > 0) {
+            err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
+            if (err != hipSuccess) return err;
+            err = hipMemsetAsync(&w.params->n_pairs, 0, 4, stream);
+            if (err != hipSuccess) return err;
+        }
         const float* slab = table + slab0 * ld;
         rank_sad_kernel<D, TPW><<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
             w.cimg + (slab0 / 64) * (D / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, words, w.acc,
