@@ -110,6 +110,11 @@ int blp_dim_supported(int model, int D) {
     return 1;
 }
 
+int blp_rank_all_supported(int model, int D, int64_t q_head, int64_t q_tail) {
+    if (!valid_model(model) || q_head < 0 || q_tail < 0) return 0;
+    return blp_dim_supported(model, D) || blp::rank_sad_wide_applicable(model, D, q_head, q_tail);
+}
+
 size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head, int64_t q_tail) {
     if (D <= 0 || N < 0 || q_head < 0 || q_tail < 0) return 0;
     return blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
@@ -120,8 +125,10 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
                  int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
                  void* workspace, size_t workspace_bytes, int device, void* stream) {
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
-    if (!blp_dim_supported(model, D))
-        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_rank_all: D = %d not compiled (supported: 64, 128, 256)", D);
+    if (!blp_rank_all_supported(model, D, q_head, q_tail))
+        return fail(BLP_ERR_UNSUPPORTED_DIM,
+                    "blp_rank_all: D = %d not supported for this block (64 / 128 / 256 always; TransE with >= 256 "
+                    "queries at any D %% 4 == 0 up to 1024): see blp_rank_all_supported", D);
     if (N < 0 || q_head < 0 || q_tail < 0 || ld < D)
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: negative size or ld < D (N=%lld q_head=%lld q_tail=%lld ld=%lld)",
                     (long long)N, (long long)q_head, (long long)q_tail, (long long)ld);

@@ -6,6 +6,7 @@
 
 namespace blp {
 
+bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,

@@ -512,6 +512,7 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
 }
 
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
+    if (rank_sad_wide_applicable(model, D, q_head, q_tail)) return rank_sad_wide_workspace_bytes(model, D, N, q_head, q_tail);
     size_t bytes = carve_workspace(nullptr, D, q_head, q_tail).bytes;
     const size_t alt[3] = {rank_mfma_workspace_bytes(model, D, q_head, q_tail),
                            rank_gemm_workspace_bytes(model, D, N, q_head, q_tail),
@@ -619,6 +620,9 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
     if (rank_gemm_applicable(model, D, q_head, q_tail))
         return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
                                     filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    if (rank_sad_wide_applicable(model, D, q_head, q_tail))
+        return launch_rank_all_sad_wide(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,
+                                        filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     if (rank_sad_applicable(model, D, q_head, q_tail))
         return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,
                                    filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);

@@ -106,4 +106,14 @@ hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld,
                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                hipEvent_t ev_stop);
 
+// rank_sad_wide.hip: the same pre-pass for TransE at any width (D % 4 == 0, D <= 1024; the BOW / DKRL
+// encoders' 300 and 768), 128 elements of the candidate row in registers at a time.
+bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
+size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
+hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                                    const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                                    int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col,
+                                    int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
+                                    hipEvent_t ev_start, hipEvent_t ev_stop);
+
 }  // namespace blp

@@ -1,0 +1,517 @@
+// rank_sad_wide.hip -- the fixed-point TransE pre-pass (rank_sad.hip) for ANY embedding width.
+//
+// The reference's bag-of-words and DKRL encoders score with TransE at the width of their word vectors
+// (300 for GloVe, 768 for BERT word embeddings: models.py:118-135, 165-172, scripts/{glove,bert}-{bow,dkrl}-*.sh),
+// which the register-resident kernels (D = 64 / 128 / 256) do not cover.  Same scheme, same bounds and
+// the same exactness argument as rank_sad.hip; what changes:
+//   * the width is a run-time value (D % 4 == 0, D <= 1024); the 2-byte images are padded with zeros to
+//     a multiple of 128 elements (padding contributes |0 - 0| = 0 to every SAD and has no residual);
+//   * a wave keeps 128 elements of its candidate tile in registers at a time and walks the row in
+//     chunks: for each chunk it runs over the workgroup's queries, carrying the partial SADs in LDS;
+//   * the exact scores (true keys, pair / tile refinement, CSR filter) come from one run-time-width
+//     routine in the reference's operation order instead of the Scorer<> templates.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "launch.h"
+#include "rank_common.h"
+#include "sad_common.h"
+
+#pragma clang fp contract(off)
+
+namespace blp {
+
+constexpr int kWChunk = 32;    // queries per workgroup (their partial SADs live in LDS: 8 KB per wave)
+constexpr int kWQuota = 128;   // undecided pairs a workgroup can list (4 per query)
+constexpr int kWMaxD = 1024;
+
+// models.py:222-223 for one (candidate, query) pair, any width: ((h + r) - t), |.|, sequential f32 sum
+// from 0, negated.  head: the candidate replaces the head (fixed = t); else the tail (fixed = h).
+__device__ __forceinline__ float transe_key_rt(const float* __restrict__ e, const float* __restrict__ f,
+                                               const float* __restrict__ r, int D, bool head) {
+    float acc = 0.0f;
+    for (int d = 0; d < D; d += 4) {
+        const float4 ev = *reinterpret_cast<const float4*>(e + d);
+        const float4 fv = *reinterpret_cast<const float4*>(f + d);
+        const float4 rv = *reinterpret_cast<const float4*>(r + d);
+        const float es[4] = {ev.x, ev.y, ev.z, ev.w}, fs[4] = {fv.x, fv.y, fv.z, fv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = (head ? es[i] : fs[i]) + rs[i];
+            x = x - (head ? fs[i] : es[i]);
+            acc = acc + fabsf(x);
+        }
+    }
+    return -acc;
+}
+
+__global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restrict__ table, int64_t ld, int D,
+                                                            const float* __restrict__ q_fixed,
+                                                            const float* __restrict__ q_rel,
+                                                            const int64_t* __restrict__ true_row,
+                                                            const float* __restrict__ q_true, int64_t q_head, int64_t Q,
+                                                            float* __restrict__ key_true,
+                                                            unsigned long long* __restrict__ acc) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const float* e = true_row ? table + true_row[q] * ld : q_true + q * D;
+    key_true[q] = transe_key_rt(e, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+    acc[q] = 0;
+}
+
+__global__ __launch_bounds__(256) void wide_range_kernel(const float* __restrict__ table, int64_t N, int64_t ld, int D,
+                                                         const float* __restrict__ q_fixed,
+                                                         const float* __restrict__ q_rel, int64_t q_head, int64_t Q,
+                                                         SadParams* __restrict__ partial) {
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    float maxabs = 0.f;
+    bool bad = false;
+    auto see = [&](float x) {
+        const float ax = fabsf(x);
+        if (!(ax < 3.0e38f)) { bad = true; return; }
+        const int o = f2ord(x);
+        lo = o < lo ? o : lo;
+        hi = o > hi ? o : hi;
+        maxabs = ax > maxabs ? ax : maxabs;
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int quads = D / 4;
+    for (int64_t i = t0; i < N * quads; i += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(table + (i / quads) * ld + (i % quads) * 4);
+        see(v.x); see(v.y); see(v.z); see(v.w);
+    }
+    for (int64_t i = t0; i < Q * D; i += stride) {
+        const float f = q_fixed[i], r = q_rel[i];
+        const int lo_keep = lo, hi_keep = hi;
+        see(f); see(r);  // for max |value| only: the range is that of the coefficient
+        lo = lo_keep; hi = hi_keep;
+        see(sad_coef(f, r, i / D < q_head));
+    }
+    __shared__ int s_lo[4], s_hi[4], s_bad[4];
+    __shared__ float s_max[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        const float m2 = __shfl_xor(maxabs, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        maxabs = m2 > maxabs ? m2 : maxabs;
+    }
+    const bool any_bad = __any(bad);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_max[wave] = maxabs; s_bad[wave] = any_bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SadParams p = {};
+        p.lo_ord = 0x7fffffff; p.hi_ord = (int)0x80000000;
+        float m = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            p.lo_ord = s_lo[w] < p.lo_ord ? s_lo[w] : p.lo_ord;
+            p.hi_ord = s_hi[w] > p.hi_ord ? s_hi[w] : p.hi_ord;
+            m = s_max[w] > m ? s_max[w] : m;
+            p.nonfinite |= (unsigned)s_bad[w];
+        }
+        p.maxabs_bits = __float_as_uint(m);
+        partial[blockIdx.x] = p;
+    }
+}
+
+// Candidate tile image as in rank_sad.hip, Dp / 8 uint4 per lane (Dp = D rounded up to 128, zero padded).
+__global__ __launch_bounds__(256) void wide_quantize_table_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
+                                                                  int D, int Dp, const SadParams* __restrict__ p,
+                                                                  uint4* __restrict__ cimg,
+                                                                  unsigned* __restrict__ resid) {
+    const SadScale sc = sad_scale(p);
+    if (!sc.ok) return;
+    const int64_t tile = blockIdx.x;
+    const int row_in = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int64_t row = tile * 64 + row_in;
+    const float* src = table + (row < N ? row : 0) * ld;
+    float res = 0.f;
+    for (int j4 = part; j4 < Dp / 8; j4 += 4) {
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = 8 * j4 + 4 * h;
+            if (row < N && d < D) {
+                const float4 v = *reinterpret_cast<const float4*>(src + d);
+                w[2 * h] = sad_quant(v.x, sc, res);
+                w[2 * h] |= sad_quant(v.y, sc, res) << 16;
+                w[2 * h + 1] = sad_quant(v.z, sc, res);
+                w[2 * h + 1] |= sad_quant(v.w, sc, res) << 16;
+            }
+        }
+        cimg[(tile * (Dp / 8) + j4) * 64 + row_in] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    res += __shfl_xor(res, 1);
+    res += __shfl_xor(res, 2);
+    if (part == 0) resid[row] = (unsigned)(res * 1.0001f + kSResidSlack * D) + 1u;
+}
+
+// One wave per query: its 2-byte image (Dp / 2 dwords) and the two thresholds; the first candidate slab's
+// flag bitmap is zeroed on the way.
+__global__ __launch_bounds__(256) void wide_quantize_queries_kernel(const float* __restrict__ q_fixed,
+                                                                    const float* __restrict__ q_rel, int64_t q_head,
+                                                                    int64_t Q, int D, int Dp,
+                                                                    const float* __restrict__ key_true,
+                                                                    const SadParams* __restrict__ p,
+                                                                    unsigned* __restrict__ qimg, int2* __restrict__ thr,
+                                                                    unsigned* __restrict__ flags, int64_t n_flag_words) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_flag_words; j += (int64_t)gridDim.x * blockDim.x)
+        flags[j] = 0;
+    const SadScale sc = sad_scale(p);
+    if (!sc.ok) return;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const int lane = threadIdx.x & 63;
+    const bool head = q < q_head;
+    const float* f = q_fixed + q * D;
+    const float* r = q_rel + q * D;
+    float res = 0.f;
+    for (int j = lane; j < Dp / 2; j += 64) {
+        unsigned w = 0;
+        if (2 * j < D) {  // D is even: both elements exist or neither
+            w = sad_quant(sad_coef(f[2 * j], r[2 * j], head), sc, res);
+            w |= sad_quant(sad_coef(f[2 * j + 1], r[2 * j + 1], head), sc, res) << 16;
+        }
+        qimg[q * (Dp / 2) + j] = w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) res += __shfl_xor(res, off);
+    if (lane == 0) {
+        const double u = 5.9604644775390625e-8;
+        const double dt = -(double)key_true[q], s = (double)sc.scale, M = (double)__uint_as_float(p->maxabs_bits);
+        const double band = (double)res * 1.0001 + 2.0 * kSResidSlack * D + 1.0;  // E_q + both sides' slack
+        const double gamma = 1.05 * (D + 2) * u, rho = 6.0 * D * u * M;
+        int t_lo = -1, t_hi = (int)kSThrMax;  // nothing decided
+        if (dt >= 0.0 && dt < 1.0e300) {  // false for NaN
+            const double lo_v = s * (dt - rho) / (1.0 + gamma) - band;   // SAD + E_c below this: certainly above
+            const double hi_v = s * (dt + rho) / (1.0 - gamma) + band;   // SAD - E_c above this: certainly below
+            if (lo_v > 2.0) t_lo = lo_v - 1.0 < (double)kSThrMax ? (int)(lo_v - 1.0) : (int)kSThrMax;
+            if (hi_v + 2.0 < (double)kSThrMax) t_hi = (int)(hi_v + 2.0);
+        }
+        thr[q] = make_int2(t_lo, t_hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pass 1.  One candidate tile per wave; the row is walked in chunks of 128 elements (64 VGPRs), the
+// workgroup's queries run inside each chunk and their partial SADs wait in LDS between chunks.
+__global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
+    const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups,
+    const unsigned* __restrict__ qimg, const int2* __restrict__ thr, int64_t Q, int Dp, int words_per_query,
+    unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs,
+    SadParams* __restrict__ params) {
+    if (!sad_scale(params).ok) return;
+    __shared__ unsigned psum[kSW][kWChunk][64];
+    __shared__ int2 thr_s[kWChunk];
+    __shared__ unsigned cnt[kWChunk];
+    __shared__ uint2 pair_s[kWQuota];
+    __shared__ unsigned pair_n, pair_base;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int group = blockIdx.x % n_groups;
+    const int64_t q0 = (int64_t)(blockIdx.x / n_groups) * kWChunk;
+    const int nq = (int)(Q - q0 < kWChunk ? Q - q0 : kWChunk);
+
+    if (tid < kWChunk) {
+        thr_s[tid] = tid < nq ? thr[q0 + tid] : make_int2(0, 0);
+        cnt[tid] = 0;
+    }
+    if (tid < kWQuota) pair_s[tid] = make_uint2(kSNoPair, 0u);
+    if (tid == 0) pair_n = 0;
+    __syncthreads();
+
+    const int64_t n_tiles = (n_rows + 63) / 64;
+    const int64_t tile_id = (int64_t)group * kSW + wave;
+    const unsigned bias = tile_id * 64 + lane < n_rows ? 0u : kSInvalid;
+    const int64_t tile = tile_id < n_tiles ? tile_id : n_tiles - 1;
+    const unsigned ec = resid[tile * 64 + lane];
+    const int n_ch = Dp / 128, row_dwords = Dp / 2;
+
+    for (int ch = 0; ch < n_ch; ++ch) {
+        unsigned v[64];
+        const uint4* src = cimg + (tile * (Dp / 8) + ch * 16) * 64 + lane;
+        static_for<16>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            const uint4 x = src[j * 64];
+            v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+        });
+        const bool first = ch == 0, last = ch + 1 == n_ch;
+        const float* rows = reinterpret_cast<const float*>(qimg + q0 * row_dwords + ch * 64);
+        sf16 cur = sload16<0>(rows);
+        sdrain(cur);
+        for (int j = 0; j < nq; ++j) {
+            const float* row = rows + (size_t)j * row_dwords;
+            const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * row_dwords;
+            const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * row_dwords : row;
+            unsigned sad = first ? bias : psum[wave][j][lane];
+            static_for<4>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                sf16 nxt;
+                if constexpr (k + 1 < 4) nxt = sload16<(k + 1) * 64>(row); else nxt = sload16<0>(next_row);
+                if constexpr (k == 0) stouch<256>(touch_row);
+                static_for<16>([&](auto ii) {
+                    constexpr int i = decltype(ii)::value;
+                    const float qf = cur[i];
+                    sad = __builtin_amdgcn_sad_u16(__float_as_uint(qf), v[16 * k + i], sad);
+                });
+                sdrain(nxt);
+                cur = nxt;
+            });
+            if (!last) {
+                psum[wave][j][lane] = sad;
+                continue;
+            }
+            const int2 th = thr_s[j];
+            const unsigned long long above = __ballot((int)(sad + ec) < th.x);
+            const unsigned long long und = __ballot((int)(sad - ec) <= th.y) & ~above;
+            unsigned n_above = __popcll(above);
+            if (und) {  // wave-uniform
+                const unsigned n = __popcll(und);
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(&pair_n, n);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                if (slot + n <= kWQuota) {
+                    if ((und >> lane) & 1ull)
+                        pair_s[slot + __popcll(und & ((1ull << lane) - 1ull))] =
+                            make_uint2((unsigned)(q0 + j), (unsigned)(tile_id * 64 + lane));
+                } else {
+                    if (lane == 0)
+                        atomicOr(flags + (size_t)(q0 + j) * words_per_query + (tile_id >> 5), 1u << (tile_id & 31));
+                    n_above = 0;
+                }
+            }
+            if (lane == 0 && n_above) atomicAdd(&cnt[j], n_above);
+        }
+    }
+    __syncthreads();
+    if (tid < nq) {
+        const unsigned long long c = cnt[tid];
+        if (c) atomicAdd(acc + q0 + tid, c | (c << 32));  // certainly above: gt and ge
+    }
+    const unsigned used = pair_n < (unsigned)kWQuota ? pair_n : (unsigned)kWQuota;
+    if (tid == 0 && used) pair_base = atomicAdd(&params->n_pairs, used);
+    __syncthreads();
+    for (unsigned i = tid; i < used; i += kSW * 64) pairs[pair_base + i] = pair_s[i];
+}
+
+// Pass 2a: one lane per listed pair.
+__global__ __launch_bounds__(256) void wide_refine_pairs_kernel(const float* __restrict__ table, int64_t ld, int D,
+                                                                const float* __restrict__ q_fixed,
+                                                                const float* __restrict__ q_rel,
+                                                                const float* __restrict__ key_true, int64_t q_head,
+                                                                const uint2* __restrict__ pairs,
+                                                                const SadParams* __restrict__ params,
+                                                                unsigned long long* __restrict__ acc) {
+    const int64_t n = params->n_pairs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 p = pairs[i];
+        if (p.x == kSNoPair) continue;
+        const int64_t q = p.x;
+        const float key = transe_key_rt(table + (int64_t)p.y * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+        const float kt = key_true[q];
+        const unsigned long long gt = key > kt, ge = key >= kt;
+        if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
+    }
+}
+
+// Pass 2b: one wave per query over its flagged 64-candidate tiles (all tiles when the pre-pass did not run).
+__global__ __launch_bounds__(256) void wide_refine_tiles_kernel(const float* __restrict__ table, int64_t n_rows,
+                                                                int64_t ld, int D, const float* __restrict__ q_fixed,
+                                                                const float* __restrict__ q_rel,
+                                                                const float* __restrict__ key_true, int64_t q_head,
+                                                                int64_t Q, int words_per_query,
+                                                                const unsigned* __restrict__ flags,
+                                                                const SadParams* __restrict__ params,
+                                                                unsigned long long* __restrict__ acc) {
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const bool all = !sad_scale(params).ok;
+    const int lane = threadIdx.x & 63;
+    const unsigned* row = flags + q * words_per_query;
+    const float kt = key_true[q];
+    const float* f = q_fixed + q * D;
+    const float* r = q_rel + q * D;
+    const bool head = q < q_head;
+    unsigned gt = 0, ge = 0;
+    for (int w0 = 0; w0 < words_per_query; w0 += 64) {
+        const unsigned mine = w0 + lane < words_per_query ? (all ? 0xFFFFFFFFu : row[w0 + lane]) : 0u;
+        unsigned long long nonzero = __ballot(mine != 0);
+        while (nonzero) {
+            const int src = __builtin_ctzll(nonzero);
+            nonzero &= nonzero - 1;
+            unsigned bits = __shfl(mine, src);
+            const int64_t tile_base = (int64_t)(w0 + src) * 32;
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int64_t cand = (tile_base + b) * 64 + lane;
+                const bool ok = cand < n_rows;
+                if (__ballot(ok) == 0) continue;
+                const float key = transe_key_rt(table + (ok ? cand : 0) * ld, f, r, D, head);
+                gt += ok && key > kt;
+                ge += ok && key >= kt;
+            }
+        }
+    }
+    if (__ballot(gt | ge) == 0) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gt += __shfl_down(gt, off);
+        ge += __shfl_down(ge, off);
+    }
+    if (lane == 0) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+}
+
+// CSR filter: one wave per query counts the listed rows that score above / at least the true entity.
+__global__ __launch_bounds__(256) void wide_filter_kernel(const float* __restrict__ table, int64_t ld, int D,
+                                                          const float* __restrict__ q_fixed,
+                                                          const float* __restrict__ q_rel,
+                                                          const float* __restrict__ key_true, int64_t q_head, int64_t Q,
+                                                          const int64_t* __restrict__ rowptr,
+                                                          const int64_t* __restrict__ col,
+                                                          unsigned long long* __restrict__ acc_f) {
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const int lane = threadIdx.x & 63;
+    const float kt = key_true[q];
+    unsigned gt = 0, ge = 0;
+    for (int64_t i = rowptr[q] + lane; i < rowptr[q + 1]; i += 64) {
+        const float key = transe_key_rt(table + col[i] * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+        gt += key > kt;
+        ge += key >= kt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gt += __shfl_down(gt, off);
+        ge += __shfl_down(ge, off);
+    }
+    if (lane == 0) acc_f[q] = (unsigned long long)gt | ((unsigned long long)ge << 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WideWorkspace {
+    float* key_true;
+    unsigned long long* acc; unsigned long long* acc_f;
+    SadParams* params; SadParams* partial; int2* thr; unsigned* qimg; uint4* cimg; unsigned* resid; unsigned* flags;
+    uint2* pairs;
+    int64_t pass_groups;
+    size_t bytes;
+};
+
+static int padded_width(int D) { return (D + 127) / 128 * 128; }
+
+static int64_t wide_groups_per_pass(int64_t N, int64_t Q) {
+    const int64_t n_groups = ((N + 63) / 64 + kSW - 1) / kSW;
+    const int64_t n_chunks = (Q + kWChunk - 1) / kWChunk;
+    const int64_t cap = (int64_t)256 << 20;
+    const int64_t by_pairs = cap / (kWQuota * 8) / (n_chunks > 0 ? n_chunks : 1);
+    const int64_t by_flags = cap / 4 / (Q > 0 ? Q : 1) * 32 / kSW;
+    int64_t g = n_groups;
+    if (g > by_pairs) g = by_pairs;
+    if (g > by_flags) g = by_flags;
+    if (const char* env = getenv("BLP_SAD_PASS_GROUPS")) {  // test knob: force the multi-slab path
+        const int64_t forced = atoll(env);
+        if (forced > 0 && forced < g) g = forced;
+    }
+    return g < 1 ? 1 : g;
+}
+
+static WideWorkspace carve_wide(void* base, int D, int64_t N, int64_t Q) {
+    WideWorkspace w;
+    const int Dp = padded_width(D);
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
+    w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
+    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
+    w.params = reinterpret_cast<SadParams*>(p + off);  off = align_up(off + sizeof(SadParams), 256);
+    w.partial = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams) * kSRangeBlocks, 256);
+    w.thr = reinterpret_cast<int2*>(p + off);          off = align_up(off + (size_t)Q * 8, 256);
+    w.qimg = reinterpret_cast<unsigned*>(p + off);     off = align_up(off + (size_t)Q * (Dp / 2) * 4 + 64, 256);
+    w.cimg = reinterpret_cast<uint4*>(p + off);        off = align_up(off + (size_t)((N + 63) / 64) * 64 * (Dp / 2) * 4, 256);
+    w.resid = reinterpret_cast<unsigned*>(p + off);    off = align_up(off + (size_t)((N + 63) / 64) * 64 * 4, 256);
+    w.pass_groups = wide_groups_per_pass(N, Q);
+    const int64_t words = (w.pass_groups * kSW + 31) / 32;
+    w.flags = reinterpret_cast<unsigned*>(p + off); off = align_up(off + (size_t)Q * words * 4, 256);
+    w.pairs = reinterpret_cast<uint2*>(p + off);
+    off = align_up(off + (size_t)w.pass_groups * ((Q + kWChunk - 1) / kWChunk) * kWQuota * 8, 256);
+    w.bytes = off;
+    return w;
+}
+
+// TransE at a width the register-resident kernels are not compiled for, with enough queries to pay for
+// the quantisation passes.
+bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
+    return model == TRANSE && D != 64 && D != 128 && D != 256 && D >= 4 && D % 4 == 0 && D <= kWMaxD &&
+           q_head + q_tail >= 256;
+}
+
+size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
+    if (!rank_sad_wide_applicable(model, D, q_head, q_tail)) return 0;
+    return carve_wide(nullptr, D, N, q_head + q_tail).bytes;
+}
+
+hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                                    const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                                    int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col,
+                                    int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
+                                    hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const int64_t Q = q_head + q_tail;
+    const int Dp = padded_width(D);
+    WideWorkspace w = carve_wide(workspace, D, N, Q);
+    wide_true_key_kernel<<<dim3((unsigned)((Q + 255) / 256)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, true_row, q_true,
+                                                                               q_head, Q, w.key_true, w.acc);
+    if (ev_start) (void)hipEventRecord(ev_start, stream);
+    const int64_t n_tiles = (N + 63) / 64;
+    {
+        const int64_t items = N * (D / 4) > Q * D ? N * (D / 4) : Q * D;
+        int64_t blocks = (items + 255) / 256;
+        blocks = blocks < kSRangeBlocks ? (blocks > 0 ? blocks : 1) : kSRangeBlocks;
+        wide_range_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(table, N, ld, D, q_fixed, q_rel, q_head, Q, w.partial);
+        sad_range_finish_kernel<<<1, 64, 0, stream>>>(w.partial, (int)blocks, w.params);
+    }
+    const int64_t pass_rows = w.pass_groups * kSW * 64;
+    const int64_t first_rows = N < pass_rows ? N : pass_rows;
+    const int64_t first_words = ((((first_rows + 63) / 64 + kSW - 1) / kSW) * kSW + 31) / 32;
+    if (n_tiles > 0)
+        wide_quantize_table_kernel<<<dim3((unsigned)n_tiles), 256, 0, stream>>>(table, N, ld, D, Dp, w.params, w.cimg, w.resid);
+    wide_quantize_queries_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
+        q_fixed, q_rel, q_head, Q, D, Dp, w.key_true, w.params, w.qimg, w.thr, w.flags, first_words * Q);
+
+    const int64_t n_chunks = (Q + kWChunk - 1) / kWChunk;
+    hipError_t err = hipSuccess;
+    for (int64_t slab0 = 0; slab0 < N; slab0 += pass_rows) {  // one iteration unless the caps bind
+        const int64_t n_rows = N - slab0 < pass_rows ? N - slab0 : pass_rows;
+        const int64_t n_groups = ((n_rows + 63) / 64 + kSW - 1) / kSW;
+        const int words = (int)((n_groups * kSW + 31) / 32);
+        const int64_t n_blocks = n_groups * n_chunks;
+        if (slab0 > 0) {
+            err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
+            if (err != hipSuccess) return err;
+            err = hipMemsetAsync(&w.params->n_pairs, 0, 4, stream);
+            if (err != hipSuccess) return err;
+        }
+        const float* slab = table + slab0 * ld;
+        wide_rank_sad_kernel<<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
+            w.cimg + (slab0 / 64) * (Dp / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, Dp, words, w.acc,
+            w.flags, w.pairs, w.params);
+        const int64_t pair_blocks = (n_blocks * kWQuota + 255) / 256;
+        wide_refine_pairs_kernel<<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 16 ? pair_blocks : (int64_t)n_cu * 16)), 256, 0,
+                                   stream>>>(slab, ld, D, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc);
+        wide_refine_tiles_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
+            slab, n_rows, ld, D, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
+    }
+    if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+    const bool filtered = filt_rowptr != nullptr;
+    if (filtered)
+        wide_filter_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, w.key_true, q_head, Q,
+                                                                              filt_rowptr, filt_col, w.acc_f);
+    err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);
+    return err != hipSuccess ? err : hipGetLastError();
+}
+
+}  // namespace blp

@@ -47,6 +47,12 @@ def dim_supported(rel_model, dim):
     return bool(_lib.lib().blp_dim_supported(_lib.MODEL_IDS[rel_model], int(dim)))
 
 
+def rank_all_supported(rel_model, dim, q_head, q_tail):
+    """True if rank_all takes a block of this shape (fused kernels at 64 / 128 / 256, or the any-width
+    TransE pre-pass for blocks of >= 256 queries); otherwise use score + rank_from_scores."""
+    return bool(_lib.lib().blp_rank_all_supported(_lib.MODEL_IDS[rel_model], int(dim), int(q_head), int(q_tail)))
+
+
 def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
              filt_rowptr=None, filt_col=None, out=None, rel_ids=None):
     """Rank-count every query against every row of ``table`` in one pass over the table.

@@ -63,7 +63,7 @@ def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
                rel_ids=None):
     """Counts (Q, 4) int32 {gt, ge, gt_filtered, ge_filtered} for a block of queries against ``table``.
     Queries [0, q_head) replace the head, the rest replace the tail (train.py:149 order)."""
-    if table.is_cuda and not ops.dim_supported(model.rel_model, table.shape[1]):
+    if table.is_cuda and not ops.rank_all_supported(model.rel_model, table.shape[1], q_head, q_fixed.shape[0] - q_head):
         return _rank_block_generic_width(model, table, q_fixed, q_rel, q_head, true_row, q_true, filt_rowptr, filt_col)
     if table.is_cuda:
         dev = table.device

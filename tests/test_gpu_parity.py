@@ -189,6 +189,46 @@ def test_sad_candidate_slabs_and_shard_vectors(ops, oracle, monkeypatch):
     assert np.array_equal(slabs, want)
 
 
+@pytest.mark.parametrize("D", [300, 768, 100, 4, 1024])
+def test_transe_any_width_prepass(ops, oracle, D, monkeypatch):
+    """TransE at the widths of the reference's BOW / DKRL encoders (300 GloVe, 768 BERT) and other widths
+    the register-resident kernels are not compiled for: blocks of >= 256 queries take the any-width
+    fixed-point pre-pass (rank_sad_wide.hip).  Counts identical to the oracle with a CSR filter, with the
+    true entity given as a row or as a vector, with exact ties, and over candidate slabs."""
+    assert not ops.dim_supported("transe", D) and ops.rank_all_supported("transe", D, 150, 170)
+    assert not ops.rank_all_supported("transe", D, 100, 100) and not ops.rank_all_supported("distmult", D, 150, 170)
+    N, q_head, q_tail = 1000 + 37, 150, 170
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=D)
+    table[::9] = table[1::9][: table[::9].shape[0]]  # exact ties
+    q_fixed = table[torch.arange(q_head + q_tail) * 3 % N].clone()
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + 1)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    args = ("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+    got = ops.rank_all(*args, true_row=true_row.cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+    by_vector = ops.rank_all(*args, q_true=table[true_row].cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col))
+    assert np.array_equal(by_vector.cpu().numpy(), want)
+    monkeypatch.setenv("BLP_SAD_PASS_GROUPS", "2")  # 512-candidate slabs
+    slabs = ops.rank_all(*args, true_row=true_row.cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(slabs, want)
+    assert (want[:, 1] - want[:, 0]).max() > 1
+
+
+@pytest.mark.parametrize("case", ["nan", "constant", "huge"])
+def test_transe_any_width_degenerate_inputs(ops, oracle, case):
+    D, N, q_head, q_tail = 300, 500, 130, 140
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=77)
+    if case == "nan":
+        table[17, 3] = float("nan"); q_rel[7, 9] = float("inf")
+    elif case == "constant":
+        table[:] = 0.25; q_fixed[:] = 0.25; q_rel[:] = 0.0
+    else:
+        table[11] = 1e37; table[12] = -1e37
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row)
+    got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
 @pytest.mark.parametrize("D", [64, 128])
 def test_gemm_band_adversarial(ops, oracle, model, D):

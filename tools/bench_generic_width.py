@@ -1,5 +1,6 @@
 """All-entity ranking at the embedding widths of the reference's BOW / DKRL encoders (300 = GloVe,
-768 = BERT word embeddings; scripts/{glove,bert}-{bow,dkrl}-*.sh, all TransE), FB15k-237 shape."""
+768 = BERT word embeddings; scripts/{glove,bert}-{bow,dkrl}-*.sh, all TransE), FB15k-237 shape:
+the any-width fixed-point pre-pass (rank_sad_wide.hip) through blp_amd.ranking.rank_block."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blp_amd import models, ranking
