@@ -148,3 +148,12 @@ def test_generic_width_route_matches_oracle(rel_model, D, oracle):
     got = ranking._rank_block_generic_width(model, t, f, r, q_head, None, t[true_row.cuda()], rp.cuda(), cl.cuda(),
                                             max_matrix_bytes=4 * N * 7)  # 7-query slabs
     assert np.array_equal(got.cpu().numpy(), want)
+    # a block of >= 256 queries: rank_block routes TransE to the any-width pre-pass, the rest stays dense
+    q_head, q_tail = 140, 131
+    table, q_fixed, q_rel, true_row = random_problem(rel_model, N, D, q_head, q_tail, seed=D + 1)
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + 1)
+    want = oracle_counts(oracle, rel_model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    assert ops.rank_all_supported(rel_model, D, q_head, q_tail) == (rel_model == "transe")
+    got = ranking.rank_block(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                             filt_rowptr=torch.from_numpy(rowptr), filt_col=torch.from_numpy(col))
+    assert np.array_equal(got.cpu().numpy(), want)
