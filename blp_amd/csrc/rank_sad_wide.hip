@@ -31,7 +31,29 @@ constexpr int kWMaxD = 1024;
 __device__ __forceinline__ float transe_key_rt(const float* __restrict__ e, const float* __restrict__ f,
                                                const float* __restrict__ r, int D, bool head) {
     float acc = 0.0f;
-    for (int d = 0; d < D; d += 4) {
+    auto piece = [&](int d) {  // 16 elements: all twelve 16-byte loads are issued before the dependent adds
+        float4 ev[4], fv[4], rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ev[j] = *reinterpret_cast<const float4*>(e + d + 4 * j);
+            fv[j] = *reinterpret_cast<const float4*>(f + d + 4 * j);
+            rv[j] = *reinterpret_cast<const float4*>(r + d + 4 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float es[4] = {ev[j].x, ev[j].y, ev[j].z, ev[j].w}, fs[4] = {fv[j].x, fv[j].y, fv[j].z, fv[j].w},
+                        rs[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x = (head ? es[i] : fs[i]) + rs[i];
+                x = x - (head ? fs[i] : es[i]);
+                acc = acc + fabsf(x);
+            }
+        }
+    };
+    int d = 0;
+    for (; d + 16 <= D; d += 16) piece(d);
+    for (; d < D; d += 4) {
         const float4 ev = *reinterpret_cast<const float4*>(e + d);
         const float4 fv = *reinterpret_cast<const float4*>(f + d);
         const float4 rv = *reinterpret_cast<const float4*>(r + d);
