@@ -45,6 +45,8 @@ WORKLOADS = {
     "fb15k237-distmult": dict(model="distmult", N=14541, D=128, R=237, triples=52870, passes=1),
     "fb15k237-complex": dict(model="complex", N=14541, D=128, R=237, triples=52870, passes=1),
     "fb15k237-simple": dict(model="simple", N=14541, D=128, R=237, triples=52870, passes=1),
+    # the BERT-BOW / BERT-DKRL width (models.py:118-135, 165-172): TransE at the word-embedding width 768
+    "fb15k237-transe-d768": dict(model="transe", N=14541, D=768, R=237, triples=52870, passes=1),
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=2, passes=64),
     # the same table with the whole Wikidata5M test set (6 894 triples) as ONE query block
     "wikidata5m-transe-block": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, passes=1),
@@ -352,6 +354,8 @@ def main():
         if not sad_path and roofline["bound"] == "mfma":
             roofline["mfma_busy"] = load_pmc(args.workload, "mfma_busy_frac_at_2.4GHz")
         roofline["kernel"] = (DOMINANT_KERNEL[model] if Q >= 64 else "rank_tiles_kernel<STATIC> (lane-per-candidate VALU)")
+        if model == "transe" and D not in (64, 128, 256) and Q >= 256:
+            roofline["kernel"] = "wide_rank_sad_kernel + wide_refine_* (any-width u16 v_sad_u16 pre-pass, 128 elements at a time)"
         roofline["kernel_ms"] = kernel_ms
         roofline["algorithmic_bytes_per_launch"] = alg_bytes
         roofline["algorithmic_flops_per_launch"] = alg_flops
