@@ -459,8 +459,7 @@ __global__ __launch_bounds__(1024) void rank_metric_sums_kernel(const int32_t* _
                                                                int k0, int k1, int k2, double* __restrict__ sums) {
     __shared__ double sh[16][8];
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t q = threadIdx.x; q < Q; q += blockDim.x) {
-        const int4 c = reinterpret_cast<const int4*>(counts)[q];
+    auto add = [&](const int4& c) {
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int64_t best = (int64_t)(v ? c.z : c.x) + 1, worst = v ? c.w : c.y;
@@ -470,7 +469,17 @@ __global__ __launch_bounds__(1024) void rank_metric_sums_kernel(const int32_t* _
             acc[2 + 3 * v + 1] += avg <= (float)k1;
             acc[2 + 3 * v + 2] += avg <= (float)k2;
         }
+    };
+    const int4* rows = reinterpret_cast<const int4*>(counts);
+    int64_t q = threadIdx.x;
+    for (; q + 7 * (int64_t)blockDim.x < Q; q += 8 * (int64_t)blockDim.x) {  // eight loads in flight (one block: latency-bound)
+        int4 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = rows[q + j * (int64_t)blockDim.x];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) add(c[j]);
     }
+    for (; q < Q; q += blockDim.x) add(rows[q]);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
