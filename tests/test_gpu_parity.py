@@ -327,6 +327,22 @@ def test_transe_relation_id_hint(ops, oracle, D, sort):
         assert np.array_equal(got.cpu().numpy(), want), ("with ids" if ids is not None else "without ids")
 
 
+@pytest.mark.parametrize("model,D", [("transe", 128), ("transe", 300), ("distmult", 128), ("complex", 64)])
+def test_prepass_paths_are_repeatable(ops, model, D):
+    """Integer counts cannot depend on the order in which workgroups finish: 12 runs of a block big enough
+    for several waves of workgroups (pair lists, flag bitmap, LDS counters, global atomics) are identical."""
+    N, q_head, q_tail = 5000 + 11, 900, 1000
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=D + 5)
+    table[::13] = table[1::13][: table[::13].shape[0]]  # ties keep the refinement paths busy
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D)
+    args = (model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+    kw = dict(true_row=true_row.cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col))
+    first = ops.rank_all(*args, **kw)
+    for _ in range(11):
+        assert torch.equal(ops.rank_all(*args, **kw), first)
+    assert int(first[:, 1].min()) >= 1
+
+
 @pytest.mark.parametrize("model", REL_MODELS)
 def test_edge_shapes(ops, oracle, model):
     D = 128
