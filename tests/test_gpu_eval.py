@@ -157,3 +157,33 @@ def test_generic_width_route_matches_oracle(rel_model, D, oracle):
     got = ranking.rank_block(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
                              filt_rowptr=torch.from_numpy(rowptr), filt_col=torch.from_numpy(col))
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("amp", [None, "bf16"])
+def test_link_prediction_cli_on_gpu(tmp_path, amp):
+    """python train.py link_prediction on the GPU: GloVe-BOW encoder at the GloVe width (300), TransE, the
+    fused in-batch loss in the training step (optionally under autocast), evaluation through the any-width
+    ranking pre-pass (320 queries per split), raw + filtered metrics, saved embeddings."""
+    import os
+    import subprocess
+    import sys
+    from blp_amd.data import write_synthetic_dataset
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    write_synthetic_dataset(str(tmp_path / "data"), "umls-synth", num_entities=135, num_relations=46,
+                            num_train=1280, num_valid=160, num_test=160, vocab_size=500, emb_dim=300, seed=0)
+    cmd = [sys.executable, os.path.join(root, "train.py"), "link_prediction", "with", "dataset=umls-synth",
+           "inductive=False", "model=glove-bow", "rel_model=transe", "loss_fn=margin", "regularizer=1e-2",
+           "max_len=32", "num_negatives=16", "lr=1e-3", "use_scheduler=False", "batch_size=64",
+           "emb_batch_size=512", "eval_batch_size=64", "max_epochs=2", f"data_root={tmp_path / 'data'}", "seed=1"]
+    if amp:
+        cmd.append(f"amp={amp}")
+    proc = subprocess.run(cmd, cwd=tmp_path, env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True,
+                          timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    log = proc.stderr + proc.stdout
+    for needle in ("valid mrr:", "test mrr:", "mrr_filt:", "hits@10_filt:"):
+        assert needle in log, needle
+    assert "Training on CPU" not in log
+    ent_emb = torch.load(tmp_path / "output" / "ent_emb-None.pt")
+    assert ent_emb.shape == (1, 135, 300)
+    assert torch.allclose(ent_emb[0].float().norm(dim=-1).cpu(), torch.ones(135), atol=1e-3)
