@@ -191,8 +191,7 @@ __global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const float* 
 template <int D, int TPW>
 struct SadTiles {
     unsigned v[TPW][D / 2];
-    unsigned bias[TPW];  // accumulator start: 0, or kSInvalid for padding rows
-    unsigned ec[TPW];    // the row's rounding residual E_c
+    unsigned bias[TPW];  // accumulator start: the row's rounding residual E_c, or kSInvalid for padding rows
 };
 
 template <int D, int TPW>
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     __shared__ int2 thr_s[kSChunk];
     __shared__ unsigned cnt[kSChunk];
     __shared__ uint2 pair_s[kSQuota];
-    __shared__ unsigned pair_n, pair_base;
+    __shared__ unsigned pair_n, pair_base, ec_max_s;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -213,23 +212,27 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     const int64_t q0 = (int64_t)(blockIdx.x / n_groups) * kSChunk;
     const int nq = (int)(Q - q0 < kSChunk ? Q - q0 : kSChunk);
 
-    for (int i = tid; i < kSChunk; i += kSW * 64) {
-        thr_s[i] = i < nq ? thr[q0 + i] : make_int2(0, 0);
-        cnt[i] = 0;
-    }
+    for (int i = tid; i < kSChunk; i += kSW * 64) cnt[i] = 0;
     for (int i = tid; i < kSQuota; i += kSW * 64) pair_s[i] = make_uint2(kSNoPair, 0u);
-    if (tid == 0) pair_n = 0;
+    if (tid == 0) { pair_n = 0; ec_max_s = 0; }
+    __syncthreads();
 
-    // this wave's TPW candidate tiles: one row per lane, D/2 packed dwords each
+    // this wave's TPW candidate tiles: one row per lane, D/2 packed dwords each.  The row's residual E_c is
+    // folded into the accumulator's start value (SAD + E_c is what the lower threshold is compared with);
+    // the upper threshold takes 2 x the workgroup's largest E_c instead of the row's own (a slightly wider
+    // band for the other rows, two VALU instructions fewer per (query, tile)).
     SadTiles<D, TPW> c;
     const int64_t n_tiles = (n_rows + 63) / 64;
     const int64_t tile0 = ((int64_t)group * kSW + wave) * TPW;
+    unsigned ec_max = 0;
     static_for<TPW>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
         int64_t tile = tile0 + t;
-        c.bias[t] = tile * 64 + lane < n_rows ? 0u : kSInvalid;
+        const bool exists = tile * 64 + lane < n_rows;
         tile = tile < n_tiles ? tile : n_tiles - 1;
-        c.ec[t] = resid[tile * 64 + lane];
+        const unsigned ec = resid[tile * 64 + lane];
+        c.bias[t] = exists ? ec : kSInvalid;
+        ec_max = exists && ec > ec_max ? ec : ec_max;
         const uint4* src = cimg + tile * (D / 8) * 64 + lane;
         static_for<D / 8>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -237,6 +240,19 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
             c.v[t][4 * j] = x.x; c.v[t][4 * j + 1] = x.y; c.v[t][4 * j + 2] = x.z; c.v[t][4 * j + 3] = x.w;
         });
     });
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_xor(ec_max, off);
+        ec_max = o > ec_max ? o : ec_max;
+    }
+    if (lane == 0) atomicMax(&ec_max_s, ec_max);
+    __syncthreads();
+    for (int i = tid; i < kSChunk; i += kSW * 64) {
+        int2 t2 = i < nq ? thr[q0 + i] : make_int2(0, 0);
+        const long long hi2 = (long long)t2.y + 2ll * ec_max_s;       // SAD + E_c above this: certainly below
+        t2.y = hi2 < (long long)kSThrMax ? (int)hi2 : (int)kSThrMax;
+        thr_s[i] = t2;
+    }
     __syncthreads();
 
     const float* rows = reinterpret_cast<const float*>(qimg + q0 * (D / 2));
@@ -270,8 +286,8 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
         unsigned n_above = 0;
         static_for<TPW>([&](auto tt) {
             constexpr int t = decltype(tt)::value;
-            const unsigned long long above = __ballot((int)(sad[t] + c.ec[t]) < th.x);
-            const unsigned long long und = __ballot((int)(sad[t] - c.ec[t]) <= th.y) & ~above;
+            const unsigned long long above = __ballot((int)sad[t] < th.x);
+            const unsigned long long und = __ballot((int)sad[t] <= th.y) & ~above;
             unsigned n_t = __popcll(above);
             if (und) {  // wave-uniform
                 const unsigned n = __popcll(und);
