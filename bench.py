@@ -50,6 +50,7 @@ WORKLOADS = {
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=2, passes=64),
     # the same table with the whole Wikidata5M test set (6 894 triples) as ONE query block
     "wikidata5m-transe-block": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, passes=1),
+    "wikidata5m-complex-block": dict(model="complex", N=4_600_000, D=128, R=822, triples=6894, passes=1),
 }
 # Algorithmic f32 operations per (candidate, query, element), head-side / tail-side:
 # TransE: one subtract and one |.|-accumulate once the query-only part is hoisted (h + r | t - r per
