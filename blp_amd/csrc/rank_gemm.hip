@@ -1,25 +1,29 @@
 // rank_gemm.hip -- all-entities ranking for the bilinear models (DistMult / ComplEx / SimplE) as a dense
-// f32 MFMA GEMM with a fused rank-count epilogue, made bit-exact by a rigorous error band and an
-// exact refinement pass.  ("K2".)
+// MFMA GEMM with a fused rank-count epilogue, made bit-exact by a rigorous error band and an exact
+// refinement pass.  ("K2".)
 //
 // Scoring every entity against a query block IS a GEMM for these models: score(q, c) = <W_q, e_c> with
 // a query-side vector W_q (DistMult: h*r; ComplEx: the complex product of r with h, or with conj t;
 // SimplE: the two half-products).  But the reference's result is not that dot product rounded once:
 // it rounds every elementwise product and sums in torch's vectorised order, and the ranks must be
 // bit-identical.  So:
-//   pass 1  S~ = W E^T on v_mfma_f32_32x32x2_f32 (64 chained MFMAs per 32 x 32 tile, K = D = 128),
-//           and per pair a three-way decision against the EXACT true-entity score s_true:
+//   pass 1  S~ = W E^T on the matrix cores and per pair a three-way decision against the EXACT
+//           true-entity score s_true:
 //              S~ > s_true + eps  -> certainly ranked above   (count it)
 //              S~ < s_true - eps  -> certainly below          (ignore it)
 //              otherwise          -> undecided
 //           eps(q, c) = C u ||B_q|| ||e_c|| bounds |S~ - S_ref| for ANY evaluation order: both the GEMM and
-//           the reference are within (n + O(1)) u sum_k B_q[k] |e_c[k]| of the real-number score, where
-//           B_q[k] >= |W_q[k]| is the sum of the absolute values of the products W_q[k] is made of
-//           (Cauchy-Schwarz turns the sum into the two norms).  u = 2^-24, C = 320 for n <= 128 terms.
-//           Undecided pairs (the true entity itself plus near-ties, ~3 per query on FB15k-237) go to a
-//           per-workgroup pair list (kPairQuota entries, a fixed region per workgroup: no global
-//           atomics, nothing to overflow).  When a workgroup's quota is used up, the lane's whole
-//           (query, 16-candidate) half-segment contributes nothing and its bit is set in a flag bitmap.
+//           the reference are within a small multiple of u sum_k B_q[k] |e_c[k]| of the real-number score,
+//           where B_q[k] >= |W_q[k]| is the sum of the absolute values of the products W_q[k] is made of
+//           (Cauchy-Schwarz turns the sum into the two norms); u = 2^-24.  Two kernels:
+//             rank_gemm_bf16_kernel (default)  every f32 operand split into bf16 hi + lo, three
+//                                   v_mfma_f32_32x32x16_bf16 products per K-step, C = 1150 (see its header)
+//             rank_gemm_kernel (BLP_GEMM_KERNEL=f32)  v_mfma_f32_32x32x2_f32, an exact f32 fma chain, 64 per
+//                                   32 x 32 tile at K = 128, C = 320 = 2 (n + 2) + slack for n <= 128 terms
+//           Undecided pairs (the true entity itself plus near-ties, a few per query on FB15k-237) go to a
+//           per-workgroup pair list (a fixed region per workgroup: no global atomics, nothing to
+//           overflow).  When a workgroup's quota is used up, the lane's whole (query, 16-candidate)
+//           half-segment contributes nothing and its bit is set in a flag bitmap.
 //   pass 2  a) every listed pair and b) every flagged half-segment is re-scored with the order-exact
 //           Scorer<> routine (the same code that produced s_true) and counted exactly.  If everything
 //           is flagged the result is still exact, just slower.
