@@ -2,7 +2,10 @@
 // every query into its rank counts without materialising the (Q, N) score matrix.
 // Replaces train.py:146-171 + utils.py:103-105 of the reference (see include/blp_hip.h).
 //
-// Kernel pipeline of one blp_rank_all call (all on the caller's stream, no host sync):
+// This file: the dispatch (launch_rank_all: which kernel family ranks a block), the exact
+// f32 kernels, and the building blocks the pre-pass paths (rank_sad*.hip, rank_gemm.hip) share with them.
+//
+// Kernel pipeline of one blp_rank_all call on the exact path (all on the caller's stream, no host sync):
 //   1. prep_coef    (q, i) elementwise: hoist the query-only part of the score into C coefficients
 //   2. true_key     one lane per query: score of the true entity, by the same Scorer<> routine
 //   3. rank_tiles   the hot kernel, below

@@ -72,16 +72,19 @@ int blp_dim_supported(int model, int D);
  * One call streams the (N, D) candidate table once and serves Q = q_head + q_tail queries:
  * queries [0, q_head) replace the HEAD (q_fixed = tail embedding), queries [q_head, Q) replace
  * the TAIL (q_fixed = head embedding) -- the same "head queries first" order as train.py:149.
- * The (Q, N) score matrix is never materialised.
+ * The (Q, N) score matrix is never materialised.  Results are the reference's, bit for bit, whichever
+ * kernel serves the block: exact f32 kernels for small blocks; for blocks of many
+ * queries a cheap pre-pass (16-bit fixed-point v_sad_u16 for TransE, bf16 x 3 MFMA GEMM for the
+ * bilinear models) with a rigorous error band, then exact re-scoring of the undecided pairs.
  *
  *   table      (N, D) f32, row stride ld floats (ld % 4 == 0, 16-byte aligned base)
  *   q_fixed    (Q, D) f32  the entity kept fixed (tail_embs for head queries, head_embs for tail)
  *   q_rel      (Q, D) f32  rel_emb(rels)
  *   q_rel_id   (Q) int64   OPTIONAL (may be NULL) relation id of each query (`rels`, train.py:132).
  *                          Contract: queries with equal ids have identical q_rel rows.  Lets the
- *                          head-replacing TransE queries of one relation share e + r (2 instead of 3
- *                          VALU ops per element); sort the block by relation to benefit.  Never
- *                          changes a result.
+ *                          head-replacing TransE queries of one relation share e + r in the exact f32
+ *                          kernel (2 instead of 3 VALU ops per element); sort the block by relation
+ *                          to benefit.  Never changes a result; the pre-pass paths ignore it.
  *   true_row   (Q) int64   row of the true entity in `table` (true_ents, train.py:150), or NULL
  *   q_true     (Q, D) f32  the true entity's vector, used when true_row == NULL (candidate-axis
  *                          sharding: the true row may live in another shard).  Exactly one of
@@ -109,7 +112,7 @@ int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
 
 /* Measurement aid (bench.py): the NEXT blp_rank_all issued by the calling thread records the two
  * hipEvent_t (created by the caller with timing enabled) on its stream immediately before and after
- * the dominant kernel (rank_tiles), so its duration can be read without a profiler.  One-shot;
+ * the rank pass (rank_tiles, or pre-pass + refinement), so its duration can be read without a profiler.  One-shot;
  * NULL, NULL cancels.  Has no effect on results. */
 int blp_profile_next_rank_kernel(void *start_event, void *stop_event);
 
