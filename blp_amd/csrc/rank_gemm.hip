@@ -418,7 +418,6 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     float* nrm = reinterpret_cast<float*>(cnt + kBfTilesPerChunk * kGQT);        // [kBfW][kBfTPW][32]
     uint2* pair_s = reinterpret_cast<uint2*>(nrm + kBfW * kBfTPW * 32);          // [kBfQuota]
     float2* kq_s = reinterpret_cast<float2*>(pair_s + kBfQuota);                 // [kBfTilesPerChunk * 32] {s_true, eps_q}
-    unsigned* pair_n = reinterpret_cast<unsigned*>(kq_s + kBfTilesPerChunk * kGQT);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, half = lane >> 5;
@@ -438,7 +437,6 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         kq_s[i] = make_float2(key_true[q], eps_q[q]);
     }
     for (int i = tid; i < kBfQuota; i += kBfW * 64) pair_s[i] = make_uint2(kNoPair, 0u);
-    if (tid == 0) *pair_n = 0;
 
     // this wave's candidate tiles: lane (row l & 31, K-half l >> 5) reads its 8 floats of every K-step
     // straight from the table, splits them, and keeps them as MFMA A operands
@@ -499,6 +497,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     });
 
     const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
+    unsigned my_pairs = 0;  // entries this wave has listed (wave-uniform)
     // K-step st of a query tile against both candidate tiles (bh / bl = its hi / lo B operands); the two
     // accumulator chains are interleaved so that no MFMA reads the accumulator the previous one writes
     auto load_b = [&](auto kk, const float* buf, bf16x8& bh, bf16x8& bl) {
@@ -550,35 +549,44 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
             });
         });
     };
-    // Rare per lane: which registers are undecided; list them, or flag the half-segment when the
-    // workgroup's quota is used up.  Adds the decided-above count to the query's LDS counter.
+    // Rare: some lane of the wave has an undecided register.  Every wave owns a slice of the workgroup's pair
+    // list and keeps its fill count in a scalar register, so listing needs no LDS atomic (a slot
+    // reservation through LDS cost several hundred cycles under the DMA / operand traffic): the lanes
+    // with undecided registers are visited one by one.  When the slice is full the lane's half-segment is
+    // flagged instead and contributes no count.
     auto settle = [&](int t, int q, bool q_ok, const f32x16 (&s)[kBfTPW], const float (&thr_hi)[kBfTPW],
-                      const float (&thr_lo)[kBfTPW], const unsigned (&above)[kBfTPW], const bool (&any_und)[kBfTPW]) {
+                      const float (&thr_lo)[kBfTPW], const unsigned (&above_in)[kBfTPW], const bool (&any_und)[kBfTPW]) {
+        unsigned total_above = 0;
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            if (!q_ok) return;
-            bool listed = true;
-            if (any_und[ti]) {
+            unsigned above = q_ok ? above_in[ti] : 0u;
+            if (__ballot(q_ok && any_und[ti])) {  // wave-uniform
                 unsigned und = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) und |= (unsigned)!(s[ti][r] > thr_hi[ti] || s[ti][r] < thr_lo[ti]) << r;
-                und &= c[ti].row_mask;
-                if (und) {
-                    const int ctile = ctile0 + ti;
-                    const unsigned n_und = __popc(und);
-                    unsigned slot = atomicAdd(pair_n, n_und);
-                    listed = slot + n_und <= kBfQuota;
-                    if (listed) {
-                        for (unsigned mm = und; mm; mm &= mm - 1)
-                            pair_s[slot++] = make_uint2((unsigned)q, (unsigned)(ctile * kGCT + acc_row(__builtin_ctz(mm), half)));
-                    } else {
-                        const int hseg = ctile * 2 + half;
-                        atomicOr(flags + (size_t)q * words_per_query + (hseg >> 5), 1u << (hseg & 31));
+                und = q_ok ? und & c[ti].row_mask : 0u;
+                const int ctile = ctile0 + ti;
+                for (unsigned long long todo = __ballot(und != 0); todo; todo &= todo - 1) {
+                    const int src = __builtin_ctzll(todo);
+                    const unsigned n = __popc(__builtin_amdgcn_readlane(und, src));  // scalar
+                    const bool fits = my_pairs + n <= kBfQuota / kBfW;
+                    if (lane == src) {
+                        if (fits) {
+                            unsigned slot = wave * (kBfQuota / kBfW) + my_pairs;
+                            for (unsigned mm = und; mm; mm &= mm - 1)
+                                pair_s[slot++] = make_uint2((unsigned)q, (unsigned)(ctile * kGCT + acc_row(__builtin_ctz(mm), half)));
+                        } else {
+                            const int hseg = ctile * 2 + half;
+                            atomicOr(flags + (size_t)q * words_per_query + (hseg >> 5), 1u << (hseg & 31));
+                            above = 0;
+                        }
                     }
+                    my_pairs += fits ? n : 0u;
                 }
             }
-            if (listed && above[ti]) atomicAdd(cnt + t * kGQT + (lane & 31), above[ti]);
+            total_above += above;
         });
+        if (total_above) atomicAdd(cnt + t * kGQT + (lane & 31), total_above);
     };
     auto zero_acc = [&](f32x16 (&s)[kBfTPW]) {
         static_for<kBfTPW>([&](auto tt) {
