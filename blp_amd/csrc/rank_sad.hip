@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     __shared__ int2 thr_s[kSChunk];
     __shared__ unsigned cnt[kSChunk];
     __shared__ uint2 pair_s[kSQuota];
-    __shared__ unsigned pair_n, pair_base, ec_max_s;
+    __shared__ unsigned wave_used[kSW], wave_base[kSW], ec_max_s;  // per-wave slices of pair_s: fill counts, global offsets
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -213,8 +213,7 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     const int nq = (int)(Q - q0 < kSChunk ? Q - q0 : kSChunk);
 
     for (int i = tid; i < kSChunk; i += kSW * 64) cnt[i] = 0;
-    for (int i = tid; i < kSQuota; i += kSW * 64) pair_s[i] = make_uint2(kSNoPair, 0u);
-    if (tid == 0) { pair_n = 0; ec_max_s = 0; }
+    if (tid == 0) ec_max_s = 0;
     __syncthreads();
 
     // this wave's TPW candidate tiles: one row per lane, D/2 packed dwords each.  The row's residual E_c is
@@ -255,6 +254,7 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     }
     __syncthreads();
 
+    unsigned my_pairs = 0;  // entries in this wave's slice of pair_s (wave-uniform)
     const float* rows = reinterpret_cast<const float*>(qimg + q0 * (D / 2));
     sf16 cur = sload16<0>(rows);
     sdrain(cur);
@@ -289,15 +289,13 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
             const unsigned long long above = __ballot((int)sad[t] < th.x);
             const unsigned long long und = __ballot((int)sad[t] <= th.y) & ~above;
             unsigned n_t = __popcll(above);
-            if (und) {  // wave-uniform
+            if (und) {  // wave-uniform.  The wave fills its own slice of the list: no LDS round trip for a slot
                 const unsigned n = __popcll(und);
-                unsigned slot = 0;
-                if (lane == 0) slot = atomicAdd(&pair_n, n);
-                slot = __builtin_amdgcn_readfirstlane(slot);
-                if (slot + n <= kSQuota) {
+                if (my_pairs + n <= kSQuota / kSW) {
                     if ((und >> lane) & 1ull)
-                        pair_s[slot + __popcll(und & ((1ull << lane) - 1ull))] =
+                        pair_s[wave * (kSQuota / kSW) + my_pairs + __popcll(und & ((1ull << lane) - 1ull))] =
                             make_uint2((unsigned)(q0 + j), (unsigned)((tile0 + t) * 64 + lane));
+                    my_pairs += n;
                 } else {
                     const int64_t tile = tile0 + t;
                     if (lane == 0) atomicOr(flags + (size_t)(q0 + j) * words_per_query + (tile >> 5), 1u << (tile & 31));
@@ -313,10 +311,17 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
         const unsigned long long v = cnt[i];
         if (v) atomicAdd(acc + q0 + i, v | (v << 32));  // certainly above: gt and ge
     }
-    const unsigned used = pair_n < (unsigned)kSQuota ? pair_n : (unsigned)kSQuota;
-    if (tid == 0 && used) pair_base = atomicAdd(&params->n_pairs, used);
+    if (lane == 0) wave_used[wave] = my_pairs;
     __syncthreads();
-    for (unsigned i = tid; i < used; i += kSW * 64) pairs[pair_base + i] = pair_s[i];
+    if (tid == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < kSW; ++w) { wave_base[w] = total; total += wave_used[w]; }
+        const unsigned base = total ? atomicAdd(&params->n_pairs, total) : 0u;
+        for (int w = 0; w < kSW; ++w) wave_base[w] += base;
+    }
+    __syncthreads();
+    for (int w = 0; w < kSW; ++w)
+        for (unsigned i = tid; i < wave_used[w]; i += kSW * 64) pairs[wave_base[w] + i] = pair_s[w * (kSQuota / kSW) + i];
 }
 
 // Pass 2a: one lane per listed pair.
