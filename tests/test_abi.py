@@ -34,6 +34,12 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 16)
+    # blocks blp_rank_all takes: the compiled widths always; TransE with >= 256 queries at any D % 4 == 0
+    assert L.blp_rank_all_supported(0, 128, 1, 1) == 1 and L.blp_rank_all_supported(2, 128, 1, 1) == 1
+    assert L.blp_rank_all_supported(0, 300, 150, 170) == 1 and L.blp_rank_all_supported(0, 768, 256, 0) == 1
+    assert L.blp_rank_all_supported(0, 300, 10, 10) == 0 and L.blp_rank_all_supported(1, 300, 150, 170) == 0
+    assert L.blp_rank_all_supported(0, 302, 150, 170) == 0 and L.blp_rank_all_supported(0, 2048, 150, 170) == 0
+    assert L.blp_rank_all_workspace_bytes(0, 14541, 768, 300, 300) > 14541 * 768 * 2  # holds the 2-byte table image
 
 
 def test_bad_arguments_return_status_not_crash(built_lib):
@@ -46,5 +52,12 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     assert rc == -2
     rc = L.blp_score_fwd(1, 100, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
     assert rc == -2
+    one = ctypes.c_void_p(16)  # non-NULL placeholders: validation fails before anything is dereferenced
+    rc = L.blp_inbatch_loss_fwd_t(0, 0, 5, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, 0, None)
+    assert rc == -1 and b"dtype" in L.blp_last_error()
+    rc = L.blp_inbatch_loss_fwd_t(0, 0, 0, 1, one, one, one, 4, 4, 128, 0.0, one, one, one, 0, None)
+    assert rc == -1  # relation rows narrower than the embeddings
+    rc = L.blp_rank_metric_sums(None, 5, None, None, 0, None)
+    assert rc == -1
     with pytest.raises(RuntimeError, match="BLP_ERR_BAD_ARG"):
         _lib.check(-1, "demo")
