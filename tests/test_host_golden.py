@@ -175,6 +175,47 @@ def test_link_prediction_compute_loss_cpu_route(name):
     np.testing.assert_allclose(model.rel_emb.weight.grad.numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
 
 
+def test_loader_triples_fast_path_equals_iteration():
+    """ranking._loader_triples reads a sequential default-collate loader over a dataset that stores its
+    triples as one tensor as a slice; it must see exactly what `for i, triples in enumerate(loader)`
+    sees (train.py:128-131), including max_num_batches, drop_last, and must fall back to iteration for
+    shuffled loaders, custom collates and datasets without a `triples` tensor."""
+    from torch.utils.data import DataLoader, Dataset, TensorDataset
+
+    class Triples(Dataset):
+        def __init__(self, t):
+            self.triples = t
+
+        def __getitem__(self, i):
+            return self.triples[i]
+
+        def __len__(self):
+            return self.triples.shape[0]
+
+    g = torch.Generator().manual_seed(0)
+    t = torch.randint(0, 50, (203, 3), generator=g)
+
+    def iterate(loader, max_num_batches):
+        out = []
+        for i, batch in enumerate(loader):
+            if max_num_batches is not None and i == max_num_batches:
+                break
+            out.append(batch)
+        return torch.cat(out) if out else torch.zeros((0, 3), dtype=torch.long)
+
+    for kw in (dict(batch_size=64), dict(batch_size=64, drop_last=True), dict(batch_size=7)):
+        for mb in (None, 0, 2, 100):
+            loader = DataLoader(Triples(t), **kw)
+            assert torch.equal(ranking._loader_triples(loader, mb), iterate(loader, mb)), (kw, mb)
+    # not the fast path: still the same triples as the plain loop
+    torch.manual_seed(1)
+    shuffled = DataLoader(Triples(t), batch_size=64, shuffle=True)
+    assert sorted(map(tuple, ranking._loader_triples(shuffled, None).tolist())) == sorted(map(tuple, t.tolist()))
+    plain = DataLoader(TensorDataset(t), batch_size=64, collate_fn=lambda rows: torch.stack([r[0] for r in rows]))
+    assert torch.equal(ranking._loader_triples(plain, 2), t[:128])
+    assert torch.equal(ranking._loader_triples([t[:5], t[5:9]], None), t[:9])  # any iterable of batches
+
+
 def test_model_interface_and_errors():
     with pytest.raises(ValueError, match="Unknown relational model"):
         models.LinkPrediction(8, "rotate", "margin", 3, 0)
