@@ -754,21 +754,20 @@ struct GemmWorkspace {
     size_t bytes;
 };
 
-// pair-list entries needed for T candidate tiles x one query chunk: the larger of the two pass-1 kernels
-static int64_t pair_entries_per_chunk(int64_t T) {
-    const int64_t f32_kernel = (T + kGW - 1) / kGW * kPairQuota;
-    const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * (8 * kBfTPW * kGTilesPerChunk);  // per 8 query tiles
+// Pair-list entries one pass over T candidate tiles can write: every workgroup owns a fixed region of its
+// kernel's quota, so this is (candidate groups) x (query chunks) x quota -- for whichever of the two
+// pass-1 kernels needs more (their groupings of tiles and of query tiles differ).
+static int64_t pair_entries(int64_t T, int64_t q_head, int64_t q_tail) {
+    const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
+    auto chunks = [&](int64_t per) { return (th + per - 1) / per + (tt + per - 1) / per; };
+    const int64_t f32_kernel = (T + kGW - 1) / kGW * chunks(kGTilesPerChunk) * kPairQuota;
+    const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * chunks(kBfTilesPerChunk) * kBfQuota;
     return f32_kernel > bf16_kernel ? f32_kernel : bf16_kernel;
 }
 
 static bool gemm_use_f32() {  // BLP_GEMM_KERNEL=f32: the exact-f32-chain MFMA kernel instead of bf16 x 3
     const char* pick = getenv("BLP_GEMM_KERNEL");
     return pick && pick[0] == 'f';
-}
-
-static int64_t query_chunks(int64_t q_head, int64_t q_tail) {
-    const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
-    return (th + kGTilesPerChunk - 1) / kGTilesPerChunk + (tt + kGTilesPerChunk - 1) / kGTilesPerChunk;
 }
 
 // Candidate tiles handled per GEMM + refine pass (a multiple of 16 = one flag word per query): the flag
@@ -779,7 +778,7 @@ static int64_t tiles_per_pass(int64_t N, int64_t q_head, int64_t q_tail) {
     const int64_t cap = (int64_t)256 << 20;
     int64_t words = ((N + kGCT - 1) / kGCT + 15) / 16;
     const int64_t by_flags = cap / 4 / Q;
-    const int64_t by_pairs = cap / 8 / query_chunks(q_head, q_tail) / pair_entries_per_chunk(16);
+    const int64_t by_pairs = cap / 8 / pair_entries(16, q_head, q_tail);  // entries grow linearly in whole 16-tile words
     if (words > by_flags) words = by_flags;
     if (words > by_pairs) words = by_pairs;
     if (const char* env = getenv("BLP_GEMM_PASS_WORDS")) {  // test knob: force the multi-slab path
@@ -807,7 +806,7 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     w.flags = reinterpret_cast<unsigned*>(p + off);
     off = align_up(off + (size_t)Q * (size_t)(w.pass_ctiles / 16) * 4, 256);
     w.pairs = reinterpret_cast<uint2*>(p + off);
-    off = align_up(off + (size_t)pair_entries_per_chunk(w.pass_ctiles) * query_chunks(q_head, q_tail) * 8, 256);
+    off = align_up(off + (size_t)pair_entries(w.pass_ctiles, q_head, q_tail) * 8, 256);
     w.bytes = off;
     return w;
 }

@@ -343,6 +343,43 @@ def test_prepass_paths_are_repeatable(ops, model, D):
     assert int(first[:, 1].min()) >= 1
 
 
+@pytest.mark.parametrize("model,D", [("transe", 128), ("transe", 64), ("transe", 300), ("distmult", 128), ("complex", 64),
+                                     ("simple", 128)])
+@pytest.mark.parametrize("gemm_kernel", [None, "f32"])
+def test_workspace_is_never_overrun(model, D, gemm_kernel, monkeypatch):
+    """blp_rank_all through the raw C-ABI with a workspace of exactly blp_rank_all_workspace_bytes bytes
+    followed by a canary: every kernel path, for query-block shapes whose tile / chunk counts do not
+    divide evenly (1 tile on one side, 17 on the other, ...), must leave the canary intact.  (A
+    randomised soak found the bilinear pair list sized for the wrong chunking: a write past the end
+    that only faulted when the allocation happened to end a mapped segment.)"""
+    from blp_amd import _lib
+    if gemm_kernel:
+        if model == "transe":
+            pytest.skip("bilinear knob")
+        monkeypatch.setenv("BLP_GEMM_KERNEL", gemm_kernel)
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(D)
+    guard = 1 << 16
+    for N, q_head, q_tail in ((1692, 241, 208), (1668, 456, 4), (700, 4, 540), (2100, 33, 513), (97, 1, 300), (4099, 300, 300)):
+        table = torch.randn(N, D, generator=g).cuda()
+        dup = table[1::3]
+        table[0:3 * dup.shape[0]:3] = dup  # ties: plenty of undecided pairs
+        Q = q_head + q_tail
+        q_fixed = table[torch.randint(0, N, (Q,), generator=g).cuda()].contiguous()
+        q_rel = (torch.randn(Q, D, generator=g) * 0.1).cuda()
+        true_row = torch.randint(0, N, (Q,), generator=g).cuda()
+        counts = torch.empty((Q, 4), dtype=torch.int32, device="cuda")
+        need = L.blp_rank_all_workspace_bytes(_lib.MODEL_IDS[model], N, D, q_head, q_tail)
+        ws = torch.full((need + guard,), 0xA5, dtype=torch.uint8, device="cuda")
+        rc = L.blp_rank_all(_lib.MODEL_IDS[model], table.data_ptr(), N, D, D, q_fixed.data_ptr(), q_rel.data_ptr(), None,
+                            true_row.data_ptr(), None, q_head, q_tail, None, None, counts.data_ptr(), ws.data_ptr(), need,
+                            0, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "blp_rank_all")
+        torch.cuda.synchronize()
+        assert bool((ws[need:] == 0xA5).all()), (N, q_head, q_tail)
+        assert int(counts[:, 1].min()) >= 1
+
+
 @pytest.mark.parametrize("model", REL_MODELS)
 def test_edge_shapes(ops, oracle, model):
     D = 128

@@ -1,0 +1,98 @@
+"""Randomised parity soak: random model / width / sizes / data shapes / filter / true-entity form / slab
+knobs, HIP ranking through the C-ABI against the CPU oracle (test infrastructure), for a wall-clock budget.
+    python tools/fuzz_parity.py [seconds] [seed]
+Prints every mismatch with the seed that reproduces it; exit code 1 if there was one."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from blp_amd import ops  # noqa: E402
+from oracle import oracle  # noqa: E402
+from test_gpu_parity import oracle_counts, random_csr  # noqa: E402
+
+
+def make_case(rng):
+    model = rng.choice(["transe", "distmult", "complex", "simple"])
+    if model == "transe":
+        D = int(rng.choice([64, 128, 256, 300, 100, 768, 36]))
+    else:
+        D = int(rng.choice([64, 128, 256]))
+    N = int(rng.integers(1, 2500))
+    q_head, q_tail = int(rng.integers(0, 500)), int(rng.integers(0, 500))
+    if q_head + q_tail == 0:
+        q_tail = 1
+    if D not in (64, 128, 256) and q_head + q_tail < 256:
+        q_head += 256
+    g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
+    kind = rng.choice(["normal", "normalized", "dyadic", "ties", "outlier", "tiny", "mixed_scale"])
+    table = torch.randn(N, D, generator=g)
+    if kind == "normalized":
+        table = torch.nn.functional.normalize(table, dim=-1)
+    elif kind == "dyadic":
+        table = torch.randint(-8, 9, (N, D), generator=g).float() / 8
+    elif kind == "ties":
+        table = table[torch.randint(0, max(1, N // 5), (N,), generator=g)]
+    elif kind == "outlier":
+        table[int(rng.integers(0, N)), int(rng.integers(0, D))] = float(rng.choice([1e4, -1e6, 1e30]))
+    elif kind == "tiny":
+        table = table * 1e-25
+    elif kind == "mixed_scale":
+        table = table * torch.exp(torch.randn(N, 1, generator=g) * 3)
+    Q = q_head + q_tail
+    q_fixed = table[torch.randint(0, N, (Q,), generator=g)].clone()
+    q_rel = torch.randn(Q, D, generator=g) * float(rng.choice([0.0, 0.1, 1.0]))
+    true_row = torch.randint(0, N, (Q,), generator=g)
+    csr = random_csr(Q, N, true_row.numpy(), seed=int(rng.integers(0, 2 ** 31))) if rng.random() < 0.5 else None
+    by_vector = rng.random() < 0.3
+    env = {}
+    if rng.random() < 0.3:
+        env["BLP_SAD_PASS_GROUPS"] = str(int(rng.integers(1, 4)))
+        env["BLP_GEMM_PASS_WORDS"] = str(int(rng.integers(1, 3)))
+    if rng.random() < 0.15:
+        env["BLP_GEMM_KERNEL"] = "f32"
+    if rng.random() < 0.15:
+        env["BLP_RANK_KERNEL"] = str(rng.choice(["valu", "mfma"]))
+    return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        seed = seed0 + n
+        rng = np.random.default_rng(seed)
+        model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env = make_case(rng)
+        if os.environ.get("BLP_FUZZ_TRACE"):  # the last line names the case a crash happened in
+            print(f"seed={seed} model={model} D={D} N={N} q=({q_head},{q_tail}) data={kind} csr={csr is not None} "
+                  f"by_vector={by_vector} env={env}", file=sys.stderr, flush=True)
+        kw = dict(true_row=true_row) if not by_vector else dict(q_true=table[true_row])
+        want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, csr=csr, **kw)
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            gkw = {k: v.cuda() for k, v in kw.items()}
+            if csr is not None:
+                gkw.update(filt_rowptr=torch.from_numpy(csr[0]).cuda(), filt_col=torch.from_numpy(csr[1]).cuda())
+            got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, **gkw).cpu().numpy()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        if not np.array_equal(got, want):
+            bad += 1
+            rows = np.nonzero((got != want).any(axis=1))[0]
+            print(f"MISMATCH seed={seed} model={model} D={D} N={N} q=({q_head},{q_tail}) data={kind} csr={csr is not None} "
+                  f"by_vector={by_vector} env={env}: {len(rows)} queries differ, first {rows[:3].tolist()} "
+                  f"got {got[rows[0]].tolist()} want {want[rows[0]].tolist()}", flush=True)
+        n += 1
+    print(f"{n} cases in {time.time() - t0:.0f} s, {bad} mismatches (seeds {seed0}..{seed0 + n - 1})")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
