@@ -1,0 +1,61 @@
+"""Randomised soak of the fused in-batch loss (forward + backward) and of score_fn against the torch port
+(test infrastructure), random shapes / models / losses / storage types.  python tools/fuzz_loss.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from blp_amd import ops  # noqa: E402
+from oracle import ref_port  # noqa: E402
+
+TOL = {torch.float32: 3e-5, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        seed = seed0 + n
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(seed)
+        model = str(rng.choice(["transe", "distmult", "complex", "simple"]))
+        loss_fn = str(rng.choice(["margin", "nll"]))
+        D = int(rng.choice([64, 128, 256, 320])) if model != "transe" else int(rng.choice([64, 128, 300, 768, 36]))
+        B, K = int(rng.integers(2, 160)), int(rng.integers(2, 80))
+        dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
+        rel_f32 = dtype == torch.float32 or rng.random() < 0.5
+        reg = float(rng.choice([0.0, 1e-3, 1e-2]))
+        ent = (torch.randn(B, 2, D) * float(rng.choice([0.1, 0.4, 1.0]))).to(dtype)
+        rel = torch.randn(B, 1, D) * 0.3
+        rel = rel if rel_f32 else rel.to(dtype)
+        neg_idx = torch.randint(0, 2 * B, (B, K, 2))
+        e_ref, r_ref = ent.float().clone().requires_grad_(True), rel.float().clone().requires_grad_(True)
+        ref = ref_port.compute_loss(model, loss_fn, e_ref, r_ref, neg_idx, reg)
+        ref.backward()
+        e, r = ent.cuda().requires_grad_(True), rel.cuda().requires_grad_(True)
+        loss = ops.inbatch_loss(model, loss_fn, e, r, neg_idx.cuda(), reg)
+        loss.backward()
+        ok = abs(loss.item() - ref.item()) <= 3e-6 * max(1.0, abs(ref.item()))
+        ok &= np.allclose(e.grad.float().cpu().numpy(), e_ref.grad.numpy(), rtol=TOL[dtype], atol=2e-7)
+        ok &= np.allclose(r.grad.float().cpu().numpy(), r_ref.grad.numpy(), rtol=TOL[rel.dtype], atol=2e-7)
+        # score_fn forward on the training broadcast (B, K, D) x (B, 1, D): bit-identical in f32
+        if dtype == torch.float32 and D % 32 == 0 or model == "transe" and dtype == torch.float32:
+            h, t = ent[:, :1].float(), torch.randn(B, K, D)
+            want = ref_port.SCORE_FNS[model](h, t, rel.float())
+            got = ops.score(model, h.cuda(), t.cuda(), rel.float().cuda()).cpu()
+            ok &= bool(torch.equal(got, want))
+        if not ok:
+            bad += 1
+            print(f"MISMATCH seed={seed} {model} {loss_fn} B={B} K={K} D={D} {dtype} rel_f32={rel_f32} reg={reg}: "
+                  f"loss {loss.item()} vs {ref.item()}", flush=True)
+        n += 1
+    print(f"{n} cases in {time.time() - t0:.0f} s, {bad} mismatches (seeds {seed0}..{seed0 + n - 1})")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -22,14 +22,17 @@ def make_case(rng):
         D = int(rng.choice([64, 128, 256, 300, 100, 768, 36]))
     else:
         D = int(rng.choice([64, 128, 256]))
-    N = int(rng.integers(1, 2500))
+    N = int(rng.integers(1, 2500)) if rng.random() < 0.9 else int(rng.integers(2500, 12000))
     q_head, q_tail = int(rng.integers(0, 500)), int(rng.integers(0, 500))
+    if rng.random() < 0.1:
+        q_head, q_tail = int(rng.integers(0, 3)), int(rng.integers(0, 3))  # the few-queries (HBM-streaming) mode
     if q_head + q_tail == 0:
         q_tail = 1
     if D not in (64, 128, 256) and q_head + q_tail < 256:
         q_head += 256
     g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
-    kind = rng.choice(["normal", "normalized", "dyadic", "ties", "outlier", "tiny", "mixed_scale"])
+    kind = rng.choice(["normal", "normalized", "dyadic", "ties", "outlier", "tiny", "mixed_scale", "nan", "inf", "zero_rows",
+                       "constant"])
     table = torch.randn(N, D, generator=g)
     if kind == "normalized":
         table = torch.nn.functional.normalize(table, dim=-1)
@@ -43,12 +46,30 @@ def make_case(rng):
         table = table * 1e-25
     elif kind == "mixed_scale":
         table = table * torch.exp(torch.randn(N, 1, generator=g) * 3)
+    elif kind == "nan":
+        table[int(rng.integers(0, N)), int(rng.integers(0, D))] = float("nan")
+    elif kind == "inf":
+        table[int(rng.integers(0, N)), int(rng.integers(0, D))] = float(rng.choice([float("inf"), -float("inf")]))
+    elif kind == "zero_rows":
+        table[torch.rand(N, generator=g) < 0.3] = 0.0
+    elif kind == "constant":
+        table[:] = float(rng.choice([0.0, 0.25, -3.0]))
     Q = q_head + q_tail
     q_fixed = table[torch.randint(0, N, (Q,), generator=g)].clone()
     q_rel = torch.randn(Q, D, generator=g) * float(rng.choice([0.0, 0.1, 1.0]))
     true_row = torch.randint(0, N, (Q,), generator=g)
+    rel_ids = None
+    if model == "transe" and rng.random() < 0.3:
+        rel_ids = torch.randint(0, 7, (Q,), generator=g)
+        if rng.random() < 0.5:
+            rel_ids[:q_head] = torch.sort(rel_ids[:q_head]).values
+        q_rel = (torch.randn(7, D, generator=g) * 0.2)[rel_ids]
     csr = random_csr(Q, N, true_row.numpy(), seed=int(rng.integers(0, 2 ** 31))) if rng.random() < 0.5 else None
     by_vector = rng.random() < 0.3
+    if rng.random() < 0.2:  # a strided view (ld > D)
+        wide = torch.zeros(N, D + 4 * int(rng.integers(1, 5)))
+        wide[:, :D] = table
+        table = wide[:, :D]
     env = {}
     if rng.random() < 0.3:
         env["BLP_SAD_PASS_GROUPS"] = str(int(rng.integers(1, 4)))
@@ -57,7 +78,7 @@ def make_case(rng):
         env["BLP_GEMM_KERNEL"] = "f32"
     if rng.random() < 0.15:
         env["BLP_RANK_KERNEL"] = str(rng.choice(["valu", "mfma"]))
-    return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env
+    return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids
 
 
 def main():
@@ -67,19 +88,22 @@ def main():
     while time.time() - t0 < budget:
         seed = seed0 + n
         rng = np.random.default_rng(seed)
-        model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env = make_case(rng)
+        model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids = make_case(rng)
         if os.environ.get("BLP_FUZZ_TRACE"):  # the last line names the case a crash happened in
             print(f"seed={seed} model={model} D={D} N={N} q=({q_head},{q_tail}) data={kind} csr={csr is not None} "
                   f"by_vector={by_vector} env={env}", file=sys.stderr, flush=True)
         kw = dict(true_row=true_row) if not by_vector else dict(q_true=table[true_row])
-        want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, csr=csr, **kw)
+        want = oracle_counts(oracle, model, table.contiguous(), q_fixed, q_rel, q_head, csr=csr, **kw)
         for k, v in env.items():
             os.environ[k] = v
         try:
             gkw = {k: v.cuda() for k, v in kw.items()}
             if csr is not None:
                 gkw.update(filt_rowptr=torch.from_numpy(csr[0]).cuda(), filt_col=torch.from_numpy(csr[1]).cuda())
-            got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, **gkw).cpu().numpy()
+            if rel_ids is not None:
+                gkw["rel_ids"] = rel_ids.cuda()
+            dev_table = table.cuda() if table.is_contiguous() else table._base.cuda()[:, :D]
+            got = ops.rank_all(model, dev_table, q_fixed.cuda(), q_rel.cuda(), q_head, **gkw).cpu().numpy()
         finally:
             for k in env:
                 os.environ.pop(k, None)
