@@ -40,8 +40,11 @@ def main():
         loss = ops.inbatch_loss(model, loss_fn, e, r, neg_idx.cuda(), reg)
         loss.backward()
         ok = abs(loss.item() - ref.item()) <= 3e-6 * max(1.0, abs(ref.item()))
-        ok &= np.allclose(e.grad.float().cpu().numpy(), e_ref.grad.numpy(), rtol=TOL[dtype], atol=2e-7)
-        ok &= np.allclose(r.grad.float().cpu().numpy(), r_ref.grad.numpy(), rtol=TOL[rel.dtype], atol=2e-7)
+        # a gradient element is a sum of up to B (K + 1) terms of either sign: the summation order moves it by a
+        # few ulps of the LARGEST partial sum, so the absolute tolerance scales with max |grad| (seed 604)
+        for got_g, want_g, tol in ((e.grad, e_ref.grad, TOL[dtype]), (r.grad, r_ref.grad, TOL[rel.dtype])):
+            want_np = want_g.numpy()
+            ok &= np.allclose(got_g.float().cpu().numpy(), want_np, rtol=tol, atol=max(2e-7, 2e-6 * float(np.abs(want_np).max())))
         # score_fn forward on the training broadcast (B, K, D) x (B, 1, D): bit-identical in f32
         if dtype == torch.float32 and D % 32 == 0 or model == "transe" and dtype == torch.float32:
             h, t = ent[:, :1].float(), torch.randn(B, K, D)
