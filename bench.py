@@ -202,6 +202,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="fb15k237-transe", choices=sorted(WORKLOADS))
+    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
+                    help="replay a step's launches from a captured hipGraph (auto: fall back to eager launches if capture "
+                         "fails).  Off by default: measured equal to eager launches (tools/graph_shard_ab.py), the host "
+                         "launch loop is 10-70x ahead of the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--shard-axis", default="auto", choices=["auto", "candidate", "query"],
@@ -266,12 +270,42 @@ def main():
     local_all = torch.empty((passes, Q, 4), dtype=torch.int32, device=device)
     gathered = torch.empty((world, passes * Q, 4), dtype=torch.int32, device=device) if q_true is not None else None
 
-    def step():
+    sum_pick = torch.tensor([0, 2, 3, 4], device=device)  # raw: sum of reciprocal ranks, hits@1/3/10
+
+    def local_work():
+        """This rank's launches of one step: `passes` table passes, and (unless per-shard counts have to be
+        added up first) the metric sums.  Everything is asynchronous on the current stream, writes fixed
+        buffers and needs no host decision, so the whole step can be replayed from a captured hipGraph."""
         for i in range(passes):
             if q_true is not None:
                 ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids, out=local_all[i])
             else:
                 ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids, out=local_all[i])
+        if q_true is None:
+            return ops.rank_metric_sums(local_all.view(passes * Q, 4)).index_select(0, sum_pick)
+        return None
+
+    graph, graph_note, static_sums = None, "eager launches", None
+    if args.graph != "off" and backend != "gloo":
+        try:
+            local_work()  # lazy initialisation (module load, allocator) happens outside the capture
+            torch.cuda.synchronize()
+            captured = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(captured):
+                static_sums = local_work()
+            graph, graph_note = captured, "hipGraph replay"
+        except Exception as exc:  # noqa: BLE001 -- the eager path below is the same work
+            if args.graph == "on":
+                raise
+            graph, graph_note = None, f"eager launches (graph capture failed: {type(exc).__name__})"
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            sums = static_sums
+        else:
+            sums = local_work()
         counts = local_all.view(passes * Q, 4)
         if q_true is not None:  # candidate shards: per-shard counts add up
             if backend == "gloo":
@@ -281,13 +315,14 @@ def main():
             else:
                 dist.all_gather_into_tensor(gathered.view(-1), counts.reshape(-1))
             counts = gathered.sum(dim=0, dtype=torch.int32)
-        sums = ops.rank_metric_sums(counts)[[0, 2, 3, 4]]  # raw: sum of reciprocal ranks, hits@1/3/10
-        if world > 1 and axis == "query":  # query shards: only the metric sums travel
+            sums = ops.rank_metric_sums(counts).index_select(0, sum_pick)
+        elif world > 1:  # query shards: only the metric sums travel
             if backend == "gloo":
                 host = sums.cpu()
                 dist.all_reduce(host)
                 sums = host.to(device)
             else:
+                sums = sums.clone()
                 dist.all_reduce(sums)
         return counts[-Q:], sums[0] / (Q_global * passes), sums[1:] / (Q_global * passes)
 
@@ -375,7 +410,8 @@ def main():
             "data": "synthetic (seeded randn table, Xavier rel_emb, uniform random test triples)",
             "config": {"workload": args.workload, "rel_model": model, "entities": N, "dim": D,
                        "queries_per_step": Q_global * passes, "table_passes_per_step": passes,
-                       "parallelism": f"{axis}-axis shards x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"{axis}-axis shards x{world}" if world > 1 else "single GPU",
+                       "launch": graph_note},
             "mrr": mrr.item(),
             "hits@1,3,10": [x.item() for x in hits],
             "roofline": roofline,

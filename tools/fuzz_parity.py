@@ -26,6 +26,9 @@ def make_case(rng):
     q_head, q_tail = int(rng.integers(0, 500)), int(rng.integers(0, 500))
     if rng.random() < 0.1:
         q_head, q_tail = int(rng.integers(0, 3)), int(rng.integers(0, 3))  # the few-queries (HBM-streaming) mode
+    elif rng.random() < 0.1:  # many query tiles per side (chunking of the pair lists), few candidates
+        q_head, q_tail = int(rng.integers(0, 4000)), int(rng.integers(0, 4000))
+        N = int(rng.integers(1, 600))
     if q_head + q_tail == 0:
         q_tail = 1
     if D not in (64, 128, 256) and q_head + q_tail < 256:
