@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libblp_hip.so")
 SOURCES = ["rank_all.hip", "rank_mfma.hip", "rank_gemm.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_dense.hip", "score.hip", "inbatch_loss.hip", "api.cpp"]
-HEADERS = ["score_core.h", "score_direct.h", "launch.h", "rank_common.h", os.path.join("..", "..", "include", "blp_hip.h")]
+PUBLIC_HEADER = os.path.join(HERE, "..", "include", "blp_hip.h")
 # -ffp-contract=off: the kernels restate the reference's per-operation rounding; an FMA would change
 # the last bit of a score and with it a rank.  No fast-math for the same reason.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
@@ -27,7 +27,9 @@ def hipcc():
 
 
 def _newest_header():
-    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    # every header under csrc/ (a changed constant must rebuild its users) + the public C-ABI header
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [PUBLIC_HEADER]
+    return max(os.path.getmtime(h) for h in headers)
 
 
 def build(force=False, verbose=False):

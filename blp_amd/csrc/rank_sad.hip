@@ -463,7 +463,9 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
 bool rank_sad_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
     if (const char* pick = getenv("BLP_RANK_KERNEL"))
         if (pick[0] == 'v' || pick[0] == 'm') return false;  // "valu" / "mfma": the exact f32 kernels
-    return model == TRANSE && (D == 64 || D == 128 || D == 256) && q_head + q_tail >= 256;
+    int64_t min_queries = kSadMinQueries;
+    if (const char* v = getenv("BLP_SAD_MIN_QUERIES")) min_queries = atoll(v) > 0 ? atoll(v) : 1;  // A/B knob
+    return model == TRANSE && (D == 64 || D == 128 || D == 256) && q_head + q_tail >= min_queries;
 }
 
 size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {

@@ -11,6 +11,7 @@ namespace blp {
 
 constexpr int kSW = 4;                       // waves per workgroup
 constexpr int kSChunk = 128;                 // queries per workgroup
+constexpr int kSadMinQueries = 64;          // below this the exact f32 kernels win (tools/bench_small_blocks.py)
 constexpr int kSQuota = 512;                 // undecided pairs a workgroup can list
 constexpr unsigned kSInvalid = 0x40001000u;  // accumulator bias of padding rows: beyond every T_hi + E_c
 constexpr unsigned kSThrMax = 0x3fffffffu;
