@@ -196,7 +196,7 @@ struct SadTiles {
 
 template <int D, int TPW>
 __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 128 ? 3 : 2)) void rank_sad_kernel(
-    const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups,
+    const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups, int q_per_group,
     const unsigned* __restrict__ qimg, const int2* __restrict__ thr, int64_t Q, int words_per_query,
     unsigned long long* __restrict__ acc,
     unsigned* __restrict__ flags, uint2* __restrict__ pairs, SadParams* __restrict__ params) {
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int group = blockIdx.x % n_groups;
-    const int64_t q0 = (int64_t)(blockIdx.x / n_groups) * kSChunk;
-    const int nq = (int)(Q - q0 < kSChunk ? Q - q0 : kSChunk);
+    const int64_t q0 = (int64_t)(blockIdx.x / n_groups) * q_per_group;  // q_per_group <= kSChunk
+    const int nq = (int)(Q - q0 < q_per_group ? Q - q0 : q_per_group);
 
     for (int i = tid; i < kSChunk; i += kSW * 64) cnt[i] = 0;
     if (tid == 0) ec_max_s = 0;
@@ -416,10 +416,22 @@ struct SadWorkspace {
 // Candidate groups per pass: the flag bitmap (one bit per (query, tile)) and the pair list (kSQuota
 // entries per workgroup, worst case) are each capped at ~256 MB; larger (Q x N) problems are
 // processed in candidate slabs.
+// Queries per workgroup: kSChunk when the (candidate group, query chunk) grid fills the chip anyway; a small
+// block (the reference's eval batch: 128 queries x 14 541 candidates = 57 groups) gets shorter chunks so that
+// the grid still has ~1000 workgroups instead of 57 long-running ones (52 -> 14 us for that batch).
+static int sad_queries_per_group(int D, int64_t N, int64_t Q) {
+    const int64_t tiles_per_group = kSW * sad_tiles_per_wave(D);
+    const int64_t n_groups = ((N + 63) / 64 + tiles_per_group - 1) / tiles_per_group;
+    int per_group = kSChunk;
+    while (per_group > 16 && n_groups * ((Q + per_group - 1) / per_group) < 1024) per_group >>= 1;
+    return per_group;
+}
+
 static int64_t sad_groups_per_pass(int D, int64_t N, int64_t Q) {
     const int64_t tiles_per_group = kSW * sad_tiles_per_wave(D);
     const int64_t n_groups = ((N + 63) / 64 + tiles_per_group - 1) / tiles_per_group;
-    const int64_t n_chunks = (Q + kSChunk - 1) / kSChunk;
+    const int64_t per_group = sad_queries_per_group(D, N, Q);
+    const int64_t n_chunks = (Q + per_group - 1) / per_group;
     const int64_t cap = (int64_t)256 << 20;
     int64_t by_pairs = cap / (kSQuota * 8) / (n_chunks > 0 ? n_chunks : 1);
     int64_t by_flags = cap / 4 / (Q > 0 ? Q : 1) * 32 / tiles_per_group;
@@ -454,7 +466,8 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     const int64_t words = (w.pass_groups * tiles_per_group + 31) / 32;
     w.flags = reinterpret_cast<unsigned*>(p + off); off = align_up(off + (size_t)Q * words * 4, 256);
     w.pairs = reinterpret_cast<uint2*>(p + off);
-    off = align_up(off + (size_t)w.pass_groups * ((Q + kSChunk - 1) / kSChunk) * kSQuota * 8, 256);
+    const int64_t per_group = sad_queries_per_group(D, N, Q);
+    off = align_up(off + (size_t)w.pass_groups * ((Q + per_group - 1) / per_group) * kSQuota * 8, 256);
     w.bytes = off;
     return w;
 }
@@ -503,7 +516,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         q_fixed, q_rel, q_head, Q, w.key_true, w.params, w.qimg, w.thr, w.flags, first_words * Q);
 
     const int64_t tiles_per_group = kSW * TPW;
-    const int64_t n_chunks = (Q + kSChunk - 1) / kSChunk;
+    const int per_group = sad_queries_per_group(D, N, Q);
+    const int64_t n_chunks = (Q + per_group - 1) / per_group;
     const int64_t pass_rows = w.pass_groups * tiles_per_group * 64;
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_rows) {  // one iteration unless the caps bind
         const int64_t n_rows = N - slab0 < pass_rows ? N - slab0 : pass_rows;
@@ -519,7 +533,7 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         }
         const float* slab = table + slab0 * ld;
         rank_sad_kernel<D, TPW><<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
-            w.cimg + (slab0 / 64) * (D / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, words, w.acc,
+            w.cimg + (slab0 / 64) * (D / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, per_group, w.qimg, w.thr, Q, words, w.acc,
             w.flags, w.pairs, w.params);
         const int64_t pair_blocks = (n_blocks * kSQuota + 255) / 256;
         sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 16 ? pair_blocks : (int64_t)n_cu * 16)), 256, 0, stream>>>(

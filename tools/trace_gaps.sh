@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel-by-kernel timeline (durations and the idle gaps between consecutive launches) of one ranking
-# call at the per-rank size of an 8-GPU query-sharded FB15k-237 evaluation.  usage: bash tools/trace_gaps.sh [model]
+# call at the per-rank size of an 8-GPU query-sharded FB15k-237 evaluation (SHARDS=827: one reference
+# eval batch of 64 triples).  usage: [SHARDS=n] bash tools/trace_gaps.sh [model]
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 M=${1:-transe}
@@ -13,7 +14,7 @@ cfg = bench.WORKLOADS["fb15k237-$M"]
 dev = torch.device("cuda", 0)
 table, rel_w, heads, tails, rels = bench.make_data(cfg, dev)
 q_fixed, q_rel, true_row = bench.build_queries(table, rel_w, heads, tails, rels)
-T = heads.shape[0]; t = (T + 7) // 8
+T = heads.shape[0]; t = (T + ${SHARDS:-8} - 1) // ${SHARDS:-8}
 qf = torch.cat((q_fixed[:t], q_fixed[T:T + t])); qr = torch.cat((q_rel[:t], q_rel[T:T + t])); tr = torch.cat((true_row[:t], true_row[T:T + t]))
 for _ in range(6):
     c = ops.rank_all("$M", table, qf, qr, t, true_row=tr)
