@@ -285,6 +285,7 @@ def main():
             return ops.rank_metric_sums(local_all.view(passes * Q, 4)).index_select(0, sum_pick)
         return None
 
+    pending = []  # outstanding collectives (query-axis shards)
     graph, graph_note, static_sums = None, "eager launches", None
     if args.graph != "off" and backend != "gloo":
         try:
@@ -321,12 +322,15 @@ def main():
                 host = sums.cpu()
                 dist.all_reduce(host)
                 sums = host.to(device)
-            else:
+            else:  # asynchronous on RCCL's stream: the next step's kernels do not wait for this one's exchange
                 sums = sums.clone()
-                dist.all_reduce(sums)
-        return counts[-Q:], sums[0] / (Q_global * passes), sums[1:] / (Q_global * passes)
+                pending.append(dist.all_reduce(sums, async_op=True))
+        return counts[-Q:], sums  # sums are valid once fence() has waited for the exchange
 
     def fence():
+        for work in pending:
+            work.wait()
+        pending.clear()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -336,9 +340,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        counts, mrr, hits = step()
+        counts, sums = step()
     fence()
     elapsed = time.perf_counter() - t0
+    mrr, hits = sums[0] / (Q_global * passes), sums[1:] / (Q_global * passes)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

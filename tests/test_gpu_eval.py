@@ -99,6 +99,38 @@ def test_rank_metric_sums_equals_reduced_rank_metrics():
     assert ops.rank_metric_sums(counts[:0]).tolist() == [0.0] * 8
 
 
+@pytest.mark.parametrize("rel_model, q", [("transe", 700), ("transe", 9), ("distmult", 700), ("complex", 130)])
+def test_rank_all_replays_from_a_captured_graph(rel_model, q, oracle):
+    """The C-ABI contract: asynchronous on the caller's stream, no host-side decision that depends on
+    the data, no hidden synchronisation, no allocation.  So a call captured into a hipGraph and replayed
+    on NEW contents of the same buffers gives the counts of the new contents (bench.py --graph)."""
+    from blp_amd import ops
+    from test_gpu_parity import oracle_counts
+    g = torch.Generator().manual_seed(q)
+    n, d = 3000, 128
+    def make():
+        table = torch.randn(n, d, generator=g) * 0.2
+        return table, table[torch.randint(0, n, (2 * q,), generator=g)].clone(), \
+            torch.randn(2 * q, d, generator=g) * 0.1, torch.randint(0, n, (2 * q,), generator=g)
+    first, second = make(), make()
+    bufs = [t.cuda() for t in first]
+    out = torch.empty((2 * q, 4), dtype=torch.int32, device="cuda")
+    ops.rank_all(rel_model, bufs[0], bufs[1], bufs[2], q, true_row=bufs[3], out=out)  # lazy init outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.rank_all(rel_model, bufs[0], bufs[1], bufs[2], q, true_row=bufs[3], out=out)
+        sums = ops.rank_metric_sums(out)
+    for buf, new in zip(bufs, second):
+        buf.copy_(new)
+    out.fill_(-1)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = oracle_counts(oracle, rel_model, second[0], second[1], second[2], q, true_row=second[3])
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert torch.equal(sums.cpu(), ops.rank_metric_sums(torch.from_numpy(want).cuda()).cpu())
+
+
 @pytest.mark.parametrize("axis", ["candidate", "query"])
 def test_bench_two_ranks_share_one_gpu_functional(axis):
     """bench.py's N > 1 paths run as 2 ranks on this one GPU with the gloo backend.  Candidate shards:

@@ -51,6 +51,25 @@ def main():
             want = ref_port.SCORE_FNS[model](h, t, rel.float())
             got = ops.score(model, h.cuda(), t.cuda(), rel.float().cuda()).cpu()
             ok &= bool(torch.equal(got, want))
+        # score_fn on a random broadcast (each leading dim present or 1 per operand): forward bit-identical where
+        # the reduction order is pinned, backward against autograd of the reference expressions
+        if dtype == torch.float32 and (D % 32 == 0 or model == "transe"):
+            lead = [int(rng.integers(1, 7)) for _ in range(int(rng.integers(1, 4)))]
+            shapes = [[n if rng.random() < 0.6 else 1 for n in lead] + [D] for _ in range(3)]
+            cpu_in = [(torch.randn(*sh) * 0.5).requires_grad_(True) for sh in shapes]
+            gpu_in = [x.detach().cuda().requires_grad_(True) for x in cpu_in]
+            want = ref_port.SCORE_FNS[model](*cpu_in)
+            got = ops.score(model, *gpu_in)
+            ok_b = bool(torch.equal(got.cpu(), want.detach()))
+            w = torch.randn(want.shape)
+            (want * w).sum().backward()
+            (got * w.cuda()).sum().backward()
+            for a, b in zip(gpu_in, cpu_in):
+                bn = b.grad.numpy()
+                ok_b &= np.allclose(a.grad.cpu().numpy(), bn, rtol=3e-5, atol=max(2e-7, 2e-6 * float(np.abs(bn).max())))
+            if not ok_b:
+                print(f"  (score broadcast shapes {shapes})", flush=True)
+            ok &= ok_b
         if not ok:
             bad += 1
             print(f"MISMATCH seed={seed} {model} {loss_fn} B={B} K={K} D={D} {dtype} rel_f32={rel_f32} reg={reg}: "
