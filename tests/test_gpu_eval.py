@@ -160,6 +160,36 @@ def test_bench_two_ranks_share_one_gpu_functional(axis):
     assert b["parity_check"].endswith("identical counts")
 
 
+def test_bench_line_keeps_the_contract():
+    """`python bench.py` with its defaults: ONE JSON line on stdout with the driver's keys, the roofline of
+    the dominant kernel and the CPU baseline; value, ms_per_step and the workload size agree."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["vs_baseline"] is None and r["config"]["workload"] == "fb15k237-transe"
+    scored = 2 * 52870 * 14541
+    assert r["value"] == pytest.approx(scored / (r["ms_per_step"] * 1e-3), rel=1e-6)
+    roof = r["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-6) and 0.0 < roof["frac"] < 1.0
+    assert roof["kernel_ms"] <= r["ms_per_step"] * 1.05  # the dominant kernel's bracket is part of a step
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert r["parity_check"].endswith("identical counts")
+
+
 @pytest.mark.parametrize("rel_model,D", [("transe", 300), ("transe", 768), ("distmult", 96), ("complex", 192)])
 def test_generic_width_route_matches_oracle(rel_model, D, oracle):
     """Widths without a fused ranking kernel (GloVe 300, BERT-embedding 768, ...): dense order-exact
