@@ -26,6 +26,7 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supporte
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h
+METRIC_SUMS_DOUBLES = 520  # BLP_METRIC_SUMS_DOUBLES: room the `sums` argument of blp_rank_metric_sums needs
 
 
 class HipLibraryError(RuntimeError):

@@ -163,13 +163,13 @@ def rank_metrics(counts, k_values=(1, 3, 10)):
 
 def rank_metric_sums(counts, k_values=(1, 3, 10)):
     """counts (Q, 4) int32 -> (8,) f64: [sum rr raw, sum rr filtered, hits@k raw x 3, hits@k filtered x 3]
-    (train.py:152-157 accumulated on the device in one launch, fixed summation order)."""
+    (train.py:152-157 accumulated on the device, fixed summation order)."""
     _require_device(counts)
-    sums = torch.empty(8, dtype=torch.float64, device=counts.device)
+    sums = torch.empty(_lib.METRIC_SUMS_DOUBLES, dtype=torch.float64, device=counts.device)  # 8 results + scratch
     status = _lib.lib().blp_rank_metric_sums(_ptr(counts.contiguous()), counts.shape[0], _K_VALUES(*k_values),
                                              _ptr(sums), counts.device.index, _stream(counts.device))
     _lib.check(status, "blp_rank_metric_sums")
-    return sums
+    return sums[:8]
 
 
 # ------------------------------------------------------------------------------------- score_fn

@@ -133,7 +133,10 @@ int blp_rank_metrics(const int32_t *counts, int64_t Q, const int32_t k_values[3]
 
 /* The accumulation of train.py:152-157 on the device: sums[0..1] = sum over queries of the reciprocal
  * rank (raw, filtered), sums[2 + 3 v + j] = number of queries with avg rank <= k_values[j] (v = 0 raw,
- * 1 filtered), all f64, summed in a fixed order (reproducible).  Divide by Q for MRR / Hits@k. */
+ * 1 filtered), all f64, summed in a fixed order (reproducible).  Divide by Q for MRR / Hits@k.
+ * `sums` must have room for BLP_METRIC_SUMS_DOUBLES doubles: the 8 results come first, the rest is
+ * scratch for the per-block partial sums of large Q. */
+#define BLP_METRIC_SUMS_DOUBLES 520
 int blp_rank_metric_sums(const int32_t *counts, int64_t Q, const int32_t k_values[3], double *sums,
                          int device, void *stream);
 

@@ -61,3 +61,10 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     assert rc == -1
     with pytest.raises(RuntimeError, match="BLP_ERR_BAD_ARG"):
         _lib.check(-1, "demo")
+
+
+def test_metric_sums_buffer_size_matches_the_header():
+    import re
+    from blp_amd import _lib
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "blp_hip.h")).read()
+    assert int(re.search(r"#define BLP_METRIC_SUMS_DOUBLES (\d+)", header).group(1)) == _lib.METRIC_SUMS_DOUBLES

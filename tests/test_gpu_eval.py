@@ -83,13 +83,15 @@ def test_link_prediction_module_on_gpu_uses_fused_loss(name):
     np.testing.assert_allclose(model.rel_emb.weight.grad.cpu().numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
 
 
-def test_rank_metric_sums_equals_reduced_rank_metrics():
-    """blp_rank_metric_sums = get_metrics + the accumulation of train.py:152-157 in one launch."""
+@pytest.mark.parametrize("n", [10_007, 5, 8192, 8193, 700_001])
+def test_rank_metric_sums_equals_reduced_rank_metrics(n):
+    """blp_rank_metric_sums = get_metrics + the accumulation of train.py:152-157 on the device (one block up
+    to 8192 queries, per-block partial sums added in block order above: reproducible either way)."""
     from blp_amd import ops
     g = torch.Generator().manual_seed(3)
-    gt = torch.randint(0, 5000, (10_007,), generator=g)
-    ties = torch.randint(1, 4, (10_007,), generator=g)
-    f_gt = (gt.float() * torch.rand(10_007, generator=g)).long()
+    gt = torch.randint(0, 5000, (n,), generator=g)
+    ties = torch.randint(1, 4, (n,), generator=g)
+    f_gt = (gt.float() * torch.rand(n, generator=g)).long()
     counts = torch.stack((gt, gt + ties, f_gt, f_gt + ties), dim=1).int().cuda()
     rr, hits = ops.rank_metrics(counts)
     sums = ops.rank_metric_sums(counts).cpu()
