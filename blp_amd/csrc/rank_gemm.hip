@@ -700,9 +700,12 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
                                                      const float* __restrict__ key_true, int64_t q_head, int64_t Q,
                                                      int words_per_query, const unsigned* __restrict__ flags,
                                                      unsigned long long* __restrict__ acc) {
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
+    __shared__ int list[kSweepQueries], n_list;
     const int lane = threadIdx.x & 63, part = lane >> 4;
+    const int64_t q_base = (int64_t)blockIdx.x * kSweepQueries;
+    const int n = flagged_queries(flags, q_base, Q, words_per_query, false, list, &n_list);
+    for (int i = threadIdx.x >> 6; i < n; i += 4) {
+    const int64_t q = q_base + list[i];
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
     const float* coef = q < q_head ? coef_head + q * Scorer<MODEL, HEAD, D>::C
@@ -736,13 +739,14 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
             }
         }
     }
-    if (__ballot(gt | ge) == 0) return;
+    if (__ballot(gt | ge) == 0) continue;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         gt += __shfl_down(gt, off);
         ge += __shfl_down(ge, off);
     }
     if (lane == 0) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -870,7 +874,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                 w.pairs);
         refine_pairs_kernel<MODEL, D><<<dim3((unsigned)((n_entries + 255) / 256)), 256, 0, stream>>>(
             slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_entries, w.acc);
-        refine_kernel<MODEL, D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
+        refine_kernel<MODEL, D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);

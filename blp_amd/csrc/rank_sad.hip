@@ -360,10 +360,13 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
                                                                const unsigned* __restrict__ flags,
                                                                const SadParams* __restrict__ params,
                                                                unsigned long long* __restrict__ acc) {
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
+    __shared__ int list[kSweepQueries], n_list;
     const bool all = !sad_scale(params).ok;
     const int lane = threadIdx.x & 63;
+    const int64_t q_base = (int64_t)blockIdx.x * kSweepQueries;
+    const int n = flagged_queries(flags, q_base, Q, words_per_query, all, list, &n_list);
+    for (int i = threadIdx.x >> 6; i < n; i += 4) {
+    const int64_t q = q_base + list[i];
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
     const float* coef = q < q_head ? coef_head + q * Scorer<TRANSE, HEAD, D>::C
@@ -392,13 +395,14 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
             }
         }
     }
-    if (__ballot(gt | ge) == 0) return;
+    if (__ballot(gt | ge) == 0) continue;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         gt += __shfl_down(gt, off);
         ge += __shfl_down(ge, off);
     }
     if (lane == 0) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,7 +542,7 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         const int64_t pair_blocks = (n_blocks * kSQuota + 255) / 256;
         sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 16 ? pair_blocks : (int64_t)n_cu * 16)), 256, 0, stream>>>(
             slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, w.params, w.acc);
-        sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
+        sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
