@@ -311,8 +311,11 @@ constexpr float kBandCBf16 = 1150.0f;
 constexpr int kBfW = 4;          // waves per workgroup
 constexpr int kBfTPW = 2;        // candidate tiles per wave (4 at one wave/SIMD spills and runs 1.8x slower)
 constexpr int kBfWavesPerSimd = 2;  // launch bound: <= 256 VGPRs (128 of them hold the A operands)
-constexpr int kBfTilesPerChunk = 16;             // query tiles per workgroup (a multiple of kGTilesPerChunk)
-constexpr int kBfQuota = 8 * kBfTPW * kBfTilesPerChunk;  // undecided pairs a workgroup can list
+constexpr int kBfMinTilesPerChunk = 16;          // query tiles per workgroup: 16 / 32 / 64, chosen per launch --
+constexpr int kBfMaxTilesPerChunk = 64;          // the most that still gives the grid >= kBfWantGroups workgroups
+constexpr int kBfWantGroups = 2048;              // (each workgroup pays the candidate split once: 64 tiles 1.47 ms,
+                                                 // 32: 1.49, 16: 1.64 on the FB15k-237 block; 8-way shards keep 16)
+constexpr int kBfQuotaPerTile = 8 * kBfTPW;      // undecided pairs a workgroup can list, per query tile of its chunk
 
 // band factor of a row from its norm / largest magnitude (see above); exact zero rows need no band
 __device__ __forceinline__ float band_norm(float sumsq, float maxabs) {
@@ -407,17 +410,18 @@ template <int MODEL, int D>
 __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const uint4* __restrict__ img_head,
     const uint4* __restrict__ img_tail, const float* __restrict__ key_true, const float* __restrict__ eps_q,
-    int q_head, int q_tail, int n_groups, int chunks_head, int words_per_query,
+    int q_head, int q_tail, int n_groups, int chunks_head, int tiles_per_chunk, int words_per_query,
     unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs) {
     constexpr int STEPS = D / 16;
     constexpr int TILE_BYTES = 2 * STEPS * 64 * 16;  // hi + lo parts: 16 KB at D = 128
+    const int quota = kBfQuotaPerTile * tiles_per_chunk;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf0 = smem;
     float* buf1 = smem + TILE_BYTES / 4;
-    unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * (TILE_BYTES / 4));   // [kBfTilesPerChunk * 32]
-    float* nrm = reinterpret_cast<float*>(cnt + kBfTilesPerChunk * kGQT);        // [kBfW][kBfTPW][32]
-    uint2* pair_s = reinterpret_cast<uint2*>(nrm + kBfW * kBfTPW * 32);          // [kBfQuota]
-    float2* kq_s = reinterpret_cast<float2*>(pair_s + kBfQuota);                 // [kBfTilesPerChunk * 32] {s_true, eps_q}
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * (TILE_BYTES / 4));   // [tiles_per_chunk * 32]
+    float* nrm = reinterpret_cast<float*>(cnt + tiles_per_chunk * kGQT);         // [kBfW][kBfTPW][32]
+    uint2* pair_s = reinterpret_cast<uint2*>(nrm + kBfW * kBfTPW * 32);          // [quota]
+    float2* kq_s = reinterpret_cast<float2*>(pair_s + quota);                    // [tiles_per_chunk * 32] {s_true, eps_q}
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, half = lane >> 5;
@@ -426,17 +430,17 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     const bool head = chunk < chunks_head;
     const int side_chunk = head ? chunk : chunk - chunks_head;
     const int n_side = head ? q_head : q_tail, q_base = head ? 0 : q_head;
-    const int tile0 = side_chunk * kBfTilesPerChunk;
+    const int tile0 = side_chunk * tiles_per_chunk;
     const int n_side_tiles = (n_side + kGQT - 1) / kGQT;
-    const int n_tiles = n_side_tiles - tile0 < kBfTilesPerChunk ? n_side_tiles - tile0 : kBfTilesPerChunk;
+    const int n_tiles = n_side_tiles - tile0 < tiles_per_chunk ? n_side_tiles - tile0 : tiles_per_chunk;
 
-    for (int i = tid; i < kBfTilesPerChunk * kGQT; i += kBfW * 64) {
+    for (int i = tid; i < tiles_per_chunk * kGQT; i += kBfW * 64) {
         cnt[i] = 0;
         const int q_local = tile0 * kGQT + i;
         const int q = q_base + (q_local < n_side ? q_local : n_side - 1);
         kq_s[i] = make_float2(key_true[q], eps_q[q]);
     }
-    for (int i = tid; i < kBfQuota; i += kBfW * 64) pair_s[i] = make_uint2(kNoPair, 0u);
+    for (int i = tid; i < quota; i += kBfW * 64) pair_s[i] = make_uint2(kNoPair, 0u);
 
     // this wave's candidate tiles: lane (row l & 31, K-half l >> 5) reads its 8 floats of every K-step
     // straight from the table, splits them, and keeps them as MFMA A operands
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
 
     const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
     unsigned my_pairs = 0;  // entries this wave has listed (wave-uniform)
+    const unsigned wave_quota = (unsigned)quota / kBfW;
     // K-step st of a query tile against both candidate tiles (bh / bl = its hi / lo B operands); the two
     // accumulator chains are interleaved so that no MFMA reads the accumulator the previous one writes
     auto load_b = [&](auto kk, const float* buf, bf16x8& bh, bf16x8& bl) {
@@ -569,10 +574,10 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
                 for (unsigned long long todo = __ballot(und != 0); todo; todo &= todo - 1) {
                     const int src = __builtin_ctzll(todo);
                     const unsigned n = __popc(__builtin_amdgcn_readlane(und, src));  // scalar
-                    const bool fits = my_pairs + n <= kBfQuota / kBfW;
+                    const bool fits = my_pairs + n <= wave_quota;
                     if (lane == src) {
                         if (fits) {
-                            unsigned slot = wave * (kBfQuota / kBfW) + my_pairs;
+                            unsigned slot = wave * wave_quota + my_pairs;
                             for (unsigned mm = und; mm; mm &= mm - 1)
                                 pair_s[slot++] = make_uint2((unsigned)q, (unsigned)(ctile * kGCT + acc_row(__builtin_ctz(mm), half)));
                         } else {
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         const unsigned long long v = cnt[i];
         if (q_local < n_side && v) atomicAdd(acc + q_base + q_local, v | (v << 32));  // certainly above: gt and ge
     }
-    for (int i = tid; i < kBfQuota; i += kBfW * 64) pairs[(size_t)blockIdx.x * kBfQuota + i] = pair_s[i];
+    for (int i = tid; i < quota; i += kBfW * 64) pairs[(size_t)blockIdx.x * quota + i] = pair_s[i];
 #ifdef BLP_TIMING
     BLP_T(5);
     if (lane == 0) {
@@ -765,8 +770,12 @@ static int64_t pair_entries(int64_t T, int64_t q_head, int64_t q_tail) {
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
     auto chunks = [&](int64_t per) { return (th + per - 1) / per + (tt + per - 1) / per; };
     const int64_t f32_kernel = (T + kGW - 1) / kGW * chunks(kGTilesPerChunk) * kPairQuota;
-    const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * chunks(kBfTilesPerChunk) * kBfQuota;
-    return f32_kernel > bf16_kernel ? f32_kernel : bf16_kernel;
+    int64_t most = f32_kernel;
+    for (int per = kBfMinTilesPerChunk; per <= kBfMaxTilesPerChunk; per *= 2) {  // whichever chunking a launch picks
+        const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * chunks(per) * kBfQuotaPerTile * per;
+        most = bf16_kernel > most ? bf16_kernel : most;
+    }
+    return most;
 }
 
 static bool gemm_use_f32() {  // BLP_GEMM_KERNEL=f32: the exact-f32-chain MFMA kernel instead of bf16 x 3
@@ -846,11 +855,6 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             w.eps_q);
     const size_t lds_f32 = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
                            (size_t)kPairQuota * 8 + 16;
-    const size_t lds_bf16 = (size_t)2 * (2 * (D / 16) * 64 * 16) + (size_t)kBfTilesPerChunk * kGQT * 4 +
-                            (size_t)kBfW * kBfTPW * 32 * 4 + (size_t)kBfQuota * 8 + (size_t)kBfTilesPerChunk * kGQT * 8 + 16;
-    const int tiles_per_chunk = f32_kernel ? kGTilesPerChunk : kBfTilesPerChunk;
-    const int64_t chunks_head = (th + tiles_per_chunk - 1) / tiles_per_chunk;
-    const int64_t chunks_tail = (tt + tiles_per_chunk - 1) / tiles_per_chunk;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_tiles * kGCT) {  // one iteration unless the bitmap is capped
         const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
@@ -858,8 +862,24 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         const int tiles_per_group = f32_kernel ? kGW : kBfW * kBfTPW;
         const int64_t n_groups = (n_ctiles + tiles_per_group - 1) / tiles_per_group;
         const int words = (int)((n_ctiles + 15) / 16);
+        int tiles_per_chunk = kGTilesPerChunk;
+        if (!f32_kernel) {  // the longest chunks that still leave the grid kBfWantGroups workgroups
+            tiles_per_chunk = kBfMaxTilesPerChunk;
+            while (tiles_per_chunk > kBfMinTilesPerChunk &&
+                   n_groups * ((th + tiles_per_chunk - 1) / tiles_per_chunk + (tt + tiles_per_chunk - 1) / tiles_per_chunk) < kBfWantGroups)
+                tiles_per_chunk /= 2;
+            if (const char* env = getenv("BLP_GEMM_TILES_PER_CHUNK")) {  // test knob: long chunks on small problems
+                const int forced = atoi(env);
+                if (forced == 16 || forced == 32 || forced == 64) tiles_per_chunk = forced;
+            }
+        }
+        const int64_t chunks_head = (th + tiles_per_chunk - 1) / tiles_per_chunk;
+        const int64_t chunks_tail = (tt + tiles_per_chunk - 1) / tiles_per_chunk;
+        const size_t lds_bf16 = (size_t)2 * (2 * (D / 16) * 64 * 16) + (size_t)tiles_per_chunk * kGQT * 4 +
+                                (size_t)kBfW * kBfTPW * 32 * 4 + (size_t)kBfQuotaPerTile * tiles_per_chunk * 8 +
+                                (size_t)tiles_per_chunk * kGQT * 8 + 16;
         const int64_t n_blocks = n_groups * (chunks_head + chunks_tail);
-        const int64_t n_entries = n_blocks * (f32_kernel ? kPairQuota : kBfQuota);
+        const int64_t n_entries = n_blocks * (f32_kernel ? kPairQuota : kBfQuotaPerTile * tiles_per_chunk);
         err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
         if (err != hipSuccess) return err;
         const float* slab = table + slab0 * ld;
@@ -870,8 +890,8 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         else
             rank_gemm_bf16_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kBfW * 64, lds_bf16, stream>>>(
                 slab, n_rows, ld, reinterpret_cast<const uint4*>(w.img_head), reinterpret_cast<const uint4*>(w.img_tail),
-                w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head, words, w.acc, w.flags,
-                w.pairs);
+                w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head, tiles_per_chunk, words, w.acc,
+                w.flags, w.pairs);
         refine_pairs_kernel<MODEL, D><<<dim3((unsigned)((n_entries + 255) / 256)), 256, 0, stream>>>(
             slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_entries, w.acc);
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(

@@ -509,6 +509,28 @@ def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, monkeyp
         assert np.array_equal(part.cpu().numpy(), want), model
 
 
+@pytest.mark.parametrize("tiles", ["16", "32", "64"])
+@pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
+def test_gemm_query_chunk_lengths(ops, oracle, model, tiles, monkeypatch):
+    """A workgroup of the bf16 pre-pass takes 16, 32 or 64 query tiles (the longest that still fills the
+    chip; BLP_GEMM_TILES_PER_CHUNK forces one).  Ragged sides (1 .. 8 tiles past a multiple of the chunk), exact
+    ties (pair lists), a constant block (quota overflow -> flags) and a CSR filter: same counts."""
+    monkeypatch.setenv("BLP_GEMM_TILES_PER_CHUNK", tiles)
+    D, N, q_head, q_tail = 128, 700 + 5, 32 * 67 + 3, 32 * 33 - 7
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=77)
+    table[::5] = table[1::5]
+    table[300:420] = 0.25   # many candidates tie exactly for the queries below
+    q_fixed[100:160] = 0.5
+    q_rel[100:160] = -0.125
+    true_row[100:160] = torch.arange(300, 360)
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=5)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert (want[100:160, 1] - want[100:160, 0]).min() >= 119
+
+
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
 def test_gemm_f32_chain_variant(ops, oracle, model, monkeypatch):
     """BLP_GEMM_KERNEL=f32 selects the f32 MFMA chain pre-pass (band constant 320) instead of bf16 x 3."""
