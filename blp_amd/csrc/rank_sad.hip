@@ -420,15 +420,25 @@ struct SadWorkspace {
 // Candidate groups per pass: the flag bitmap (one bit per (query, tile)) and the pair list (kSQuota
 // entries per workgroup, worst case) are each capped at ~256 MB; larger (Q x N) problems are
 // processed in candidate slabs.
-// Queries per workgroup: kSChunk when the (candidate group, query chunk) grid fills the chip anyway; a small
-// block (the reference's eval batch: 128 queries x 14 541 candidates = 57 groups) gets shorter chunks so that
-// the grid still has ~1000 workgroups instead of 57 long-running ones (52 -> 14 us for that batch).
+// Queries per workgroup, 16 .. kSChunk: long chunks amortise a workgroup's set-up (its candidate tile, thresholds,
+// two barriers: about as much as 45 queries of work), short ones keep the (candidate group, query chunk) grid
+// balanced over the resident workgroups.  Picks the length with the smallest estimated time
+// rounds(grid / resident) x (set-up + queries x cycles per query).  Measured on the FB15k-237 table: 128
+// queries (the reference's eval batch) 52 us at 128 per workgroup, 16 us at 16; 1 024 queries: 32; an 8-way
+// shard of the test set (13 k queries): 128 (0.54 -> 0.52 ms); the whole test set: 256 (3.79 -> 3.75 ms).
 static int sad_queries_per_group(int D, int64_t N, int64_t Q) {
     const int64_t tiles_per_group = kSW * sad_tiles_per_wave(D);
     const int64_t n_groups = ((N + 63) / 64 + tiles_per_group - 1) / tiles_per_group;
-    int per_group = kSChunk;
-    while (per_group > 16 && n_groups * ((Q + per_group - 1) / per_group) < 1024) per_group >>= 1;
-    return per_group;
+    const int64_t resident = D >= 256 ? 256 * 3 : 256 * 5;  // workgroups the chip holds (launch bounds of rank_sad_kernel)
+    const int64_t query_cycles = (int64_t)(D / 2) * sad_tiles_per_wave(D) * 17 / 4, setup_cycles = 12000;
+    int best = kSChunk;
+    int64_t best_cost = INT64_MAX;
+    for (int per_group = kSChunk; per_group >= 16; per_group >>= 1) {
+        const int64_t grid = n_groups * ((Q + per_group - 1) / per_group);
+        const int64_t cost = ((grid + resident - 1) / resident) * (setup_cycles + per_group * query_cycles);
+        if (cost < best_cost) { best_cost = cost; best = per_group; }
+    }
+    return best;
 }
 
 static int64_t sad_groups_per_pass(int D, int64_t N, int64_t Q) {
