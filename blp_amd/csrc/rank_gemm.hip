@@ -311,10 +311,10 @@ constexpr float kBandCBf16 = 1150.0f;
 constexpr int kBfW = 4;          // waves per workgroup
 constexpr int kBfTPW = 2;        // candidate tiles per wave (4 at one wave/SIMD spills and runs 1.8x slower)
 constexpr int kBfWavesPerSimd = 2;  // launch bound: <= 256 VGPRs (128 of them hold the A operands)
-constexpr int kBfMinTilesPerChunk = 16;          // query tiles per workgroup: 16 / 32 / 64, chosen per launch --
-constexpr int kBfMaxTilesPerChunk = 64;          // the most that still gives the grid >= kBfWantGroups workgroups
-constexpr int kBfWantGroups = 2048;              // (each workgroup pays the candidate split once: 64 tiles 1.47 ms,
-                                                 // 32: 1.49, 16: 1.64 on the FB15k-237 block; 8-way shards keep 16)
+constexpr int kBfMinTilesPerChunk = 16;          // query tiles per workgroup: 16 / 32 / 64, chosen per launch by a
+constexpr int kBfMaxTilesPerChunk = 64;          // small cost model (see rank_gemm_impl)
+constexpr int kBfResident = 512;                 // workgroups the chip holds (2 per CU)
+constexpr int kBfSetupTiles = 5;                 // a workgroup's set-up, in query tiles of work
 constexpr int kBfQuotaPerTile = 8 * kBfTPW;      // undecided pairs a workgroup can list, per query tile of its chunk
 
 // band factor of a row from its norm / largest magnitude (see above); exact zero rows need no band
@@ -863,11 +863,16 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         const int64_t n_groups = (n_ctiles + tiles_per_group - 1) / tiles_per_group;
         const int words = (int)((n_ctiles + 15) / 16);
         int tiles_per_chunk = kGTilesPerChunk;
-        if (!f32_kernel) {  // the longest chunks that still leave the grid kBfWantGroups workgroups
-            tiles_per_chunk = kBfMaxTilesPerChunk;
-            while (tiles_per_chunk > kBfMinTilesPerChunk &&
-                   n_groups * ((th + tiles_per_chunk - 1) / tiles_per_chunk + (tt + tiles_per_chunk - 1) / tiles_per_chunk) < kBfWantGroups)
-                tiles_per_chunk /= 2;
+        if (!f32_kernel) {
+            // smallest estimated time: rounds of the resident workgroups (2 per CU) x (set-up + query tiles).  A
+            // workgroup's set-up (candidate split, LDS tables, pipeline ramp, list write-out) costs about as much
+            // as kBfSetupTiles query tiles (fitted on the FB15k-237 block: 1.64 / 1.49 / 1.47 ms at 16 / 32 / 64).
+            int64_t best_cost = INT64_MAX;
+            for (int per = kBfMaxTilesPerChunk; per >= kBfMinTilesPerChunk; per /= 2) {
+                const int64_t grid = n_groups * ((th + per - 1) / per + (tt + per - 1) / per);
+                const int64_t cost = ((grid + kBfResident - 1) / kBfResident) * (kBfSetupTiles + per);
+                if (cost < best_cost) { best_cost = cost; tiles_per_chunk = per; }
+            }
             if (const char* env = getenv("BLP_GEMM_TILES_PER_CHUNK")) {  // test knob: long chunks on small problems
                 const int forced = atoi(env);
                 if (forced == 16 || forced == 32 || forced == 64) tiles_per_chunk = forced;
