@@ -431,6 +431,10 @@ static int sad_queries_per_group(int D, int64_t N, int64_t Q) {
     const int64_t n_groups = ((N + 63) / 64 + tiles_per_group - 1) / tiles_per_group;
     const int64_t resident = D >= 256 ? 256 * 3 : 256 * 5;  // workgroups the chip holds (launch bounds of rank_sad_kernel)
     const int64_t query_cycles = (int64_t)(D / 2) * sad_tiles_per_wave(D) * 17 / 4, setup_cycles = 12000;
+    if (const char* env = getenv("BLP_SAD_QUERIES_PER_GROUP")) {  // test knob
+        const int forced = atoi(env);
+        if (forced >= 16 && forced <= kSChunk && (forced & (forced - 1)) == 0) return forced;
+    }
     int best = kSChunk;
     int64_t best_cost = INT64_MAX;
     for (int per_group = kSChunk; per_group >= 16; per_group >>= 1) {

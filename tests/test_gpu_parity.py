@@ -509,6 +509,28 @@ def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, monkeyp
         assert np.array_equal(part.cpu().numpy(), want), model
 
 
+@pytest.mark.parametrize("per_group", ["16", "32", "64", "128", "256"])
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_sad_queries_per_workgroup(ops, oracle, D, per_group, monkeypatch):
+    """A workgroup of the TransE pre-pass takes 16 .. 256 queries (a cost model picks; BLP_SAD_QUERIES_PER_GROUP
+    forces).  Ragged last chunk, exact ties (pair lists), a block of identical rows that overflows the pair quota
+    (flags -> sweep), a CSR filter: same counts for every chunk length."""
+    monkeypatch.setenv("BLP_SAD_QUERIES_PER_GROUP", per_group)
+    N, q_head, q_tail = 900 + 7, 256 * 3 + 5, 256 + 131
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=91)
+    table[::5] = table[1::5]
+    table[300:560] = table[300]          # 260 identical candidates ...
+    true_row[40:300] = torch.arange(300, 560)  # ... each the true entity of one of 260 consecutive queries
+    q_fixed[40:300] = q_fixed[40]
+    q_rel[40:300] = q_rel[40]
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=6)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert (want[40:300, 1] - want[40:300, 0]).min() >= 259
+
+
 @pytest.mark.parametrize("tiles", ["16", "32", "64"])
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
 def test_gemm_query_chunk_lengths(ops, oracle, model, tiles, monkeypatch):
