@@ -117,21 +117,25 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
                                     hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // Exact sweeps of flagged (query, candidate segment) bits: a workgroup of four waves owns kSweepQueries
-// consecutive queries.  Its first wave looks at one query per lane (any flag word set? -- or `all`, the
-// fallback when the pre-pass did not run) and leaves the offsets of the flagged ones, in order, in list[];
-// the waves then take them round-robin.  Flags are rare: a workgroup per four queries (one wave each) spent
+// consecutive queries.  It scans their flag words together (coalesced; or takes every query when `all`, the
+// fallback when the pre-pass did not run), leaves the offsets of the flagged queries, in order, in list[],
+// and its waves then take them round-robin.  Flags are rare: a workgroup per four queries (one wave each) spent
 // 37 us launching 26 k workgroups that found nothing (FB15k-237 block); this layout: 8 us.
 constexpr int kSweepQueries = 64;
 __device__ __forceinline__ int flagged_queries(const unsigned* __restrict__ flags, int64_t q_base, int64_t Q,
                                                int words_per_query, bool all, int* list, int* n_list) {
-    if (threadIdx.x < 64) {
-        const int64_t q = q_base + threadIdx.x;
-        bool any = false;
-        if (q < Q) {
-            any = all;
-            const unsigned* row = flags + q * words_per_query;
-            for (int w = 0; !any && w < words_per_query; ++w) any = row[w] != 0;
-        }
+    const int nq = (int)(Q - q_base < kSweepQueries ? Q - q_base : kSweepQueries);
+    if (threadIdx.x < kSweepQueries) list[threadIdx.x] = (int)threadIdx.x < nq && all;
+    __syncthreads();
+    if (!all) {  // the workgroup reads its queries' flag words (contiguous) together, whatever their number
+        const unsigned* base = flags + q_base * words_per_query;
+        const int total = nq * words_per_query;
+        for (int i = threadIdx.x; i < total; i += blockDim.x)
+            if (base[i]) list[i / words_per_query] = 1;  // every writer stores the same value
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {  // first wave: marks -> ordered list of offsets (all lanes read before any writes)
+        const bool any = list[threadIdx.x] != 0;
         const unsigned long long mask = __ballot(any);
         if (any) list[__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (int)threadIdx.x;
         if (threadIdx.x == 0) *n_list = __popcll(mask);
