@@ -92,6 +92,9 @@ int blp_dim_supported(int model, int D);
  *   filt_rowptr (Q+1) int64, filt_col (nnz) int64: CSR of table rows that the filtered setting
  *                          removes for each query (the True entries of utils.get_triple_filters'
  *                          mask, utils.py:46-83); NULL/NULL = no filtering (filtered == raw).
+ *                          Each row at most once per query (a mask bit is set once however many
+ *                          parallel edges the graph has), rows in [0, N), never the true entity
+ *                          (utils.py:71,78); blp_amd.utils.FilterIndex produces exactly that.
  *   counts     (Q, 4) int32 OUT: {#(pred > true), #(pred >= true), same two over the
  *                          non-filtered candidates}.  Overwritten.  With the candidate axis
  *                          sharded, per-shard counts add up to the unsharded ones.
