@@ -22,7 +22,9 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
            "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
-           "blp_inbatch_loss_bwd_t")
+           "blp_inbatch_loss_bwd_t", "blp_debug_set_knob")
+KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
+         "gemm_pass_words", "gemm_tiles_per_chunk")  # blp_amd/csrc/knobs.h
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h
@@ -100,8 +102,20 @@ def lib():
     L.blp_inbatch_loss_bwd_t.restype = _i
     L.blp_inbatch_loss_bwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                          _i, _vp]
+    L.blp_debug_set_knob.restype = _i
+    L.blp_debug_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     _lib = L
     return L
+
+
+def set_knob(name, value):
+    """Test / A-B hook (include/blp_hip.h: blp_debug_set_knob); 0 restores the automatic choice."""
+    check(lib().blp_debug_set_knob(name.encode(), int(value)), "blp_debug_set_knob")
+
+
+def reset_knobs():
+    for name in KNOBS:
+        set_knob(name, 0)
 
 
 def check(status, what):

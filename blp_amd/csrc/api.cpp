@@ -2,11 +2,13 @@
 // error reporting and dispatch to the launchers in the .hip files.  No kernel code here.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 
 #include "../../include/blp_hip.h"
+#include "knobs.h"
 #include "launch.h"
 
 namespace {
@@ -81,9 +83,27 @@ int check_score_dim(int model, int D) {
     return BLP_OK;
 }
 
+std::atomic<long long> g_knobs[blp::KNOB_COUNT];  // zero-initialised: every knob automatic
+const char* const kKnobNames[blp::KNOB_COUNT] = {"rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups",
+                                                 "sad_min_queries", "gemm_pass_words", "gemm_tiles_per_chunk"};
+
 }  // namespace
 
+namespace blp {
+long long knob(int which) { return g_knobs[which].load(std::memory_order_relaxed); }
+}  // namespace blp
+
 extern "C" {
+
+int blp_debug_set_knob(const char* name, long long value) {
+    if (!name) return fail(BLP_ERR_BAD_ARG, "blp_debug_set_knob: NULL name");
+    for (int i = 0; i < blp::KNOB_COUNT; ++i)
+        if (std::strcmp(name, kKnobNames[i]) == 0) {
+            g_knobs[i].store(value, std::memory_order_relaxed);
+            return BLP_OK;
+        }
+    return fail(BLP_ERR_BAD_ARG, "blp_debug_set_knob: unknown knob '%s'", name);
+}
 
 int blp_version(void) { return BLP_HIP_VERSION; }
 
@@ -134,16 +154,20 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
                     (long long)N, (long long)q_head, (long long)q_tail, (long long)ld);
     const int64_t Q = q_head + q_tail;
     if (Q == 0) return BLP_OK;
-    if (Q > (1ll << 30) || N > (1ll << 36))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: Q or N too large for one call; split the query block");
+    // counts are int32, the two accumulators of a query share one 64-bit word and pair lists hold 32-bit rows
+    if (Q > (1ll << 30) || N >= (1ll << 31))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: Q > 2^30 or N >= 2^31 (counts are int32): split the query block / "
+                                     "shard the candidate axis");
     if (!q_fixed || !q_rel || !counts) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL q_fixed / q_rel / counts");
     if (N > 0 && !table) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL table");
     if ((true_row == nullptr) == (q_true == nullptr))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: exactly one of true_row / q_true must be given");
     if ((filt_rowptr == nullptr) != (filt_col == nullptr))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filt_rowptr and filt_col must both be given or both NULL");
-    if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: table / q_true / counts must be 16-byte aligned and ld %% 4 == 0");
+    if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts) || !aligned16(q_fixed) ||
+        !aligned16(q_rel) || (D & 3))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: table / q_fixed / q_rel / q_true / counts must be 16-byte aligned, "
+                                     "ld %% 4 == 0 and D %% 4 == 0");
     const size_t need = blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail(BLP_ERR_WORKSPACE, "blp_rank_all: workspace must be 256-byte aligned and >= %zu bytes (got %zu)",

@@ -1,0 +1,22 @@
+// knobs.h -- test / A-B hooks of libblp_hip.so (blp_debug_set_knob in include/blp_hip.h).  Process-wide
+// relaxed atomics, 0 = automatic.  Nothing in the product path sets them; there is no getenv() anywhere
+// in the library, so blp_rank_all_workspace_bytes and blp_rank_all always see the same values unless a
+// test changes a knob between the two calls.
+#pragma once
+
+namespace blp {
+
+enum Knob : int {
+    KNOB_RANK_KERNEL = 0,        // 1: TransE through the exact f32 kernels whatever the block size
+    KNOB_GEMM_KERNEL,            // 1: bilinear pre-pass on the f32 MFMA chain instead of bf16 x 3
+    KNOB_SAD_QUERIES_PER_GROUP,  // 16 .. 256 (power of two): queries per workgroup of the TransE pre-pass
+    KNOB_SAD_PASS_GROUPS,        // candidate groups per pre-pass slab (forces the multi-slab path)
+    KNOB_SAD_MIN_QUERIES,        // smallest block the TransE pre-pass takes
+    KNOB_GEMM_PASS_WORDS,        // flag words per query and slab of the bilinear pre-pass (multi-slab path)
+    KNOB_GEMM_TILES_PER_CHUNK,   // 16 / 32 / 64 query tiles per workgroup of the bilinear pre-pass
+    KNOB_COUNT
+};
+
+long long knob(int which);  // api.cpp
+
+}  // namespace blp

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include "../../include/blp_hip.h"  // BLP_METRIC_SUMS_DOUBLES
+#include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
 #include "score_core.h"
@@ -402,7 +403,7 @@ template <int MODEL, int D>
 __global__ __launch_bounds__(256) void filt_counts_kernel(
     const float* __restrict__ table, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int64_t q_head,
-    int64_t q_tail, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+    int64_t q_tail, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col, int64_t N,
     unsigned long long* __restrict__ acc_f) {
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -411,8 +412,10 @@ __global__ __launch_bounds__(256) void filt_counts_kernel(
     const float kt = key_true[q];
     unsigned gt = 0, ge = 0;
     for (int64_t k = lo + lane; k < hi; k += 64) {
+        const int64_t row = col[k];
+        if ((uint64_t)row >= (uint64_t)N) continue;  // not a row of this table (another candidate shard's)
         float e[D];
-        load_row<D>(e, table + col[k] * ld);
+        load_row<D>(e, table + row * ld);
         const float key = q < q_head
             ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C})
             : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
@@ -534,8 +537,7 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
     if (rank_sad_wide_applicable(model, D, q_head, q_tail)) return rank_sad_wide_workspace_bytes(model, D, N, q_head, q_tail);
     size_t bytes = carve_workspace(nullptr, D, q_head, q_tail).bytes;
-    const size_t alt[3] = {rank_mfma_workspace_bytes(model, D, q_head, q_tail),
-                           rank_gemm_workspace_bytes(model, D, N, q_head, q_tail),
+    const size_t alt[2] = {rank_gemm_workspace_bytes(model, D, N, q_head, q_tail),
                            rank_sad_workspace_bytes(model, D, N, q_head, q_tail)};
     for (size_t a : alt) bytes = a > bytes ? a : bytes;
     return bytes;
@@ -606,7 +608,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
     const bool filtered = filt_rowptr != nullptr;
     if (filtered)
         filt_counts_kernel<MODEL, D><<<(int)((Q + 3) / 4), 256, 0, stream>>>(
-            table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filt_rowptr, filt_col, w.acc_f);
+            table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filt_rowptr, filt_col, N, w.acc_f);
     finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(w.acc, filtered ? w.acc_f : nullptr, Q, counts);
     return hipGetLastError();
 }
@@ -646,12 +648,7 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
     if (rank_sad_applicable(model, D, q_head, q_tail))
         return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,
                                    filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    // TransE, exact f32 kernels (few queries, or BLP_RANK_KERNEL=valu|mfma): the hand-pipelined
-    // scalar-cache VALU kernel below is the default, "mfma" selects the matrix-core variant.
-    const char* pick = getenv("BLP_RANK_KERNEL");
-    if (pick && strcmp(pick, "mfma") == 0 && rank_mfma_applicable(model, D, q_head, q_tail))
-        return launch_rank_all_mfma(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
-                                    filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    // everything else: the exact f32 kernels (few queries, D = 256 bilinear, or the rank_kernel knob)
     switch (model) {
     case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
     case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
@@ -679,9 +676,9 @@ static hipError_t exact_prep_impl(const float* q_fixed, const float* q_rel, int6
 template <int MODEL, int D>
 static hipError_t exact_filter_impl(const float* table, int64_t ld, const float* coef_head, const float* coef_tail,
                                     const float* key_true, int64_t q_head, int64_t q_tail, const int64_t* rowptr,
-                                    const int64_t* col, unsigned long long* acc_f, hipStream_t stream) {
+                                    const int64_t* col, int64_t N, unsigned long long* acc_f, hipStream_t stream) {
     filt_counts_kernel<MODEL, D><<<(int)((q_head + q_tail + 3) / 4), 256, 0, stream>>>(
-        table, ld, coef_head, coef_tail, key_true, q_head, q_tail, rowptr, col, acc_f);
+        table, ld, coef_head, coef_tail, key_true, q_head, q_tail, rowptr, col, N, acc_f);
     return hipGetLastError();
 }
 
@@ -709,10 +706,10 @@ hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float
 
 hipError_t launch_exact_filter(int model, int D, const float* table, int64_t ld, const float* coef_head,
                                const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                               const int64_t* rowptr, const int64_t* col, unsigned long long* acc_f,
+                               const int64_t* rowptr, const int64_t* col, int64_t N, unsigned long long* acc_f,
                                hipStream_t stream) {
     BLP_DISPATCH_MODEL_DIM(exact_filter_impl, table, ld, coef_head, coef_tail, key_true, q_head, q_tail, rowptr, col,
-                           acc_f, stream)
+                           N, acc_f, stream)
 }
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,

@@ -1,5 +1,5 @@
-// rank_common.h -- helpers shared by the ranking kernels (rank_all.hip: one-lane-per-candidate VALU
-// kernel; rank_mfma.hip: 32x32 MFMA tile kernel).
+// rank_common.h -- helpers shared by the ranking kernels (rank_all.hip: exact one-lane-per-candidate VALU
+// kernels; rank_sad*.hip, rank_gemm.hip: the pre-pass paths).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,16 +65,6 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 hipError_t launch_finalize_counts(const unsigned long long* acc, const unsigned long long* acc_f, int64_t Q,
                                   int32_t* counts, hipStream_t stream);
 
-// rank_mfma.hip: MFMA-tile pipeline for large query blocks; same contract as launch_rank_all.
-bool rank_mfma_applicable(int model, int D, int64_t q_head, int64_t q_tail);
-size_t rank_mfma_workspace_bytes(int model, int D, int64_t q_head, int64_t q_tail);
-hipError_t launch_rank_all_mfma(int model, int D, const float* table, int64_t N, int64_t ld,
-                                const float* q_fixed, const float* q_rel, const int64_t* true_row,
-                                const float* q_true, int64_t q_head, int64_t q_tail,
-                                const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
-                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
-                                hipEvent_t ev_stop);
-
 // rank_all.hip: exact-path building blocks (row-major coefficients + true keys, the Q rank-count
 // accumulators `acc` zeroed on the way; CSR filter counts)
 hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head,
@@ -83,7 +73,7 @@ hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float
                              unsigned long long* acc, hipStream_t stream);
 hipError_t launch_exact_filter(int model, int D, const float* table, int64_t ld, const float* coef_head,
                                const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                               const int64_t* rowptr, const int64_t* col, unsigned long long* acc_f,
+                               const int64_t* rowptr, const int64_t* col, int64_t N, unsigned long long* acc_f,
                                hipStream_t stream);
 
 // rank_gemm.hip: bilinear models as an f32 MFMA GEMM + error band + exact refinement.

@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void rank_from_scores_kernel(const float* __re
     }
     if (rowptr) {
         for (int64_t k = rowptr[q] + lane; k < rowptr[q + 1]; k += 64) {
-            const float s = row[col[k]];
+            const int64_t c = col[k];
+            if ((uint64_t)c >= (uint64_t)N) continue;  // not a column of this matrix (another candidate shard's)
+            const float s = row[c];
             fgt += s > t;
             fge += s >= t;
         }

@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
 #include "score_core.h"
@@ -778,10 +779,7 @@ static int64_t pair_entries(int64_t T, int64_t q_head, int64_t q_tail) {
     return most;
 }
 
-static bool gemm_use_f32() {  // BLP_GEMM_KERNEL=f32: the exact-f32-chain MFMA kernel instead of bf16 x 3
-    const char* pick = getenv("BLP_GEMM_KERNEL");
-    return pick && pick[0] == 'f';
-}
+static bool gemm_use_f32() { return knob(KNOB_GEMM_KERNEL) == 1; }  // the exact-f32-chain MFMA kernel instead of bf16 x 3
 
 // Candidate tiles handled per GEMM + refine pass (a multiple of 16 = one flag word per query): the flag
 // bitmap (2 bits per (query, tile)) and the pair regions (kPairQuota entries per workgroup) are each
@@ -794,10 +792,8 @@ static int64_t tiles_per_pass(int64_t N, int64_t q_head, int64_t q_tail) {
     const int64_t by_pairs = cap / 8 / pair_entries(16, q_head, q_tail);  // entries grow linearly in whole 16-tile words
     if (words > by_flags) words = by_flags;
     if (words > by_pairs) words = by_pairs;
-    if (const char* env = getenv("BLP_GEMM_PASS_WORDS")) {  // test knob: force the multi-slab path
-        const int64_t forced = atoll(env);
+    if (const int64_t forced = knob(KNOB_GEMM_PASS_WORDS))  // test knob: force the multi-slab path
         if (forced > 0 && forced < words) words = forced;
-    }
     return (words < 1 ? 1 : words) * 16;
 }
 
@@ -873,10 +869,8 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                 const int64_t cost = ((grid + kBfResident - 1) / kBfResident) * (kBfSetupTiles + per);
                 if (cost < best_cost) { best_cost = cost; tiles_per_chunk = per; }
             }
-            if (const char* env = getenv("BLP_GEMM_TILES_PER_CHUNK")) {  // test knob: long chunks on small problems
-                const int forced = atoi(env);
-                if (forced == 16 || forced == 32 || forced == 64) tiles_per_chunk = forced;
-            }
+            const int forced = (int)knob(KNOB_GEMM_TILES_PER_CHUNK);  // test knob: long chunks on small problems
+            if (forced == 16 || forced == 32 || forced == 64) tiles_per_chunk = forced;
         }
         const int64_t chunks_head = (th + tiles_per_chunk - 1) / tiles_per_chunk;
         const int64_t chunks_tail = (tt + tiles_per_chunk - 1) / tiles_per_chunk;
@@ -906,7 +900,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     const bool filtered = filt_rowptr != nullptr;
     if (filtered) {
         err = launch_exact_filter(MODEL, D, table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
-                                  filt_rowptr, filt_col, w.acc_f, stream);
+                                  filt_rowptr, filt_col, N, w.acc_f, stream);
         if (err != hipSuccess) return err;
     }
     err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);

@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
 #include "sad_common.h"
@@ -431,10 +432,8 @@ static int sad_queries_per_group(int D, int64_t N, int64_t Q) {
     const int64_t n_groups = ((N + 63) / 64 + tiles_per_group - 1) / tiles_per_group;
     const int64_t resident = D >= 256 ? 256 * 3 : 256 * 5;  // workgroups the chip holds (launch bounds of rank_sad_kernel)
     const int64_t query_cycles = (int64_t)(D / 2) * sad_tiles_per_wave(D) * 17 / 4, setup_cycles = 12000;
-    if (const char* env = getenv("BLP_SAD_QUERIES_PER_GROUP")) {  // test knob
-        const int forced = atoi(env);
+    if (const int forced = (int)knob(KNOB_SAD_QUERIES_PER_GROUP))  // test knob
         if (forced >= 16 && forced <= kSChunk && (forced & (forced - 1)) == 0) return forced;
-    }
     int best = kSChunk;
     int64_t best_cost = INT64_MAX;
     for (int per_group = kSChunk; per_group >= 16; per_group >>= 1) {
@@ -456,10 +455,8 @@ static int64_t sad_groups_per_pass(int D, int64_t N, int64_t Q) {
     int64_t g = n_groups;
     if (g > by_pairs) g = by_pairs;
     if (g > by_flags) g = by_flags;
-    if (const char* env = getenv("BLP_SAD_PASS_GROUPS")) {  // test knob: force the multi-slab path
-        const int64_t forced = atoll(env);
+    if (const int64_t forced = knob(KNOB_SAD_PASS_GROUPS))  // test knob: force the multi-slab path
         if (forced > 0 && forced < g) g = forced;
-    }
     return g < 1 ? 1 : g;
 }
 
@@ -492,10 +489,9 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
 
 // Worth it once the quantisation passes over the table (~2.5 table reads) are amortised.
 bool rank_sad_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
-    if (const char* pick = getenv("BLP_RANK_KERNEL"))
-        if (pick[0] == 'v' || pick[0] == 'm') return false;  // "valu" / "mfma": the exact f32 kernels
+    if (knob(KNOB_RANK_KERNEL) == 1) return false;  // test knob: the exact f32 kernels
     int64_t min_queries = kSadMinQueries;
-    if (const char* v = getenv("BLP_SAD_MIN_QUERIES")) min_queries = atoll(v) > 0 ? atoll(v) : 1;  // A/B knob
+    if (const int64_t v = knob(KNOB_SAD_MIN_QUERIES)) min_queries = v > 0 ? v : 1;  // A/B knob
     return model == TRANSE && (D == 64 || D == 128 || D == 256) && q_head + q_tail >= min_queries;
 }
 
@@ -563,7 +559,7 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     const bool filtered = filt_rowptr != nullptr;
     if (filtered) {
         err = launch_exact_filter(TRANSE, D, table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
-                                  filt_rowptr, filt_col, w.acc_f, stream);
+                                  filt_rowptr, filt_col, N, w.acc_f, stream);
         if (err != hipSuccess) return err;
     }
     err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);

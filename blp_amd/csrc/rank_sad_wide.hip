@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
 #include "sad_common.h"
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void wide_filter_kernel(const float* __restric
                                                           const float* __restrict__ q_rel,
                                                           const float* __restrict__ key_true, int64_t q_head, int64_t Q,
                                                           const int64_t* __restrict__ rowptr,
-                                                          const int64_t* __restrict__ col,
+                                                          const int64_t* __restrict__ col, int64_t N,
                                                           unsigned long long* __restrict__ acc_f) {
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
@@ -406,7 +407,9 @@ __global__ __launch_bounds__(256) void wide_filter_kernel(const float* __restric
     const float kt = key_true[q];
     unsigned gt = 0, ge = 0;
     for (int64_t i = rowptr[q] + lane; i < rowptr[q + 1]; i += 64) {
-        const float key = transe_key_rt(table + col[i] * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+        const int64_t row = col[i];
+        if ((uint64_t)row >= (uint64_t)N) continue;  // not a row of this table (another candidate shard's)
+        const float key = transe_key_rt(table + row * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
         gt += key > kt;
         ge += key >= kt;
     }
@@ -439,10 +442,8 @@ static int64_t wide_groups_per_pass(int64_t N, int64_t Q) {
     int64_t g = n_groups;
     if (g > by_pairs) g = by_pairs;
     if (g > by_flags) g = by_flags;
-    if (const char* env = getenv("BLP_SAD_PASS_GROUPS")) {  // test knob: force the multi-slab path
-        const int64_t forced = atoll(env);
+    if (const int64_t forced = knob(KNOB_SAD_PASS_GROUPS))  // test knob: force the multi-slab path
         if (forced > 0 && forced < g) g = forced;
-    }
     return g < 1 ? 1 : g;
 }
 
@@ -535,7 +536,7 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
     const bool filtered = filt_rowptr != nullptr;
     if (filtered)
         wide_filter_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, w.key_true, q_head, Q,
-                                                                              filt_rowptr, filt_col, w.acc_f);
+                                                                              filt_rowptr, filt_col, N, w.acc_f);
     err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);
     return err != hipSuccess ? err : hipGetLastError();
 }

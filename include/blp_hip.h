@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+#define BLP_HIP_VERSION 200 /* major*10000 + minor*100 + patch */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -93,13 +93,16 @@ int blp_dim_supported(int model, int D);
  *                          removes for each query (the True entries of utils.get_triple_filters'
  *                          mask, utils.py:46-83); NULL/NULL = no filtering (filtered == raw).
  *                          Each row at most once per query (a mask bit is set once however many
- *                          parallel edges the graph has), rows in [0, N), never the true entity
- *                          (utils.py:71,78); blp_amd.utils.FilterIndex produces exactly that.
+ *                          parallel edges the graph has), never the true entity (utils.py:71,78);
+ *                          blp_amd.utils.FilterIndex produces exactly that.  Entries outside [0, N)
+ *                          are ignored, so a candidate shard holding global rows [lo, lo + N) takes
+ *                          the global CSR with lo subtracted from every entry.
  *   counts     (Q, 4) int32 OUT: {#(pred > true), #(pred >= true), same two over the
  *                          non-filtered candidates}.  Overwritten.  With the candidate axis
  *                          sharded, per-shard counts add up to the unsharded ones.
  *   workspace  caller-owned scratch of >= blp_rank_all_workspace_bytes(model, N, D, q_head, q_tail)
  *              bytes, 256-B aligned.
+ * Limits: Q <= 2^30, N < 2^31 per call (int32 counts); q_fixed / q_rel / q_true 16-byte aligned.
  * -------------------------------------------------------------------------------------------- */
 size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head, int64_t q_tail);
 
@@ -204,6 +207,15 @@ int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, co
                            float regularizer, const float *grad_loss, const float *save_pos,
                            const float *save_neg, void *grad_ent, void *grad_rel, int device,
                            void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Test / A-B hook.  The library never reads the environment; the kernel-selection and slab-size
+ * overrides the parity tests need (force the exact f32 kernels, the f32-chain GEMM, tiny candidate
+ * slabs, ...) are process-wide integer knobs, 0 = automatic (names: blp_amd/csrc/knobs.h).  Not for
+ * production callers: a knob changed between blp_rank_all_workspace_bytes and blp_rank_all can make
+ * the two disagree.  Results never depend on a knob.
+ * -------------------------------------------------------------------------------------------- */
+int blp_debug_set_knob(const char *name, long long value);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,7 @@ void blp_oracle_score_pairs(int model, const float *h, const float *t, const flo
  * out is (Q, N) row-major. */
 void blp_oracle_score_all(int model, int side, const float *table, int64_t N, int D, int64_t ld,
                           const float *q_fixed, const float *q_rel, int64_t Q, float *out) {
+#pragma omp parallel for schedule(dynamic, 4)
     for (int64_t q = 0; q < Q; ++q) {
         const float *f = q_fixed + q * D, *r = q_rel + q * D;
         for (int64_t n = 0; n < N; ++n) {
@@ -203,6 +204,9 @@ void blp_oracle_rank_counts(int model, int side, const float *table, int64_t N, 
                             const float *q_fixed, const float *q_rel, const int64_t *true_row,
                             const float *q_true, int64_t Q, const int64_t *filt_rowptr,
                             const int64_t *filt_col, int32_t *counts) {
+    /* queries are independent: with -fopenmp (oracle/Makefile) they are spread over the host cores, which
+     * changes nothing in any query's arithmetic (full-size parity tests check thousands of queries) */
+#pragma omp parallel for schedule(dynamic, 4)
     for (int64_t q = 0; q < Q; ++q) {
         const float *f = q_fixed + q * D, *r = q_rel + q * D;
         const float *te = true_row ? table + true_row[q] * ld : q_true + q * D;

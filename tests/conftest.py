@@ -31,3 +31,11 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture
+def knobs():
+    """Set test knobs of libblp_hip.so (blp_debug_set_knob) for one test; every knob is automatic again afterwards."""
+    from blp_amd import _lib
+    yield _lib.set_knob
+    _lib.reset_knobs()

@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     L = _lib.lib()
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.blp_version() == 100
+    assert L.blp_version() == 200
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 16)
@@ -59,6 +59,24 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     assert rc == -1  # relation rows narrower than the embeddings
     rc = L.blp_rank_metric_sums(None, 5, None, None, 0, None)
     assert rc == -1
+    # int32 counts: N >= 2^31 is refused; q_fixed / q_rel feed 16-byte vector loads
+    rc = L.blp_rank_all(0, one, 1 << 31, 128, 128, one, one, None, one, None, 1, 1, None, None, one, one, 1 << 40, 0, None)
+    assert rc == -1 and b"2^31" in L.blp_last_error()
+    rc = L.blp_rank_all(0, one, 10, 128, 128, ctypes.c_void_p(20), one, None, one, None, 1, 1, None, None, one, one,
+                        1 << 40, 0, None)
+    assert rc == -1 and b"aligned" in L.blp_last_error()
+
+
+def test_knobs_are_named_and_reset(built_lib):
+    from blp_amd import _lib
+    L = _lib.lib()
+    before = L.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300)
+    _lib.set_knob("rank_kernel", 1)  # exact f32 kernels: no images, no pair lists
+    assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300) < before
+    _lib.reset_knobs()
+    assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300) == before
+    with pytest.raises(RuntimeError, match="unknown knob"):
+        _lib.set_knob("no_such_knob", 1)
     with pytest.raises(RuntimeError, match="BLP_ERR_BAD_ARG"):
         _lib.check(-1, "demo")
 

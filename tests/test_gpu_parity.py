@@ -112,11 +112,10 @@ def test_random_vs_oracle_ragged(ops, oracle, model, D):
 
 
 @pytest.mark.parametrize("D", [64, 128, 256])
-@pytest.mark.parametrize("kernel", ["valu", "mfma"])
-def test_transe_exact_kernels_many_queries(ops, oracle, D, kernel, monkeypatch):
-    """Q >= 256 TransE normally takes the fixed-point pre-pass; BLP_RANK_KERNEL selects the exact f32
-    kernels (hand-pipelined VALU, MFMA) for the same block.  Same counts."""
-    monkeypatch.setenv("BLP_RANK_KERNEL", kernel)
+def test_transe_exact_kernels_many_queries(ops, oracle, D, knobs):
+    """Q >= 256 TransE normally takes the fixed-point pre-pass; the rank_kernel knob selects the exact f32
+    kernel (hand-pipelined VALU) for the same block.  Same counts."""
+    knobs("rank_kernel", 1)
     N, q_head, q_tail = 1000 + D // 64, 300, 41
     table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=D + 3)
     rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D)
@@ -173,7 +172,7 @@ def test_sad_degenerate_inputs_stay_exact(ops, oracle, case):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-def test_sad_candidate_slabs_and_shard_vectors(ops, oracle, monkeypatch):
+def test_sad_candidate_slabs_and_shard_vectors(ops, oracle, knobs):
     """BLP_SAD_PASS_GROUPS=1 forces 512-candidate slabs (ragged last slab); q_true instead of true_row
     (the form a candidate shard sees) gives the same counts."""
     D, N, q_head, q_tail = 128, 2000 + 37, 170, 190
@@ -182,7 +181,7 @@ def test_sad_candidate_slabs_and_shard_vectors(ops, oracle, monkeypatch):
     args = ("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
     one_pass = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
     by_vector = ops.rank_all(*args, q_true=table[true_row].cuda()).cpu().numpy()
-    monkeypatch.setenv("BLP_SAD_PASS_GROUPS", "1")
+    knobs("sad_pass_groups", 1)
     slabs = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
     assert np.array_equal(one_pass, want)
     assert np.array_equal(by_vector, want)
@@ -190,7 +189,7 @@ def test_sad_candidate_slabs_and_shard_vectors(ops, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("D", [300, 768, 100, 4, 1024])
-def test_transe_any_width_prepass(ops, oracle, D, monkeypatch):
+def test_transe_any_width_prepass(ops, oracle, D, knobs):
     """TransE at the widths of the reference's BOW / DKRL encoders (300 GloVe, 768 BERT) and other widths
     the register-resident kernels are not compiled for: blocks of >= 256 queries take the any-width
     fixed-point pre-pass (rank_sad_wide.hip).  Counts identical to the oracle with a CSR filter, with the
@@ -208,7 +207,7 @@ def test_transe_any_width_prepass(ops, oracle, D, monkeypatch):
     assert np.array_equal(got, want)
     by_vector = ops.rank_all(*args, q_true=table[true_row].cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col))
     assert np.array_equal(by_vector.cpu().numpy(), want)
-    monkeypatch.setenv("BLP_SAD_PASS_GROUPS", "2")  # 512-candidate slabs
+    knobs("sad_pass_groups", 2)  # 512-candidate slabs
     slabs = ops.rank_all(*args, true_row=true_row.cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
     assert np.array_equal(slabs, want)
     assert (want[:, 1] - want[:, 0]).max() > 1
@@ -258,7 +257,7 @@ def test_gemm_band_adversarial(ops, oracle, model, D):
 
 
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
-def test_gemm_candidate_slabs(ops, oracle, model, monkeypatch):
+def test_gemm_candidate_slabs(ops, oracle, model, knobs):
     """When the flag bitmap / pair regions would exceed their cap the candidate axis is processed in
     slabs.  BLP_GEMM_PASS_WORDS=1 forces 512-candidate slabs: counts must equal the one-pass result
     and the oracle's (ragged last slab, true entities in every slab)."""
@@ -267,7 +266,7 @@ def test_gemm_candidate_slabs(ops, oracle, model, monkeypatch):
     want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
     args = (model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
     one_pass = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
-    monkeypatch.setenv("BLP_GEMM_PASS_WORDS", "1")
+    knobs("gemm_pass_words", 1)
     slabs = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
     assert np.array_equal(one_pass, want)
     assert np.array_equal(slabs, want)
@@ -346,7 +345,7 @@ def test_prepass_paths_are_repeatable(ops, model, D):
 @pytest.mark.parametrize("model,D", [("transe", 128), ("transe", 64), ("transe", 300), ("distmult", 128), ("complex", 64),
                                      ("simple", 128)])
 @pytest.mark.parametrize("gemm_kernel", [None, "f32"])
-def test_workspace_is_never_overrun(model, D, gemm_kernel, monkeypatch):
+def test_workspace_is_never_overrun(model, D, gemm_kernel, knobs):
     """blp_rank_all through the raw C-ABI with a workspace of exactly blp_rank_all_workspace_bytes bytes
     followed by a canary: every kernel path, for query-block shapes whose tile / chunk counts do not
     divide evenly (1 tile on one side, 17 on the other, ...), must leave the canary intact.  (A
@@ -356,7 +355,7 @@ def test_workspace_is_never_overrun(model, D, gemm_kernel, monkeypatch):
     if gemm_kernel:
         if model == "transe":
             pytest.skip("bilinear knob")
-        monkeypatch.setenv("BLP_GEMM_KERNEL", gemm_kernel)
+        knobs("gemm_kernel", 1)
     L = _lib.lib()
     g = torch.Generator().manual_seed(D)
     guard = 1 << 16
@@ -476,7 +475,7 @@ def test_wikidata5m_scale_properties(ops, oracle):
     assert int(whole[:, 1].min()) >= 1  # the true entity itself is always >=
 
 
-def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, monkeypatch):
+def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, knobs):
     """4.6 M x 128 with enough queries for the pre-pass paths (TransE: fixed-point SAD, Q = 512;
     DistMult: bf16 x 3 GEMM, Q = 128).  Their counts must equal (a) the exact f32 kernels' on the whole
     table and (b) the oracle's on a 100k-row slab (true entities as vectors, the sharded form)."""
@@ -491,9 +490,9 @@ def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, monkeyp
         q_rel = (torch.rand(Q, D, device="cuda", generator=g) - 0.5) * (0.25 if model == "transe" else 2.0)
         fast = ops.rank_all(model, table, q_fixed, q_rel, q_half, true_row=true_row)
         if model == "transe":
-            monkeypatch.setenv("BLP_RANK_KERNEL", "valu")
+            knobs("rank_kernel", 1)
             exact = ops.rank_all(model, table, q_fixed, q_rel, q_half, true_row=true_row)
-            monkeypatch.delenv("BLP_RANK_KERNEL")
+            knobs("rank_kernel", 0)
         else:  # blocks of < 64 queries take the exact VALU kernel
             parts_h = [ops.rank_all(model, table, q_fixed[a:a + 32], q_rel[a:a + 32], 32, true_row=true_row[a:a + 32])
                        for a in range(0, q_half, 32)]
@@ -511,11 +510,11 @@ def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, monkeyp
 
 @pytest.mark.parametrize("per_group", ["16", "32", "64", "128", "256"])
 @pytest.mark.parametrize("D", [64, 128, 256])
-def test_sad_queries_per_workgroup(ops, oracle, D, per_group, monkeypatch):
+def test_sad_queries_per_workgroup(ops, oracle, D, per_group, knobs):
     """A workgroup of the TransE pre-pass takes 16 .. 256 queries (a cost model picks; BLP_SAD_QUERIES_PER_GROUP
     forces).  Ragged last chunk, exact ties (pair lists), a block of identical rows that overflows the pair quota
     (flags -> sweep), a CSR filter: same counts for every chunk length."""
-    monkeypatch.setenv("BLP_SAD_QUERIES_PER_GROUP", per_group)
+    knobs("sad_queries_per_group", int(per_group))
     N, q_head, q_tail = 900 + 7, 256 * 3 + 5, 256 + 131
     table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=91)
     table[::5] = table[1::5]
@@ -533,11 +532,11 @@ def test_sad_queries_per_workgroup(ops, oracle, D, per_group, monkeypatch):
 
 @pytest.mark.parametrize("tiles", ["16", "32", "64"])
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
-def test_gemm_query_chunk_lengths(ops, oracle, model, tiles, monkeypatch):
+def test_gemm_query_chunk_lengths(ops, oracle, model, tiles, knobs):
     """A workgroup of the bf16 pre-pass takes 16, 32 or 64 query tiles (the longest that still fills the
     chip; BLP_GEMM_TILES_PER_CHUNK forces one).  Ragged sides (1 .. 8 tiles past a multiple of the chunk), exact
     ties (pair lists), a constant block (quota overflow -> flags) and a CSR filter: same counts."""
-    monkeypatch.setenv("BLP_GEMM_TILES_PER_CHUNK", tiles)
+    knobs("gemm_tiles_per_chunk", int(tiles))
     D, N, q_head, q_tail = 128, 700 + 5, 32 * 67 + 3, 32 * 33 - 7
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=77)
     table[::5] = table[1::5]
@@ -554,9 +553,9 @@ def test_gemm_query_chunk_lengths(ops, oracle, model, tiles, monkeypatch):
 
 
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
-def test_gemm_f32_chain_variant(ops, oracle, model, monkeypatch):
+def test_gemm_f32_chain_variant(ops, oracle, model, knobs):
     """BLP_GEMM_KERNEL=f32 selects the f32 MFMA chain pre-pass (band constant 320) instead of bf16 x 3."""
-    monkeypatch.setenv("BLP_GEMM_KERNEL", "f32")
+    knobs("gemm_kernel", 1)
     D, N, q_head, q_tail = 128, 1000 + 9, 150, 141
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=41)
     table[::5] = table[1::5]  # exact ties

@@ -2,7 +2,7 @@
 # sweep) at the FB15k-237 block size: how slow is "still exact"?
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from blp_amd import ops
+from blp_amd import _lib, ops
 import bench
 dev = torch.device("cuda", 0)
 cfg = bench.WORKLOADS["fb15k237-transe"]
@@ -18,6 +18,6 @@ print(f"finite table: {ms:.2f} ms")
 bad = table.clone(); bad[7, 3] = float("inf")
 ms, c = run(bad)
 print(f"one inf in the table (pre-pass off, every tile swept exactly): {ms:.2f} ms")
-os.environ["BLP_RANK_KERNEL"] = "valu"
+_lib.set_knob("rank_kernel", 1)
 ms, c2 = run(bad)
 print(f"same through the exact f32 kernel: {ms:.2f} ms; identical counts: {torch.equal(c, c2)}")

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from blp_amd import ops  # noqa: E402
+from blp_amd import _lib, ops  # noqa: E402
 from oracle import oracle  # noqa: E402
 from test_gpu_parity import oracle_counts, random_csr  # noqa: E402
 
@@ -73,14 +73,14 @@ def make_case(rng):
         wide = torch.zeros(N, D + 4 * int(rng.integers(1, 5)))
         wide[:, :D] = table
         table = wide[:, :D]
-    env = {}
+    env = {}  # test knobs of the library (blp_debug_set_knob)
     if rng.random() < 0.3:
-        env["BLP_SAD_PASS_GROUPS"] = str(int(rng.integers(1, 4)))
-        env["BLP_GEMM_PASS_WORDS"] = str(int(rng.integers(1, 3)))
+        env["sad_pass_groups"] = int(rng.integers(1, 4))
+        env["gemm_pass_words"] = int(rng.integers(1, 3))
     if rng.random() < 0.15:
-        env["BLP_GEMM_KERNEL"] = "f32"
+        env["gemm_kernel"] = 1
     if rng.random() < 0.15:
-        env["BLP_RANK_KERNEL"] = str(rng.choice(["valu", "mfma"]))
+        env["rank_kernel"] = 1
     return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids
 
 
@@ -98,7 +98,7 @@ def main():
         kw = dict(true_row=true_row) if not by_vector else dict(q_true=table[true_row])
         want = oracle_counts(oracle, model, table.contiguous(), q_fixed, q_rel, q_head, csr=csr, **kw)
         for k, v in env.items():
-            os.environ[k] = v
+            _lib.set_knob(k, v)
         try:
             gkw = {k: v.cuda() for k, v in kw.items()}
             if csr is not None:
@@ -108,8 +108,7 @@ def main():
             dev_table = table.cuda() if table.is_contiguous() else table._base.cuda()[:, :D]
             got = ops.rank_all(model, dev_table, q_fixed.cuda(), q_rel.cuda(), q_head, **gkw).cpu().numpy()
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            _lib.reset_knobs()
         if not np.array_equal(got, want):
             bad += 1
             rows = np.nonzero((got != want).any(axis=1))[0]
