@@ -20,7 +20,8 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 
 # every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
-           "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
+           "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex",
+           "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t", "blp_debug_set_knob")
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
@@ -39,6 +40,12 @@ class BlpCaps(ctypes.Structure):
     _fields_ = [("compute_units", ctypes.c_int), ("wavefront_size", ctypes.c_int),
                 ("lds_bytes_per_cu", ctypes.c_int), ("clock_mhz", ctypes.c_int),
                 ("hbm_bytes", ctypes.c_int64), ("arch", ctypes.c_char * 32)]
+
+
+class BlpFilter(ctypes.Structure):  # blp_filter of include/blp_hip.h
+    _fields_ = [("seg_lo", ctypes.c_void_p), ("seg_hi", ctypes.c_void_p), ("values", ctypes.c_void_p),
+                ("exclude", ctypes.c_void_p), ("ent2idx", ctypes.c_void_p), ("ent2idx_len", ctypes.c_int64),
+                ("row_base", ctypes.c_int64)]
 
 
 _lib = None
@@ -78,6 +85,9 @@ def lib():
     L.blp_rank_all.restype = _i
     L.blp_rank_all.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
                                _vp, _sz, _i, _vp]
+    L.blp_rank_all_ex.restype = _i
+    L.blp_rank_all_ex.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.POINTER(BlpFilter),
+                                  _vp, _vp, _sz, _i, _vp]
     L.blp_profile_next_rank_kernel.restype = _i
     L.blp_profile_next_rank_kernel.argtypes = [_vp, _vp]
     L.blp_rank_from_scores.restype = _i

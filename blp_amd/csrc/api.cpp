@@ -71,15 +71,14 @@ int compute_units(int device, int* out) {
 
 blp::StridedRows rows(const float* p, int64_t s0, int64_t s1) { return blp::StridedRows{p, s0, s1}; }
 
-// score_fn operands: D floats readable at every addressed row; the bilinear models use the
-// torch.sum order implemented for widths that are multiples of 32 below 512.
+// score_fn operands: D floats readable at every addressed row.  Any width (the reference takes any `dim`): the
+// torch.sum order of the bilinear models runs from registers at the scripts' widths (reduction width a multiple
+// of 32 below 512) and through the general, slower routine otherwise (score_direct.h).  ComplEx / SimplE split
+// the vector into halves.
 int check_score_dim(int model, int D) {
     if (D <= 0) return fail(BLP_ERR_BAD_ARG, "D must be positive (got %d)", D);
-    if (model == BLP_TRANSE) return BLP_OK;
-    const int n = model == BLP_DISTMULT ? D : D / 2;
-    if ((model != BLP_DISTMULT && D % 2) || n % 32 || n >= 512)
-        return fail(BLP_ERR_UNSUPPORTED_DIM,
-                    "model %d: reduction width %d must be a multiple of 32 below 512 (D = %d)", model, n, D);
+    if ((model == BLP_COMPLEX || model == BLP_SIMPLE) && D % 2)
+        return fail(BLP_ERR_UNSUPPORTED_DIM, "model %d splits the embedding into halves: D = %d must be even", model, D);
     return BLP_OK;
 }
 
@@ -140,10 +139,10 @@ size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head,
     return blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
 }
 
-int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
-                 const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true, int64_t q_head,
-                 int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
-                 void* workspace, size_t workspace_bytes, int device, void* stream) {
+int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
+                    const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+                    int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
+                    size_t workspace_bytes, int device, void* stream) {
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
     if (!blp_rank_all_supported(model, D, q_head, q_tail))
         return fail(BLP_ERR_UNSUPPORTED_DIM,
@@ -162,8 +161,16 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
     if (N > 0 && !table) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL table");
     if ((true_row == nullptr) == (q_true == nullptr))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: exactly one of true_row / q_true must be given");
-    if ((filt_rowptr == nullptr) != (filt_col == nullptr))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filt_rowptr and filt_col must both be given or both NULL");
+    blp::FilterSpec spec;
+    if (filter) {
+        if (!filter->seg_lo || !filter->seg_hi || !filter->values)
+            return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filter needs seg_lo, seg_hi and values");
+        if (filter->ent2idx && filter->ent2idx_len < 0)
+            return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filter ent2idx_len is negative");
+        spec.lo = filter->seg_lo; spec.hi = filter->seg_hi; spec.val = filter->values; spec.exclude = filter->exclude;
+        spec.ent2idx = filter->ent2idx; spec.ent2idx_len = filter->ent2idx ? filter->ent2idx_len : 0;
+        spec.row_base = filter->row_base;
+    }
     if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts) || !aligned16(q_fixed) ||
         !aligned16(q_rel) || (D & 3))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: table / q_fixed / q_rel / q_true / counts must be 16-byte aligned, "
@@ -179,10 +186,25 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail,
-                                          filt_rowptr, filt_col, counts, workspace, cu,
-                                          static_cast<hipStream_t>(stream), ev0, ev1);
+                                          spec, counts, workspace, cu, static_cast<hipStream_t>(stream), ev0, ev1);
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all launch");
     return BLP_OK;
+}
+
+int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
+                 const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true, int64_t q_head,
+                 int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                 void* workspace, size_t workspace_bytes, int device, void* stream) {
+    if ((filt_rowptr == nullptr) != (filt_col == nullptr))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filt_rowptr and filt_col must both be given or both NULL");
+    blp_filter csr = {};
+    if (filt_rowptr) {  // CSR = segments [rowptr[q], rowptr[q + 1]) of a list of table rows
+        csr.seg_lo = filt_rowptr;
+        csr.seg_hi = filt_rowptr + 1;
+        csr.values = filt_col;
+    }
+    return blp_rank_all_ex(model, table, N, D, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail,
+                           filt_rowptr ? &csr : nullptr, counts, workspace, workspace_bytes, device, stream);
 }
 
 int blp_profile_next_rank_kernel(void* start_event, void* stop_event) {
@@ -276,7 +298,6 @@ static int check_inbatch(const char* who, int model, int loss, const void* ent, 
     if (loss != BLP_LOSS_MARGIN && loss != BLP_LOSS_NLL) return fail(BLP_ERR_BAD_ARG, "%s: unknown loss %d", who, loss);
     if (B <= 0 || K <= 0) return fail(BLP_ERR_BAD_ARG, "%s: B and K must be positive (B=%d K=%d)", who, B, K);
     if (int rc = check_score_dim(model, D)) return rc;
-    if (D > 768) return fail(BLP_ERR_UNSUPPORTED_DIM, "%s: D = %d > 768", who, D);
     if (!ent || !rel || !neg_idx) return fail(BLP_ERR_BAD_ARG, "%s: NULL pointer", who);
     return BLP_OK;
 }

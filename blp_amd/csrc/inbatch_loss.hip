@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
     const int j = blockIdx.x, lane = threadIdx.x;
     const int b = j >> 1, slot = j & 1;
     const float gl = grad_loss[0];
-    constexpr int MAXR = 12;  // d handled by this lane: lane, lane + 64, ... (D <= 768)
+    constexpr int MAXR = 12;  // d handled by this lane per sweep: d0 + lane, d0 + lane + 64, ... (768 per sweep)
+    for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {  // one sweep up to D = 768; wider rows repeat the scan
     float g[MAXR];
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) g[i] = 0.0f;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
         const RowF<TR> r{rel + (size_t)b * D};
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
-            const int d = lane + 64 * i;
+            const int d = d0 + lane + 64 * i;
             if (d < D) g[i] += gp * dscore<MODEL>(slot, h, t, r, d, D);
         }
     }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
                 const RowF<TR> r{rel + (size_t)pb * D};
 #pragma unroll
                 for (int q = 0; q < MAXR; ++q) {
-                    const int d = lane + 64 * q;
+                    const int d = d0 + lane + 64 * q;
                     if (d < D) g[q] += gn * dscore<MODEL>(s, h, t, r, d, D);
                 }
             }
@@ -167,8 +168,9 @@ __global__ __launch_bounds__(64) void inbatch_grad_ent_kernel(
     const float reg_scale = regularizer > 0.0f ? regularizer * 2.0f / (3.0f * B * D) : 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
-        const int d = lane + 64 * i;
+        const int d = d0 + lane + 64 * i;
         if (d < D) grad_ent[(size_t)j * D + d] = (TE)(gl * (g[i] + reg_scale * (float)ent[(size_t)j * D + d]));
+    }
     }
 }
 

@@ -6,13 +6,31 @@
 
 namespace blp {
 
+// The filtered setting (train.py:159-171) for a block of Q queries: query q loses the candidates listed in
+// val[lo[q] .. hi[q]).  Two layouts share these fields (include/blp_hip.h: blp_filter):
+//   CSR       lo = rowptr, hi = rowptr + 1, val = table rows, nothing else set;
+//   segments  [lo[q], hi[q]) is a slice of a sorted index of the filtering graph (blp_amd.utils.FilterIndex),
+//             val = entity ids, exclude[q] = the triple's own entity (never filtered, utils.py:71,78), ent2idx maps
+//             ids to table rows (-1 or beyond its length: not a candidate, utils.py:72,79).
+// row_base is subtracted from every row and rows outside [0, N) are skipped (candidate shards).
+struct FilterSpec {
+    const int64_t* lo = nullptr;
+    const int64_t* hi = nullptr;
+    const int64_t* val = nullptr;
+    const int64_t* exclude = nullptr;
+    const int64_t* ent2idx = nullptr;
+    int64_t ent2idx_len = 0;
+    int64_t row_base = 0;
+    __host__ __device__ bool on() const { return lo != nullptr; }
+};
+
 bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
                            const float* q_fixed, const float* q_rel, const int64_t* q_rel_id,
                            const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
-                           const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                           const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
                            hipEvent_t ev_stop = nullptr);
 

@@ -9,8 +9,8 @@
 //   1. prep_coef    (q, i) elementwise: hoist the query-only part of the score into C coefficients
 //   2. true_key     one lane per query: score of the true entity, by the same Scorer<> routine
 //   3. rank_tiles   the hot kernel, below
-//   4. filt_counts  one wave per query: scores of the CSR-listed (filtered) rows vs the true score
-//   5. finalize     counts[q] = {gt, ge, gt - fgt, ge - fge}
+//   4. filter_finalize  one wave per query: scores of the filtered rows vs the true score, then
+//                       counts[q] = {gt, ge, gt - fgt, ge - fge}  (no filter: a plain unpack of the accumulators)
 //
 // rank_tiles layout.  One wavefront owns a tile of 64 consecutive table rows, one row per lane, held
 // in D VGPRs (the sequential f32 sum of the reference forces one lane per (candidate, query) chain).
@@ -398,22 +398,23 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// Filtered setting: one wave per query, lanes stride over the query's CSR-listed rows.
+// Last kernel of a call.  Filtered setting (train.py:159-171): one wave per query, lanes stride over the query's
+// filter entries, score the rows they remove with the exact routine and count those at or above the true
+// entity; lane 0 then writes the query's four counts.  FILTERED = false: counts from the accumulators alone.
 template <int MODEL, int D>
-__global__ __launch_bounds__(256) void filt_counts_kernel(
-    const float* __restrict__ table, int64_t ld, const float* __restrict__ coef_head,
+__global__ __launch_bounds__(256) void filter_finalize_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int64_t q_head,
-    int64_t q_tail, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col, int64_t N,
-    unsigned long long* __restrict__ acc_f) {
+    int64_t q_tail, const FilterSpec filter, const unsigned long long* __restrict__ acc, int32_t* __restrict__ counts) {
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= q_head + q_tail) return;
-    const int64_t lo = rowptr[q], hi = rowptr[q + 1];
+    const int64_t lo = filter.lo[q], hi = filter.hi[q];
     const float kt = key_true[q];
     unsigned gt = 0, ge = 0;
     for (int64_t k = lo + lane; k < hi; k += 64) {
-        const int64_t row = col[k];
-        if ((uint64_t)row >= (uint64_t)N) continue;  // not a row of this table (another candidate shard's)
+        const int64_t row = filter_row(filter, q, k, N);
+        if (row < 0) continue;
         float e[D];
         load_row<D>(e, table + row * ld);
         const float key = q < q_head
@@ -427,19 +428,20 @@ __global__ __launch_bounds__(256) void filt_counts_kernel(
         gt += __shfl_down(gt, off);
         ge += __shfl_down(ge, off);
     }
-    if (lane == 0) acc_f[q] = (unsigned long long)gt | ((unsigned long long)ge << 32);
+    if (lane == 0) {
+        const unsigned long long a = acc[q];
+        const int32_t all_gt = (int32_t)(a & 0xffffffffull), all_ge = (int32_t)(a >> 32);
+        reinterpret_cast<int4*>(counts)[q] = make_int4(all_gt, all_ge, all_gt - (int32_t)gt, all_ge - (int32_t)ge);
+    }
 }
 
-__global__ void finalize_counts_kernel(const unsigned long long* __restrict__ acc,
-                                       const unsigned long long* __restrict__ acc_f, int64_t Q,
+__global__ void finalize_counts_kernel(const unsigned long long* __restrict__ acc, int64_t Q,
                                        int32_t* __restrict__ counts) {
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (q >= Q) return;
     const unsigned long long a = acc[q];
-    const unsigned long long f = acc_f ? acc_f[q] : 0ull;
     const int32_t gt = (int32_t)(a & 0xffffffffull), ge = (int32_t)(a >> 32);
-    const int32_t fgt = (int32_t)(f & 0xffffffffull), fge = (int32_t)(f >> 32);
-    reinterpret_cast<int4*>(counts)[q] = make_int4(gt, ge, gt - fgt, ge - fge);
+    reinterpret_cast<int4*>(counts)[q] = make_int4(gt, ge, gt, ge);
 }
 
 // utils.py:104-109 from the counts
@@ -515,7 +517,6 @@ struct RankWorkspace {
     float* coef_tail;
     float* key_true;
     unsigned long long* acc;
-    unsigned long long* acc_f;
     size_t bytes;
 };
 
@@ -529,7 +530,6 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
     w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * max_coef(D) * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
-    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
     w.bytes = off;
     return w;
 }
@@ -543,17 +543,10 @@ size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
     return bytes;
 }
 
-hipError_t launch_finalize_counts(const unsigned long long* acc, const unsigned long long* acc_f, int64_t Q,
-                                  int32_t* counts, hipStream_t stream) {
-    finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(acc, acc_f, Q, counts);
-    return hipGetLastError();
-}
-
 template <int MODEL, int D>
 static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                 const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
-                                int64_t q_head, int64_t q_tail, const int64_t* filt_rowptr,
-                                const int64_t* filt_col, int32_t* counts, void* workspace,
+                                int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
     if (Q == 0) return hipSuccess;
@@ -605,24 +598,19 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
 
-    const bool filtered = filt_rowptr != nullptr;
-    if (filtered)
-        filt_counts_kernel<MODEL, D><<<(int)((Q + 3) / 4), 256, 0, stream>>>(
-            table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filt_rowptr, filt_col, N, w.acc_f);
-    finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(w.acc, filtered ? w.acc_f : nullptr, Q, counts);
-    return hipGetLastError();
+    return launch_filter_finalize(MODEL, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filter,
+                                  w.acc, counts, stream);
 }
 
 template <int MODEL>
 static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
-                               int64_t q_head, int64_t q_tail, const int64_t* filt_rowptr,
-                               const int64_t* filt_col, int32_t* counts, void* workspace, int n_cu,
+                               int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace, int n_cu,
                                hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define BLP_RANK_CASE(DD)                                                                              \
     case DD:                                                                                           \
         return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, \
-                                        filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+                                        filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (D) {
         BLP_RANK_CASE(64)
         BLP_RANK_CASE(128)
@@ -636,24 +624,24 @@ static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld,
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
                            const float* q_fixed, const float* q_rel, const int64_t* q_rel_id,
                            const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
-                           const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                           const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                            hipEvent_t ev_stop) {
     if (rank_gemm_applicable(model, D, q_head, q_tail))
         return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
-                                    filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+                                    filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     if (rank_sad_wide_applicable(model, D, q_head, q_tail))
-        return launch_rank_all_sad_wide(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,
-                                        filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+        return launch_rank_all_sad_wide(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
+                                        counts, workspace, n_cu, stream, ev_start, ev_stop);
     if (rank_sad_applicable(model, D, q_head, q_tail))
-        return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,
-                                   filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+        return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
+                                   counts, workspace, n_cu, stream, ev_start, ev_stop);
     // everything else: the exact f32 kernels (few queries, D = 256 bilinear, or the rank_kernel knob)
     switch (model) {
-    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filt_rowptr, filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     default:       return hipErrorInvalidValue;
     }
 }
@@ -674,11 +662,12 @@ static hipError_t exact_prep_impl(const float* q_fixed, const float* q_rel, int6
 }
 
 template <int MODEL, int D>
-static hipError_t exact_filter_impl(const float* table, int64_t ld, const float* coef_head, const float* coef_tail,
-                                    const float* key_true, int64_t q_head, int64_t q_tail, const int64_t* rowptr,
-                                    const int64_t* col, int64_t N, unsigned long long* acc_f, hipStream_t stream) {
-    filt_counts_kernel<MODEL, D><<<(int)((q_head + q_tail + 3) / 4), 256, 0, stream>>>(
-        table, ld, coef_head, coef_tail, key_true, q_head, q_tail, rowptr, col, N, acc_f);
+static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const float* coef_head,
+                                       const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+                                       const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
+                                       hipStream_t stream) {
+    filter_finalize_kernel<MODEL, D><<<(int)((q_head + q_tail + 3) / 4), 256, 0, stream>>>(
+        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, filter, acc, counts);
     return hipGetLastError();
 }
 
@@ -704,12 +693,17 @@ hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float
                            coef_tail, key_true, acc, stream)
 }
 
-hipError_t launch_exact_filter(int model, int D, const float* table, int64_t ld, const float* coef_head,
-                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                               const int64_t* rowptr, const int64_t* col, int64_t N, unsigned long long* acc_f,
-                               hipStream_t stream) {
-    BLP_DISPATCH_MODEL_DIM(exact_filter_impl, table, ld, coef_head, coef_tail, key_true, q_head, q_tail, rowptr, col,
-                           N, acc_f, stream)
+hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
+                                  const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+                                  const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
+                                  hipStream_t stream) {
+    const int64_t Q = q_head + q_tail;
+    if (!filter.on()) {
+        finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(acc, Q, counts);
+        return hipGetLastError();
+    }
+    BLP_DISPATCH_MODEL_DIM(filter_finalize_impl, table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, filter, acc,
+                           counts, stream)
 }
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,

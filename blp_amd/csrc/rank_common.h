@@ -6,6 +6,7 @@
 
 #include <utility>
 
+#include "launch.h"
 #include "score_core.h"
 
 namespace blp {
@@ -61,9 +62,22 @@ __device__ __forceinline__ void stouch(const float* row) {  // one dword per 64-
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// counts[q] = {gt, ge, gt - fgt, ge - fge} from the packed 64-bit accumulators (rank_all.hip)
-hipError_t launch_finalize_counts(const unsigned long long* acc, const unsigned long long* acc_f, int64_t Q,
-                                  int32_t* counts, hipStream_t stream);
+// Row of `table` that entry k of query q's filter list removes, or -1 if it removes nothing here.
+__device__ __forceinline__ int64_t filter_row(const FilterSpec& f, int64_t q, int64_t k, int64_t N) {
+    int64_t v = f.val[k];
+    if (f.exclude && v == f.exclude[q]) return -1;
+    if (f.ent2idx) v = (uint64_t)v < (uint64_t)f.ent2idx_len ? f.ent2idx[v] : -1;
+    v -= f.row_base;
+    return (uint64_t)v < (uint64_t)N ? v : -1;
+}
+
+// Last step of every ranking path: counts[q] = {gt, ge, gt - fgt, ge - fge} from the packed 64-bit accumulators,
+// fgt / fge = the filtered candidates that score above / at least the true entity (one wave per query, exact
+// Scorer<> arithmetic).  Without a filter the last two equal the first two.
+hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
+                                  const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+                                  const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
+                                  hipStream_t stream);
 
 // rank_all.hip: exact-path building blocks (row-major coefficients + true keys, the Q rank-count
 // accumulators `acc` zeroed on the way; CSR filter counts)
@@ -71,10 +85,6 @@ hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float
                              int64_t q_tail, const float* table, int64_t ld, const int64_t* true_row,
                              const float* q_true, float* coef_head, float* coef_tail, float* key_true,
                              unsigned long long* acc, hipStream_t stream);
-hipError_t launch_exact_filter(int model, int D, const float* table, int64_t ld, const float* coef_head,
-                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                               const int64_t* rowptr, const int64_t* col, int64_t N, unsigned long long* acc_f,
-                               hipStream_t stream);
 
 // rank_gemm.hip: bilinear models as an f32 MFMA GEMM + error band + exact refinement.
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail);
@@ -82,7 +92,7 @@ size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, in
 hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,
                                 const float* q_fixed, const float* q_rel, const int64_t* true_row,
                                 const float* q_true, int64_t q_head, int64_t q_tail,
-                                const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                                const FilterSpec& filter, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop);
 
@@ -92,7 +102,7 @@ bool rank_sad_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
-                               int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                               int64_t q_tail, const FilterSpec& filter, int32_t* counts,
                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                hipEvent_t ev_stop);
 
@@ -102,7 +112,7 @@ bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                     const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
-                                    int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col,
+                                    int64_t q_tail, const FilterSpec& filter,
                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
                                     hipEvent_t ev_start, hipEvent_t ev_stop);
 

@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
 struct GemmWorkspace {
     float* coef_head; float* coef_tail; float* key_true; float* eps_q;
     float4* img_head; float4* img_tail;
-    unsigned long long* acc; unsigned long long* acc_f; unsigned* flags; uint2* pairs;
+    unsigned long long* acc; unsigned* flags; uint2* pairs;
     int64_t pass_ctiles;  // candidate tiles per GEMM + refine pass
     size_t bytes;
 };
@@ -810,7 +810,6 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     w.img_head = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_head + kGQT - 1) / kGQT) * tile_bytes, 256);
     w.img_tail = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_tail + kGQT - 1) / kGQT) * tile_bytes, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
-    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
     w.pass_ctiles = tiles_per_pass(N, q_head, q_tail);
     w.flags = reinterpret_cast<unsigned*>(p + off);
     off = align_up(off + (size_t)Q * (size_t)(w.pass_ctiles / 16) * 4, 256);
@@ -832,7 +831,7 @@ size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, in
 template <int MODEL, int D>
 static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
                                  const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
-                                 const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts, void* workspace,
+                                 const FilterSpec& filter, int32_t* counts, void* workspace,
                                  hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
     GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
@@ -897,27 +896,22 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-    const bool filtered = filt_rowptr != nullptr;
-    if (filtered) {
-        err = launch_exact_filter(MODEL, D, table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
-                                  filt_rowptr, filt_col, N, w.acc_f, stream);
-        if (err != hipSuccess) return err;
-    }
-    err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);
+    err = launch_filter_finalize(MODEL, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filter,
+                                 w.acc, counts, stream);
     return err != hipSuccess ? err : hipGetLastError();
 }
 
 hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,
                                 const float* q_fixed, const float* q_rel, const int64_t* true_row,
                                 const float* q_true, int64_t q_head, int64_t q_tail,
-                                const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                                const FilterSpec& filter, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop) {
     (void)n_cu;
 #define BLP_GEMM_CASE(M, DD)                                                                                    \
     if (model == M && D == DD)                                                                                  \
-        return rank_gemm_impl<M, DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr, \
-                                     filt_col, counts, workspace, stream, ev_start, ev_stop);
+        return rank_gemm_impl<M, DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter, \
+                                     counts, workspace, stream, ev_start, ev_stop);
     BLP_GEMM_CASE(DISTMULT, 128) BLP_GEMM_CASE(DISTMULT, 64)
     BLP_GEMM_CASE(COMPLEX, 128) BLP_GEMM_CASE(COMPLEX, 64)
     BLP_GEMM_CASE(SIMPLE, 128) BLP_GEMM_CASE(SIMPLE, 64)

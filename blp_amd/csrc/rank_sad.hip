@@ -411,7 +411,7 @@ static constexpr int sad_tiles_per_wave(int D) { return D <= 64 ? 2 : 1; }
 
 struct SadWorkspace {
     float* coef_head; float* coef_tail; float* key_true;
-    unsigned long long* acc; unsigned long long* acc_f;
+    unsigned long long* acc;
     SadParams* params; SadParams* partial; int2* thr; unsigned* qimg; uint4* cimg; unsigned* resid; unsigned* flags;
     uint2* pairs;
     int64_t pass_groups;  // candidate groups (kSW * TPW tiles) per pre-pass + refine pass
@@ -469,7 +469,6 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * 2 * D * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
-    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
     w.params = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams), 256);
     w.partial = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams) * kSRangeBlocks, 256);
     w.thr = reinterpret_cast<int2*>(p + off);         off = align_up(off + (size_t)Q * 8, 256);
@@ -503,7 +502,7 @@ size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
 template <int D>
 static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
                                 const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
-                                const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts, void* workspace,
+                                const FilterSpec& filter, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     constexpr int TPW = sad_tiles_per_wave(D);
     const int64_t Q = q_head + q_tail;
@@ -556,25 +555,20 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-    const bool filtered = filt_rowptr != nullptr;
-    if (filtered) {
-        err = launch_exact_filter(TRANSE, D, table, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
-                                  filt_rowptr, filt_col, N, w.acc_f, stream);
-        if (err != hipSuccess) return err;
-    }
-    err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);
+    err = launch_filter_finalize(TRANSE, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filter,
+                                 w.acc, counts, stream);
     return err != hipSuccess ? err : hipGetLastError();
 }
 
 hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
-                               int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
+                               int64_t q_tail, const FilterSpec& filter, int32_t* counts,
                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                hipEvent_t ev_stop) {
 #define BLP_SAD_CASE(DD)                                                                                          \
     if (D == DD)                                                                                                  \
-        return rank_sad_impl<DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filt_rowptr,     \
-                                 filt_col, counts, workspace, n_cu, stream, ev_start, ev_stop);
+        return rank_sad_impl<DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,          \
+                                 counts, workspace, n_cu, stream, ev_start, ev_stop);
     BLP_SAD_CASE(64) BLP_SAD_CASE(128) BLP_SAD_CASE(256)
 #undef BLP_SAD_CASE
     return hipErrorInvalidValue;

@@ -393,38 +393,45 @@ __global__ __launch_bounds__(256) void wide_refine_tiles_kernel(const float* __r
     }
 }
 
-// CSR filter: one wave per query counts the listed rows that score above / at least the true entity.
-__global__ __launch_bounds__(256) void wide_filter_kernel(const float* __restrict__ table, int64_t ld, int D,
-                                                          const float* __restrict__ q_fixed,
-                                                          const float* __restrict__ q_rel,
-                                                          const float* __restrict__ key_true, int64_t q_head, int64_t Q,
-                                                          const int64_t* __restrict__ rowptr,
-                                                          const int64_t* __restrict__ col, int64_t N,
-                                                          unsigned long long* __restrict__ acc_f) {
+// Last kernel of a call (as rank_all.hip's filter_finalize_kernel, run-time width): one wave per query scores
+// the rows its filter entries remove and writes the query's four counts.
+__global__ __launch_bounds__(256) void wide_filter_finalize_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
+                                                                   int D, const float* __restrict__ q_fixed,
+                                                                   const float* __restrict__ q_rel,
+                                                                   const float* __restrict__ key_true, int64_t q_head,
+                                                                   int64_t Q, const FilterSpec filter,
+                                                                   const unsigned long long* __restrict__ acc,
+                                                                   int32_t* __restrict__ counts) {
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
     const int lane = threadIdx.x & 63;
     const float kt = key_true[q];
     unsigned gt = 0, ge = 0;
-    for (int64_t i = rowptr[q] + lane; i < rowptr[q + 1]; i += 64) {
-        const int64_t row = col[i];
-        if ((uint64_t)row >= (uint64_t)N) continue;  // not a row of this table (another candidate shard's)
-        const float key = transe_key_rt(table + row * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
-        gt += key > kt;
-        ge += key >= kt;
-    }
+    if (filter.on()) {
+        for (int64_t i = filter.lo[q] + lane; i < filter.hi[q]; i += 64) {
+            const int64_t row = filter_row(filter, q, i, N);
+            if (row < 0) continue;
+            const float key = transe_key_rt(table + row * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+            gt += key > kt;
+            ge += key >= kt;
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        gt += __shfl_down(gt, off);
-        ge += __shfl_down(ge, off);
+        for (int off = 32; off > 0; off >>= 1) {
+            gt += __shfl_down(gt, off);
+            ge += __shfl_down(ge, off);
+        }
     }
-    if (lane == 0) acc_f[q] = (unsigned long long)gt | ((unsigned long long)ge << 32);
+    if (lane == 0) {
+        const unsigned long long a = acc[q];
+        const int32_t all_gt = (int32_t)(a & 0xffffffffull), all_ge = (int32_t)(a >> 32);
+        reinterpret_cast<int4*>(counts)[q] = make_int4(all_gt, all_ge, all_gt - (int32_t)gt, all_ge - (int32_t)ge);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 struct WideWorkspace {
     float* key_true;
-    unsigned long long* acc; unsigned long long* acc_f;
+    unsigned long long* acc;
     SadParams* params; SadParams* partial; int2* thr; unsigned* qimg; uint4* cimg; unsigned* resid; unsigned* flags;
     uint2* pairs;
     int64_t pass_groups;
@@ -454,7 +461,6 @@ static WideWorkspace carve_wide(void* base, int D, int64_t N, int64_t Q) {
     size_t off = 0;
     w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
-    w.acc_f = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)Q * 8, 256);
     w.params = reinterpret_cast<SadParams*>(p + off);  off = align_up(off + sizeof(SadParams), 256);
     w.partial = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams) * kSRangeBlocks, 256);
     w.thr = reinterpret_cast<int2*>(p + off);          off = align_up(off + (size_t)Q * 8, 256);
@@ -484,7 +490,7 @@ size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head
 
 hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                     const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
-                                    int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col,
+                                    int64_t q_tail, const FilterSpec& filter,
                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
                                     hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
@@ -533,12 +539,9 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
             slab, n_rows, ld, D, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-    const bool filtered = filt_rowptr != nullptr;
-    if (filtered)
-        wide_filter_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, w.key_true, q_head, Q,
-                                                                              filt_rowptr, filt_col, N, w.acc_f);
-    err = launch_finalize_counts(w.acc, filtered ? w.acc_f : nullptr, Q, counts, stream);
-    return err != hipSuccess ? err : hipGetLastError();
+    wide_filter_finalize_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, N, ld, D, q_fixed, q_rel, w.key_true,
+                                                                                  q_head, Q, filter, w.acc, counts);
+    return hipGetLastError();
 }
 
 }  // namespace blp

@@ -12,9 +12,56 @@
 
 namespace blp {
 
-// torch.sum(dim=-1) order, runtime n (n % 32 == 0, 32 <= n < 512); literal "0 + x" first adds.
+// torch.sum(dim=-1) order at ANY width n (ATen SumKernel.cpp: vectorized_inner_sum -> row_sum -> multi_row_sum;
+// restated in oracle/blp_oracle.c: blp_oracle_torch_inner_sum): rows of 4 vectors x 8 lanes accumulate into
+// acc[0]; every level_step rows the partial cascades one level up (four levels); then the leftover whole vectors
+// go to the first accumulator vector, the four vectors fold into one, the scalar tail (n % 8 elements) is added
+// FIRST and the eight lanes left to right.  Slow (the accumulators live in scratch memory) and rare: the widths
+// the reference's scripts use for the bilinear models (128) take the register version below.
+template <class Term>
+__device__ __noinline__ float torch_inner_sum_any(int n, Term term) {
+    const int vec_size = n / 8, size_ilp = vec_size / 4;
+    int log2_rows = 1;  // ceil(log2(size_ilp)), 1 for size_ilp <= 2 (utils::CeilLog2)
+    if (size_ilp > 2) {
+        log2_rows = 0;
+        for (int v = size_ilp - 1; v > 0; v >>= 1) ++log2_rows;
+    }
+    const int level_power = log2_rows / 4 > 4 ? log2_rows / 4 : 4;
+    const int level_step = 1 << level_power, level_mask = level_step - 1;
+    float acc[4][32];
+    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 32; ++e) acc[j][e] = 0.0f;
+    int i = 0;
+    while (i + level_step <= size_ilp) {
+        for (int j = 0; j < level_step; ++j, ++i)
+            for (int e = 0; e < 32; ++e) acc[0][e] = acc[0][e] + term(i * 32 + e);
+        for (int j = 1; j < 4; ++j) {
+            for (int e = 0; e < 32; ++e) {
+                acc[j][e] = acc[j][e] + acc[j - 1][e];
+                acc[j - 1][e] = 0.0f;
+            }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < size_ilp; ++i)
+        for (int e = 0; e < 32; ++e) acc[0][e] = acc[0][e] + term(i * 32 + e);
+    for (int j = 1; j < 4; ++j)
+        for (int e = 0; e < 32; ++e) acc[0][e] = acc[0][e] + acc[j][e];
+    for (int v = size_ilp * 4; v < vec_size; ++v)
+        for (int l = 0; l < 8; ++l) acc[0][l] = acc[0][l] + term(v * 8 + l);
+    for (int k = 1; k < 4; ++k)
+        for (int l = 0; l < 8; ++l) acc[0][l] = acc[0][l] + acc[0][8 * k + l];
+    float s = 0.0f;
+    for (int k = vec_size * 8; k < n; ++k) s = s + term(k);
+    for (int l = 0; l < 8; ++l) s = s + acc[0][l];
+    return s;
+}
+
+// The same order for n % 32 == 0, 32 <= n < 512 (no cascade level is reached, no leftovers): 32 register
+// accumulators; literal "0 + x" first adds.  Other widths go to torch_inner_sum_any.
 template <class Term>
 __device__ __forceinline__ float torch_inner_sum_rt(int n, Term term) {
+    if (n % 32 != 0 || n >= 512 || n < 32) return torch_inner_sum_any(n, term);
     float A[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) A[i] = 0.0f + term(i);

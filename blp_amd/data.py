@@ -137,6 +137,15 @@ class GraphDataset(Dataset):
         self.maps_path = maps_path
         self.neg_samples = neg_samples
         self.num_devices = num_devices
+        self.sampler_device = None  # a HIP device: draw neg_idx there (train.py `device_sampler=True`)
+
+    def _neg_idx(self, batch_size, repeats):
+        """In-batch negative indices (B * repeats, K, 2): the reference's CPU sampler, or -- with sampler_device
+        set -- the same law drawn on the GPU, one independent draw per device slice (indices local to the slice)."""
+        if self.sampler_device is None:
+            return get_negative_sampling_indices(batch_size, self.neg_samples, repeats=repeats)
+        return torch.cat([get_negative_sampling_indices_on_device(batch_size, self.neg_samples, self.sampler_device)
+                          for _ in range(repeats)])
 
     def __getitem__(self, index):
         return self.triples[index]
@@ -147,7 +156,7 @@ class GraphDataset(Dataset):
     def collate_fn(self, data_list):
         """Batch of triples -> (pos_pairs (B, 2), rels (B, 1), neg_idx (B, K, 2))."""
         pos_pairs, rels = torch.stack(data_list).split(2, dim=1)
-        return pos_pairs, rels, get_negative_sampling_indices(len(data_list), self.neg_samples)
+        return pos_pairs, rels, self._neg_idx(len(data_list), 1)
 
 
 class TextGraphDataset(GraphDataset):
@@ -211,7 +220,7 @@ class TextGraphDataset(GraphDataset):
             raise ValueError("collate_text can only work with batch sizes larger than 1.")
         pos_pairs, rels = torch.stack(data_list).split(2, dim=1)
         text_tok, text_mask, _ = self.get_entity_description(pos_pairs)
-        neg_idx = get_negative_sampling_indices(batch_size, self.neg_samples, repeats=self.num_devices)
+        neg_idx = self._neg_idx(batch_size, self.num_devices)
         return text_tok, text_mask, rels, neg_idx
 
 

@@ -9,6 +9,7 @@ device memory and the stream; every arithmetic step of the hot path runs in the 
 Tensors must live on a HIP device; there is no CPU implementation behind these functions (CPU
 tensors are handled one level up, in blp_amd.models, with plain torch expressions).
 """
+import collections
 import ctypes
 
 import torch
@@ -42,6 +43,13 @@ def _f32_rows(t, name):
     return t
 
 
+# The filtered setting as segments of a sorted index of the filtering graph (include/blp_hip.h: blp_filter;
+# built by blp_amd.utils.FilterIndex.segments): seg_lo, seg_hi (Q,) int64 slices of `values` (entity ids),
+# exclude (Q,) the triple's own entity, ent2idx the id -> table row map (None: values are rows), row_base the
+# first global row of a candidate shard.  Everything stays on the device; nothing is materialised per batch.
+SegmentFilter = collections.namedtuple("SegmentFilter", "seg_lo seg_hi values exclude ent2idx row_base")
+
+
 def dim_supported(rel_model, dim):
     """True if the fused ranking kernels are compiled for this embedding width."""
     return bool(_lib.lib().blp_dim_supported(_lib.MODEL_IDS[rel_model], int(dim)))
@@ -54,13 +62,14 @@ def rank_all_supported(rel_model, dim, q_head, q_tail):
 
 
 def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
-             filt_rowptr=None, filt_col=None, out=None, rel_ids=None):
+             filt_rowptr=None, filt_col=None, out=None, rel_ids=None, filter=None):
     """Rank-count every query against every row of ``table`` in one pass over the table.
 
     table (N, D) f32; q_fixed, q_rel (Q, D) f32; queries [0, q_head) replace the head (q_fixed is the
     tail embedding), queries [q_head, Q) replace the tail (q_fixed is the head embedding).
     true_row (Q,) int64 rows of the true entities in ``table``  -- or -- q_true (Q, D) their vectors
-    (sharded ranking).  filt_rowptr (Q+1,), filt_col (nnz,) int64: CSR of filtered rows per query.
+    (sharded ranking).  filt_rowptr (Q+1,), filt_col (nnz,) int64: CSR of filtered rows per query -- or --
+    filter: a SegmentFilter (slices of a FilterIndex on the device; no per-batch list).
     rel_ids (Q,) int64, optional: the relation id of each query (equal id => identical q_rel row); a
     performance hint for TransE (sort the block by relation to benefit), never changes a result.
     Returns counts (Q, 4) int32: gt, ge, gt_filtered, ge_filtered.
@@ -93,6 +102,8 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
             raise ValueError("rel_ids must have one entry per query")
     if (filt_rowptr is None) != (filt_col is None):
         raise ValueError("filt_rowptr and filt_col go together")
+    if filter is not None and filt_rowptr is not None:
+        raise ValueError("give the filter as a CSR or as a SegmentFilter, not both")
     if filt_rowptr is not None:
         filt_rowptr = filt_rowptr.to(torch.int64).contiguous()
         filt_col = filt_col.to(torch.int64).contiguous()
@@ -110,10 +121,22 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     model = _lib.MODEL_IDS[rel_model]
     ws_bytes = L.blp_rank_all_workspace_bytes(model, N, D, q_head, Q - q_head)
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    status = L.blp_rank_all(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
-                            _ptr(q_rel), _ptr(rel_ids), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
-                            _ptr(filt_rowptr), _ptr(filt_col), _ptr(counts), _ptr(workspace), ws_bytes,
-                            dev.index, _stream(dev))
+    if filter is not None:
+        seg = [None if x is None else x.to(device=dev, dtype=torch.int64).contiguous()
+               for x in (filter.seg_lo, filter.seg_hi, filter.values, filter.exclude, filter.ent2idx)]
+        if seg[0].shape[0] != Q or seg[1].shape[0] != Q or (seg[3] is not None and seg[3].shape[0] != Q):
+            raise ValueError("SegmentFilter: seg_lo, seg_hi and exclude need one entry per query")
+        spec = _lib.BlpFilter(seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr() if seg[2].numel() else seg[0].data_ptr(),
+                              None if seg[3] is None else seg[3].data_ptr(), None if seg[4] is None else seg[4].data_ptr(),
+                              0 if seg[4] is None else seg[4].shape[0], int(filter.row_base))
+        status = L.blp_rank_all_ex(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
+                                   _ptr(q_rel), _ptr(rel_ids), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
+                                   ctypes.byref(spec), _ptr(counts), _ptr(workspace), ws_bytes, dev.index, _stream(dev))
+    else:
+        status = L.blp_rank_all(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
+                                _ptr(q_rel), _ptr(rel_ids), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
+                                _ptr(filt_rowptr), _ptr(filt_col), _ptr(counts), _ptr(workspace), ws_bytes,
+                                dev.index, _stream(dev))
     _lib.check(status, "blp_rank_all")
     return counts
 

@@ -59,11 +59,21 @@ def _rank_block_dense(score_fn, table, q_fixed, q_rel, q_head, true_scores_from,
     return counts
 
 
+def fused_ranking_takes(model, table, num_queries):
+    """True if a block of ``num_queries`` (half per side) against ``table`` goes through blp_rank_all (which takes
+    the filter as device-side segments); otherwise the block takes a dense route that wants a CSR."""
+    half = num_queries // 2
+    return table.is_cuda and ops.rank_all_supported(model.rel_model, table.shape[1], half, num_queries - half)
+
+
 def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None, filt_rowptr=None, filt_col=None,
-               rel_ids=None):
+               rel_ids=None, filter=None):
     """Counts (Q, 4) int32 {gt, ge, gt_filtered, ge_filtered} for a block of queries against ``table``.
-    Queries [0, q_head) replace the head, the rest replace the tail (train.py:149 order)."""
+    Queries [0, q_head) replace the head, the rest replace the tail (train.py:149 order).  The filter is a CSR
+    (filt_rowptr, filt_col) or, on a HIP device, an ops.SegmentFilter (``filter``)."""
     if table.is_cuda and not ops.rank_all_supported(model.rel_model, table.shape[1], q_head, q_fixed.shape[0] - q_head):
+        if filter is not None:
+            raise ValueError("the dense any-width route takes the filter as a CSR (utils.FilterIndex.csr)")
         return _rank_block_generic_width(model, table, q_fixed, q_rel, q_head, true_row, q_true, filt_rowptr, filt_col)
     if table.is_cuda:
         dev = table.device
@@ -72,7 +82,9 @@ def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
                             q_true=q_true,
                             filt_rowptr=None if filt_rowptr is None else filt_rowptr.to(dev),
                             filt_col=None if filt_col is None else filt_col.to(dev),
-                            rel_ids=None if rel_ids is None else rel_ids.to(dev))
+                            rel_ids=None if rel_ids is None else rel_ids.to(dev), filter=filter)
+    if filter is not None:
+        raise ValueError("SegmentFilter is the HIP path's filter form; CPU tensors take a CSR")
     source = ("row", true_row) if true_row is not None else ("vec", q_true)
     return _rank_block_dense(model.score_fn, table, q_fixed, q_rel, q_head, source, filt_rowptr, filt_col)
 
@@ -178,19 +190,25 @@ class ShardedRanker:
     def gather_rows(self, rows):
         """Vectors of the given global table rows on every rank: owners fill, one all-reduce (adding
         exact zeros) replicates.  Called once per evaluation for the entities of the test triples."""
-        rows = rows.to(torch.long)
+        rows = rows.to(device=self.table.device, dtype=torch.long)
         out = torch.zeros((rows.shape[0], self.table.shape[1]), dtype=self.table.dtype, device=self.table.device)
-        mine = (rows >= self.lo) & (rows < self.hi)
-        if mine.any():
-            out[mine.to(out.device)] = self.table[(rows[mine] - self.lo).to(self.table.device)]
+        if self.hi > self.lo:  # no host decision on the data: rows of other shards read row 0 and are zeroed
+            mine = (rows >= self.lo) & (rows < self.hi)
+            local = torch.where(mine, rows - self.lo, torch.zeros_like(rows))
+            out = torch.where(mine.unsqueeze(1), self.table[local], out)
         if self.world > 1:
             dist.all_reduce(out, group=self.group)
         return out
 
-    def rank_block(self, q_fixed, q_rel, q_true, q_head, filt_rowptr=None, filt_col=None, rel_ids=None):
+    def rank_block(self, q_fixed, q_rel, q_true, q_head, filt_rowptr=None, filt_col=None, rel_ids=None, filter=None):
         """Local counts of one query block against this rank's shard (queued for the final exchange).
-        filt_col are GLOBAL table rows; only the ones this shard owns are kept."""
-        if filt_rowptr is not None:
+        filt_col are GLOBAL table rows; only the ones this shard owns are kept (a SegmentFilter carries this
+        shard's first row as row_base and the kernel skips the rows of other shards)."""
+        if filter is not None:
+            filter = filter._replace(row_base=self.lo)
+        if filt_rowptr is not None and self.table.is_cuda:  # global rows minus this shard's first row; others are skipped
+            filt_col = filt_col.to(self.table.device) - self.lo
+        elif filt_rowptr is not None:
             owned = (filt_col >= self.lo) & (filt_col < self.hi)
             per_row = torch.zeros(filt_rowptr.shape[0] - 1, dtype=torch.long)
             rows = torch.repeat_interleave(torch.arange(per_row.shape[0]), filt_rowptr[1:] - filt_rowptr[:-1])
@@ -198,7 +216,7 @@ class ShardedRanker:
             filt_rowptr = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(per_row, 0)))
             filt_col = filt_col[owned] - self.lo
         counts = rank_block(self.model, self.table, q_fixed, q_rel, q_head, q_true=q_true,
-                            filt_rowptr=filt_rowptr, filt_col=filt_col, rel_ids=rel_ids)
+                            filt_rowptr=filt_rowptr, filt_col=filt_col, rel_ids=rel_ids, filter=filter)
         self._blocks.append(counts)
         return counts
 
@@ -270,10 +288,16 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
 @torch.no_grad()
 def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, emb_batch_size, _run, _log,
                          prefix="", max_num_batches=None, filtering_graph=None, new_entities=None,
-                         return_embeddings=False, device=None, group=None, block_size=65536, shard_axis="auto"):
+                         return_embeddings=False, device=None, group=None, block_size=65536, shard_axis="auto",
+                         eval_mode=True):
     """Drop-in for train.eval_link_prediction (same positional arguments, metric names and return
     value).  ``device`` defaults to the model's device; ``group`` (or an initialised default process
-    group) shards the evaluation, along ``shard_axis`` = "candidate" | "query" | "auto"."""
+    group) shards the evaluation, along ``shard_axis`` = "candidate" | "query" | "auto".
+
+    One deliberate deviation: the reference never leaves train mode (train.py:57-121 has no model.eval()), so its
+    entity table is built with BERT's dropout active and its metrics are not reproducible run to run.  Here the
+    encoder is put in eval mode for the table build and restored afterwards; ``eval_mode=False`` keeps whatever
+    mode the model is in, i.e. the reference's behaviour."""
     model = _module(model)
     if device is None:
         device = next(model.parameters()).device
@@ -300,17 +324,23 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     rank = dist.get_rank(group) if sharded else 0
     lo, hi = shard_bounds(num_entities, world, rank)
     was_training = model.training
-    model.eval()
+    if eval_mode:
+        model.eval()
     table = build_entity_table(model, text_dataset, entities, emb_batch_size, device, _log, rows=(lo, hi))
 
-    triples = _loader_triples(triples_loader, max_num_batches)  # in loader order (train.py:128-131)
+    # Everything from here to the final reduction runs on `device` without a host round trip: the triples and
+    # the id -> row map go over once, the relation sort, the id lookups (train.py:134-135), the query gathers and
+    # the filter segments are device work, and the reference's assertion on the ids (train.py:137-138) is checked
+    # after the last launch together with the metrics.
+    triples = _loader_triples(triples_loader, max_num_batches).to(device)  # in loader order (train.py:128-131)
+    ent2idx_dev = ent2idx.to(device)
     # The metrics are sums over triples, so the evaluation order is free: group by relation, which lets
     # the TransE kernel share e + r among the head-replacing queries of a relation.
     triples = triples[torch.argsort(triples[:, 2], stable=True)]
-    heads = ent2idx[triples[:, 0]]
-    tails = ent2idx[triples[:, 1]]
-    assert triples.shape[0] == 0 or (heads.min() >= 0 and tails.min() >= 0)
+    heads = ent2idx_dev[triples[:, 0]]
+    tails = ent2idx_dev[triples[:, 1]]
     num_triples = triples.shape[0]
+    ids_ok = torch.minimum(heads.min(), tails.min()) >= 0 if num_triples else None
     _log.info("Computing metrics on set of triples")
 
     axis = shard_axis if shard_axis != "auto" else choose_shard_axis(num_entities, table.shape[1], 2 * num_triples, world)
@@ -332,19 +362,23 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     for start in range(t_lo, t_hi, block_size):
         sl = slice(start, min(start + block_size, t_hi))
         b = sl.stop - sl.start
-        rel_vecs = model.rel_emb(triples[sl, 2].to(device))
+        rel_vecs = model.rel_emb(triples[sl, 2])
         rel_ids = torch.cat((triples[sl, 2], triples[sl, 2]))
-        filt = index.csr(triples[sl], ent2idx, device if not sharded else "cpu") if compute_filtered else (None, None)
+        filt = {}
+        if compute_filtered and fused_ranking_takes(model, table, 2 * b):  # slices of the sorted index, no list
+            filt = dict(filter=index.segments(triples[sl], ent2idx_dev, device))
+        elif compute_filtered:
+            rowptr, col = index.csr(triples[sl], ent2idx_dev, device)
+            filt = dict(filt_rowptr=rowptr, filt_col=col)
         if sharded:
-            h_vec, t_vec = vectors[head_pos[sl].to(device)], vectors[tail_pos[sl].to(device)]
+            h_vec, t_vec = vectors[head_pos[sl]], vectors[tail_pos[sl]]
             ranker.rank_block(torch.cat((t_vec, h_vec)), torch.cat((rel_vecs, rel_vecs)), torch.cat((h_vec, t_vec)),
-                              b, filt[0], filt[1], rel_ids=rel_ids)
+                              b, rel_ids=rel_ids, **filt)
         else:
-            h_rows, t_rows = heads[sl].to(device), tails[sl].to(device)
+            h_rows, t_rows = heads[sl], tails[sl]
             counts_blocks.append(rank_block(model, table, torch.cat((table[t_rows], table[h_rows])),
-                                            torch.cat((rel_vecs, rel_vecs)), b,
-                                            true_row=torch.cat((heads[sl], tails[sl])).to(device),
-                                            filt_rowptr=filt[0], filt_col=filt[1], rel_ids=rel_ids))
+                                            torch.cat((rel_vecs, rel_vecs)), b, true_row=torch.cat((h_rows, t_rows)),
+                                            rel_ids=rel_ids, **filt))
     if sharded:
         block_counts = ranker.finish()  # ONE all-gather for the whole evaluation
         counts_blocks, offset = [], 0
@@ -368,6 +402,7 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     denom = max(num_predictions, 1)
     sums = rr.double().sum(dim=0).tolist() if num_predictions else [0.0, 0.0]
     hit_sums = hits.double().sum(dim=0).tolist() if num_predictions else [[0.0] * 3, [0.0] * 3]
+    assert ids_ok is None or bool(ids_ok), "a test triple names an entity that is not among the candidates"
     mrr, mrr_filt = sums[0] / denom, (sums[1] / denom if compute_filtered else 0.0)
 
     log_str = f"{prefix} mrr: {mrr:.4f}  "
@@ -408,7 +443,7 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
                 log_str += f"{cat}_mrr: {by_cat[i, cat_id]:.4f}  "
             _log.info(log_str)
 
-    if was_training:
+    if was_training and eval_mode:
         model.train()
     if return_embeddings:
         if sharded and world > 1:  # the full table only on request: all-gather of the shards

@@ -65,7 +65,10 @@ class FilterIndex:
         edges = edges.to(torch.long).cpu()
         self.num_edges = edges.shape[0]
         self.max_node = int(edges[:, :2].max()) if self.num_edges else -1
-        self.R = int(num_relations) if num_relations is not None else (int(edges[:, 2].max()) + 1 if self.num_edges else 1)
+        seen = int(edges[:, 2].max()) + 1 if self.num_edges else 1
+        # keys pack (entity, relation) as entity * R + relation; a queried relation >= R (one the graph never
+        # saw, e.g. Wikidata5M's per-split graphs) matches nothing instead of aliasing onto another key
+        self.R = max(int(num_relations), seen) if num_relations is not None else seen
         h, t, r = edges[:, 0], edges[:, 1], edges[:, 2]
         self.tails_key, self.tails_val = self._build(h * self.R + r, t)   # (h, r) -> tails
         self.heads_key, self.heads_val = self._build(t * self.R + r, h)   # (t, r) -> heads
@@ -101,6 +104,34 @@ class FilterIndex:
         counts = torch.bincount(owner, minlength=key.shape[0])
         return counts, mapped
 
+    def _keys(self, triples):
+        """Packed lookup keys of a batch: (tail, rel) for the head side, (head, rel) for the tail side; -1 (which no
+        edge has) for relations outside the index."""
+        h, t, r = triples[:, 0], triples[:, 1], triples[:, 2]
+        known = (r >= 0) & (r < self.R)
+        return torch.where(known, t * self.R + r, -1), torch.where(known, h * self.R + r, -1)
+
+    def segments(self, triples, ent2idx, device, row_base=0):
+        """The filter of a batch as a blp_amd.ops.SegmentFilter over 2B queries in the ranking order (B head-
+        replacing, then B tail-replacing): four binary searches on the device, no list is built and the host
+        never waits.  ``ent2idx`` should already live on ``device`` (it is moved if not)."""
+        from .ops import SegmentFilter
+        cache = self.__dict__.setdefault("_segment_cache", {})
+        device = torch.device(device)
+        if device not in cache:
+            heads_key, heads_val, tails_key, tails_val = self._on(device)
+            cache[device] = (heads_key.contiguous(), tails_key.contiguous(), torch.cat((heads_val, tails_val)).contiguous(),
+                             heads_val.shape[0])
+        heads_key, tails_key, values, n_head_vals = cache[device]
+        triples = triples.to(device=device, dtype=torch.long)
+        key_head, key_tail = self._keys(triples)
+        lo = torch.cat((torch.searchsorted(heads_key, key_head, right=False),
+                        torch.searchsorted(tails_key, key_tail, right=False) + n_head_vals))
+        hi = torch.cat((torch.searchsorted(heads_key, key_head, right=True),
+                        torch.searchsorted(tails_key, key_tail, right=True) + n_head_vals))
+        exclude = torch.cat((triples[:, 0], triples[:, 1]))
+        return SegmentFilter(lo, hi, values, exclude, ent2idx.to(device), row_base)
+
     def _on(self, device):
         """The four sorted arrays on ``device`` (moved once, cached)."""
         device = torch.device(device)
@@ -118,9 +149,10 @@ class FilterIndex:
         heads_key, heads_val, tails_key, tails_val = self._on(device)
         triples = triples.to(device=device, dtype=torch.long)
         ent2idx = ent2idx.to(device)
-        h, t, r = triples[:, 0], triples[:, 1], triples[:, 2]
-        n_head, col_head = self._lookup(heads_key, heads_val, t * self.R + r, h, ent2idx)
-        n_tail, col_tail = self._lookup(tails_key, tails_val, h * self.R + r, t, ent2idx)
+        h, t = triples[:, 0], triples[:, 1]
+        key_head, key_tail = self._keys(triples)
+        n_head, col_head = self._lookup(heads_key, heads_val, key_head, h, ent2idx)
+        n_tail, col_tail = self._lookup(tails_key, tails_val, key_tail, t, ent2idx)
         rowptr = torch.zeros(2 * triples.shape[0] + 1, dtype=torch.long, device=triples.device)
         rowptr[1:] = torch.cumsum(torch.cat((n_head, n_tail)), 0)
         return rowptr, torch.cat((col_head, col_tail))
@@ -166,18 +198,19 @@ def get_metrics(pred_scores, true_idx, k_values):
 
 
 def split_by_new_position(triples, mrr_values, new_entities):
-    """MRR broken down by where the new (unseen-in-training) entity sits: both / head / tail.
-    mrr_values has 2B entries (head-replacing first); a triple's value is the mean of its two."""
+    """MRR broken down by where the new (unseen-in-training) entity sits: both / head / tail (utils.py:114-148).
+    mrr_values has 2B entries (head-replacing first); a triple's value is the mean of its two.  Runs on the
+    device of ``mrr_values`` (one masked sum instead of a Python loop with two .item() calls per triple)."""
     num_triples = triples.shape[0]
-    values = mrr_values.detach().to("cpu", torch.float64).reshape(-1)
+    dev = mrr_values.device
+    values = mrr_values.detach().to(torch.float64).reshape(-1)
     per_triple = (values[:num_triples] + values[num_triples:2 * num_triples]) / 2.0
-    new = torch.tensor(sorted(new_entities), dtype=torch.long) if len(new_entities) else torch.empty(0, dtype=torch.long)
-    head_new = torch.isin(triples[:, 0].cpu(), new)
-    tail_new = torch.isin(triples[:, 1].cpu(), new)
-    groups = (head_new & tail_new, head_new & ~tail_new, ~head_new & tail_new)
-    sums = torch.tensor([float(per_triple[g].sum()) for g in groups], dtype=torch.float)
-    counts = torch.tensor([float(g.sum()) for g in groups], dtype=torch.float)
-    return sums.to(mrr_values.device), counts.to(mrr_values.device)
+    new = torch.tensor(sorted(new_entities), dtype=torch.long, device=dev)
+    triples = triples.to(dev)
+    head_new = torch.isin(triples[:, 0], new)
+    tail_new = torch.isin(triples[:, 1], new)
+    groups = torch.stack((head_new & tail_new, head_new & ~tail_new, ~head_new & tail_new)).to(torch.float64)
+    return (groups @ per_triple).float(), groups.sum(dim=1).float()
 
 
 def split_by_category(triples, mrr_values, rel_categories):

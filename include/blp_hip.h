@@ -116,6 +116,33 @@ int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
                  const int64_t *filt_rowptr, const int64_t *filt_col, int32_t *counts,
                  void *workspace, size_t workspace_bytes, int device, void *stream);
 
+/* The same call with the filter given as SEGMENTS of a sorted index of the filtering graph, so that
+ * utils.get_triple_filters (utils.py:46-83: a Python walk over a networkx graph per batch, then a dense
+ * (2B, N) mask copied to the device) needs no per-batch list at all:
+ *   the graph's edges are sorted once by key (head, rel) with value tail -- and by (tail, rel) with value
+ *   head -- into one `values` array of ENTITY IDS (blp_amd.utils.FilterIndex); for query q the caller
+ *   binary-searches the key of its triple and passes the slice [seg_lo[q], seg_hi[q]) of `values`;
+ *   exclude[q] is the triple's own entity at the replaced position, which is never filtered (utils.py:71,78);
+ *   ent2idx (utils.make_ent2idx, utils.py:31-43) maps an entity id to its table row, -1 (or an id beyond
+ *   ent2idx_len) = not a candidate (utils.py:72,79); NULL = the values are table rows already;
+ *   row_base is subtracted from every row and rows outside [0, N) are skipped (a candidate shard).
+ * A value may occur once per segment (parallel edges collapsed when the index is built).
+ * The CSR of blp_rank_all is the special case seg_lo = rowptr, seg_hi = rowptr + 1, values = col.
+ * filter == NULL: no filtering. */
+typedef struct blp_filter {
+    const int64_t *seg_lo;   /* (Q) */
+    const int64_t *seg_hi;   /* (Q) */
+    const int64_t *values;
+    const int64_t *exclude;  /* (Q) or NULL */
+    const int64_t *ent2idx;  /* (ent2idx_len) or NULL */
+    int64_t ent2idx_len;
+    int64_t row_base;
+} blp_filter;
+int blp_rank_all_ex(int model, const float *table, int64_t N, int D, int64_t ld,
+                    const float *q_fixed, const float *q_rel, const int64_t *q_rel_id, const int64_t *true_row,
+                    const float *q_true, int64_t q_head, int64_t q_tail, const blp_filter *filter,
+                    int32_t *counts, void *workspace, size_t workspace_bytes, int device, void *stream);
+
 /* Measurement aid (bench.py): the NEXT blp_rank_all issued by the calling thread records the two
  * hipEvent_t (created by the caller with timing enabled) on its stream immediately before and after
  * the rank pass (rank_tiles, or pre-pass + refinement), so its duration can be read without a profiler.  One-shot;

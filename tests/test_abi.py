@@ -51,7 +51,9 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     rc = L.blp_rank_all(0, None, 0, 100, 100, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
     assert rc == -2
     rc = L.blp_score_fwd(1, 100, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
-    assert rc == -2
+    assert rc == -1 and b"NULL" in L.blp_last_error()  # any width is scored; the pointers are what is wrong here
+    rc = L.blp_score_fwd(2, 101, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
+    assert rc == -2 and b"halves" in L.blp_last_error()  # ComplEx / SimplE split the vector
     one = ctypes.c_void_p(16)  # non-NULL placeholders: validation fails before anything is dereferenced
     rc = L.blp_inbatch_loss_fwd_t(0, 0, 5, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, 0, None)
     assert rc == -1 and b"dtype" in L.blp_last_error()

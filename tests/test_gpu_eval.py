@@ -192,11 +192,15 @@ def test_bench_line_keeps_the_contract():
     assert r["parity_check"].endswith("identical counts")
 
 
-@pytest.mark.parametrize("rel_model,D", [("transe", 300), ("transe", 768), ("distmult", 96), ("complex", 192)])
+@pytest.mark.parametrize("rel_model,D", [("transe", 300), ("transe", 768), ("distmult", 96), ("complex", 192),
+                                         ("distmult", 100), ("complex", 200), ("simple", 300), ("distmult", 1100),
+                                         ("complex", 12)])
 def test_generic_width_route_matches_oracle(rel_model, D, oracle):
     """Widths without a fused ranking kernel (GloVe 300, BERT-embedding 768, ...): dense order-exact
     scores (blp_score_fwd) + blp_rank_from_scores, in query slabs; counts identical to the oracle, with
-    row-index and vector forms of the true entity, with a CSR filter."""
+    row-index and vector forms of the true entity, with a CSR filter.  The bilinear models at reduction widths
+    that are not a multiple of 32 (100, 150), or reach torch.sum's cascade (1100 >= 512), or are shorter than one
+    row of accumulators (6) go through the general summation routine (score_direct.h: torch_inner_sum_any)."""
     from blp_amd import models, ops, ranking
     from test_gpu_parity import oracle_counts, random_csr, random_problem
     assert not ops.dim_supported(rel_model, D)

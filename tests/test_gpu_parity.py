@@ -613,6 +613,33 @@ def test_inbatch_loss_training_shape_vs_port(ops, model, loss_fn):
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
 
 
+@pytest.mark.parametrize("model,D", [("distmult", 100), ("complex", 200), ("simple", 300), ("transe", 1000),
+                                     ("distmult", 1100)])
+def test_inbatch_loss_any_width(ops, model, D):
+    """The reference takes any `dim` (glove-bow 300, bert-bow 768, a user's 100 / 200): the fused loss does too --
+    reduction widths off the 32-grid or past torch.sum's first cascade (>= 512) and rows wider than one 768-element
+    sweep of the backward.  Same tolerances as the training-shape test."""
+    from oracle import ref_port
+    torch.manual_seed(D)
+    B, K = 16, 8
+    ent = torch.randn(B, 2, D) * (1.0 if model == "transe" else 0.4)
+    rel = torch.randn(B, 1, D) * 0.3
+    neg_idx = torch.randint(0, 2 * B, (B, K, 2))
+    e_ref, r_ref = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    ref = ref_port.compute_loss(model, "margin", e_ref, r_ref, neg_idx, 1e-2)
+    ref.backward()
+    e, r = ent.cuda().requires_grad_(True), rel.cuda().requires_grad_(True)
+    loss = ops.inbatch_loss(model, "margin", e, r, neg_idx.cuda(), 1e-2)
+    loss.backward()
+    assert loss.item() == pytest.approx(ref.item(), rel=2e-6, abs=1e-7)
+    np.testing.assert_allclose(e.grad.cpu().numpy(), e_ref.grad.numpy(), rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(r.grad.cpu().numpy(), r_ref.grad.numpy(), rtol=2e-5, atol=2e-7)
+    # and the scores themselves are the reference's bit for bit at these widths
+    pos = ops.score(model, e.detach()[:, 0], e.detach()[:, 1], r.detach()[:, 0]).cpu()
+    want = ref_port.SCORE_FNS[model](ent[:, 0], ent[:, 1], rel[:, 0])
+    assert torch.equal(pos, want)
+
+
 @pytest.mark.parametrize("model", REL_MODELS)
 @pytest.mark.parametrize("loss_fn", ["margin", "nll"])
 @pytest.mark.parametrize("dtype,rel_f32", [(torch.float16, False), (torch.float16, True), (torch.bfloat16, False),

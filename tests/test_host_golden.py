@@ -89,6 +89,54 @@ def test_filter_index_matches_reference_masks():
     assert torch.equal(hf, hf3) and torch.equal(tf, tf3)
 
 
+def expand_segments(seg, num_rows):
+    """What the kernels' filter_row (blp_amd/csrc/rank_common.h) makes of a SegmentFilter: per query the table
+    rows removed, as a dense (Q, num_rows) mask."""
+    mask = torch.zeros((seg.seg_lo.shape[0], num_rows), dtype=torch.bool)
+    for q in range(seg.seg_lo.shape[0]):
+        for v in seg.values[int(seg.seg_lo[q]):int(seg.seg_hi[q])].tolist():
+            if v == int(seg.exclude[q]):
+                continue
+            row = int(seg.ent2idx[v]) if 0 <= v < seg.ent2idx.shape[0] else -1
+            row -= seg.row_base
+            if 0 <= row < num_rows:
+                assert not mask[q, row], "a row listed twice in one segment"
+                mask[q, row] = True
+    return mask
+
+
+def test_filter_segments_match_reference_masks():
+    """FilterIndex.segments (the device-side form the HIP ranking takes) removes exactly the rows of the
+    reference's masks (utils.py:46-83), also seen from a candidate shard (row_base)."""
+    g = golden("filters_toy")
+    triples = torch.from_numpy(g["triples"])
+    index = utils.FilterIndex(torch.from_numpy(g["graph_edges"]))
+    ent2idx = torch.from_numpy(g["ent2idx"])
+    n = g["entities"].shape[0]
+    want = np.concatenate((g["heads_filter"], g["tails_filter"]))
+    seg = index.segments(triples, ent2idx, "cpu")
+    assert np.array_equal(expand_segments(seg, n).numpy(), want)
+    lo = n // 3
+    shard = expand_segments(seg._replace(row_base=lo), n - lo)
+    assert np.array_equal(shard.numpy(), want[:, lo:])
+
+
+def test_filter_index_ignores_relations_it_never_saw():
+    """Keys pack (entity, relation) as entity * R + relation with R taken from the graph: a query with a relation
+    id >= R must match nothing (it used to alias onto (entity + 1, relation - R))."""
+    edges = torch.tensor([[0, 1, 0], [0, 2, 1], [1, 2, 1], [3, 2, 0]])  # (head, tail, rel), R = 2
+    index = utils.FilterIndex(edges)
+    ent2idx = torch.arange(4)
+    triples = torch.tensor([[0, 3, 2], [2, 1, 3], [0, 3, -1]])  # relation 2 would alias onto (1, rel 0) / (4, rel 0)
+    rowptr, cols = index.csr(triples, ent2idx)
+    assert rowptr.tolist() == [0] * 7 and cols.numel() == 0
+    assert not expand_segments(index.segments(triples, ent2idx, "cpu"), 4).any()
+    known = torch.tensor([[0, 3, 1]])  # (0, rel 1) -> tail 2 is a known edge
+    assert expand_segments(index.segments(known, ent2idx, "cpu"), 4)[1].tolist() == [False, False, True, False]
+    wide = utils.FilterIndex(edges, num_relations=5)  # the dataset's count, as train.py passes it
+    assert expand_segments(wide.segments(known, ent2idx, "cpu"), 4)[1].tolist() == [False, False, True, False]
+
+
 def test_get_metrics_matches_golden():
     g = golden("scores_transe_ties_d128")
     pred = torch.from_numpy(np.concatenate((g["head_pred"], g["tail_pred"])))
