@@ -1,24 +1,38 @@
-"""bench.py -- scored triples/sec of the all-entities ranking hot path on MI355X.
+"""bench.py -- scored triples/sec of the all-entities evaluation hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full evaluation pass of the workload's query set against the entity table: every
-query is scored against every candidate and ranked (raw counts -> reciprocal rank, Hits@{1,3,10}).
-One scored triple = one (query, candidate) score evaluated and ranked.
+A "step" is ONE WHOLE EVALUATION of the workload's test triples against the entity table, exactly what
+blp_amd.ranking.eval_link_prediction runs after the table build (it is the same function,
+ranking.rank_triples): relation sort, id -> row lookups, query gathers (train.py:132-150), the filter
+of every query from the sorted index of the filtering graph (utils.py:46-83), the ranking pass -- every
+query scored against every candidate and counted, raw AND filtered (train.py:146-171) -- and the metric
+sums (utils.py:86-111, train.py:152-157).  Inputs resident in HBM when the clock starts: the entity table,
+rel_emb, the test triples, the id -> row map and the sorted filter index.  One scored triple = one
+(query, candidate) score evaluated and ranked.
 
 Workloads (synthetic data of the published shapes, seeded; BASELINE.json configs):
-  fb15k237-transe   (default; configs[1]) 14 541 x 128 table, 52 870 test triples -> 105 740 queries
+  fb15k237-transe   (default; configs[1]) 14 541 x 128 table, 52 870 test triples -> 105 740 queries,
+                    filtering graph of 310 116 edges (the test triples + Zipf(0.8)-popular random edges)
   fb15k237-distmult / -complex / -simple   (configs[2]) same shapes, un-normalised table
-  wikidata5m-transe (configs[3]) 4.6 M x 128 table (2.36 GB), reference batching: 2 triples =
-                    4 queries per table pass; a step = 64 passes
-With N > 1 the candidate axis is sharded across ranks (rows [lo, hi) per rank), the queries and the
-true entities' vectors are replicated, and the per-shard (Q, 4) int32 counts are combined by one RCCL
-all-gather per step.  Total work is fixed as N grows -> "scaling": "strong".
+  wikidata5m-transe (configs[3]) 4.6 M x 128 table (2.36 GB), reference batching: 2 triples = 4 queries per
+                    table pass (scripts/blp-transe-wikidata5m.sh:18); a step = 64 passes
+  wikidata5m-transe-block / -complex-block   the same table, the 6 894 test triples as ONE query block
+The default single-GPU run also reports fb15k237-distmult, fb15k237-complex and wikidata5m-transe-block as
+`sub_results` (each with its own roofline), and the HBM-bound operating point as `hbm_probe`.
 
-Only the cpu_baseline leg and the parity spot-check touch oracle/ (as the checker / the thing timed
-on the host); the measured GPU path goes through libblp_hip.so only.
+With N > 1 the evaluation is sharded along one axis (blp_amd.ranking.choose_shard_axis, --shard-axis):
+  "candidate" (north_star; the default for the Wikidata5M-scale table): rank r ranks every query against table
+              rows [lo, hi); one all-reduce replicates the vectors of the entities in the test triples, ONE RCCL
+              all-gather of the int32 counts + a sum per evaluation;
+  "query"     (small table, many triples -- FB15k-237): the table is replicated, rank r ranks its slice of the
+              triples, ONE all-gather of the per-triple counts.
+Total work is fixed as N grows -> "scaling": "strong".
+
+Only the cpu_baseline leg and the parity spot-check touch oracle/ (as the thing timed on the host / the
+checker); the measured GPU path goes through libblp_hip.so only.
 """
 import argparse
 import ctypes
@@ -36,36 +50,31 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-F32_PEAK_TFLOPS = 157.3         # f32 MFMA peak == f32 vector (FMA) peak; plain add/sub ops reach half
+F32_PEAK_TFLOPS = 157.3         # f32 vector (FMA) peak == f32 MFMA peak; plain add/sub ops reach half
 BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md); the bilinear pre-pass spends 3 bf16
 BF16X3_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3   # products per f32-equivalent product, so its roof is a third of it
 
 WORKLOADS = {
-    "fb15k237-transe": dict(model="transe", N=14541, D=128, R=237, triples=52870, passes=1),
-    "fb15k237-distmult": dict(model="distmult", N=14541, D=128, R=237, triples=52870, passes=1),
-    "fb15k237-complex": dict(model="complex", N=14541, D=128, R=237, triples=52870, passes=1),
-    "fb15k237-simple": dict(model="simple", N=14541, D=128, R=237, triples=52870, passes=1),
+    "fb15k237-transe": dict(model="transe", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
+    "fb15k237-distmult": dict(model="distmult", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
+    "fb15k237-complex": dict(model="complex", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
+    "fb15k237-simple": dict(model="simple", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
     # the BERT-BOW / BERT-DKRL width (models.py:118-135, 165-172): TransE at the word-embedding width 768
-    "fb15k237-transe-d768": dict(model="transe", N=14541, D=768, R=237, triples=52870, passes=1),
-    "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=2, passes=64),
+    "fb15k237-transe-d768": dict(model="transe", N=14541, D=768, R=237, triples=52870, block=65536, edges=310116),
+    # reference batching: eval_batch_size = 2 triples per table pass, 64 passes per step; the reference's
+    # Wikidata5M filtering graph is the evaluated split's own triples (train.py:381-393)
+    "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0),
     # the same table with the whole Wikidata5M test set (6 894 triples) as ONE query block
-    "wikidata5m-transe-block": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, passes=1),
-    "wikidata5m-complex-block": dict(model="complex", N=4_600_000, D=128, R=822, triples=6894, passes=1),
+    "wikidata5m-transe-block": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
+    "wikidata5m-complex-block": dict(model="complex", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
 }
-# Algorithmic f32 operations per (candidate, query, element), head-side / tail-side:
-# TransE: one subtract and one |.|-accumulate once the query-only part is hoisted (h + r | t - r per
-# query); bilinear models: the all-entities
-# score is a (Q x D) . (D x N) GEMM = 2 flops per (pair, element).
-OPS_PER_ELEM = {"transe": (2, 2), "distmult": (2, 2), "complex": (2, 2), "simple": (2, 2)}
-DOMINANT_KERNEL = {"transe": "rank_sad_kernel<128> + sad_refine_* (u16 fixed-point v_sad_u16 pre-pass + band + exact f32 refinement; prep kernels included)",
-                   "distmult": "rank_gemm_bf16_kernel<DISTMULT,128> + refine_pairs/refine (bf16 x 3 split MFMA GEMM + band + exact f32 refinement)",
-                   "complex": "rank_gemm_bf16_kernel<COMPLEX,128> + refine_pairs/refine",
-                   "simple": "rank_gemm_bf16_kernel<SIMPLE,128> + refine_pairs/refine"}
+SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe-block")
 
 
-def make_data(cfg, device, seed=1):
+def make_data(cfg, device, seed=1, sort=True):
     """Synthetic FB15k-237 / Wikidata5M-shaped inputs: table rows L2-normalised for
-    TransE (models.py:40-41), 0.1 * randn otherwise; rel_emb Xavier-uniform (models.py:28-29)."""
+    TransE (models.py:40-41), 0.1 * randn otherwise; rel_emb Xavier-uniform (models.py:28-29).  ``sort``:
+    triples grouped by relation (tools that call ops.rank_all directly); the bench step sorts by itself."""
     g = torch.Generator(device=device).manual_seed(seed)
     N, D, R, T = cfg["N"], cfg["D"], cfg["R"], cfg["triples"]
     table = torch.randn(N, D, device=device, generator=g)
@@ -75,8 +84,10 @@ def make_data(cfg, device, seed=1):
     heads = torch.randint(0, N, (T,), device=device, generator=g)
     tails = torch.randint(0, N, (T,), device=device, generator=g)
     rels = torch.randint(0, R, (T,), device=device, generator=g)
-    order = torch.argsort(rels, stable=True)  # evaluation order is free; blp_amd.ranking groups by relation too
-    return table, rel_w, heads[order], tails[order], rels[order]
+    if sort:
+        order = torch.argsort(rels, stable=True)
+        heads, tails, rels = heads[order], tails[order], rels[order]
+    return table, rel_w, heads, tails, rels
 
 
 def build_queries(table, rel_w, heads, tails, rels):
@@ -85,6 +96,22 @@ def build_queries(table, rel_w, heads, tails, rels):
     q_rel = torch.cat((rel_w[rels], rel_w[rels]))
     true_row = torch.cat((heads, tails))
     return q_fixed.contiguous(), q_rel.contiguous(), true_row.contiguous()
+
+
+def make_filter_index(cfg, heads, tails, rels, seed=3):
+    """The filtering graph (train.py:298-302: every known triple): the test triples themselves plus random edges
+    up to cfg['edges'] in total, node popularity Zipf(0.8) over a random permutation of the entities, uniform
+    relations (310 116 edges, seed 3).  Wikidata5M-style: the split's own triples only."""
+    from blp_amd import utils
+    test = torch.stack((heads, tails, rels), dim=1).cpu()
+    extra = max(cfg["edges"] - test.shape[0], 0)
+    if extra:
+        g = torch.Generator().manual_seed(seed)
+        weight = torch.arange(1, cfg["N"] + 1, dtype=torch.float64).pow(-0.8)[torch.randperm(cfg["N"], generator=g)]
+        nodes = torch.multinomial(weight, 2 * extra, replacement=True, generator=g).reshape(2, extra)
+        rel = torch.randint(0, cfg["R"], (extra,), generator=g)
+        test = torch.cat((test, torch.stack((nodes[0], nodes[1], rel), dim=1)))
+    return utils.FilterIndex(test, num_relations=cfg["R"])
 
 
 class HipEvents:
@@ -110,48 +137,209 @@ class HipEvents:
         return ms.value
 
 
-def cpu_baseline(cfg, table, rel_w, heads, tails, rels, budget_s=12.0):
-    """The reference's CPU path restated (oracle/ref_port.py: same torch CPU kernels), timed on this
-    box's host cores on a bounded sample of reference batches (eval_batch_size = 64 triples for
-    FB15k-237, 2 for Wikidata5M: scripts/blp-transe-{fb15k237,wikidata5m}.sh:18)."""
+class Job:
+    """One workload prepared on this rank's device; step() is one whole evaluation."""
+
+    def __init__(self, name, device, world=1, rank=0, shard_axis="auto", backend="nccl"):
+        from blp_amd import models, ranking
+        self.name, self.cfg, self.device, self.world, self.rank, self.backend = name, WORKLOADS[name], device, world, rank, backend
+        cfg = self.cfg
+        table, rel_w, heads, tails, rels = make_data(cfg, device, sort=False)
+        self.N, self.D, self.T = cfg["N"], cfg["D"], cfg["triples"]
+        self.model = models.LinkPrediction(cfg["D"], cfg["model"], "margin", cfg["R"], 0)
+        self.model.rel_emb.weight.data = rel_w.cpu()
+        self.model = self.model.to(device)
+        self.triples = torch.stack((heads, tails, rels), dim=1).contiguous()   # (T, 3) entity / relation ids
+        self.ent2idx = torch.arange(self.N, device=device)                    # ids are table rows in the synthetic sets
+        self.index = make_filter_index(cfg, heads, tails, rels)
+        self.index.segments(self.triples[:1], self.ent2idx, device)           # sorted arrays resident before the clock starts
+        axis = ranking.choose_shard_axis(self.N, self.D, 2 * self.T, world)
+        if world > 1 and cfg["N"] > 1_000_000:
+            axis = "candidate"  # north_star: the 4.6 M-entity ranking is sharded along the candidate axis
+        if world > 1 and shard_axis != "auto":
+            axis = shard_axis
+        self.axis = axis if world > 1 else "none"
+        self.lo, self.hi = ranking.shard_bounds(self.N, world, rank) if self.axis == "candidate" else (0, self.N)
+        self.full_table = table if rank == 0 or self.axis != "candidate" else None  # rank 0 keeps it for the parity check
+        self.table = table[self.lo:self.hi].contiguous() if self.axis == "candidate" else table
+        del table
+        self.ranking = ranking
+
+    def step(self, filtered=True):
+        from blp_amd import ops
+        triples, counts, ids_ok = self.ranking.rank_triples(
+            self.model, self.table, self.triples, self.ent2idx, self.index if filtered else None,
+            num_entities=self.N, world=self.world, rank=self.rank, axis=self.axis if self.world > 1 else "candidate",
+            block_size=self.cfg["block"])
+        sums = ops.rank_metric_sums(counts)
+        return triples, counts, sums
+
+    def timed(self, steps, warmup, filtered=True):
+        """K steps between barrier + synchronize on both sides; the MAX over ranks."""
+        for _ in range(warmup):
+            self.step(filtered)
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = self.step(filtered)
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.backend == "gloo" else self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        return elapsed, out
+
+    def fence(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def kernel_ms(self, events, reps):
+        """Duration of the ranking pass proper (pre-pass + exact refinement, or the exact kernel), measured with HIP
+        events recorded by the library on the stream the kernels run on (blp_profile_next_rank_kernel arms the
+        NEXT blp_rank_all of this thread: the first block of a step)."""
+        from blp_amd import _lib
+        pairs = []
+        for _ in range(reps):
+            a, b = events.pair()
+            _lib.check(_lib.lib().blp_profile_next_rank_kernel(a, b), "blp_profile_next_rank_kernel")
+            self.step()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        return sum(events.elapsed_ms(a, b) for a, b in pairs) / len(pairs)
+
+    def roofline(self, kernel_ms):
+        """Roof of the dominant kernel: algorithmic work of ONE ranking launch on this rank / its time."""
+        model, D, Q = self.cfg["model"], self.D, 2 * min(self.T, self.cfg["block"])
+        if self.axis == "query":
+            t_lo, t_hi = self.ranking.shard_bounds(self.T, self.world, self.rank)
+            Q = 2 * (t_hi - t_lo)
+        n_local = self.hi - self.lo
+        alg_flops = 2.0 * n_local * D * Q          # TransE: subtract + |.|-accumulate per element; bilinear: the GEMM
+        alg_bytes = n_local * D * 4 + Q * (2 * D * 4 + 24)
+        t_k = kernel_ms * 1e-3
+        transe = model == "transe"
+        peak_tf = F32_PEAK_TFLOPS if transe else BF16X3_PEAK_TFLOPS
+        if alg_bytes / (HBM_PEAK_GBPS * 1e9) >= alg_flops / (peak_tf * 1e12):
+            roof = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "kernel": "rank_tiles_kernel<STATIC> (lane-per-candidate exact f32 VALU kernel, table streamed once)"}
+        elif transe:
+            wide = D not in (64, 128, 256)
+            roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "kernel": ("wide_rank_sad_kernel + wide_refine_* (any-width u16 v_sad_u16 pre-pass)" if wide else
+                               "rank_sad_kernel<128> + sad_refine_* (u16 fixed-point v_sad_u16 pre-pass + band + exact f32 "
+                               "refinement; range / quantise kernels included)"),
+                    "note": "VALU roof (an L1 norm has no matrix-core form): 157.3 Tops/s is the f32 vector-FMA peak and "
+                            "also what v_sad_u16 delivers at 4 cycles/instruction (2 elements x (subtract + |.|-accumulate) "
+                            "x 64 lanes); the exact f32 add/sub kernel tops out at half of it.  achieved = 2 ops x D x Q x N "
+                            "/ time of the whole rank pass."}
+        else:
+            roof = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "kernel": f"rank_gemm_bf16_kernel<{model.upper()},128> + refine_* (bf16 x 3 split MFMA GEMM + band + exact "
+                              "f32 refinement)",
+                    "note": "achieved = 2 flops x D x Q x N (the f32 GEMM the reference's scores amount to) / time of GEMM "
+                            "pre-pass + exact refinement.  Every f32 product is three bf16 MFMA products (hi*hi + hi*lo + "
+                            "lo*hi), so the roof is the dense bf16 MFMA peak / 3 = 833 TF (5.3x the f32 MFMA peak).",
+                    "mfma_busy": load_pmc(self.name, "mfma_busy_frac_at_2.4GHz")}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = load_pmc(self.name)
+        roof["kernel_ms"] = kernel_ms
+        roof["algorithmic_bytes_per_launch"] = alg_bytes
+        roof["algorithmic_flops_per_launch"] = alg_flops
+        return roof
+
+    def measure(self, steps, warmup, events):
+        """The JSON fields of this workload: whole evaluation (raw + filtered) and raw-only, the roofline."""
+        elapsed, (triples, counts, sums) = self.timed(steps, warmup, filtered=True)
+        raw_elapsed, _ = self.timed(max(1, min(steps, 5)), 1, filtered=False)
+        kernel_ms = self.kernel_ms(events, max(1, min(steps, 10)))
+        scored = 2.0 * self.T * self.N
+        per_rank = [kernel_ms]
+        if self.world > 1:
+            box = [None] * self.world
+            dist.all_gather_object(box, kernel_ms)
+            per_rank = box
+        sums = sums.cpu()
+        out = {
+            "value": scored * steps / elapsed,
+            "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_raw_only": raw_elapsed / max(1, min(steps, 5)) * 1e3,
+            "mrr": sums[0].item() / (2 * self.T), "mrr_filtered": sums[1].item() / (2 * self.T),
+            "hits@1,3,10": [x.item() / (2 * self.T) for x in sums[2:5]],
+            "hits@1,3,10_filtered": [x.item() / (2 * self.T) for x in sums[5:8]],
+            "roofline": self.roofline(kernel_ms),
+            "kernel_ms_per_rank": per_rank,
+        }
+        return out, triples, counts
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(job, budget_s=10.0, budget_1t_s=8.0):
+    """The reference's CPU path restated (oracle/ref_port.py: same torch CPU kernels, incl. the dense filter mask
+    overwrite of train.py:159-171), timed on this box's host cores on a bounded sample of reference batches
+    (eval_batch_size = 64 triples for FB15k-237, 2 for Wikidata5M: scripts/blp-transe-{fb15k237,wikidata5m}.sh:18),
+    with all host threads and with one."""
     from oracle import ref_port
+    cfg = job.cfg
     B = 64 if cfg["N"] < 1_000_000 else 2
-    tab, rw = table.cpu(), rel_w.cpu()
-    h, t, r = heads.cpu(), tails.cpu(), rels.cpu()
-    T = h.shape[0]
-
-    def batch(i):
-        sl = slice((i * B) % max(T - B + 1, 1), (i * B) % max(T - B + 1, 1) + B)
-        return ref_port.eval_batch(cfg["model"], tab, h[sl], t[sl], rw[r[sl]])
-
-    batch(0)  # warm-up
-    done, t0 = 0, time.perf_counter()
-    while True:
-        batch(done + 1)
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or done >= 64:
-            break
-    value = 2.0 * B * cfg["N"] * done / el
-    return {"value": value, "unit": "scored triples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} reference batches of {B} triples ({2 * B} queries) x {cfg['N']} candidates, "
-                      f"{el:.1f} s of torch-CPU work ({os.cpu_count()} logical CPUs)"}
-
-
-def torch_gpu_baseline(cfg, table, rel_w, heads, tails, rels, budget_s=3.0):
-    """The reference's own expressions (torch broadcasting score_fn + get_metrics, restated in
-    oracle/ref_port.py) on THIS GPU through stock PyTorch-ROCm, reference batch size -- what the
-    unmodified reference does on a MI355X.  Bounded sample; a reported baseline, not the target."""
-    from oracle import ref_port
-    if cfg["N"] > 1_000_000:
-        return None
-    B = 64
-    T = heads.shape[0]
+    tab, rw = job.full_table.cpu(), job.model.rel_emb.weight.detach().cpu()
+    trip = job.triples.cpu()
+    T = trip.shape[0]
+    ent2idx = torch.arange(cfg["N"])
 
     def batch(i):
         lo = (i * B) % max(T - B + 1, 1)
-        sl = slice(lo, lo + B)
-        out = ref_port.eval_batch(cfg["model"], table, heads[sl], tails[sl], rel_w[rels[sl]])
+        t = trip[lo:lo + B]
+        hf, tf = job.index.masks(t, cfg["N"], ent2idx)  # the vectorised filter, not the reference's networkx walk
+        return ref_port.eval_batch(cfg["model"], tab, t[:, 0], t[:, 1], rw[t[:, 2]], filter_mask=torch.cat((hf, tf)))
+
+    def run(budget, max_batches):
+        batch(0)  # warm-up
+        done, t0 = 0, time.perf_counter()
+        while True:
+            batch(done + 1)
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= budget or done >= max_batches:
+                return done, el
+
+    threads = torch.get_num_threads()
+    done, el = run(budget_s, 64)
+    torch.set_num_threads(1)
+    done1, el1 = run(budget_1t_s, 4)
+    torch.set_num_threads(threads)
+    return {"value": 2.0 * B * cfg["N"] * done / el, "unit": "scored triples/s", "cores": threads, "kind": "port",
+            "value_1_thread": 2.0 * B * cfg["N"] * done1 / el1, "cpu_model": cpu_model_name(),
+            "logical_cpus": os.cpu_count(),
+            "sample": f"{done} reference batches of {B} triples ({2 * B} queries) x {cfg['N']} candidates, raw + filtered, "
+                      f"{el:.1f} s of torch-CPU work on {threads} threads; {done1} batches in {el1:.1f} s on 1 thread"}
+
+
+def torch_gpu_baseline(job, budget_s=3.0):
+    """The reference's own expressions (torch broadcasting score_fn + get_metrics, restated in
+    oracle/ref_port.py) on THIS GPU through stock PyTorch-ROCm, reference batch size, raw ranking only -- what the
+    unmodified reference's scoring does on a MI355X.  Bounded sample; a reported baseline, not the target."""
+    from oracle import ref_port
+    cfg = job.cfg
+    if cfg["N"] > 1_000_000:
+        return None
+    B, T = 64, job.T
+    rel_w = job.model.rel_emb.weight.detach()
+
+    def batch(i):
+        lo = (i * B) % max(T - B + 1, 1)
+        t = job.triples[lo:lo + B]
+        out = ref_port.eval_batch(cfg["model"], job.full_table, t[:, 0], t[:, 1], rel_w[t[:, 2]])
         return out["rr"].sum().item()  # the reference syncs per batch (train.py:154)
 
     batch(0)
@@ -164,26 +352,29 @@ def torch_gpu_baseline(cfg, table, rel_w, heads, tails, rels, budget_s=3.0):
         if el >= budget_s or done >= 400:
             break
     return {"value": 2.0 * B * cfg["N"] * done / el, "unit": "scored triples/s", "kind": "reference expressions on "
-            "PyTorch-ROCm (same GPU)", "sample": f"{done} reference batches of {B} triples, {el:.2f} s"}
+            "PyTorch-ROCm (same GPU), raw ranking only", "sample": f"{done} reference batches of {B} triples, {el:.2f} s"}
 
 
-def parity_spot_check(cfg, table, q_fixed, q_rel, true_row, q_head, counts, n=32):
-    """First n head- and first n tail-queries of the measured run against the CPU oracle."""
+def parity_spot_check(job, triples, counts, n=32):
+    """First n head- and first n tail-queries of the measured evaluation (relation-sorted order) against the CPU
+    oracle, raw and filtered counts."""
     import numpy as np
     from oracle import oracle as orc
+    cfg = job.cfg
     if cfg["N"] > 100_000:
         return "skipped (table too large for the CPU oracle inside bench; see tests)"
-    tab = table.cpu().numpy()
-    idx_h = torch.arange(0, min(n, q_head))
-    idx_t = torch.arange(q_head, min(q_head + n, q_fixed.shape[0]))
-    ok = True
-    for side, idx in ((orc.SIDE_HEAD, idx_h), (orc.SIDE_TAIL, idx_t)):
-        if idx.numel() == 0:
-            continue
-        want = orc.rank_counts(cfg["model"], side, tab, q_fixed[idx].cpu().numpy(), q_rel[idx].cpu().numpy(),
-                               true_row=true_row[idx].cpu().numpy())
-        ok &= bool(np.array_equal(want, counts[idx].cpu().numpy()))
-    return f"{idx_h.numel() + idx_t.numel()} queries vs CPU oracle: " + ("identical counts" if ok else "MISMATCH")
+    tab = job.full_table.cpu().numpy()
+    t = triples[:n].cpu()
+    rel = job.model.rel_emb.weight.detach().cpu()[t[:, 2]].numpy()
+    rowptr, col = job.index.csr(t, torch.arange(cfg["N"]))
+    b = t.shape[0]
+    T = triples.shape[0]
+    want_h = orc.rank_counts(cfg["model"], orc.SIDE_HEAD, tab, tab[t[:, 1].numpy()], rel, true_row=t[:, 0].numpy(),
+                             filt_rowptr=rowptr[:b + 1].numpy(), filt_col=col[:rowptr[b]].numpy())
+    want_t = orc.rank_counts(cfg["model"], orc.SIDE_TAIL, tab, tab[t[:, 0].numpy()], rel, true_row=t[:, 1].numpy(),
+                             filt_rowptr=(rowptr[b:] - rowptr[b]).numpy(), filt_col=col[rowptr[b]:].numpy())
+    ok = np.array_equal(want_h, counts[:b].cpu().numpy()) and np.array_equal(want_t, counts[T:T + b].cpu().numpy())
+    return f"{2 * b} queries vs CPU oracle (raw + filtered): " + ("identical counts" if ok else "MISMATCH")
 
 
 def load_pmc(workload, key="hbm_bytes_per_launch"):
@@ -196,250 +387,13 @@ def load_pmc(workload, key="hbm_bytes_per_launch"):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="fb15k237-transe", choices=sorted(WORKLOADS))
-    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
-                    help="replay a step's launches from a captured hipGraph (auto: fall back to eager launches if capture "
-                         "fails).  Off by default: measured equal to eager launches (tools/graph_shard_ab.py), the host "
-                         "launch loop is 10-70x ahead of the GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-hbm-probe", action="store_true")
-    ap.add_argument("--shard-axis", default="auto", choices=["auto", "candidate", "query"],
-                    help="N > 1: which axis to shard (default: what blp_amd.ranking.choose_shard_axis picks)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
-        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the measured path)")
-    # BLP_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks
-    # (ranks share devices, counts are exchanged through host memory).  Timings are then meaningless.
-    backend = os.environ.get("BLP_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
-
-    from blp_amd import _lib, ops, ranking
-
-    cfg = WORKLOADS[args.workload]
-    model, N, D = cfg["model"], cfg["N"], cfg["D"]
-    table, rel_w, heads, tails, rels = make_data(cfg, device)
-    q_fixed, q_rel, true_row = build_queries(table, rel_w, heads, tails, rels)
-    q_head = heads.shape[0]
-    Q = q_fixed.shape[0]
-    rel_ids = torch.cat((rels, rels)).contiguous()
-    passes = cfg["passes"]
-    # N > 1: shard along the axis blp_amd.ranking would pick for this shape (see choose_shard_axis).
-    #   "candidate": rank r ranks every query against table rows [lo, hi); ONE all-gather of the int32
-    #                counts + a sum per pass.  Right when the table pass dominates (Wikidata5M).
-    #   "query":     the table is replicated (inputs resident: like the table build itself, its one
-    #                all-gather per evaluation happens before the hot path), rank r ranks its slice of
-    #                the test triples against the whole table; the only collective is the all-reduce
-    #                of four metric sums.  Right when per-query work dominates (FB15k-237).
-    axis = ranking.choose_shard_axis(N, D, Q, world)
-    if args.shard_axis != "auto" and world > 1:
-        axis = args.shard_axis
-    lo, hi = ranking.shard_bounds(N, world, rank) if axis == "candidate" else (0, N)
-    shard = table[lo:hi]
-    if world > 1 and axis == "query":
-        t_lo, t_hi = ranking.shard_bounds(q_head, world, rank)
-        pick = torch.cat((torch.arange(t_lo, t_hi), torch.arange(q_head + t_lo, q_head + t_hi))).to(device)
-        q_fixed, q_rel, true_row, rel_ids = q_fixed[pick].contiguous(), q_rel[pick].contiguous(), true_row[pick], rel_ids[pick]
-        Q_global, q_head = Q, t_hi - t_lo
-        Q = q_fixed.shape[0]
-    else:
-        Q_global = Q
-    q_true = table[true_row].contiguous() if (world > 1 and axis == "candidate") else None
-    # one step = `passes` table passes (reference batches); their counts are exchanged ONCE per step
-    local_all = torch.empty((passes, Q, 4), dtype=torch.int32, device=device)
-    gathered = torch.empty((world, passes * Q, 4), dtype=torch.int32, device=device) if q_true is not None else None
-
-    sum_pick = torch.tensor([0, 2, 3, 4], device=device)  # raw: sum of reciprocal ranks, hits@1/3/10
-
-    def local_work():
-        """This rank's launches of one step: `passes` table passes, and (unless per-shard counts have to be
-        added up first) the metric sums.  Everything is asynchronous on the current stream, writes fixed
-        buffers and needs no host decision, so the whole step can be replayed from a captured hipGraph."""
-        for i in range(passes):
-            if q_true is not None:
-                ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids, out=local_all[i])
-            else:
-                ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids, out=local_all[i])
-        if q_true is None:
-            return ops.rank_metric_sums(local_all.view(passes * Q, 4)).index_select(0, sum_pick)
-        return None
-
-    pending = []  # outstanding collectives (query-axis shards)
-    graph, graph_note, static_sums = None, "eager launches", None
-    if args.graph != "off" and backend != "gloo":
-        try:
-            local_work()  # lazy initialisation (module load, allocator) happens outside the capture
-            torch.cuda.synchronize()
-            captured = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(captured):
-                static_sums = local_work()
-            graph, graph_note = captured, "hipGraph replay"
-        except Exception as exc:  # noqa: BLE001 -- the eager path below is the same work
-            if args.graph == "on":
-                raise
-            graph, graph_note = None, f"eager launches (graph capture failed: {type(exc).__name__})"
-            torch.cuda.synchronize()
-
-    def step():
-        if graph is not None:
-            graph.replay()
-            sums = static_sums
-        else:
-            sums = local_work()
-        counts = local_all.view(passes * Q, 4)
-        if q_true is not None:  # candidate shards: per-shard counts add up
-            if backend == "gloo":
-                parts = [torch.empty(counts.shape, dtype=counts.dtype) for _ in range(world)]
-                dist.all_gather(parts, counts.cpu())
-                gathered.copy_(torch.stack(parts))
-            else:
-                dist.all_gather_into_tensor(gathered.view(-1), counts.reshape(-1))
-            counts = gathered.sum(dim=0, dtype=torch.int32)
-            sums = ops.rank_metric_sums(counts).index_select(0, sum_pick)
-        elif world > 1:  # query shards: only the metric sums travel
-            if backend == "gloo":
-                host = sums.cpu()
-                dist.all_reduce(host)
-                sums = host.to(device)
-            else:  # asynchronous on RCCL's stream: the next step's kernels do not wait for this one's exchange
-                sums = sums.clone()
-                pending.append(dist.all_reduce(sums, async_op=True))
-        return counts[-Q:], sums  # sums are valid once fence() has waited for the exchange
-
-    def fence():
-        for work in pending:
-            work.wait()
-        pending.clear()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts, sums = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    mrr, hits = sums[0] / (Q_global * passes), sums[1:] / (Q_global * passes)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
-    # dominant-kernel duration, measured with HIP events around the rank_tiles launch (C-ABI hook),
-    # on the stream the kernel runs on, over a second run of the same steps
-    events = HipEvents()
-    pairs = []
-    for _ in range(max(1, min(args.steps, 10)) * passes):
-        a, b = events.pair()
-        _lib.check(_lib.lib().blp_profile_next_rank_kernel(a, b), "blp_profile_next_rank_kernel")
-        if q_true is not None:
-            ops.rank_all(model, shard, q_fixed, q_rel, q_head, q_true=q_true, rel_ids=rel_ids)
-        else:
-            ops.rank_all(model, shard, q_fixed, q_rel, q_head, true_row=true_row, rel_ids=rel_ids)
-        pairs.append((a, b))
-    torch.cuda.synchronize()
-    kernel_ms = sum(events.elapsed_ms(a, b) for a, b in pairs) / len(pairs)
-
-    if rank == 0:
-        n_local = hi - lo
-        scored = float(Q_global) * N * passes
-        ops_h, ops_t = OPS_PER_ELEM[model]
-        alg_flops = n_local * D * (q_head * ops_h + (Q - q_head) * ops_t)
-        alg_bytes = n_local * D * 4 + Q * (2 * D * 4 + 24)
-        t_k = kernel_ms * 1e-3
-        sad_path = model == "transe"
-        peak_tf = F32_PEAK_TFLOPS if sad_path else BF16X3_PEAK_TFLOPS
-        hbm_time, cmp_time = alg_bytes / (HBM_PEAK_GBPS * 1e9), alg_flops / (peak_tf * 1e12)
-        if hbm_time >= cmp_time:
-            roofline = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
-        else:
-            roofline = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf,
-                        "unit": "TFLOP/s",
-                        "note": ("VALU roof, not MFMA (an L1 norm has no matrix-core form): 157.3 Tops/s is the f32 vector-FMA "
-                                 "peak and also what v_sad_u16 delivers at its 4 cycles/instruction (2 elements x "
-                                 "(subtract + |.|-accumulate) x 64 lanes); the exact f32 add/sub kernel tops out at half "
-                                 "of it. achieved = 2 ops x D x Q x N / time of the whole rank pass (range + quantise + "
-                                 "SAD pre-pass + exact refinement of the undecided pairs)."
-                                 if sad_path else
-                                 "achieved = 2 flops x D x Q x N (the f32 GEMM the reference's scores amount to) / time of "
-                                 "GEMM pre-pass + exact refinement.  Every f32 product is three bf16 MFMA products "
-                                 "(hi*hi + hi*lo + lo*hi), so the roof is the dense bf16 MFMA peak / 3 = 833 TF "
-                                 "(5.3x the f32 MFMA peak of 157.3 TF, which the f32-chain variant BLP_GEMM_KERNEL=f32 "
-                                 "is bounded by).")}
-        roofline["frac"] = roofline["achieved"] / roofline["peak"]
-        roofline["traffic"] = load_pmc(args.workload)
-        if not sad_path and roofline["bound"] == "mfma":
-            roofline["mfma_busy"] = load_pmc(args.workload, "mfma_busy_frac_at_2.4GHz")
-        roofline["kernel"] = (DOMINANT_KERNEL[model] if Q >= 64 else "rank_tiles_kernel<STATIC> (lane-per-candidate VALU)")
-        if model == "transe" and D not in (64, 128, 256) and Q >= 256:
-            roofline["kernel"] = "wide_rank_sad_kernel + wide_refine_* (any-width u16 v_sad_u16 pre-pass, 128 elements at a time)"
-        roofline["kernel_ms"] = kernel_ms
-        roofline["algorithmic_bytes_per_launch"] = alg_bytes
-        roofline["algorithmic_flops_per_launch"] = alg_flops
-        result = {
-            "metric": "scored triples/sec, all-entity eval (MRR + Hits@k ranked)",
-            "value": scored * args.steps / elapsed,
-            "unit": "scored triples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic (seeded randn table, Xavier rel_emb, uniform random test triples)",
-            "config": {"workload": args.workload, "rel_model": model, "entities": N, "dim": D,
-                       "queries_per_step": Q_global * passes, "table_passes_per_step": passes,
-                       "parallelism": f"{axis}-axis shards x{world}" if world > 1 else "single GPU",
-                       "launch": graph_note},
-            "mrr": mrr.item(),
-            "hits@1,3,10": [x.item() for x in hits],
-            "roofline": roofline,
-        }
-        result["parity_check"] = parity_spot_check(cfg, table, q_fixed, q_rel, true_row, q_head, counts)
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, table, rel_w, heads, tails, rels)
-            result["torch_gpu_baseline"] = torch_gpu_baseline(cfg, table, rel_w, heads, tails, rels)
-        if world == 1 and not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
-            result["hbm_probe"] = hbm_probe(device, events)
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
 def hbm_probe(device, events, reps=10):
-    """The same rank_tiles kernel at its HBM-bound operating point (BASELINE config 4 at 1 GPU):
-    4.6 M x 128 f32 table = 2.355 GB, reference batching 2 triples = 4 queries per table pass."""
+    """The exact ranking kernel at its HBM-bound operating point (BASELINE config 4 at 1 GPU): 4.6 M x 128 f32
+    table = 2.355 GB, reference batching 2 triples = 4 queries per table pass, the bare C-ABI call."""
     from blp_amd import _lib, ops
     cfg = WORKLOADS["wikidata5m-transe"]
     table, rel_w, heads, tails, rels = make_data(cfg, device, seed=5)
-    q_fixed, q_rel, true_row = build_queries(table, rel_w, heads, tails, rels)
+    q_fixed, q_rel, true_row = build_queries(table, rel_w, heads[:2], tails[:2], rels[:2])
     for _ in range(2):
         ops.rank_all("transe", table, q_fixed, q_rel, 2, true_row=true_row)
     pairs = []
@@ -457,10 +411,105 @@ def hbm_probe(device, events, reps=10):
     call_ms = (time.perf_counter() - t0) / reps * 1e3
     alg_bytes = cfg["N"] * cfg["D"] * 4 + 4 * (2 * cfg["D"] * 4 + 24)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    return {"workload": "wikidata5m-transe, 4 queries per table pass", "bound": "hbm", "achieved": achieved,
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "kernel_ms": ms,
+    return {"workload": "wikidata5m-transe, 4 queries per table pass (bare blp_rank_all call)", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "kernel_ms": ms,
             "whole_call_ms": call_ms, "scored_triples_per_s": 4.0 * cfg["N"] / (call_ms * 1e-3),
             "traffic": load_pmc("wikidata5m-transe")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="fb15k237-transe", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true")
+    ap.add_argument("--no-sub-results", action="store_true")
+    ap.add_argument("--shard-axis", default="auto", choices=["auto", "candidate", "query"],
+                    help="N > 1: which axis to shard (default: blp_amd.ranking.choose_shard_axis; the Wikidata5M-scale "
+                         "table always along the candidate axis)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the measured path)")
+    # BLP_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks
+    # (ranks share devices, collectives go through host memory).  Timings are then meaningless.
+    backend = os.environ.get("BLP_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    ranks_seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        ranks_seen = dist.get_world_size()
+
+    events = HipEvents()
+    job = Job(args.workload, device, world, rank, args.shard_axis, backend)
+    fields, triples, counts = job.measure(args.steps, args.warmup, events)
+    cfg = job.cfg
+    if rank == 0:
+        result = {
+            "metric": "scored triples/sec, all-entity eval (raw + filtered ranks, MRR + Hits@k)",
+            "value": fields.pop("value"),
+            "unit": "scored triples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": fields.pop("ms_per_step"),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded randn table, Xavier rel_emb, uniform random test triples, Zipf(0.8) filtering graph)",
+            "config": {"workload": args.workload, "rel_model": cfg["model"], "entities": cfg["N"], "dim": cfg["D"],
+                       "queries_per_step": 2 * cfg["triples"], "triples_per_ranking_call": min(cfg["triples"], cfg["block"]),
+                       "filter_graph_edges": job.index.num_edges,
+                       "step": "whole evaluation: relation sort + id lookups + query gathers + filter segments + raw and "
+                               "filtered ranking + metric sums",
+                       "parallelism": f"{job.axis}-axis shards x{world}" if world > 1 else "single GPU",
+                       "shard_axis": job.axis, "ranks_in_process_group": ranks_seen, "backend": backend if world > 1 else None},
+        }
+        result.update(fields)
+        result["parity_check"] = parity_spot_check(job, triples, counts)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(job)
+            result["torch_gpu_baseline"] = torch_gpu_baseline(job)
+    del triples, counts
+    if world == 1:
+        subs = {}
+        if not args.no_sub_results and args.workload == "fb15k237-transe":
+            del job
+            torch.cuda.empty_cache()
+            for name in SUB_RESULTS:
+                sub = Job(name, device)
+                f, t, c = sub.measure(max(2, min(args.steps, 5)), 1, events)
+                f["unit"] = "scored triples/s"
+                f["parity_check"] = parity_spot_check(sub, t, c)
+                f.pop("kernel_ms_per_rank")
+                subs[name] = f
+                del sub, t, c
+                torch.cuda.empty_cache()
+            result["sub_results"] = subs
+        if not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
+            result["hbm_probe"] = hbm_probe(device, events)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

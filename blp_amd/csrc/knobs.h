@@ -7,7 +7,7 @@
 namespace blp {
 
 enum Knob : int {
-    KNOB_RANK_KERNEL = 0,        // 1: TransE through the exact f32 kernels whatever the block size
+    KNOB_RANK_KERNEL = 0,        // 1: every model through the exact f32 kernels whatever the block size
     KNOB_GEMM_KERNEL,            // 1: bilinear pre-pass on the f32 MFMA chain instead of bf16 x 3
     KNOB_SAD_QUERIES_PER_GROUP,  // 16 .. 256 (power of two): queries per workgroup of the TransE pre-pass
     KNOB_SAD_PASS_GROUPS,        // candidate groups per pre-pass slab (forces the multi-slab path)

@@ -820,6 +820,7 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
 }
 
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
+    if (knob(KNOB_RANK_KERNEL) == 1) return false;  // test knob: the exact f32 kernels
     return (model == DISTMULT || model == COMPLEX || model == SIMPLE) && (D == 64 || D == 128) && q_head + q_tail >= 64;
 }
 

@@ -154,6 +154,30 @@ def choose_shard_axis(num_rows, dim, num_queries, world_size):
     return "query" if small_table and num_queries // world_size >= QUERY_AXIS_MIN_QUERIES else "candidate"
 
 
+def _via_host(tensor, group):
+    """gloo carries host memory only: device tensors go through a host copy there (functional runs of the N > 1
+    path on fewer GPUs than ranks, tests); RCCL takes them as they are."""
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(tensor, group=None):
+    if _via_host(tensor, group):
+        host = tensor.cpu()
+        dist.all_reduce(host, group=group)
+        tensor.copy_(host)
+    else:
+        dist.all_reduce(tensor, group=group)
+
+
+def _all_gather_into(full, part, group=None):
+    if _via_host(part, group):
+        host = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(host, part.cpu(), group=group)
+        full.copy_(host)
+    else:
+        dist.all_gather_into_tensor(full, part, group=group)
+
+
 def all_gather_rows(local, num_rows, world_size, group=None):
     """Row shards (shard_bounds layout) -> the full (num_rows, ...) tensor on every rank: ONE all-gather."""
     if world_size == 1:
@@ -162,7 +186,7 @@ def all_gather_rows(local, num_rows, world_size, group=None):
     padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     full = torch.empty((world_size * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, padded, group=group)
+    _all_gather_into(full, padded, group)
     return full[:num_rows]
 
 
@@ -197,7 +221,7 @@ class ShardedRanker:
             local = torch.where(mine, rows - self.lo, torch.zeros_like(rows))
             out = torch.where(mine.unsqueeze(1), self.table[local], out)
         if self.world > 1:
-            dist.all_reduce(out, group=self.group)
+            _all_reduce(out, self.group)
         return out
 
     def rank_block(self, q_fixed, q_rel, q_true, q_head, filt_rowptr=None, filt_col=None, rel_ids=None, filter=None):
@@ -227,8 +251,91 @@ class ShardedRanker:
         if self.world == 1:
             return local
         gathered = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(gathered.view(-1), local.contiguous().view(-1), group=self.group)
+        _all_gather_into(gathered.view(-1), local.contiguous().view(-1), self.group)
         return gathered.sum(dim=0, dtype=torch.int32)
+
+
+# ----------------------------------------------------------------------------------- a set of triples
+def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=None, group=None, world=1, rank=0,
+                 axis="candidate", block_size=65536):
+    """The reference's evaluation loop body (train.py:128-171) for a whole set of triples at once: rank counts of
+    every triple's head and tail query against all ``num_entities`` candidates, raw and filtered.
+
+    triples   (T, 3) int64 on the table's device, rows (head, tail, rel) entity / relation ids, any order
+    ent2idx   utils.make_ent2idx map (entity id -> table row) on the same device
+    index     utils.FilterIndex of the filtering graph, or None (filtered counts = raw counts)
+    table     world == 1 or axis == "query": the full (num_entities, D) table; axis == "candidate": this rank's
+              rows shard_bounds(num_entities, world, rank) of it
+    Returns (triples sorted by relation, counts (2T, 4) int32 in that order with every head query first,
+    ids_ok: 0-dim bool tensor or None -- the reference's assertion train.py:137-138, left on the device).
+
+    Everything runs on the table's device without a host round trip: the relation sort, the id lookups
+    (train.py:134-135), the query gathers and the filter segments are device work.  The metrics are sums over
+    triples, so the evaluation order is free: triples are grouped by relation, which lets the exact TransE kernel
+    share e + r among the head-replacing queries of a relation.  Collectives: candidate axis -- one all-reduce of
+    the vectors of the entities in the triples and ONE all-gather of the (2T, 4) counts; query axis -- ONE
+    all-gather of the per-triple counts."""
+    device = table.device
+    num_entities = table.shape[0] if num_entities is None else num_entities
+    triples = triples[torch.argsort(triples[:, 2], stable=True)]
+    heads = ent2idx[triples[:, 0]]
+    tails = ent2idx[triples[:, 1]]
+    num_triples = triples.shape[0]
+    ids_ok = torch.minimum(heads.min(), tails.min()) >= 0 if num_triples else None
+    by_query = world > 1 and axis == "query"
+    by_candidate = world > 1 and not by_query
+    t_lo, t_hi = shard_bounds(num_triples, world, rank) if by_query else (0, num_triples)
+    ranker = ShardedRanker(model, table, num_entities, group) if by_candidate else None
+    if by_candidate:  # replicate the vectors of every entity that occurs in a triple: one exchange
+        if num_triples > 512:
+            uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
+            vectors = ranker.gather_rows(uniq)
+            head_pos, tail_pos = inverse[:num_triples], inverse[num_triples:]
+        else:  # a reference-sized batch: no host decision at all (torch.unique sizes its output on the host)
+            vectors = ranker.gather_rows(torch.cat((heads, tails)))
+            head_pos = torch.arange(num_triples, device=device)
+            tail_pos = head_pos + num_triples
+
+    counts_blocks = []
+    for start in range(t_lo, t_hi, block_size):
+        sl = slice(start, min(start + block_size, t_hi))
+        b = sl.stop - sl.start
+        rel_vecs = model.rel_emb(triples[sl, 2])
+        rel_ids = torch.cat((triples[sl, 2], triples[sl, 2]))
+        filt = {}
+        if index is not None and fused_ranking_takes(model, table, 2 * b):  # slices of the sorted index, no list
+            filt = dict(filter=index.segments(triples[sl], ent2idx, device))
+        elif index is not None:
+            rowptr, col = index.csr(triples[sl], ent2idx, device)
+            filt = dict(filt_rowptr=rowptr, filt_col=col)
+        if by_candidate:
+            h_vec, t_vec = vectors[head_pos[sl]], vectors[tail_pos[sl]]
+            ranker.rank_block(torch.cat((t_vec, h_vec)), torch.cat((rel_vecs, rel_vecs)), torch.cat((h_vec, t_vec)),
+                              b, rel_ids=rel_ids, **filt)
+        else:
+            h_rows, t_rows = heads[sl], tails[sl]
+            counts_blocks.append(rank_block(model, table, torch.cat((table[t_rows], table[h_rows])),
+                                            torch.cat((rel_vecs, rel_vecs)), b, true_row=torch.cat((h_rows, t_rows)),
+                                            rel_ids=rel_ids, **filt))
+    if by_candidate:
+        block_counts = ranker.finish()  # ONE all-gather for the whole set
+        counts_blocks, offset = [], 0
+        for start in range(0, num_triples, block_size):
+            b = min(start + block_size, num_triples) - start
+            counts_blocks.append(block_counts[offset: offset + 2 * b])
+            offset += 2 * b
+
+    # per-block layout is [head queries | tail queries]; put every head query first, like one big batch
+    if len(counts_blocks) == 1 and not by_query:
+        return triples, counts_blocks[0], ids_ok
+    sizes = [c.shape[0] // 2 for c in counts_blocks]
+    empty = [torch.zeros((0, 4), dtype=torch.int32, device=device)]
+    head_counts = torch.cat(empty + [c[:s] for c, s in zip(counts_blocks, sizes)])
+    tail_counts = torch.cat(empty + [c[s:] for c, s in zip(counts_blocks, sizes)])
+    if by_query:  # per-triple counts of every rank's slice: ONE all-gather for the whole set
+        both = all_gather_rows(torch.cat((head_counts, tail_counts), dim=1), num_triples, world, group)
+        head_counts, tail_counts = both[:, :4], both[:, 4:]
+    return triples, torch.cat((head_counts, tail_counts)).contiguous(), ids_ok
 
 
 # ----------------------------------------------------------------------------------- evaluation
@@ -328,74 +435,14 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
         model.eval()
     table = build_entity_table(model, text_dataset, entities, emb_batch_size, device, _log, rows=(lo, hi))
 
-    # Everything from here to the final reduction runs on `device` without a host round trip: the triples and
-    # the id -> row map go over once, the relation sort, the id lookups (train.py:134-135), the query gathers and
-    # the filter segments are device work, and the reference's assertion on the ids (train.py:137-138) is checked
-    # after the last launch together with the metrics.
     triples = _loader_triples(triples_loader, max_num_batches).to(device)  # in loader order (train.py:128-131)
-    ent2idx_dev = ent2idx.to(device)
-    # The metrics are sums over triples, so the evaluation order is free: group by relation, which lets
-    # the TransE kernel share e + r among the head-replacing queries of a relation.
-    triples = triples[torch.argsort(triples[:, 2], stable=True)]
-    heads = ent2idx_dev[triples[:, 0]]
-    tails = ent2idx_dev[triples[:, 1]]
     num_triples = triples.shape[0]
-    ids_ok = torch.minimum(heads.min(), tails.min()) >= 0 if num_triples else None
     _log.info("Computing metrics on set of triples")
-
     axis = shard_axis if shard_axis != "auto" else choose_shard_axis(num_entities, table.shape[1], 2 * num_triples, world)
-    by_query = sharded and world > 1 and axis == "query"
-    if by_query:  # full table everywhere, this rank's slice of the triples
+    if sharded and world > 1 and axis == "query":  # full table everywhere, each rank takes a slice of the triples
         table = all_gather_rows(table, num_entities, world, group)
-        t_lo, t_hi = shard_bounds(num_triples, world, rank)
-        sharded = False
-    else:
-        t_lo, t_hi = 0, num_triples
-    ranker = ShardedRanker(model, table, num_entities, group) if sharded else None
-
-    if sharded:  # replicate the vectors of every entity that occurs in a test triple: one exchange
-        uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
-        vectors = ranker.gather_rows(uniq)
-        head_pos, tail_pos = inverse[:num_triples], inverse[num_triples:]
-
-    counts_blocks = []
-    for start in range(t_lo, t_hi, block_size):
-        sl = slice(start, min(start + block_size, t_hi))
-        b = sl.stop - sl.start
-        rel_vecs = model.rel_emb(triples[sl, 2])
-        rel_ids = torch.cat((triples[sl, 2], triples[sl, 2]))
-        filt = {}
-        if compute_filtered and fused_ranking_takes(model, table, 2 * b):  # slices of the sorted index, no list
-            filt = dict(filter=index.segments(triples[sl], ent2idx_dev, device))
-        elif compute_filtered:
-            rowptr, col = index.csr(triples[sl], ent2idx_dev, device)
-            filt = dict(filt_rowptr=rowptr, filt_col=col)
-        if sharded:
-            h_vec, t_vec = vectors[head_pos[sl]], vectors[tail_pos[sl]]
-            ranker.rank_block(torch.cat((t_vec, h_vec)), torch.cat((rel_vecs, rel_vecs)), torch.cat((h_vec, t_vec)),
-                              b, rel_ids=rel_ids, **filt)
-        else:
-            h_rows, t_rows = heads[sl], tails[sl]
-            counts_blocks.append(rank_block(model, table, torch.cat((table[t_rows], table[h_rows])),
-                                            torch.cat((rel_vecs, rel_vecs)), b, true_row=torch.cat((h_rows, t_rows)),
-                                            rel_ids=rel_ids, **filt))
-    if sharded:
-        block_counts = ranker.finish()  # ONE all-gather for the whole evaluation
-        counts_blocks, offset = [], 0
-        for start in range(0, num_triples, block_size):
-            b = min(start + block_size, num_triples) - start
-            counts_blocks.append(block_counts[offset: offset + 2 * b])
-            offset += 2 * b
-
-    # per-block layout is [head queries | tail queries]; put every head query first, like one big batch
-    sizes = [c.shape[0] // 2 for c in counts_blocks]
-    empty = [torch.zeros((0, 4), dtype=torch.int32, device=device)]
-    head_counts = torch.cat(empty + [c[:s] for c, s in zip(counts_blocks, sizes)])
-    tail_counts = torch.cat(empty + [c[s:] for c, s in zip(counts_blocks, sizes)])
-    if by_query:  # per-triple counts of every rank's slice: ONE all-gather for the whole evaluation
-        both = all_gather_rows(torch.cat((head_counts, tail_counts), dim=1), num_triples, world, group)
-        head_counts, tail_counts = both[:, :4], both[:, 4:]
-    counts = torch.cat((head_counts, tail_counts)).contiguous()
+    triples, counts, ids_ok = rank_triples(model, table, triples, ent2idx.to(device), index, num_entities=num_entities,
+                                           group=group, world=world, rank=rank, axis=axis, block_size=block_size)
     rr, hits = metrics_from_counts(counts)
     num_predictions = 2 * num_triples
     _log.info(f"The total number of predictions is {num_predictions:,}")
@@ -446,7 +493,7 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     if was_training and eval_mode:
         model.train()
     if return_embeddings:
-        if sharded and world > 1:  # the full table only on request: all-gather of the shards
+        if sharded and world > 1 and axis != "query":  # the full table only on request: all-gather of the shards
             table = all_gather_rows(table, num_entities, world, group)
         return mrr, table.unsqueeze(0)
     return mrr, None

@@ -144,7 +144,8 @@ def test_bench_two_ranks_share_one_gpu_functional(axis):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "1", "--warmup", "0", "--workload", "fb15k237-transe", "--no-cpu-baseline", "--no-hbm-probe"]
+    common = ["--steps", "1", "--warmup", "0", "--workload", "fb15k237-transe", "--no-cpu-baseline", "--no-hbm-probe",
+              "--no-sub-results"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True,
                          timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -158,38 +159,56 @@ def test_bench_two_ranks_share_one_gpu_functional(axis):
     b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == 2 and a["n_gpus"] == 1
     assert b["config"]["parallelism"] == f"{axis}-axis shards x2"
+    assert b["config"]["ranks_in_process_group"] == 2 and len(b["kernel_ms_per_rank"]) == 2
     assert abs(a["mrr"] - b["mrr"]) < 1e-12 and a["hits@1,3,10"] == pytest.approx(b["hits@1,3,10"], abs=1e-12)
+    assert abs(a["mrr_filtered"] - b["mrr_filtered"]) < 1e-12
+    assert a["hits@1,3,10_filtered"] == pytest.approx(b["hits@1,3,10_filtered"], abs=1e-12)
     assert b["parity_check"].endswith("identical counts")
 
 
 def test_bench_line_keeps_the_contract():
-    """`python bench.py` with its defaults: ONE JSON line on stdout with the driver's keys, the roofline of
-    the dominant kernel and the CPU baseline; value, ms_per_step and the workload size agree."""
+    """`python bench.py` with its defaults: ONE JSON line on stdout with the driver's keys; the step is the whole
+    evaluation (raw + filtered), with the raw-only time beside it; the roofline of the dominant kernel; the CPU
+    baseline on all threads and on one, with the CPU model; driver-timed sub-results for the bilinear configs and the
+    Wikidata5M-scale block, each with its own roofline; value, ms_per_step and the workload size agree."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=900, cwd=root)
+                         capture_output=True, text=True, timeout=1500, cwd=root)
     assert run.returncode == 0, run.stderr[-2000:]
     lines = [l for l in run.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "ms_per_step_raw_only", "mrr",
+                "mrr_filtered", "sub_results", "hbm_probe"):
         assert key in r, key
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
     assert r["vs_baseline"] is None and r["config"]["workload"] == "fb15k237-transe"
+    assert r["config"]["filter_graph_edges"] == 310116
     scored = 2 * 52870 * 14541
     assert r["value"] == pytest.approx(scored / (r["ms_per_step"] * 1e-3), rel=1e-6)
+    assert r["ms_per_step_raw_only"] <= r["ms_per_step"] * 1.1  # the filtered pass is on top of the raw one
+    assert 0.0 < r["mrr"] <= r["mrr_filtered"] <= 1.0           # removing candidates can only improve a rank
     roof = r["roofline"]
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert roof["bound"] == "valu" and roof["unit"] == "TFLOP/s"  # TransE: no matrix-core form of an L1 norm
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-6) and 0.0 < roof["frac"] < 1.0
-    assert roof["kernel_ms"] <= r["ms_per_step"] * 1.25  # the dominant kernel's bracket is part of a step (separate loops: noise)
+    assert roof["kernel_ms"] <= r["ms_per_step"] * 1.25  # the ranking pass is part of a step (separate loops: noise)
     cpu = r["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert cpu["value_1_thread"] > 0 and cpu["cpu_model"] and cpu["logical_cpus"] >= cpu["cores"]
     assert r["parity_check"].endswith("identical counts")
+    subs = r["sub_results"]
+    assert set(subs) == {"fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe-block"}
+    for name, sub in subs.items():
+        assert sub["value"] > 0 and sub["ms_per_step"] > 0 and sub["ms_per_step_raw_only"] > 0, name
+        assert 0.0 < sub["roofline"]["frac"] < 1.0 and sub["roofline"]["kernel_ms"] <= sub["ms_per_step"] * 1.25, name
+        assert sub["roofline"]["bound"] == ("mfma" if "transe" not in name else "valu"), name
+    assert subs["fb15k237-distmult"]["parity_check"].endswith("identical counts")
+    assert r["hbm_probe"]["bound"] == "hbm" and 0.0 < r["hbm_probe"]["frac"] < 1.0
 
 
 @pytest.mark.parametrize("rel_model,D", [("transe", 300), ("transe", 768), ("distmult", 96), ("complex", 192),
@@ -227,6 +246,34 @@ def test_generic_width_route_matches_oracle(rel_model, D, oracle):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_device_sampler_law_on_the_gpu():
+    """data.get_negative_sampling_indices_on_device drawn on the GPU (what train.py `device_sampler=True` puts into
+    collate_fn): the law of the reference's sampler (data.py:35-81) -- one slot of the pair kept, the other replaced
+    by a slot of ANOTHER row, uniformly over the 2B - 2 foreign slots and over the two columns."""
+    from blp_amd import data
+    g = torch.Generator(device="cuda").manual_seed(3)
+    b, k = 6, 4000
+    idx = data.get_negative_sampling_indices_on_device(b, k, "cuda", generator=g)
+    assert idx.is_cuda and idx.shape == (b, k, 2) and idx.dtype == torch.int64
+    idx = idx.cpu()
+    own = torch.arange(2 * b).reshape(b, 1, 2).expand(-1, k, -1)
+    kept = idx == own
+    assert torch.all(kept.sum(-1) == 1)
+    replaced = idx[~kept].reshape(b, k)
+    assert torch.all(replaced // 2 != torch.arange(b).unsqueeze(1))
+    for row in range(b):
+        hist = torch.bincount(replaced[row], minlength=2 * b).float()
+        assert hist[2 * row] == 0 and hist[2 * row + 1] == 0
+        expected = k / (2 * b - 2)
+        assert (hist[hist > 0] - expected).abs().max() < 6 * expected ** 0.5
+    assert abs(float((~kept)[..., 0].float().mean()) - 0.5) < 0.02
+    # through the dataset's collate path: indices stay on the device, one independent draw per device slice
+    ds = data.GraphDataset.__new__(data.GraphDataset)
+    ds.neg_samples, ds.num_devices, ds.sampler_device = 8, 2, torch.device("cuda", 0)
+    out = ds._neg_idx(5, 2)
+    assert out.is_cuda and out.shape == (10, 8, 2) and int(out.max()) < 10 and int(out.min()) >= 0
+
+
 @pytest.mark.parametrize("amp", [None, "bf16"])
 def test_link_prediction_cli_on_gpu(tmp_path, amp):
     """python train.py link_prediction on the GPU: GloVe-BOW encoder at the GloVe width (300), TransE, the
@@ -244,7 +291,7 @@ def test_link_prediction_cli_on_gpu(tmp_path, amp):
            "max_len=32", "num_negatives=16", "lr=1e-3", "use_scheduler=False", "batch_size=64",
            "emb_batch_size=512", "eval_batch_size=64", "max_epochs=2", f"data_root={tmp_path / 'data'}", "seed=1"]
     if amp:
-        cmd.append(f"amp={amp}")
+        cmd += [f"amp={amp}", "device_sampler=True"]
     proc = subprocess.run(cmd, cwd=tmp_path, env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True,
                           timeout=900)
     assert proc.returncode == 0, proc.stderr[-3000:]

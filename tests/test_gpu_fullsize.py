@@ -1,0 +1,107 @@
+"""GPU parity at the sizes that are TIMED: the exact tensors of bench.py's FB15k-237 workloads (105 740 queries x
+14 541 candidates, the 310 116-edge filtering graph of SURVEY.md 8d config 2).  The pre-pass paths' behaviour depends
+on the block size (queries per workgroup, grid shape, pair-list compaction, candidate slabs), so the configuration
+that is measured is the one compared here:
+  (i)   pre-pass path == the exact f32 kernels on ALL queries (raw and filtered counts);
+  (ii)  bilinear models: bf16 x 3 pre-pass == the f32-chain MFMA pre-pass (a provable fma chain) on all queries;
+  (iii) == the CPU oracle on 4 096 queries spread over the block (both sides, every 25th query or so);
+  (iv)  blp_rank_metric_sums (what bench.py reports MRR / Hits from) == the oracle's metrics on those counts.
+Integer counts: bit-exact.  MRR: f64 sums of identical f32 reciprocal ranks, compared to 1e-12 relative."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ("transe", "distmult", "complex", "simple")
+
+
+@pytest.fixture(scope="module")
+def bench():
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    return importlib.import_module("bench")
+
+
+def _block(bench, model):
+    """The bench workload's tensors and ONE evaluation of it through the product path (ranking.rank_triples)."""
+    job = bench.Job(f"fb15k237-{model}", torch.device("cuda", 0))
+    triples, counts, sums = job.step(filtered=True)
+    torch.cuda.synchronize()
+    return job, triples, counts, sums
+
+
+def _direct(job, triples, **knobs):
+    """The same block through ops.rank_all with test knobs set (kernel selection), filtered."""
+    from blp_amd import _lib, ops
+    T = triples.shape[0]
+    h, t, r = triples[:, 0], triples[:, 1], triples[:, 2]
+    table = job.table
+    rel = job.model.rel_emb.weight.detach()[r]
+    seg = job.index.segments(triples, job.ent2idx, table.device)
+    try:
+        for k, v in knobs.items():
+            _lib.set_knob(k, v)
+        out = ops.rank_all(job.cfg["model"], table, torch.cat((table[t], table[h])), torch.cat((rel, rel)), T,
+                           true_row=torch.cat((h, t)), filter=seg)
+        torch.cuda.synchronize()
+    finally:
+        _lib.reset_knobs()
+    return out
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_timed_block_equals_exact_kernels_and_oracle(bench, oracle, model):
+    from blp_amd import ops
+    job, triples, counts, sums = _block(bench, model)
+    T, N = job.T, job.N
+    assert counts.shape == (2 * T, 4)
+    # (i) every query: the pre-pass path against the exact f32 kernels
+    exact = _direct(job, triples, rank_kernel=1)
+    assert torch.equal(counts, exact), f"{int((counts != exact).any(dim=1).sum())} queries differ from the exact kernels"
+    # (ii) bilinear: the bf16 x 3 pre-pass against the f32 fma-chain pre-pass (its band is provable)
+    if model != "transe":
+        chain = _direct(job, triples, gemm_kernel=1)
+        assert torch.equal(counts, chain)
+    # filtered counts never exceed the raw ones, and a filtered candidate was counted raw
+    c = counts.cpu().numpy()
+    assert (c[:, 2] <= c[:, 0]).all() and (c[:, 3] <= c[:, 1]).all() and (c[:, 1] > c[:, 0]).all()
+    assert (c[:, :2] != c[:, 2:]).any(), "the filter of this workload removes nothing?"
+    # (iii) the CPU oracle on 2 048 triples spread over the block = 4 096 queries, both sides, with their filters
+    pick = torch.arange(0, T, max(T // 2048, 1))[:2048]
+    sub = triples.cpu()[pick]
+    tab = job.full_table.cpu().numpy()
+    rel = job.model.rel_emb.weight.detach().cpu()[sub[:, 2]].numpy()
+    rowptr, col = job.index.csr(sub, torch.arange(N))
+    b = sub.shape[0]
+    want_h = oracle.rank_counts(model, oracle.SIDE_HEAD, tab, tab[sub[:, 1].numpy()], rel, true_row=sub[:, 0].numpy(),
+                                filt_rowptr=rowptr[:b + 1].numpy(), filt_col=col[:rowptr[b]].numpy())
+    want_t = oracle.rank_counts(model, oracle.SIDE_TAIL, tab, tab[sub[:, 0].numpy()], rel, true_row=sub[:, 1].numpy(),
+                                filt_rowptr=(rowptr[b:] - rowptr[b]).numpy(), filt_col=col[rowptr[b]:].numpy())
+    assert np.array_equal(c[pick.numpy()], want_h)
+    assert np.array_equal(c[T + pick.numpy()], want_t)
+    # (iv) the device-side metric sums against the oracle's get_metrics on all 105 740 counts
+    got = sums.cpu().numpy()
+    for v, (a, bcol) in enumerate(((0, 1), (2, 3))):
+        rr, hits = oracle.metrics_from_counts(c[:, a], c[:, bcol])
+        assert got[v] == pytest.approx(rr.astype(np.float64).sum(), rel=1e-12)
+        assert got[2 + 3 * v: 5 + 3 * v].tolist() == hits.sum(axis=0).astype(np.float64).tolist()
+    mrr = got[0] / (2 * T)
+    assert abs(mrr - oracle.metrics_from_counts(c[:, 0], c[:, 1])[0].astype(np.float64).mean()) < 1e-9
+    # and the rr / hits kernel agrees with the sums kernel
+    rr_dev, hits_dev = ops.rank_metrics(counts)
+    assert got[:2].tolist() == pytest.approx(rr_dev.double().sum(dim=0).tolist(), rel=1e-12)
+
+
+def test_wikidata5m_block_prepass_equals_exact_kernel():
+    """The Wikidata5M-scale block workload (13 788 queries x 4.6 M candidates, 30 candidate slabs of the fixed-point
+    pre-pass, the split's own triples as the filtering graph): every count equals the exact f32 kernel's."""
+    import bench
+    job = bench.Job("wikidata5m-transe-block", torch.device("cuda", 0))
+    triples, counts, _ = job.step(filtered=True)
+    exact = _direct(job, triples, rank_kernel=1)
+    assert torch.equal(counts, exact)

@@ -730,3 +730,67 @@ def test_errors_are_loud(ops):
                      true_row=torch.zeros(2, dtype=torch.int64))
     with pytest.raises(KeyError):
         ops.score("rotate", table, table, table)
+
+
+def test_two_threads_two_streams_concurrently(ops, oracle):
+    """The nn.DataParallel calling pattern (train.py:329-330, 344: one Python thread per replica) on one device:
+    two threads, each on its own stream, hammer blp_rank_all (pre-pass paths: workspace + pair lists + flags per
+    call) and the fused loss forward / backward at the same time.  ctypes releases the GIL during the calls, so they
+    really overlap.  Every iteration's counts must be the oracle's and the loss / gradients the single-threaded
+    ones; an argument error raised in one thread must not leak into the other's blp_last_error."""
+    import threading
+    from blp_amd import _lib
+    from oracle import ref_port
+    problems = {}
+    for i, model in enumerate(("transe", "distmult")):
+        N, D, q_head, q_tail = 2000 + 37 * i, 128, 170, 150
+        table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=50 + i)
+        rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=60 + i)
+        want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+        g = torch.Generator().manual_seed(70 + i)
+        B, K = 32, 16
+        ent = torch.randn(B, 2, D, generator=g) * 0.4
+        rel = torch.randn(B, 1, D, generator=g) * 0.3
+        neg_idx = torch.randint(0, 2 * B, (B, K, 2), generator=g)
+        e_ref, r_ref = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+        ref = ref_port.compute_loss(model, "margin", e_ref, r_ref, neg_idx, 1e-3)
+        ref.backward()
+        problems[i] = dict(model=model, q_head=q_head, want=want, ref=ref.item(), grad=e_ref.grad.numpy(),
+                           dev=[x.cuda() for x in (table, q_fixed, q_rel, true_row, torch.from_numpy(rowptr),
+                                                   torch.from_numpy(col), ent, rel, neg_idx)])
+    torch.cuda.synchronize()
+    failures, start = [], threading.Barrier(2)
+
+    def worker(i):
+        try:
+            p = problems[i]
+            table, q_fixed, q_rel, true_row, rowptr, col, ent, rel, neg_idx = p["dev"]
+            stream = torch.cuda.Stream()
+            start.wait()
+            with torch.cuda.stream(stream):
+                for it in range(25):
+                    got = ops.rank_all(p["model"], table, q_fixed, q_rel, p["q_head"], true_row=true_row,
+                                       filt_rowptr=rowptr, filt_col=col)
+                    e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+                    loss = ops.inbatch_loss(p["model"], "margin", e, r, neg_idx, 1e-3)
+                    loss.backward()
+                    if it % 5 == i:  # an error in THIS thread only
+                        rc = _lib.lib().blp_rank_all(9 + i, None, 0, 128, 128, None, None, None, None, None, 1, 1, None,
+                                                     None, None, None, 0, 0, None)
+                        assert rc == -1 and f"unknown model {9 + i}".encode() in _lib.lib().blp_last_error()
+                    stream.synchronize()
+                    if not np.array_equal(got.cpu().numpy(), p["want"]):
+                        failures.append(f"thread {i} iteration {it}: counts differ")
+                    if abs(loss.item() - p["ref"]) > 2e-6 * max(1.0, abs(p["ref"])):
+                        failures.append(f"thread {i} iteration {it}: loss {loss.item()} vs {p['ref']}")
+                    if not np.allclose(e.grad.cpu().numpy(), p["grad"], rtol=2e-5, atol=2e-7):
+                        failures.append(f"thread {i} iteration {it}: gradients differ")
+        except Exception as exc:  # noqa: BLE001 -- reported by the main thread
+            failures.append(f"thread {i}: {type(exc).__name__}: {exc}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not failures, failures[:5]
