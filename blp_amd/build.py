@@ -32,7 +32,17 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in headers)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, variant_flags=()):
+    """Compile and link libblp_hip.so.  ``variant`` (a name) + ``variant_flags`` build an experiment library
+    libblp_hip.<variant>.so next to it from the same sources (own object directory; tools/ only)."""
+    global_obj, global_lib = OBJ, LIB
+    if variant:
+        global_obj = os.path.join(HERE, "csrc", "build", variant)
+        global_lib = os.path.join(HERE, f"libblp_hip.{variant}.so")
+    return _build(force, verbose, global_obj, global_lib, list(variant_flags))
+
+
+def _build(force, verbose, OBJ, LIB, variant_flags):
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     dep_time = max(_newest_header(), os.path.getmtime(__file__))
@@ -42,7 +52,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ, src + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src_path), dep_time):
             extra = os.environ.get("BLP_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
-            cmd = [cc, *FLAGS, *extra, "-x", "hip", "-c", src_path, "-o", obj]
+            cmd = [cc, *FLAGS, *extra, *variant_flags, "-x", "hip", "-c", src_path, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

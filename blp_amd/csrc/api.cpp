@@ -10,6 +10,7 @@
 #include "../../include/blp_hip.h"
 #include "knobs.h"
 #include "launch.h"
+#include "rank_common.h"
 
 namespace {
 
@@ -102,6 +103,12 @@ int blp_debug_set_knob(const char* name, long long value) {
             return BLP_OK;
         }
     return fail(BLP_ERR_BAD_ARG, "blp_debug_set_knob: unknown knob '%s'", name);
+}
+
+int blp_debug_gemm_dump(float* scores, float* eps) {
+    if ((scores == nullptr) != (eps == nullptr)) return fail(BLP_ERR_BAD_ARG, "blp_debug_gemm_dump: give both matrices or neither");
+    blp::gemm_set_dump(scores, eps);
+    return BLP_OK;
 }
 
 int blp_version(void) { return BLP_HIP_VERSION; }

@@ -678,10 +678,13 @@ static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld
     case TRANSE * 1000 + 256: return FN<TRANSE, 256>(__VA_ARGS__);                          \
     case DISTMULT * 1000 + 64: return FN<DISTMULT, 64>(__VA_ARGS__);                        \
     case DISTMULT * 1000 + 128: return FN<DISTMULT, 128>(__VA_ARGS__);                      \
+    case DISTMULT * 1000 + 256: return FN<DISTMULT, 256>(__VA_ARGS__);                      \
     case COMPLEX * 1000 + 64: return FN<COMPLEX, 64>(__VA_ARGS__);                          \
     case COMPLEX * 1000 + 128: return FN<COMPLEX, 128>(__VA_ARGS__);                        \
+    case COMPLEX * 1000 + 256: return FN<COMPLEX, 256>(__VA_ARGS__);                        \
     case SIMPLE * 1000 + 64: return FN<SIMPLE, 64>(__VA_ARGS__);                            \
     case SIMPLE * 1000 + 128: return FN<SIMPLE, 128>(__VA_ARGS__);                          \
+    case SIMPLE * 1000 + 256: return FN<SIMPLE, 256>(__VA_ARGS__);                          \
     default: return hipErrorInvalidValue;                                                   \
     }
 

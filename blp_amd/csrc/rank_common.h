@@ -86,7 +86,8 @@ hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float
                              const float* q_true, float* coef_head, float* coef_tail, float* key_true,
                              unsigned long long* acc, hipStream_t stream);
 
-// rank_gemm.hip: bilinear models as an f32 MFMA GEMM + error band + exact refinement.
+// rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
+void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,

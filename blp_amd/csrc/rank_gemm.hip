@@ -392,11 +392,70 @@ __global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const float* __rest
     }
 }
 
+// Candidate image for the bf16 kernel (built once per call by prep_cand_bf16_kernel): per 32-row tile the hi parts of
+// the D/16 K-steps, then the lo parts; uint4 index ((tile * 2 + part) * STEPS + st) * 64 + l holds
+// e_{row = tile * 32 + (l & 31)}[16 st + 8 (l >> 5) + j], j = 0..7, as four packed bf16 pairs: a wave's load of one
+// (part, K-step) is 1 KB contiguous, and lands in the registers as the MFMA A operand.  Rows past the table end are
+// NaN (S~ = NaN is never decided and their bit of row_mask drops them).  cnmax[tile * 2 + half] = the largest band
+// factor (||e|| rounded up, inf for rows the relative bounds do not cover) among the 16 rows the accumulator
+// registers of a lane in that half hold.  Tiles are padded to whole workgroup loads (kBfW * kBfTPW tiles).
+template <int D>
+__global__ __launch_bounds__(64) void prep_cand_bf16_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
+                                                            uint4* __restrict__ cimg, float* __restrict__ cnmax) {
+    constexpr int STEPS = D / 16;
+    __shared__ float nrm[32];
+    const int lane = threadIdx.x, half = lane >> 5;
+    const int64_t tile = blockIdx.x;
+    const int64_t row = tile * kGCT + (lane & 31);
+    const bool exists = row < N;
+    const float* src = table + (exists ? row : 0) * ld + 8 * half;
+    uint4* dst = cimg + (size_t)tile * 2 * STEPS * 64 + lane;
+    float ss = 0.f, mx = 0.f;
+    bool bad = false;
+    static_for<STEPS>([&](auto kk) {
+        constexpr int st = decltype(kk)::value;
+        uint4 hi = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u), lo = make_uint4(0u, 0u, 0u, 0u);
+        if (exists) {
+            const float4 x = *reinterpret_cast<const float4*>(src + 16 * st);
+            const float4 y = *reinterpret_cast<const float4*>(src + 16 * st + 4);
+            split_bf16(x.x, x.y, hi.x, lo.x);
+            split_bf16(x.z, x.w, hi.y, lo.y);
+            split_bf16(y.x, y.y, hi.z, lo.z);
+            split_bf16(y.z, y.w, hi.w, lo.w);
+            const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ss += v[j] * v[j];
+                const float a = fabsf(v[j]);
+                bad |= !(a <= 3.0e38f);  // NaN too
+                mx = a > mx ? a : mx;
+            }
+        }
+        dst[st * 64] = hi;
+        dst[(STEPS + st) * 64] = lo;
+    });
+    ss += __shfl_xor(ss, 32);
+    const float m2 = __shfl_xor(mx, 32);
+    mx = m2 > mx ? m2 : mx;
+    bad |= (bool)__shfl_xor((int)bad, 32);
+    if (lane < 32) nrm[lane] = exists ? band_norm(ss, bad ? __builtin_inff() : mx) : 0.f;
+    __syncthreads();
+    if (lane < 2) {  // lane = half
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float nr = nrm[acc_row(r, lane)];
+            m = nr > m ? nr : m;  // inf propagates; norms are never NaN
+        }
+        cnmax[tile * 2 + lane] = m;
+    }
+}
+
 template <int D>
 struct BfTile {
-    uint4 hi[D / 16], lo[D / 16];  // A operands of the D/16 K-steps (rows that do not exist: NaN)
+    uint4 hi[D / 16], lo[D / 16];  // A operands of the D/16 K-steps
     float nmax;                    // largest band factor among the 16 candidates this lane's accumulators hold
-    unsigned row_mask;             // bit r: the candidate of accumulator register r exists (row < N)
+    unsigned row_mask;             // bit 15 - r: the candidate of accumulator register r exists (row < N)
 };
 
 // -DBLP_TIMING: per-phase cycle counts of the kernel below, summed over waves (tools/gemm_phase_timing.py)
@@ -407,12 +466,101 @@ __device__ unsigned long long g_bf16_timing[8];
 #define BLP_T(i) do { } while (0)
 #endif
 
-template <int MODEL, int D>
+// Two accumulator registers against the two thresholds: gm = 4 gm + {s0 > hi, s1 > hi}, lm likewise with < lo.
+// Hand-written: the compiler turns `m = 2 m + (s > thr)` into compare + select + shift + or (7 VALU per register with
+// both masks); here every compare shifts its result into the mask with one add-with-carry (m + m + carry): 4 VALU per
+// register, no scalar instruction.  Two registers per block so that every carry is read >= 2 instructions after the
+// compare that wrote it (gfx950: a VALU reading an SGPR a VALU wrote needs 2 wait states, and the assembler does not
+// insert them inside inline asm).
+__device__ __forceinline__ void decide_pair(unsigned& gm, unsigned& lm, float s0, float s1, float hi, float lo) {
+    unsigned long long c0, c1, c2, c3;  // the four carries: one SGPR pair each
+    asm("v_cmp_gt_f32_e64 %2, %6, %8\n\t"
+        "v_cmp_lt_f32_e64 %3, %6, %9\n\t"
+        "v_cmp_gt_f32_e64 %4, %7, %8\n\t"
+        "v_cmp_lt_f32_e64 %5, %7, %9\n\t"
+        "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %1, %3, %1, %1, %3\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
+        "v_addc_co_u32_e64 %1, %5, %1, %1, %5"
+        : "+v"(gm), "+v"(lm), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+        : "v"(s0), "v"(s1), "v"(hi), "v"(lo));
+}
+
+// One K-step of the pipelined stage with the instruction order fixed by hand: the six MFMAs of the NEXT query
+// tile (both candidate tiles: n += lo x bh, then hi x bl, then hi x bh -- bf16 products are exact in f32 -- the two
+// accumulator chains alternating so that no MFMA reads the accumulator the previous one writes) with the decision of
+// two accumulator registers per candidate tile of the CURRENT query tile (decide_pair's instructions) in their
+// shadow: 16 VALU behind 6 MFMAs, 3 + 3 + 3 + 3 + 2 + 2.  Left to itself the compiler issues a tile's 48 MFMAs back
+// to back and the 128 decision instructions after them, so within a wave neither hides behind the other.
+// Carries live in s[84:99] (clobbered): every carry is read >= 2 instructions after the compare that wrote it.
+// A and B operands are register quadruples of four packed bf16 pairs.  FIRST: the K-step that starts the
+// accumulation (SrcC = 0: no register zeroing).  BLP_GEMM_ASM_STAGE=0 builds the compiler-scheduled variant (A/B).
+#ifndef BLP_GEMM_ASM_STAGE
+#define BLP_GEMM_ASM_STAGE 1
+#endif
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));  // (HIP's uint4 is a struct: not an asm operand)
+__device__ __forceinline__ u32x4_t as_quad(const uint4& x) { return __builtin_bit_cast(u32x4_t, x); }
+#define BLP_KSTEP_BODY(C0, C1)                                                                              \
+    asm("v_mfma_f32_32x32x16_bf16 %0, %6, %10, " C0 "\n\t"                                                   \
+        "v_cmp_gt_f32_e64 s[84:85], %12, %16\n\t"                                                           \
+        "v_cmp_lt_f32_e64 s[86:87], %12, %17\n\t"                                                           \
+        "v_cmp_gt_f32_e64 s[88:89], %13, %16\n\t"                                                           \
+        "v_mfma_f32_32x32x16_bf16 %1, %8, %10, " C1 "\n\t"                                                   \
+        "v_cmp_lt_f32_e64 s[90:91], %13, %17\n\t"                                                           \
+        "v_cmp_gt_f32_e64 s[92:93], %14, %18\n\t"                                                           \
+        "v_cmp_lt_f32_e64 s[94:95], %14, %19\n\t"                                                           \
+        "v_mfma_f32_32x32x16_bf16 %0, %7, %11, %0\n\t"                                                      \
+        "v_addc_co_u32_e64 %2, s[84:85], %2, %2, s[84:85]\n\t"                                              \
+        "v_addc_co_u32_e64 %3, s[86:87], %3, %3, s[86:87]\n\t"                                              \
+        "v_cmp_gt_f32_e64 s[96:97], %15, %18\n\t"                                                           \
+        "v_mfma_f32_32x32x16_bf16 %1, %9, %11, %1\n\t"                                                      \
+        "v_cmp_lt_f32_e64 s[98:99], %15, %19\n\t"                                                           \
+        "v_addc_co_u32_e64 %2, s[88:89], %2, %2, s[88:89]\n\t"                                              \
+        "v_addc_co_u32_e64 %3, s[90:91], %3, %3, s[90:91]\n\t"                                              \
+        "v_mfma_f32_32x32x16_bf16 %0, %7, %10, %0\n\t"                                                      \
+        "v_addc_co_u32_e64 %4, s[92:93], %4, %4, s[92:93]\n\t"                                              \
+        "v_addc_co_u32_e64 %5, s[94:95], %5, %5, s[94:95]\n\t"                                              \
+        "v_mfma_f32_32x32x16_bf16 %1, %9, %10, %1\n\t"                                                      \
+        "v_addc_co_u32_e64 %4, s[96:97], %4, %4, s[96:97]\n\t"                                              \
+        "v_addc_co_u32_e64 %5, s[98:99], %5, %5, s[98:99]"
+#define BLP_KSTEP_CLOBBERS "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+template <bool FIRST>
+__device__ __forceinline__ void kstep_pair(f32x16_t& n0, f32x16_t& n1, u32x4_t lo0, u32x4_t hi0, u32x4_t lo1, u32x4_t hi1,
+                                           u32x4_t bh, u32x4_t bl, float c00, float c01, float c10, float c11, float th0,
+                                           float tl0, float th1, float tl1, unsigned& gm0, unsigned& lm0, unsigned& gm1,
+                                           unsigned& lm1) {
+    if constexpr (FIRST) {
+        BLP_KSTEP_BODY("0", "0")
+            : "=&v"(n0), "=&v"(n1), "+v"(gm0), "+v"(lm0), "+v"(gm1), "+v"(lm1)
+            : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(bh), "v"(bl), "v"(c00), "v"(c01), "v"(c10), "v"(c11), "v"(th0),
+              "v"(tl0), "v"(th1), "v"(tl1)
+            : BLP_KSTEP_CLOBBERS);
+    } else {
+        BLP_KSTEP_BODY("%0", "%1")
+            : "+v"(n0), "+v"(n1), "+v"(gm0), "+v"(lm0), "+v"(gm1), "+v"(lm1)
+            : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(bh), "v"(bl), "v"(c00), "v"(c01), "v"(c10), "v"(c11), "v"(th0),
+              "v"(tl0), "v"(th1), "v"(tl1)
+            : BLP_KSTEP_CLOBBERS);
+    }
+}
+#undef BLP_KSTEP_BODY
+#undef BLP_KSTEP_CLOBBERS
+
+// Undecided entries of the bf16 kernel: one per (query, 16-candidate half-tile) with at least one undecided pair.
+//   x = query * 2 + half ;  y = (candidate tile within the slab) << 16 | mask, bit 15 - r of the mask = accumulator
+//   register r = row acc_row(r, half) of the tile is undecided.
+constexpr int kBfMaxSlabTiles = 65536 - 16;  // the tile index must fit 16 bits
+
+// DUMP = true (tests only, blp_debug_gemm_dump): the same MFMA sequence and band arithmetic, but instead of deciding the
+// kernel stores S~ and the band half-width eps of every (query, candidate) pair into dense (Q, n_rows) matrices.
+template <int MODEL, int D, bool DUMP>
 __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_kernel(
-    const float* __restrict__ table, int64_t N, int64_t ld, const uint4* __restrict__ img_head,
+    const uint4* __restrict__ cimg, const float* __restrict__ cnmax, int64_t n_rows, const uint4* __restrict__ img_head,
     const uint4* __restrict__ img_tail, const float* __restrict__ key_true, const float* __restrict__ eps_q,
     int q_head, int q_tail, int n_groups, int chunks_head, int tiles_per_chunk, int words_per_query,
-    unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs) {
+    unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs,
+    unsigned* __restrict__ n_pairs, float* __restrict__ dump_s, float* __restrict__ dump_eps) {
     constexpr int STEPS = D / 16;
     constexpr int TILE_BYTES = 2 * STEPS * 64 * 16;  // hi + lo parts: 16 KB at D = 128
     const int quota = kBfQuotaPerTile * tiles_per_chunk;
@@ -420,14 +568,19 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     float* buf0 = smem;
     float* buf1 = smem + TILE_BYTES / 4;
     unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * (TILE_BYTES / 4));   // [tiles_per_chunk * 32]
-    float* nrm = reinterpret_cast<float*>(cnt + tiles_per_chunk * kGQT);         // [kBfW][kBfTPW][32]
-    uint2* pair_s = reinterpret_cast<uint2*>(nrm + kBfW * kBfTPW * 32);          // [quota]
+    uint2* pair_s = reinterpret_cast<uint2*>(cnt + tiles_per_chunk * kGQT);     // [quota]
     float2* kq_s = reinterpret_cast<float2*>(pair_s + quota);                    // [tiles_per_chunk * 32] {s_true, eps_q}
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, half = lane >> 5;
 
-    const int group = blockIdx.x % n_groups, chunk = blockIdx.x / n_groups;
+    // Workgroups are dispatched to the 8 XCDs round-robin (block b runs on XCD b % 8), each with its own L2.  The
+    // logical (candidate group, query chunk) index is laid out so that every XCD walks a contiguous range of it: the
+    // workgroups that share a query chunk (its 1 MB image is what a workgroup streams through LDS) run on one XCD
+    // and find it in that L2, instead of every XCD fetching every chunk.
+    const unsigned n_blocks = gridDim.x, xcd = blockIdx.x & 7u, per_xcd = n_blocks >> 3, rem = n_blocks & 7u;
+    const unsigned logical = (xcd < rem ? xcd * (per_xcd + 1) : rem * (per_xcd + 1) + (xcd - rem) * per_xcd) + (blockIdx.x >> 3);
+    const int group = (int)(logical % (unsigned)n_groups), chunk = (int)(logical / (unsigned)n_groups);
     const bool head = chunk < chunks_head;
     const int side_chunk = head ? chunk : chunk - chunks_head;
     const int n_side = head ? q_head : q_tail, q_base = head ? 0 : q_head;
@@ -441,64 +594,23 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         const int q = q_base + (q_local < n_side ? q_local : n_side - 1);
         kq_s[i] = make_float2(key_true[q], eps_q[q]);
     }
-    for (int i = tid; i < quota; i += kBfW * 64) pair_s[i] = make_uint2(kNoPair, 0u);
 
-    // this wave's candidate tiles: lane (row l & 31, K-half l >> 5) reads its 8 floats of every K-step
-    // straight from the table, splits them, and keeps them as MFMA A operands
+    // this wave's candidate tiles: the pre-split A operands straight from the image (1 KB per load instruction)
     BfTile<D> c[kBfTPW];
     const int ctile0 = (group * kBfW + wave) * kBfTPW;
     static_for<kBfTPW>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
-        const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
-        int64_t row = row0 + (lane & 31);
-        row = row < N ? row : N - 1;
-        const float* src = table + row * ld + 8 * half;
-        float ss = 0.f, mx = 0.f;
-        bool bad = false;
+        const uint4* src = cimg + (size_t)(ctile0 + t) * 2 * STEPS * 64 + lane;
         static_for<STEPS>([&](auto kk) {
             constexpr int st = decltype(kk)::value;
-            const float4 x = *reinterpret_cast<const float4*>(src + 16 * st);
-            const float4 y = *reinterpret_cast<const float4*>(src + 16 * st + 4);
-            split_bf16(x.x, x.y, c[t].hi[st].x, c[t].lo[st].x);
-            split_bf16(x.z, x.w, c[t].hi[st].y, c[t].lo[st].y);
-            split_bf16(y.x, y.y, c[t].hi[st].z, c[t].lo[st].z);
-            split_bf16(y.z, y.w, c[t].hi[st].w, c[t].lo[st].w);
-            const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                ss += v[j] * v[j];
-                const float a = fabsf(v[j]);
-                bad |= !(a <= 3.0e38f);  // NaN too
-                mx = a > mx ? a : mx;
-            }
+            c[t].hi[st] = src[st * 64];
+            c[t].lo[st] = src[(STEPS + st) * 64];
         });
-        ss += __shfl_xor(ss, 32);
-        const float m2 = __shfl_xor(mx, 32);
-        mx = m2 > mx ? m2 : mx;
-        bad |= (bool)__shfl_xor((int)bad, 32);
-        const bool exists = row0 + (lane & 31) < N;
-        if (!exists) {  // S~ = NaN for a row that does not exist: never decided, dropped by row_mask
-            static_for<STEPS>([&](auto kk) {
-                constexpr int st = decltype(kk)::value;
-                c[t].hi[st] = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
-                c[t].lo[st] = make_uint4(0u, 0u, 0u, 0u);
-            });
-        }
-        if (lane < 32) nrm[(wave * kBfTPW + t) * 32 + lane] = exists ? band_norm(ss, bad ? __builtin_inff() : mx) : 0.f;
-    });
-    __syncthreads();
-    static_for<kBfTPW>([&](auto tt) {
-        constexpr int t = decltype(tt)::value;
+        c[t].nmax = cnmax[(ctile0 + t) * 2 + half];
         const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
         c[t].row_mask = 0;
-        c[t].nmax = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, half);
-            const float nr = nrm[(wave * kBfTPW + t) * 32 + row];
-            c[t].nmax = nr > c[t].nmax ? nr : c[t].nmax;
-            c[t].row_mask |= (unsigned)(row0 + row < N) << r;
-        }
+        for (int r = 0; r < 16; ++r) c[t].row_mask |= (unsigned)(row0 + acc_row(r, half) < n_rows) << (15 - r);
     });
 
     const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
@@ -540,55 +652,47 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     };
     // Decision for accumulator registers [R0, R0 + NR) of both tiles against the two thresholds of this
     // (query, 16-candidate half-tile): s_true +- (eps_q * max ||e|| + guard).  Using the half-tile's largest
-    // band factor for all of its rows only widens the band; it makes the decision two compares and an
-    // add-with-carry per accumulator register.  NaN anywhere: neither compare holds -> undecided.
+    // band factor for all of its rows only widens the band.  Each compare shifts its result into a per-lane bit
+    // mask with one add-with-carry (m = m + m + carry): after the 16 registers gm holds "certainly above", lm
+    // "certainly below", register r at bit 15 - r; what is in neither is undecided (NaN: neither compare holds).
     auto decide_chunk = [&](auto r0, auto nr, const f32x16 (&s)[kBfTPW], const float (&thr_hi)[kBfTPW],
-                            const float (&thr_lo)[kBfTPW], unsigned (&above)[kBfTPW], bool (&any_und)[kBfTPW]) {
+                            const float (&thr_lo)[kBfTPW], unsigned (&gm)[kBfTPW], unsigned (&lm)[kBfTPW]) {
         constexpr int R0 = decltype(r0)::value, NR = decltype(nr)::value;
+        static_assert(NR % 2 == 0, "registers are decided in pairs");
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            static_for<NR>([&](auto jj) {
-                constexpr int r = R0 + decltype(jj)::value;
-                const bool ab = s[ti][r] > thr_hi[ti];
-                above[ti] += ab;
-                any_und[ti] |= !(ab || s[ti][r] < thr_lo[ti]);
+            static_for<NR / 2>([&](auto jj) {
+                constexpr int r = R0 + 2 * decltype(jj)::value;
+                decide_pair(gm[ti], lm[ti], s[ti][r], s[ti][r + 1], thr_hi[ti], thr_lo[ti]);
             });
         });
     };
-    // Rare: some lane of the wave has an undecided register.  Every wave owns a slice of the workgroup's pair
-    // list and keeps its fill count in a scalar register, so listing needs no LDS atomic (a slot
-    // reservation through LDS cost several hundred cycles under the DMA / operand traffic): the lanes
-    // with undecided registers are visited one by one.  When the slice is full the lane's half-segment is
-    // flagged instead and contributes no count.
-    auto settle = [&](int t, int q, bool q_ok, const f32x16 (&s)[kBfTPW], const float (&thr_hi)[kBfTPW],
-                      const float (&thr_lo)[kBfTPW], const unsigned (&above_in)[kBfTPW], const bool (&any_und)[kBfTPW]) {
+    // Counts and undecided entries of one (query tile, wave).  A lane whose 16 registers hold an undecided pair
+    // lists ONE entry (query, half-tile, mask): the slot is the wave's scalar fill count plus the lane's rank among
+    // the listing lanes (a ballot and a bit count, no loop, no LDS atomic).  When the wave's slice of the list
+    // is full the lane's half-segment is flagged instead and contributes no count (the sweep recounts all of it).
+    auto settle = [&](int t, int q, bool q_ok, const unsigned (&gm)[kBfTPW], const unsigned (&lm)[kBfTPW]) {
         unsigned total_above = 0;
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            unsigned above = q_ok ? above_in[ti] : 0u;
-            if (__ballot(q_ok && any_und[ti])) {  // wave-uniform
-                unsigned und = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) und |= (unsigned)!(s[ti][r] > thr_hi[ti] || s[ti][r] < thr_lo[ti]) << r;
-                und = q_ok ? und & c[ti].row_mask : 0u;
-                const int ctile = ctile0 + ti;
-                for (unsigned long long todo = __ballot(und != 0); todo; todo &= todo - 1) {
-                    const int src = __builtin_ctzll(todo);
-                    const unsigned n = __popc(__builtin_amdgcn_readlane(und, src));  // scalar
-                    const bool fits = my_pairs + n <= wave_quota;
-                    if (lane == src) {
-                        if (fits) {
-                            unsigned slot = wave * wave_quota + my_pairs;
-                            for (unsigned mm = und; mm; mm &= mm - 1)
-                                pair_s[slot++] = make_uint2((unsigned)q, (unsigned)(ctile * kGCT + acc_row(__builtin_ctz(mm), half)));
-                        } else {
-                            const int hseg = ctile * 2 + half;
-                            atomicOr(flags + (size_t)q * words_per_query + (hseg >> 5), 1u << (hseg & 31));
-                            above = 0;
-                        }
+            unsigned above = q_ok ? __popc(gm[ti]) : 0u;  // rows that do not exist score NaN: never above
+            const unsigned und = q_ok ? ~(gm[ti] | lm[ti]) & c[ti].row_mask : 0u;
+            const unsigned long long listing = __ballot(und != 0);
+            if (listing) {  // wave-uniform
+                const unsigned n = __popcll(listing);
+                const bool fits = my_pairs + n <= wave_quota;
+                if (und) {
+                    const int ctile = ctile0 + ti;
+                    if (fits) {
+                        const unsigned slot = my_pairs + __popcll(listing & ((1ull << lane) - 1ull));
+                        pair_s[wave * wave_quota + slot] = make_uint2((unsigned)q * 2u + (unsigned)half, ((unsigned)ctile << 16) | und);
+                    } else {
+                        const int hseg = ctile * 2 + half;
+                        atomicOr(flags + (size_t)q * words_per_query + (hseg >> 5), 1u << (hseg & 31));
+                        above = 0;
                     }
-                    my_pairs += fits ? n : 0u;
                 }
+                my_pairs += fits ? n : 0u;
             }
             total_above += above;
         });
@@ -616,29 +720,61 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         const float2 kq = kq_s[t * kGQT + (lane & 31)];
         const float kt = kq.x, eq = kq.y;
         const float guard = fabsf(kt) * 2.4e-7f + 1e-35f;  // rounding of the thresholds themselves, product underflow
-        unsigned above[kBfTPW];
-        bool any_und[kBfTPW];
-        float thr_hi[kBfTPW], thr_lo[kBfTPW];
+        unsigned gm[kBfTPW], lm[kBfTPW];
+        float thr_hi[kBfTPW], thr_lo[kBfTPW], eps[kBfTPW];
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            const float eps = __builtin_fmaf(eq, c[ti].nmax, guard);
-            thr_hi[ti] = kt + eps;
-            thr_lo[ti] = kt - eps;
-            above[ti] = 0;
-            any_und[ti] = false;
+            eps[ti] = __builtin_fmaf(eq, c[ti].nmax, guard);
+            thr_hi[ti] = kt + eps[ti];
+            thr_lo[ti] = kt - eps[ti];
+            gm[ti] = 0;
+            lm[ti] = 0;
         });
         if (more) {
             const float* nbuf = ((t + 1) & 1) ? buf1 : buf0;
-            zero_acc(nxt);
-            mfma_tile(nxt, nbuf, [&](auto kk) {
-                constexpr int st = decltype(kk)::value;
-                decide_chunk(ic<st * (16 / STEPS)>{}, ic<16 / STEPS>{}, cur, thr_hi, thr_lo, above, any_und);
-            });
-        } else {
-            decide_chunk(ic<0>{}, ic<16>{}, cur, thr_hi, thr_lo, above, any_und);
+            if constexpr (!DUMP && BLP_GEMM_ASM_STAGE && STEPS == 8) {  // two registers per K-step: 16 = 2 x 8
+                u32x4_t bh[2], bl[2];
+                const u32x4_t* bp = reinterpret_cast<const u32x4_t*>(nbuf) + lane;
+                bh[0] = bp[0];
+                bl[0] = bp[STEPS * 64];
+                static_for<STEPS>([&](auto kk) {
+                    constexpr int st = decltype(kk)::value;
+                    if constexpr (st + 1 < STEPS) {
+                        bh[(st + 1) & 1] = bp[(st + 1) * 64];
+                        bl[(st + 1) & 1] = bp[(STEPS + st + 1) * 64];
+                    }
+                    static_assert(kBfTPW == 2, "kstep_pair is written for two candidate tiles per wave");
+                    kstep_pair<st == 0>(nxt[0], nxt[1], as_quad(c[0].lo[st]), as_quad(c[0].hi[st]), as_quad(c[1].lo[st]),
+                                        as_quad(c[1].hi[st]), bh[st & 1], bl[st & 1], cur[0][2 * st], cur[0][2 * st + 1],
+                                        cur[1][2 * st], cur[1][2 * st + 1], thr_hi[0], thr_lo[0], thr_hi[1], thr_lo[1], gm[0],
+                                        lm[0], gm[1], lm[1]);
+                });
+            } else {
+                zero_acc(nxt);
+                mfma_tile(nxt, nbuf, [&](auto kk) {
+                    constexpr int st = decltype(kk)::value;
+                    if constexpr (!DUMP) decide_chunk(ic<st * (16 / STEPS)>{}, ic<16 / STEPS>{}, cur, thr_hi, thr_lo, gm, lm);
+                });
+            }
+        } else if constexpr (!DUMP) {
+            decide_chunk(ic<0>{}, ic<16>{}, cur, thr_hi, thr_lo, gm, lm);
         }
         BLP_T(1);
-        settle(t, q, q_ok, cur, thr_hi, thr_lo, above, any_und);
+        if constexpr (DUMP) {
+            static_for<kBfTPW>([&](auto tt) {
+                constexpr int ti = decltype(tt)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = (int64_t)(ctile0 + ti) * kGCT + acc_row(r, half);
+                    if (q_ok && row < n_rows) {
+                        dump_s[(size_t)q * n_rows + row] = cur[ti][r];
+                        dump_eps[(size_t)q * n_rows + row] = eps[ti];
+                    }
+                }
+            });
+        } else {
+            settle(t, q, q_ok, gm, lm);
+        }
         BLP_T(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BLP_T(3);
@@ -659,12 +795,19 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         stage(t, acc_a, acc_b);
         if (t + 1 < n_tiles) stage(t + 1, acc_b, acc_a);
     }
-    for (int i = tid; i < n_tiles * kGQT; i += kBfW * 64) {
-        const int q_local = tile0 * kGQT + i;
-        const unsigned long long v = cnt[i];
-        if (q_local < n_side && v) atomicAdd(acc + q_base + q_local, v | (v << 32));  // certainly above: gt and ge
+    if constexpr (!DUMP) {
+        for (int i = tid; i < n_tiles * kGQT; i += kBfW * 64) {
+            const int q_local = tile0 * kGQT + i;
+            const unsigned long long v = cnt[i];
+            if (q_local < n_side && v) atomicAdd(acc + q_base + q_local, v | (v << 32));  // certainly above: gt and ge
+        }
+        // this wave's entries go to a slice of the global list reserved with one atomic (its own LDS writes are
+        // visible to it in program order: no barrier)
+        unsigned base = 0;
+        if (lane == 0 && my_pairs) base = atomicAdd(n_pairs, my_pairs);
+        base = __shfl(base, 0);
+        for (unsigned i = lane; i < my_pairs; i += 64) pairs[base + i] = pair_s[wave * wave_quota + i];
     }
-    for (int i = tid; i < quota; i += kBfW * 64) pairs[(size_t)blockIdx.x * quota + i] = pair_s[i];
 #ifdef BLP_TIMING
     BLP_T(5);
     if (lane == 0) {
@@ -674,14 +817,120 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
 #endif
 }
 
-// Pass 2a: one lane per listed pair.
+// Term i of the reference's sum for candidate row e and query coefficients c: the arithmetic of
+// Scorer<MODEL, SIDE, D>::score (score_core.h) for one summand, addressed at run time.
+template <int MODEL, int SIDE, int D>
+__device__ __forceinline__ float score_term(const float* __restrict__ e, const float* __restrict__ c, int i) {
+    constexpr int H = D / 2;
+    if constexpr (MODEL == DISTMULT) {
+        if constexpr (SIDE == TAIL) {
+            return c[i] * e[i];
+        } else {
+            const float x = e[i] * c[i];
+            return x * c[D + i];
+        }
+    } else if constexpr (MODEL == COMPLEX) {
+        if constexpr (SIDE == TAIL) {
+            const float a = c[i] * e[i];
+            const float b = c[H + i] * e[H + i];
+            const float cc = c[2 * H + i] * e[H + i];
+            const float d = c[3 * H + i] * e[i];
+            float s = a + b;
+            s = s + cc;
+            return s - d;
+        } else {
+            float a = c[i] * e[i];          a = a * c[D + i];
+            float b = c[i] * e[H + i];      b = b * c[D + H + i];
+            float cc = c[H + i] * e[i];     cc = cc * c[D + H + i];
+            float d = c[H + i] * e[H + i];  d = d * c[D + i];
+            float s = a + b;
+            s = s + cc;
+            return s - d;
+        }
+    } else {
+        if constexpr (SIDE == TAIL) {
+            const float a = c[i] * e[H + i];
+            float b = e[i] * c[H + i];
+            b = b * c[2 * H + i];
+            return a + b;
+        } else {
+            float a = e[i] * c[i];
+            a = a * c[H + i];
+            const float b = c[2 * H + i] * e[H + i];
+            return a + b;
+        }
+    }
+}
+
+// The exact score of one (candidate, query) pair by 32 cooperating lanes, in the reference's summation order
+// (torch_inner_sum, score_core.h): lane j IS accumulator A[j] -- it adds the terms j, 32 + j, 64 + j, ... in that
+// order -- then V[l] = ((A[l] + A[8 + l]) + A[16 + l]) + A[24 + l] and the eight V left to right.  Every load is 32
+// consecutive floats (one 128-B line) instead of 64 lanes gathering 16 bytes each from 64 different rows.
+// `sub` = lane & 31; both 32-lane halves of a wave work on their own pair.  Result valid in every lane of the half.
+template <int MODEL, int SIDE, int D>
+__device__ __forceinline__ float coop_score(const float* __restrict__ e, const float* __restrict__ c, int sub) {
+    constexpr int NT = MODEL == DISTMULT ? D : D / 2;
+    float a = score_term<MODEL, SIDE, D>(e, c, sub);
+#pragma unroll
+    for (int k = 1; k < NT / 32; ++k) a = a + score_term<MODEL, SIDE, D>(e, c, 32 * k + sub);
+    float v = a + __shfl_down(a, 8, 32);
+    v = v + __shfl_down(a, 16, 32);
+    v = v + __shfl_down(a, 24, 32);
+    float s = __shfl(v, 0, 32);
+#pragma unroll
+    for (int l = 1; l < 8; ++l) s = s + __shfl(v, l, 32);
+    return MODEL == SIMPLE ? s / 2.0f : s;
+}
+
+// Pass 2a: the listed entries, one per 32-lane half-wave; every undecided pair of the entry is re-scored exactly
+// (coop_score) and counted.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
                                                            const float* __restrict__ coef_head,
                                                            const float* __restrict__ coef_tail,
                                                            const float* __restrict__ key_true, int64_t q_head,
-                                                           const uint2* __restrict__ pairs, int64_t n_entries,
+                                                           const uint2* __restrict__ pairs,
+                                                           const unsigned* __restrict__ n_pairs,
                                                            unsigned long long* __restrict__ acc) {
+    const unsigned n = *n_pairs;
+    const int lane = threadIdx.x & 63, sub = lane & 31;
+    const unsigned wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned e0 = wave_id * 2; e0 < n; e0 += n_waves * 2) {  // wave-uniform trip count
+        const unsigned ei = e0 + (lane >> 5);
+        const bool live = ei < n;
+        const uint2 p = live ? pairs[ei] : make_uint2(0u, 0u);
+        const int64_t q = p.x >> 1;
+        const int half = p.x & 1;
+        const int64_t row0 = (int64_t)(p.y >> 16) * kGCT;
+        unsigned und = live ? p.y & 0xffffu : 0u;
+        const bool is_head = q < q_head;
+        const float* coef = is_head ? coef_head + q * Scorer<MODEL, HEAD, D>::C
+                                    : coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C;
+        const float kt = key_true[q];
+        unsigned gt = 0, ge = 0;
+        while (__ballot(und != 0)) {  // the halves walk their own masks; an exhausted half idles
+            const int bit = und ? 31 - __builtin_clz(und) : 0;
+            const bool work = und != 0;
+            und &= ~(1u << bit);
+            const float* e = table + (row0 + acc_row(15 - bit, half)) * ld;
+            float key;
+            if (is_head) key = coop_score<MODEL, HEAD, D>(work ? e : table, coef, sub);
+            else key = coop_score<MODEL, TAIL, D>(work ? e : table, coef, sub);
+            gt += work && key > kt;
+            ge += work && key >= kt;
+        }
+        if (sub == 0 && (gt | ge)) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+    }
+}
+
+// Pass 2a of the f32-chain kernel: one lane per slot of the workgroups' fixed (query, row) pair regions.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __restrict__ table, int64_t ld,
+                                                                const float* __restrict__ coef_head,
+                                                                const float* __restrict__ coef_tail,
+                                                                const float* __restrict__ key_true, int64_t q_head,
+                                                                const uint2* __restrict__ pairs, int64_t n_entries,
+                                                                unsigned long long* __restrict__ acc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     const uint2 p = pairs[i];
@@ -759,7 +1008,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
 struct GemmWorkspace {
     float* coef_head; float* coef_tail; float* key_true; float* eps_q;
     float4* img_head; float4* img_tail;
-    unsigned long long* acc; unsigned* flags; uint2* pairs;
+    uint4* cimg; float* cnmax;  // bf16 candidate image (whole table) and its per-half-tile band factors
+    unsigned long long* acc; unsigned* n_pairs; unsigned* flags; uint2* pairs;
     int64_t pass_ctiles;  // candidate tiles per GEMM + refine pass
     size_t bytes;
 };
@@ -792,6 +1042,7 @@ static int64_t tiles_per_pass(int64_t N, int64_t q_head, int64_t q_tail) {
     const int64_t by_pairs = cap / 8 / pair_entries(16, q_head, q_tail);  // entries grow linearly in whole 16-tile words
     if (words > by_flags) words = by_flags;
     if (words > by_pairs) words = by_pairs;
+    if (words * 16 > kBfMaxSlabTiles) words = kBfMaxSlabTiles / 16;  // an entry holds the slab-local tile in 16 bits
     if (const int64_t forced = knob(KNOB_GEMM_PASS_WORDS))  // test knob: force the multi-slab path
         if (forced > 0 && forced < words) words = forced;
     return (words < 1 ? 1 : words) * 16;
@@ -810,7 +1061,14 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     w.img_head = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_head + kGQT - 1) / kGQT) * tile_bytes, 256);
     w.img_tail = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_tail + kGQT - 1) / kGQT) * tile_bytes, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
+    {   // candidate tiles padded to whole workgroup loads of the bf16 kernel
+        const int64_t per_group = kBfW * kBfTPW;
+        const int64_t tiles = ((N + kGCT - 1) / kGCT + per_group - 1) / per_group * per_group;
+        w.cimg = reinterpret_cast<uint4*>(p + off);  off = align_up(off + (size_t)tiles * kGCT * D * 4, 256);
+        w.cnmax = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)tiles * 2 * 4, 256);
+    }
     w.pass_ctiles = tiles_per_pass(N, q_head, q_tail);
+    w.n_pairs = reinterpret_cast<unsigned*>(p + off); off += 256;  // directly before the flags: one memset clears both
     w.flags = reinterpret_cast<unsigned*>(p + off);
     off = align_up(off + (size_t)Q * (size_t)(w.pass_ctiles / 16) * 4, 256);
     w.pairs = reinterpret_cast<uint2*>(p + off);
@@ -828,6 +1086,11 @@ size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, in
     if (!rank_gemm_applicable(model, D, q_head, q_tail)) return 0;
     return carve_gemm(nullptr, D, N, q_head, q_tail).bytes;
 }
+
+// blp_debug_gemm_dump: the next bilinear pre-pass of this thread stores S~ and eps instead of deciding (tests)
+static thread_local float* g_dump_s = nullptr;
+static thread_local float* g_dump_eps = nullptr;
+void gemm_set_dump(float* s, float* eps) { g_dump_s = s; g_dump_eps = eps; }
 
 template <int MODEL, int D>
 static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
@@ -851,7 +1114,16 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             w.eps_q);
     const size_t lds_f32 = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
                            (size_t)kPairQuota * 8 + 16;
+    float* dump_s = g_dump_s;
+    float* dump_eps = g_dump_eps;
+    g_dump_s = g_dump_eps = nullptr;
+    if (dump_s && (f32_kernel || D != 128 || N > pass_tiles * kGCT)) return hipErrorInvalidValue;  // one slab of the bf16 kernel
     if (ev_start) (void)hipEventRecord(ev_start, stream);
+    if (!f32_kernel) {  // the table as bf16 hi / lo MFMA operands + band factors, once per call
+        const int64_t per_group = kBfW * kBfTPW;
+        const int64_t tiles = ((N + kGCT - 1) / kGCT + per_group - 1) / per_group * per_group;
+        if (tiles > 0) prep_cand_bf16_kernel<D><<<dim3((unsigned)tiles), 64, 0, stream>>>(table, N, ld, w.cimg, w.cnmax);
+    }
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_tiles * kGCT) {  // one iteration unless the bitmap is capped
         const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
         const int64_t n_ctiles = (n_rows + kGCT - 1) / kGCT;
@@ -875,24 +1147,37 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         const int64_t chunks_head = (th + tiles_per_chunk - 1) / tiles_per_chunk;
         const int64_t chunks_tail = (tt + tiles_per_chunk - 1) / tiles_per_chunk;
         const size_t lds_bf16 = (size_t)2 * (2 * (D / 16) * 64 * 16) + (size_t)tiles_per_chunk * kGQT * 4 +
-                                (size_t)kBfW * kBfTPW * 32 * 4 + (size_t)kBfQuotaPerTile * tiles_per_chunk * 8 +
-                                (size_t)tiles_per_chunk * kGQT * 8 + 16;
+                                (size_t)kBfQuotaPerTile * tiles_per_chunk * 8 + (size_t)tiles_per_chunk * kGQT * 8 + 16;
         const int64_t n_blocks = n_groups * (chunks_head + chunks_tail);
-        const int64_t n_entries = n_blocks * (f32_kernel ? kPairQuota : kBfQuotaPerTile * tiles_per_chunk);
-        err = hipMemsetAsync(w.flags, 0, (size_t)Q * words * 4, stream);
+        err = hipMemsetAsync(w.n_pairs, 0, 256 + (size_t)Q * words * 4, stream);  // the entry counter and the flag bitmap
         if (err != hipSuccess) return err;
         const float* slab = table + slab0 * ld;
-        if (f32_kernel)
+        if (f32_kernel) {
+            const int64_t n_entries = n_blocks * kPairQuota;
             rank_gemm_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kGW * 64, lds_f32, stream>>>(
                 slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups,
                 (int)chunks_head, words, w.acc, w.flags, w.pairs);
-        else
-            rank_gemm_bf16_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kBfW * 64, lds_bf16, stream>>>(
-                slab, n_rows, ld, reinterpret_cast<const uint4*>(w.img_head), reinterpret_cast<const uint4*>(w.img_tail),
-                w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head, tiles_per_chunk, words, w.acc,
-                w.flags, w.pairs);
-        refine_pairs_kernel<MODEL, D><<<dim3((unsigned)((n_entries + 255) / 256)), 256, 0, stream>>>(
-            slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_entries, w.acc);
+            refine_pair_slots_kernel<MODEL, D><<<dim3((unsigned)((n_entries + 255) / 256)), 256, 0, stream>>>(
+                slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_entries, w.acc);
+        } else {
+            const uint4* cimg = w.cimg + (size_t)(slab0 / kGCT) * (D / 8) * 64;  // 2 parts x D/16 steps x 64 lanes per tile
+            const float* cnmax = w.cnmax + (slab0 / kGCT) * 2;
+            const uint4* ih = reinterpret_cast<const uint4*>(w.img_head);
+            const uint4* it = reinterpret_cast<const uint4*>(w.img_tail);
+            if constexpr (D == 128) {
+                if (dump_s) {
+                    rank_gemm_bf16_kernel<MODEL, D, true><<<dim3((unsigned)n_blocks), kBfW * 64, lds_bf16, stream>>>(
+                        cimg, cnmax, n_rows, ih, it, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups,
+                        (int)chunks_head, tiles_per_chunk, words, w.acc, w.flags, w.pairs, w.n_pairs, dump_s, dump_eps);
+                    continue;
+                }
+            }
+            rank_gemm_bf16_kernel<MODEL, D, false><<<dim3((unsigned)n_blocks), kBfW * 64, lds_bf16, stream>>>(
+                cimg, cnmax, n_rows, ih, it, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head,
+                tiles_per_chunk, words, w.acc, w.flags, w.pairs, w.n_pairs, nullptr, nullptr);
+            refine_pairs_kernel<MODEL, D><<<dim3(2048), 256, 0, stream>>>(slab, ld, w.coef_head, w.coef_tail, w.key_true,
+                                                                        q_head, w.pairs, w.n_pairs, w.acc);
+        }
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
     }

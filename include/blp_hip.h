@@ -244,6 +244,13 @@ int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, co
  * -------------------------------------------------------------------------------------------- */
 int blp_debug_set_knob(const char *name, long long value);
 
+/* Test hook for the error band of the bilinear pre-pass: the NEXT blp_rank_all of the calling thread on a DistMult /
+ * ComplEx / SimplE block (D = 128, >= 64 queries, one candidate slab) runs the SAME bf16 x 3 MFMA sequence and band
+ * arithmetic as always but, instead of deciding, stores the approximate score S~ and the band half-width eps of every
+ * (query, candidate) pair into two dense (Q, N) f32 matrices; `counts` of that call are meaningless.  One-shot; NULL,
+ * NULL cancels.  tests/test_gpu_fullsize.py compares |S~ - S_ref| with eps on whole blocks. */
+int blp_debug_gemm_dump(float *scores, float *eps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,49 @@ def test_wikidata5m_block_prepass_equals_exact_kernel():
     triples, counts, _ = job.step(filtered=True)
     exact = _direct(job, triples, rank_kernel=1)
     assert torch.equal(counts, exact)
+
+
+@pytest.mark.parametrize("data", ["bench", "scaled"])
+@pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
+def test_bf16_band_margin(bench, model, data):
+    """The one empirical ingredient of the bilinear pre-pass's band: how the MFMA rounds inside one
+    v_mfma_f32_32x32x16_bf16 is not documented, the band prices it at 2 u per addition.  This runs the kernel's own
+    MFMA sequence and band arithmetic in dump mode (blp_debug_gemm_dump) on 2 048 queries x all 14 541 candidates of
+    the timed block and compares |S~ - S_ref| (S_ref = the reference's f32 score, bit-exact from blp_score_fwd) with
+    the band half-width eps the kernel used for that pair.  Correctness needs ratio <= 1 for every pair; the test
+    pins the margin: the largest ratio must stay below 1/4.  "scaled": every table element and every relation element
+    scaled by its own power of two in 2^-8 .. 2^8 (exponent spreads inside a dot product, which the bench data
+    lacks: a few products dominate the sum), plus two all-zero rows."""
+    from blp_amd import _lib, ops
+    job = bench.Job(f"fb15k237-{model}", torch.device("cuda", 0))
+    table = job.table
+    g = torch.Generator(device="cuda").manual_seed(17)
+    if data == "scaled":
+        table = table * torch.exp2(torch.randint(-8, 9, (job.N, job.D), device="cuda", generator=g).float())
+        table[5] = 0.0
+        table[4097] = 0.0
+    pick = torch.arange(0, job.T, job.T // 1024, device="cuda")[:1024]
+    t = job.triples[pick]
+    rel = job.model.rel_emb.weight.detach()[t[:, 2]]
+    fixed = torch.cat((table[t[:, 1]], table[t[:, 0]]))
+    rel2 = torch.cat((rel, rel))
+    if data == "scaled":
+        rel2 = rel2 * torch.exp2(torch.randint(-8, 9, rel2.shape, device="cuda", generator=g).float())
+    b, Q, N = t.shape[0], 2 * t.shape[0], job.N
+    S = torch.full((Q, N), float("nan"), device="cuda")
+    E = torch.full((Q, N), float("nan"), device="cuda")
+    _lib.check(_lib.lib().blp_debug_gemm_dump(S.data_ptr(), E.data_ptr()), "blp_debug_gemm_dump")
+    ops.rank_all(model, table, fixed, rel2, b, true_row=torch.cat((t[:, 0], t[:, 1])))  # dump call: counts meaningless
+    torch.cuda.synchronize()
+    assert not torch.isnan(S).any() and not torch.isnan(E).any()
+    ent = table.unsqueeze(0)
+    ref = torch.cat((ops.score(model, ent, fixed[:b].unsqueeze(1), rel2[:b].unsqueeze(1)),
+                     ops.score(model, fixed[b:].unsqueeze(1), ent, rel2[b:].unsqueeze(1))))
+    err = (S.double() - ref.double()).abs()
+    finite = torch.isfinite(E)
+    assert finite.float().mean() > 0.99  # an infinite band (exact path) only for rows outside the relative bounds
+    ratio = torch.where(finite & (E > 0), err / E.double(), torch.zeros_like(err))
+    assert (err[E == 0] == 0).all()  # all-zero rows: no band needed, no error made
+    worst = ratio.max().item()
+    print(f"bf16 x 3 band, {model} / {data}: max |S~ - S_ref| / eps = {worst:.4f} over {Q * N:,} pairs")
+    assert worst < 0.25, worst
