@@ -48,57 +48,14 @@ __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict_
                                                         const float* __restrict__ q_fixed,
                                                         const float* __restrict__ q_rel, int64_t q_head, int64_t Q,
                                                         SadParams* __restrict__ partial) {
-    int lo = 0x7fffffff, hi = (int)0x80000000;
-    float maxabs = 0.f;
-    bool bad = false;
-    auto see = [&](float x) {
-        const float ax = fabsf(x);
-        if (!(ax < 3.0e38f)) { bad = true; return; }  // NaN, Inf or too close to overflow
-        const int o = f2ord(x);
-        lo = o < lo ? o : lo;
-        hi = o > hi ? o : hi;
-        maxabs = ax > maxabs ? ax : maxabs;
-    };
+    SadRange range;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t0; i < N * (D / 4); i += stride) {
         const float4 v = *reinterpret_cast<const float4*>(table + (i / (D / 4)) * ld + (i % (D / 4)) * 4);
-        see(v.x); see(v.y); see(v.z); see(v.w);
+        range.see(v.x); range.see(v.y); range.see(v.z); range.see(v.w);
     }
-    for (int64_t i = t0; i < Q * D; i += stride) {
-        const float f = q_fixed[i], r = q_rel[i];
-        const int lo_keep = lo, hi_keep = hi;
-        see(f); see(r);  // for max |value| only: the range is that of the coefficient
-        lo = lo_keep; hi = hi_keep;
-        see(sad_coef(f, r, i / D < q_head));
-    }
-    __shared__ int s_lo[4], s_hi[4];
-    __shared__ float s_max[4];
-    __shared__ int s_bad[4];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
-        const float m2 = __shfl_xor(maxabs, off);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-        maxabs = m2 > maxabs ? m2 : maxabs;
-    }
-    const bool any_bad = __any(bad);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_max[wave] = maxabs; s_bad[wave] = any_bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        SadParams p = {};
-        p.lo_ord = 0x7fffffff; p.hi_ord = (int)0x80000000;
-        float m = 0.f;
-        for (int w = 0; w < 4; ++w) {
-            p.lo_ord = s_lo[w] < p.lo_ord ? s_lo[w] : p.lo_ord;
-            p.hi_ord = s_hi[w] > p.hi_ord ? s_hi[w] : p.hi_ord;
-            m = s_max[w] > m ? s_max[w] : m;
-            p.nonfinite |= (unsigned)s_bad[w];
-        }
-        p.maxabs_bits = __float_as_uint(m);
-        partial[blockIdx.x] = p;
-    }
+    for (int64_t i = t0; i < Q * D; i += stride) range.see(sad_coef(q_fixed[i], q_rel[i], i / D < q_head));
+    sad_range_block_store(range, partial);
 }
 
 // Candidate tile image: 64 rows per tile, uint4 index ((tile * D/8 + j4) * 64 + lane) holds dwords
@@ -117,15 +74,16 @@ __global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __
     constexpr int F = D / 4;  // floats per thread
     unsigned w[F / 2];
     float res = 0.f;
+    bool outside = false;  // a value the map does not cover: the row is left to the exact path
     if (row < N) {
         const float* src = table + row * ld + part * F;
 #pragma unroll
         for (int i = 0; i < F / 4; ++i) {
             const float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
-            w[2 * i] = sad_quant(v.x, sc, res);
-            w[2 * i] |= sad_quant(v.y, sc, res) << 16;
-            w[2 * i + 1] = sad_quant(v.z, sc, res);
-            w[2 * i + 1] |= sad_quant(v.w, sc, res) << 16;
+            w[2 * i] = sad_quant(v.x, sc, res, outside);
+            w[2 * i] |= sad_quant(v.y, sc, res, outside) << 16;
+            w[2 * i + 1] = sad_quant(v.z, sc, res, outside);
+            w[2 * i + 1] |= sad_quant(v.w, sc, res, outside) << 16;
         }
     } else {
 #pragma unroll
@@ -133,7 +91,10 @@ __global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __
     }
     res += __shfl_xor(res, 1);
     res += __shfl_xor(res, 2);
-    if (part == 0) resid[row] = (unsigned)(res * 1.0001f + kSResidSlack * D) + 1u;  // image is padded to whole tiles
+    outside |= (bool)__shfl_xor((int)outside, 1);
+    outside |= (bool)__shfl_xor((int)outside, 2);
+    if (part == 0)  // the image is padded to whole tiles
+        resid[row] = outside ? kSRowExact : (unsigned)(res * 1.0001f + kSResidSlack * D) + 1u;
     uint4* dst = cimg + (tile * (D / 8) + part * (F / 8)) * 64 + row_in;
 #pragma unroll
     for (int i = 0; i < F / 8; ++i) dst[i * 64] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
@@ -153,32 +114,43 @@ __global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const float* 
     for (int64_t j = i; j < n_flag_words; j += (int64_t)gridDim.x * blockDim.x) flags[j] = 0;  // first slab's bitmap
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
-    __shared__ float part_res[4];
+    __shared__ float part_res[4], part_max[4];
+    __shared__ int part_out[4];
     const bool live = i < Q * (D / 2);
     const int64_t q = live ? i / (D / 2) : Q - 1;
     const bool head = q < q_head;
-    float res = 0.f;
+    float res = 0.f, qmax = 0.f;  // qmax: the query's largest |fixed|, |rel| (its share of the rounding term rho)
+    bool outside = false;         // a coefficient the map does not cover: the query is left to the exact path
     if (live) {
         const float2 f = *reinterpret_cast<const float2*>(q_fixed + 2 * i);
         const float2 r = *reinterpret_cast<const float2*>(q_rel + 2 * i);
-        unsigned w = sad_quant(sad_coef(f.x, r.x, head), sc, res);
-        w |= sad_quant(sad_coef(f.y, r.y, head), sc, res) << 16;
+        unsigned w = sad_quant(sad_coef(f.x, r.x, head), sc, res, outside);
+        w |= sad_quant(sad_coef(f.y, r.y, head), sc, res, outside) << 16;
         qimg[i] = w;
+        qmax = fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(r.x), fabsf(r.y)));  // (NaN: outside is set anyway)
     }
 #pragma unroll
-    for (int off = 1; off < (D / 2 < 64 ? D / 2 : 64); off <<= 1) res += __shfl_xor(res, off);
+    for (int off = 1; off < (D / 2 < 64 ? D / 2 : 64); off <<= 1) {
+        res += __shfl_xor(res, off);
+        qmax = fmaxf(qmax, __shfl_xor(qmax, off));
+        outside |= (bool)__shfl_xor((int)outside, off);
+    }
     if constexpr (D / 2 > 64) {  // D = 256: two waves per query
-        if ((threadIdx.x & 63) == 0) part_res[threadIdx.x >> 6] = res;
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { part_res[w] = res; part_max[w] = qmax; part_out[w] = outside; }
         __syncthreads();
-        res = part_res[(threadIdx.x >> 6) & ~1] + part_res[(threadIdx.x >> 6) | 1];
+        res = part_res[w & ~1] + part_res[w | 1];
+        qmax = fmaxf(part_max[w & ~1], part_max[w | 1]);
+        outside = part_out[w & ~1] || part_out[w | 1];
     }
     if (live && i % (D / 2) == 0) {
         const double u = 5.9604644775390625e-8;
-        const double dt = -(double)key_true[q], s = (double)sc.scale, M = (double)__uint_as_float(p->maxabs_bits);
+        const double dt = -(double)key_true[q], s = (double)sc.scale;
+        const double M = (double)fmaxf(sad_range_maxabs(sc), qmax);  // every value a decided pair of this query involves
         const double band = (double)res * 1.0001 + 2.0 * kSResidSlack * D + 1.0;  // E_q + both sides' slack
         const double gamma = 1.05 * (D + 2) * u, rho = 6.0 * D * u * M;
         int t_lo = -1, t_hi = (int)kSThrMax;  // nothing decided
-        if (dt >= 0.0 && dt < 1.0e300) {  // false for NaN
+        if (!outside && M < 3.0e38 && dt >= 0.0 && dt < 1.0e300) {  // false for NaN
             const double lo_v = s * (dt - rho) / (1.0 + gamma) - band;   // SAD + E_c below this: certainly above
             const double hi_v = s * (dt + rho) / (1.0 - gamma) + band;   // SAD - E_c above this: certainly below
             if (lo_v > 2.0) t_lo = lo_v - 1.0 < (double)kSThrMax ? (int)(lo_v - 1.0) : (int)kSThrMax;
@@ -193,6 +165,7 @@ template <int D, int TPW>
 struct SadTiles {
     unsigned v[TPW][D / 2];
     unsigned bias[TPW];  // accumulator start: the row's rounding residual E_c, or kSInvalid for padding rows
+    unsigned long long exact_rows[TPW];  // lanes whose row is marked exact-only (kSRowExact): undecided for every query
 };
 
 template <int D, int TPW>
@@ -231,8 +204,10 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
         const bool exists = tile * 64 + lane < n_rows;
         tile = tile < n_tiles ? tile : n_tiles - 1;
         const unsigned ec = resid[tile * 64 + lane];
-        c.bias[t] = exists ? ec : kSInvalid;
-        ec_max = exists && ec > ec_max ? ec : ec_max;
+        const bool marked = exists && ec == kSRowExact;
+        c.exact_rows[t] = __ballot(marked);
+        c.bias[t] = exists ? (marked ? 0u : ec) : kSInvalid;
+        ec_max = exists && !marked && ec > ec_max ? ec : ec_max;
         const uint4* src = cimg + tile * (D / 8) * 64 + lane;
         static_for<D / 8>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -287,8 +262,8 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
         unsigned n_above = 0;
         static_for<TPW>([&](auto tt) {
             constexpr int t = decltype(tt)::value;
-            const unsigned long long above = __ballot((int)sad[t] < th.x);
-            const unsigned long long und = __ballot((int)sad[t] <= th.y) & ~above;
+            const unsigned long long above = __ballot((int)sad[t] < th.x) & ~c.exact_rows[t];
+            const unsigned long long und = (__ballot((int)sad[t] <= th.y) | c.exact_rows[t]) & ~above;
             unsigned n_t = __popcll(above);
             if (und) {  // wave-uniform.  The wave fills its own slice of the list: no LDS round trip for a slot
                 const unsigned n = __popcll(und);
@@ -325,28 +300,91 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
         for (unsigned i = tid; i < wave_used[w]; i += kSW * 64) pairs[wave_base[w] + i] = pair_s[w * (kSQuota / kSW) + i];
 }
 
-// Pass 2a: one lane per listed pair.
+// Pass 2a: the listed pairs, 64 per wave, one lane per pair (the L1 sum of a pair is one sequential chain of D
+// additions: it cannot be spread over lanes without changing the rounding).  What CAN be shared is the memory
+// traffic: a lane reading its own candidate row and its own coefficient rows 16 bytes at a time makes every load
+// instruction touch 64 different cache lines.  Instead the wave fetches the 64 rows the way the exact kernel
+// fetches a tile (rank_all.hip: load_tile) -- 8 rows x 128 B per load instruction, whole lines -- 32 columns at a
+// time, and transposes them through a wave-private LDS slab so that lane p ends up with row p; the rows are
+// gathered through per-lane pointers instead of being consecutive.  Same arithmetic as Scorer<TRANSE, *, D>::score.
+constexpr int kRefStride = 36;  // dwords per slab row: conflict-free for the 16-byte reads of 16 consecutive lanes
+
+__device__ __forceinline__ const float* shfl_ptr(const float* p, int src) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
+// columns [32 s, 32 s + 32) of the 64 gathered rows: g[i] = start of row (8 i + sub_row) + sub_col, x[k] <- own row
+__device__ __forceinline__ void gather_chunk(float (&x)[32], const float* const (&g)[8], int s, float* slab, int lane) {
+    // the loads land in x[] in the coalesced layout first (plain scalars: they stay in registers across the fences)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(g[i] + 32 * s);
+        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    float* wr = slab + (lane >> 3) * kRefStride + (lane & 7) * 4;
+    wave_lds_sync();  // the previous chunk's reads are done before the slab is rewritten
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4*>(wr + 8 * i * kRefStride) = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+    wave_lds_sync();
+    const float* rd = slab + lane * kRefStride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(rd + 4 * j);
+        x[4 * j] = w.x; x[4 * j + 1] = w.y; x[4 * j + 2] = w.z; x[4 * j + 3] = w.w;
+    }
+}
+
 template <int D>
-__global__ __launch_bounds__(256) void sad_refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
-                                                               const float* __restrict__ coef_head,
-                                                               const float* __restrict__ coef_tail,
-                                                               const float* __restrict__ key_true, int64_t q_head,
-                                                               const uint2* __restrict__ pairs,
-                                                               const SadParams* __restrict__ params,
-                                                               unsigned long long* __restrict__ acc) {
+__global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
+                                                              const float* __restrict__ coef_head,
+                                                              const float* __restrict__ coef_tail,
+                                                              const float* __restrict__ key_true, int64_t q_head,
+                                                              const uint2* __restrict__ pairs,
+                                                              const SadParams* __restrict__ params,
+                                                              unsigned long long* __restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) float slab[64 * kRefStride];
+    const int lane = threadIdx.x, sub_row = lane >> 3, sub_col = (lane & 7) * 4;
     const int64_t n = params->n_pairs;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint2 p = pairs[i];
-        if (p.x == kSNoPair) continue;
-        const int64_t q = p.x;
-        float e[D];
-        load_row<D>(e, table + (int64_t)p.y * ld);
-        float key;
-        if (q < q_head) key = Scorer<TRANSE, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<TRANSE, HEAD, D>::C});
-        else key = Scorer<TRANSE, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<TRANSE, TAIL, D>::C});
-        const float kt = key_true[q];
-        const unsigned long long gt = key > kt, ge = key >= kt;
-        if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {  // wave-uniform
+        const int64_t i = base + lane;
+        const uint2 p = i < n ? pairs[i] : make_uint2(kSNoPair, 0u);
+        const bool live = p.x != kSNoPair;
+        const int64_t q = live ? p.x : 0;
+        const bool head = q < q_head;
+        // candidate row; a = r (head) | h + r (tail); b = t (head) | unused (tail: any readable row)
+        const float* pe = table + (live ? (int64_t)p.y : 0) * ld;
+        const float* pa = head ? coef_head + q * (2 * D) : coef_tail + (q - q_head) * D;
+        const float* pb = head ? pa + D : pa;
+        const float* ge[8];
+        const float* ga[8];
+        const float* gb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ge[k] = shfl_ptr(pe, 8 * k + sub_row) + sub_col;
+            ga[k] = shfl_ptr(pa, 8 * k + sub_row) + sub_col;
+            gb[k] = shfl_ptr(pb, 8 * k + sub_row) + sub_col;
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int s = 0; s < D / 32; ++s) {
+            float e[32], a[32], b[32];
+            gather_chunk(e, ge, s, slab, lane);
+            gather_chunk(a, ga, s, slab, lane);
+            gather_chunk(b, gb, s, slab, lane);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const float y = e[k] + a[k];  // head: (e + r) - t
+                const float xh = y - b[k];
+                const float xt = a[k] - e[k];  // tail: (h + r) - e
+                sum = sum + fabsf(head ? xh : xt);
+            }
+        }
+        const float key = -sum, kt = key_true[q];
+        const unsigned long long gt = live && key > kt, ge_ = live && key >= kt;
+        if (gt | ge_) atomicAdd(acc + q, gt | (ge_ << 32));
     }
 }
 
@@ -548,8 +586,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         rank_sad_kernel<D, TPW><<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
             w.cimg + (slab0 / 64) * (D / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, per_group, w.qimg, w.thr, Q, words, w.acc,
             w.flags, w.pairs, w.params);
-        const int64_t pair_blocks = (n_blocks * kSQuota + 255) / 256;
-        sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 16 ? pair_blocks : (int64_t)n_cu * 16)), 256, 0, stream>>>(
+        const int64_t pair_blocks = (n_blocks * kSQuota + 63) / 64;  // 64 pairs per single-wave workgroup and iteration
+        sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 40 ? pair_blocks : (int64_t)n_cu * 40)), 64, 0, stream>>>(
             slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, w.params, w.acc);
         sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
             slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);

@@ -87,57 +87,15 @@ __global__ __launch_bounds__(256) void wide_range_kernel(const float* __restrict
                                                          const float* __restrict__ q_fixed,
                                                          const float* __restrict__ q_rel, int64_t q_head, int64_t Q,
                                                          SadParams* __restrict__ partial) {
-    int lo = 0x7fffffff, hi = (int)0x80000000;
-    float maxabs = 0.f;
-    bool bad = false;
-    auto see = [&](float x) {
-        const float ax = fabsf(x);
-        if (!(ax < 3.0e38f)) { bad = true; return; }
-        const int o = f2ord(x);
-        lo = o < lo ? o : lo;
-        hi = o > hi ? o : hi;
-        maxabs = ax > maxabs ? ax : maxabs;
-    };
+    SadRange range;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int quads = D / 4;
     for (int64_t i = t0; i < N * quads; i += stride) {
         const float4 v = *reinterpret_cast<const float4*>(table + (i / quads) * ld + (i % quads) * 4);
-        see(v.x); see(v.y); see(v.z); see(v.w);
+        range.see(v.x); range.see(v.y); range.see(v.z); range.see(v.w);
     }
-    for (int64_t i = t0; i < Q * D; i += stride) {
-        const float f = q_fixed[i], r = q_rel[i];
-        const int lo_keep = lo, hi_keep = hi;
-        see(f); see(r);  // for max |value| only: the range is that of the coefficient
-        lo = lo_keep; hi = hi_keep;
-        see(sad_coef(f, r, i / D < q_head));
-    }
-    __shared__ int s_lo[4], s_hi[4], s_bad[4];
-    __shared__ float s_max[4];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
-        const float m2 = __shfl_xor(maxabs, off);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-        maxabs = m2 > maxabs ? m2 : maxabs;
-    }
-    const bool any_bad = __any(bad);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_max[wave] = maxabs; s_bad[wave] = any_bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        SadParams p = {};
-        p.lo_ord = 0x7fffffff; p.hi_ord = (int)0x80000000;
-        float m = 0.f;
-        for (int w = 0; w < 4; ++w) {
-            p.lo_ord = s_lo[w] < p.lo_ord ? s_lo[w] : p.lo_ord;
-            p.hi_ord = s_hi[w] > p.hi_ord ? s_hi[w] : p.hi_ord;
-            m = s_max[w] > m ? s_max[w] : m;
-            p.nonfinite |= (unsigned)s_bad[w];
-        }
-        p.maxabs_bits = __float_as_uint(m);
-        partial[blockIdx.x] = p;
-    }
+    for (int64_t i = t0; i < Q * D; i += stride) range.see(sad_coef(q_fixed[i], q_rel[i], i / D < q_head));
+    sad_range_block_store(range, partial);
 }
 
 // Candidate tile image as in rank_sad.hip, Dp / 8 uint4 per lane (Dp = D rounded up to 128, zero padded).
@@ -152,6 +110,7 @@ __global__ __launch_bounds__(256) void wide_quantize_table_kernel(const float* _
     const int64_t row = tile * 64 + row_in;
     const float* src = table + (row < N ? row : 0) * ld;
     float res = 0.f;
+    bool outside = false;  // a value the map does not cover: the row is left to the exact path
     for (int j4 = part; j4 < Dp / 8; j4 += 4) {
         unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -159,17 +118,19 @@ __global__ __launch_bounds__(256) void wide_quantize_table_kernel(const float* _
             const int d = 8 * j4 + 4 * h;
             if (row < N && d < D) {
                 const float4 v = *reinterpret_cast<const float4*>(src + d);
-                w[2 * h] = sad_quant(v.x, sc, res);
-                w[2 * h] |= sad_quant(v.y, sc, res) << 16;
-                w[2 * h + 1] = sad_quant(v.z, sc, res);
-                w[2 * h + 1] |= sad_quant(v.w, sc, res) << 16;
+                w[2 * h] = sad_quant(v.x, sc, res, outside);
+                w[2 * h] |= sad_quant(v.y, sc, res, outside) << 16;
+                w[2 * h + 1] = sad_quant(v.z, sc, res, outside);
+                w[2 * h + 1] |= sad_quant(v.w, sc, res, outside) << 16;
             }
         }
         cimg[(tile * (Dp / 8) + j4) * 64 + row_in] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     res += __shfl_xor(res, 1);
     res += __shfl_xor(res, 2);
-    if (part == 0) resid[row] = (unsigned)(res * 1.0001f + kSResidSlack * D) + 1u;
+    outside |= (bool)__shfl_xor((int)outside, 1);
+    outside |= (bool)__shfl_xor((int)outside, 2);
+    if (part == 0) resid[row] = outside ? kSRowExact : (unsigned)(res * 1.0001f + kSResidSlack * D) + 1u;
 }
 
 // One wave per query: its 2-byte image (Dp / 2 dwords) and the two thresholds; the first candidate slab's
@@ -191,24 +152,31 @@ __global__ __launch_bounds__(256) void wide_quantize_queries_kernel(const float*
     const bool head = q < q_head;
     const float* f = q_fixed + q * D;
     const float* r = q_rel + q * D;
-    float res = 0.f;
+    float res = 0.f, qmax = 0.f;
+    bool outside = false;  // a coefficient the map does not cover: the query is left to the exact path
     for (int j = lane; j < Dp / 2; j += 64) {
         unsigned w = 0;
         if (2 * j < D) {  // D is even: both elements exist or neither
-            w = sad_quant(sad_coef(f[2 * j], r[2 * j], head), sc, res);
-            w |= sad_quant(sad_coef(f[2 * j + 1], r[2 * j + 1], head), sc, res) << 16;
+            w = sad_quant(sad_coef(f[2 * j], r[2 * j], head), sc, res, outside);
+            w |= sad_quant(sad_coef(f[2 * j + 1], r[2 * j + 1], head), sc, res, outside) << 16;
+            qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(f[2 * j]), fabsf(f[2 * j + 1])), fmaxf(fabsf(r[2 * j]), fabsf(r[2 * j + 1]))));
         }
         qimg[q * (Dp / 2) + j] = w;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) res += __shfl_xor(res, off);
+    for (int off = 32; off > 0; off >>= 1) {
+        res += __shfl_xor(res, off);
+        qmax = fmaxf(qmax, __shfl_xor(qmax, off));
+        outside |= (bool)__shfl_xor((int)outside, off);
+    }
     if (lane == 0) {
         const double u = 5.9604644775390625e-8;
-        const double dt = -(double)key_true[q], s = (double)sc.scale, M = (double)__uint_as_float(p->maxabs_bits);
+        const double dt = -(double)key_true[q], s = (double)sc.scale;
+        const double M = (double)fmaxf(sad_range_maxabs(sc), qmax);  // every value a decided pair of this query involves
         const double band = (double)res * 1.0001 + 2.0 * kSResidSlack * D + 1.0;  // E_q + both sides' slack
         const double gamma = 1.05 * (D + 2) * u, rho = 6.0 * D * u * M;
         int t_lo = -1, t_hi = (int)kSThrMax;  // nothing decided
-        if (dt >= 0.0 && dt < 1.0e300) {  // false for NaN
+        if (!outside && M < 3.0e38 && dt >= 0.0 && dt < 1.0e300) {  // false for NaN
             const double lo_v = s * (dt - rho) / (1.0 + gamma) - band;   // SAD + E_c below this: certainly above
             const double hi_v = s * (dt + rho) / (1.0 - gamma) + band;   // SAD - E_c above this: certainly below
             if (lo_v > 2.0) t_lo = lo_v - 1.0 < (double)kSThrMax ? (int)(lo_v - 1.0) : (int)kSThrMax;
@@ -251,7 +219,9 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     const int64_t tile_id = (int64_t)group * kSW + wave;
     const unsigned bias = tile_id * 64 + lane < n_rows ? 0u : kSInvalid;
     const int64_t tile = tile_id < n_tiles ? tile_id : n_tiles - 1;
-    const unsigned ec = resid[tile * 64 + lane];
+    const unsigned ec_raw = resid[tile * 64 + lane];
+    const unsigned long long exact_rows = __ballot(bias == 0u && ec_raw == kSRowExact);  // rows marked exact-only
+    const unsigned ec = ec_raw == kSRowExact ? 0u : ec_raw;
     const int n_ch = Dp / 128, row_dwords = Dp / 2;
 
     for (int ch = 0; ch < n_ch; ++ch) {
@@ -289,8 +259,8 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
                 continue;
             }
             const int2 th = thr_s[j];
-            const unsigned long long above = __ballot((int)(sad + ec) < th.x);
-            const unsigned long long und = __ballot((int)(sad - ec) <= th.y) & ~above;
+            const unsigned long long above = __ballot((int)(sad + ec) < th.x) & ~exact_rows;
+            const unsigned long long und = (__ballot((int)(sad - ec) <= th.y) | exact_rows) & ~above;
             unsigned n_above = __popcll(above);
             if (und) {  // wave-uniform
                 const unsigned n = __popcll(und);
@@ -393,8 +363,8 @@ __global__ __launch_bounds__(256) void wide_refine_tiles_kernel(const float* __r
     }
 }
 
-// Last kernel of a call (as rank_all.hip's filter_finalize_kernel, run-time width): one wave per query scores
-// the rows its filter entries remove and writes the query's four counts.
+// Last kernel of a call (as rank_all.hip's filter_finalize_kernel, run-time width): a workgroup owns 64 queries, its
+// waves take the ones that have filter entries in turn, thread q writes query q's four counts.
 __global__ __launch_bounds__(256) void wide_filter_finalize_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
                                                                    int D, const float* __restrict__ q_fixed,
                                                                    const float* __restrict__ q_rel,
@@ -402,14 +372,26 @@ __global__ __launch_bounds__(256) void wide_filter_finalize_kernel(const float* 
                                                                    int64_t Q, const FilterSpec filter,
                                                                    const unsigned long long* __restrict__ acc,
                                                                    int32_t* __restrict__ counts) {
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
+    __shared__ int list[kSweepQueries], n_list;
+    __shared__ unsigned removed[kSweepQueries][2];
+    const int64_t q_base = (int64_t)blockIdx.x * kSweepQueries;
     const int lane = threadIdx.x & 63;
-    const float kt = key_true[q];
-    unsigned gt = 0, ge = 0;
-    if (filter.on()) {
-        for (int64_t i = filter.lo[q] + lane; i < filter.hi[q]; i += 64) {
-            const int64_t row = filter_row(filter, q, i, N);
+    if (threadIdx.x < 64) {
+        const int64_t q = q_base + lane;
+        const bool any = filter.on() && q < Q && filter.hi[q] > filter.lo[q];
+        removed[lane][0] = removed[lane][1] = 0;
+        const unsigned long long mask = __ballot(any);
+        if (any) list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+        if (lane == 0) n_list = __popcll(mask);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x >> 6; i < n_list; i += 4) {
+        const int slot = list[i];
+        const int64_t q = q_base + slot;
+        const float kt = key_true[q];
+        unsigned gt = 0, ge = 0;
+        for (int64_t k = filter.lo[q] + lane; k < filter.hi[q]; k += 64) {
+            const int64_t row = filter_row(filter, q, k, N);
             if (row < 0) continue;
             const float key = transe_key_rt(table + row * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
             gt += key > kt;
@@ -420,11 +402,15 @@ __global__ __launch_bounds__(256) void wide_filter_finalize_kernel(const float* 
             gt += __shfl_down(gt, off);
             ge += __shfl_down(ge, off);
         }
+        if (lane == 0) { removed[slot][0] = gt; removed[slot][1] = ge; }
     }
-    if (lane == 0) {
+    __syncthreads();
+    if (threadIdx.x < 64 && q_base + lane < Q) {
+        const int64_t q = q_base + lane;
         const unsigned long long a = acc[q];
         const int32_t all_gt = (int32_t)(a & 0xffffffffull), all_ge = (int32_t)(a >> 32);
-        reinterpret_cast<int4*>(counts)[q] = make_int4(all_gt, all_ge, all_gt - (int32_t)gt, all_ge - (int32_t)ge);
+        reinterpret_cast<int4*>(counts)[q] =
+            make_int4(all_gt, all_ge, all_gt - (int32_t)removed[lane][0], all_ge - (int32_t)removed[lane][1]);
     }
 }
 
@@ -539,7 +525,7 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
             slab, n_rows, ld, D, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-    wide_filter_finalize_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, N, ld, D, q_fixed, q_rel, w.key_true,
+    wide_filter_finalize_kernel<<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(table, N, ld, D, q_fixed, q_rel, w.key_true,
                                                                                   q_head, Q, filter, w.acc, counts);
     return hipGetLastError();
 }
