@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "exact_coop.h"
 #include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
@@ -815,71 +816,6 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         atomicAdd(&g_bf16_timing[7], 1ull);
     }
 #endif
-}
-
-// Term i of the reference's sum for candidate row e and query coefficients c: the arithmetic of
-// Scorer<MODEL, SIDE, D>::score (score_core.h) for one summand, addressed at run time.
-template <int MODEL, int SIDE, int D>
-__device__ __forceinline__ float score_term(const float* __restrict__ e, const float* __restrict__ c, int i) {
-    constexpr int H = D / 2;
-    if constexpr (MODEL == DISTMULT) {
-        if constexpr (SIDE == TAIL) {
-            return c[i] * e[i];
-        } else {
-            const float x = e[i] * c[i];
-            return x * c[D + i];
-        }
-    } else if constexpr (MODEL == COMPLEX) {
-        if constexpr (SIDE == TAIL) {
-            const float a = c[i] * e[i];
-            const float b = c[H + i] * e[H + i];
-            const float cc = c[2 * H + i] * e[H + i];
-            const float d = c[3 * H + i] * e[i];
-            float s = a + b;
-            s = s + cc;
-            return s - d;
-        } else {
-            float a = c[i] * e[i];          a = a * c[D + i];
-            float b = c[i] * e[H + i];      b = b * c[D + H + i];
-            float cc = c[H + i] * e[i];     cc = cc * c[D + H + i];
-            float d = c[H + i] * e[H + i];  d = d * c[D + i];
-            float s = a + b;
-            s = s + cc;
-            return s - d;
-        }
-    } else {
-        if constexpr (SIDE == TAIL) {
-            const float a = c[i] * e[H + i];
-            float b = e[i] * c[H + i];
-            b = b * c[2 * H + i];
-            return a + b;
-        } else {
-            float a = e[i] * c[i];
-            a = a * c[H + i];
-            const float b = c[2 * H + i] * e[H + i];
-            return a + b;
-        }
-    }
-}
-
-// The exact score of one (candidate, query) pair by 32 cooperating lanes, in the reference's summation order
-// (torch_inner_sum, score_core.h): lane j IS accumulator A[j] -- it adds the terms j, 32 + j, 64 + j, ... in that
-// order -- then V[l] = ((A[l] + A[8 + l]) + A[16 + l]) + A[24 + l] and the eight V left to right.  Every load is 32
-// consecutive floats (one 128-B line) instead of 64 lanes gathering 16 bytes each from 64 different rows.
-// `sub` = lane & 31; both 32-lane halves of a wave work on their own pair.  Result valid in every lane of the half.
-template <int MODEL, int SIDE, int D>
-__device__ __forceinline__ float coop_score(const float* __restrict__ e, const float* __restrict__ c, int sub) {
-    constexpr int NT = MODEL == DISTMULT ? D : D / 2;
-    float a = score_term<MODEL, SIDE, D>(e, c, sub);
-#pragma unroll
-    for (int k = 1; k < NT / 32; ++k) a = a + score_term<MODEL, SIDE, D>(e, c, 32 * k + sub);
-    float v = a + __shfl_down(a, 8, 32);
-    v = v + __shfl_down(a, 16, 32);
-    v = v + __shfl_down(a, 24, 32);
-    float s = __shfl(v, 0, 32);
-#pragma unroll
-    for (int l = 1; l < 8; ++l) s = s + __shfl(v, l, 32);
-    return MODEL == SIMPLE ? s / 2.0f : s;
 }
 
 // Pass 2a: the listed entries, one per 32-lane half-wave; every undecided pair of the entry is re-scored exactly

@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "exact_coop.h"
 #include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
@@ -307,36 +308,6 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
 // fetches a tile (rank_all.hip: load_tile) -- 8 rows x 128 B per load instruction, whole lines -- 32 columns at a
 // time, and transposes them through a wave-private LDS slab so that lane p ends up with row p; the rows are
 // gathered through per-lane pointers instead of being consecutive.  Same arithmetic as Scorer<TRANSE, *, D>::score.
-constexpr int kRefStride = 36;  // dwords per slab row: conflict-free for the 16-byte reads of 16 consecutive lanes
-
-__device__ __forceinline__ const float* shfl_ptr(const float* p, int src) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
-    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
-}
-
-// columns [32 s, 32 s + 32) of the 64 gathered rows: g[i] = start of row (8 i + sub_row) + sub_col, x[k] <- own row
-__device__ __forceinline__ void gather_chunk(float (&x)[32], const float* const (&g)[8], int s, float* slab, int lane) {
-    // the loads land in x[] in the coalesced layout first (plain scalars: they stay in registers across the fences)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(g[i] + 32 * s);
-        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
-    }
-    float* wr = slab + (lane >> 3) * kRefStride + (lane & 7) * 4;
-    wave_lds_sync();  // the previous chunk's reads are done before the slab is rewritten
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<float4*>(wr + 8 * i * kRefStride) = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
-    wave_lds_sync();
-    const float* rd = slab + lane * kRefStride;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float4 w = *reinterpret_cast<const float4*>(rd + 4 * j);
-        x[4 * j] = w.x; x[4 * j + 1] = w.y; x[4 * j + 2] = w.z; x[4 * j + 3] = w.w;
-    }
-}
-
 template <int D>
 __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
                                                               const float* __restrict__ coef_head,
@@ -346,7 +317,7 @@ __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __res
                                                               const SadParams* __restrict__ params,
                                                               unsigned long long* __restrict__ acc) {
     __shared__ __attribute__((aligned(16))) float slab[64 * kRefStride];
-    const int lane = threadIdx.x, sub_row = lane >> 3, sub_col = (lane & 7) * 4;
+    const int lane = threadIdx.x;
     const int64_t n = params->n_pairs;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {  // wave-uniform
         const int64_t i = base + lane;
@@ -358,31 +329,8 @@ __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __res
         const float* pe = table + (live ? (int64_t)p.y : 0) * ld;
         const float* pa = head ? coef_head + q * (2 * D) : coef_tail + (q - q_head) * D;
         const float* pb = head ? pa + D : pa;
-        const float* ge[8];
-        const float* ga[8];
-        const float* gb[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            ge[k] = shfl_ptr(pe, 8 * k + sub_row) + sub_col;
-            ga[k] = shfl_ptr(pa, 8 * k + sub_row) + sub_col;
-            gb[k] = shfl_ptr(pb, 8 * k + sub_row) + sub_col;
-        }
-        float sum = 0.0f;
-#pragma unroll
-        for (int s = 0; s < D / 32; ++s) {
-            float e[32], a[32], b[32];
-            gather_chunk(e, ge, s, slab, lane);
-            gather_chunk(a, ga, s, slab, lane);
-            gather_chunk(b, gb, s, slab, lane);
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const float y = e[k] + a[k];  // head: (e + r) - t
-                const float xh = y - b[k];
-                const float xt = a[k] - e[k];  // tail: (h + r) - e
-                sum = sum + fabsf(head ? xh : xt);
-            }
-        }
-        const float key = -sum, kt = key_true[q];
+        const float key = transe_key_64<D>(pe, pa, pb, head, slab, lane);
+        const float kt = key_true[q];
         const unsigned long long gt = live && key > kt, ge_ = live && key >= kt;
         if (gt | ge_) atomicAdd(acc + q, gt | (ge_ << 32));
     }
