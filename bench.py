@@ -495,7 +495,7 @@ def main():
             torch.cuda.empty_cache()
             for name in SUB_RESULTS:
                 sub = Job(name, device)
-                f, t, c = sub.measure(max(2, min(args.steps, 5)), 1, events)
+                f, t, c = sub.measure(max(2, min(args.steps, 5)), 3, events)  # (allocator growth / lazy loads settle in 2 steps)
                 f["unit"] = "scored triples/s"
                 f["parity_check"] = parity_spot_check(sub, t, c)
                 f.pop("kernel_ms_per_rank")

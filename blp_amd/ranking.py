@@ -67,14 +67,15 @@ def fused_ranking_takes(model, table, num_queries):
 
 
 def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None, filt_rowptr=None, filt_col=None,
-               rel_ids=None, filter=None):
+               rel_ids=None, filter=None, out=None):
     """Counts (Q, 4) int32 {gt, ge, gt_filtered, ge_filtered} for a block of queries against ``table``.
     Queries [0, q_head) replace the head, the rest replace the tail (train.py:149 order).  The filter is a CSR
     (filt_rowptr, filt_col) or, on a HIP device, an ops.SegmentFilter (``filter``)."""
     if table.is_cuda and not ops.rank_all_supported(model.rel_model, table.shape[1], q_head, q_fixed.shape[0] - q_head):
         if filter is not None:
             raise ValueError("the dense any-width route takes the filter as a CSR (utils.FilterIndex.csr)")
-        return _rank_block_generic_width(model, table, q_fixed, q_rel, q_head, true_row, q_true, filt_rowptr, filt_col)
+        counts = _rank_block_generic_width(model, table, q_fixed, q_rel, q_head, true_row, q_true, filt_rowptr, filt_col)
+        return counts if out is None else out.copy_(counts)
     if table.is_cuda:
         dev = table.device
         return ops.rank_all(model.rel_model, table, q_fixed, q_rel, q_head,
@@ -82,11 +83,12 @@ def rank_block(model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
                             q_true=q_true,
                             filt_rowptr=None if filt_rowptr is None else filt_rowptr.to(dev),
                             filt_col=None if filt_col is None else filt_col.to(dev),
-                            rel_ids=None if rel_ids is None else rel_ids.to(dev), filter=filter)
+                            rel_ids=None if rel_ids is None else rel_ids.to(dev), filter=filter, out=out)
     if filter is not None:
         raise ValueError("SegmentFilter is the HIP path's filter form; CPU tensors take a CSR")
     source = ("row", true_row) if true_row is not None else ("vec", q_true)
-    return _rank_block_dense(model.score_fn, table, q_fixed, q_rel, q_head, source, filt_rowptr, filt_col)
+    counts = _rank_block_dense(model.score_fn, table, q_fixed, q_rel, q_head, source, filt_rowptr, filt_col)
+    return counts if out is None else out.copy_(counts)
 
 
 def _rank_block_generic_width(model, table, q_fixed, q_rel, q_head, true_row, q_true, filt_rowptr, filt_col,
@@ -290,52 +292,67 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         if num_triples > 512:
             uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
             vectors = ranker.gather_rows(uniq)
-            head_pos, tail_pos = inverse[:num_triples], inverse[num_triples:]
+            head_pos_v, tail_pos_v = inverse[:num_triples], inverse[num_triples:]
         else:  # a reference-sized batch: no host decision at all (torch.unique sizes its output on the host)
             vectors = ranker.gather_rows(torch.cat((heads, tails)))
-            head_pos = torch.arange(num_triples, device=device)
-            tail_pos = head_pos + num_triples
+            head_pos_v = torch.arange(num_triples, device=device)
+            tail_pos_v = head_pos_v + num_triples
 
-    counts_blocks = []
-    for start in range(t_lo, t_hi, block_size):
-        sl = slice(start, min(start + block_size, t_hi))
-        b = sl.stop - sl.start
-        rel_vecs = model.rel_emb(triples[sl, 2])
-        rel_ids = torch.cat((triples[sl, 2], triples[sl, 2]))
+    # Everything a block needs is laid out ONCE for the whole set, block after block, each block as [its head
+    # queries | its tail queries] (train.py:149 order): one gather of the fixed-entity vectors, one of the relation
+    # vectors, one pass of binary searches for the filter segments.  A block is then a set of contiguous views --
+    # no per-block gather / cat kernels, which at the reference's Wikidata5M batching (2 triples per table pass) cost
+    # more than a sixth of the pass.
+    n = t_hi - t_lo
+    idx = torch.arange(n, device=device)
+    first = torch.div(idx, block_size, rounding_mode="floor") * block_size       # first triple of the block
+    head_pos = first + idx                                                          # = 2 * first + (idx - first)
+    tail_pos = head_pos + torch.clamp(n - first, max=block_size)
+    mine = slice(t_lo, t_hi)
+    if by_candidate:
+        source, head_ref, tail_ref = vectors, head_pos_v[mine], tail_pos_v[mine]
+    else:
+        source, head_ref, tail_ref = table, heads[mine], tails[mine]
+    fixed_src = torch.empty(2 * n, dtype=torch.long, device=device)
+    true_src = torch.empty_like(fixed_src)
+    rel_ids = torch.empty_like(fixed_src)
+    order_src = torch.empty_like(fixed_src)  # position in the [all heads | all tails] order of utils.FilterIndex
+    fixed_src[head_pos], fixed_src[tail_pos] = tail_ref, head_ref
+    true_src[head_pos], true_src[tail_pos] = head_ref, tail_ref
+    rel_ids[head_pos] = rel_ids[tail_pos] = triples[mine, 2]
+    order_src[head_pos], order_src[tail_pos] = idx, idx + n
+    q_fixed = source[fixed_src]
+    q_rel = model.rel_emb(rel_ids)
+    q_true = source[true_src] if by_candidate else None
+    fused = n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n))
+    seg = None
+    if index is not None and fused:  # slices of the sorted index: nothing is listed per batch
+        seg = index.segments(triples[mine], ent2idx, device)
+        seg = seg._replace(seg_lo=seg.seg_lo[order_src], seg_hi=seg.seg_hi[order_src], exclude=seg.exclude[order_src])
+    counts = torch.empty((2 * n, 4), dtype=torch.int32, device=device)
+
+    for start in range(0, n, block_size):
+        b = min(start + block_size, n) - start
+        sl = slice(2 * start, 2 * (start + b))
         filt = {}
-        if index is not None and fused_ranking_takes(model, table, 2 * b):  # slices of the sorted index, no list
-            filt = dict(filter=index.segments(triples[sl], ent2idx, device))
-        elif index is not None:
-            rowptr, col = index.csr(triples[sl], ent2idx, device)
+        if seg is not None:
+            filt = dict(filter=seg._replace(seg_lo=seg.seg_lo[sl], seg_hi=seg.seg_hi[sl], exclude=seg.exclude[sl]))
+        elif index is not None:  # dense any-width routes take a CSR
+            rowptr, col = index.csr(triples[t_lo + start: t_lo + start + b], ent2idx, device)
             filt = dict(filt_rowptr=rowptr, filt_col=col)
         if by_candidate:
-            h_vec, t_vec = vectors[head_pos[sl]], vectors[tail_pos[sl]]
-            ranker.rank_block(torch.cat((t_vec, h_vec)), torch.cat((rel_vecs, rel_vecs)), torch.cat((h_vec, t_vec)),
-                              b, rel_ids=rel_ids, **filt)
+            ranker.rank_block(q_fixed[sl], q_rel[sl], q_true[sl], b, rel_ids=rel_ids[sl], **filt)
         else:
-            h_rows, t_rows = heads[sl], tails[sl]
-            counts_blocks.append(rank_block(model, table, torch.cat((table[t_rows], table[h_rows])),
-                                            torch.cat((rel_vecs, rel_vecs)), b, true_row=torch.cat((h_rows, t_rows)),
-                                            rel_ids=rel_ids, **filt))
+            rank_block(model, table, q_fixed[sl], q_rel[sl], b, true_row=true_src[sl], rel_ids=rel_ids[sl], out=counts[sl],
+                       **filt)
     if by_candidate:
-        block_counts = ranker.finish()  # ONE all-gather for the whole set
-        counts_blocks, offset = [], 0
-        for start in range(0, num_triples, block_size):
-            b = min(start + block_size, num_triples) - start
-            counts_blocks.append(block_counts[offset: offset + 2 * b])
-            offset += 2 * b
-
-    # per-block layout is [head queries | tail queries]; put every head query first, like one big batch
-    if len(counts_blocks) == 1 and not by_query:
-        return triples, counts_blocks[0], ids_ok
-    sizes = [c.shape[0] // 2 for c in counts_blocks]
-    empty = [torch.zeros((0, 4), dtype=torch.int32, device=device)]
-    head_counts = torch.cat(empty + [c[:s] for c, s in zip(counts_blocks, sizes)])
-    tail_counts = torch.cat(empty + [c[s:] for c, s in zip(counts_blocks, sizes)])
+        counts = ranker.finish()  # ONE all-gather for the whole set; blocks in the order they were queued
+    if n > block_size:  # every head query first, like one big batch
+        counts = counts[torch.cat((head_pos, tail_pos))]
     if by_query:  # per-triple counts of every rank's slice: ONE all-gather for the whole set
-        both = all_gather_rows(torch.cat((head_counts, tail_counts), dim=1), num_triples, world, group)
-        head_counts, tail_counts = both[:, :4], both[:, 4:]
-    return triples, torch.cat((head_counts, tail_counts)).contiguous(), ids_ok
+        both = all_gather_rows(torch.cat((counts[:n], counts[n:]), dim=1), num_triples, world, group)
+        counts = torch.cat((both[:, :4], both[:, 4:])).contiguous()
+    return triples, counts, ids_ok
 
 
 # ----------------------------------------------------------------------------------- evaluation
