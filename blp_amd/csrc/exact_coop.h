@@ -84,6 +84,60 @@ __device__ __forceinline__ float transe_key_64(const float* pe, const float* pa,
     return -sum;
 }
 
+// The same at a run-time width D (D % 4 == 0; the bag-of-words / DKRL widths 300, 768), straight from the entity and
+// relation vectors: head-replacing query (e + r) - f with f = the tail, tail-replacing (f + r) - e with f = the head
+// (models.py:222-223).  The last chunk of a width that is not a multiple of 32 loads only the columns that exist.
+__device__ __forceinline__ void gather_chunk_rt(float (&x)[32], const float* const (&g)[8], int s, int cols, float* slab, int lane) {
+    const bool mine = (lane & 7) * 4 < cols;  // cols is a multiple of 4: a lane's four columns exist together
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mine) v = *reinterpret_cast<const float4*>(g[i] + 32 * s);
+        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    float* wr = slab + (lane >> 3) * kRefStride + (lane & 7) * 4;
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4*>(wr + 8 * i * kRefStride) = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+    wave_lds_sync();
+    const float* rd = slab + lane * kRefStride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(rd + 4 * j);
+        x[4 * j] = w.x; x[4 * j + 1] = w.y; x[4 * j + 2] = w.z; x[4 * j + 3] = w.w;
+    }
+}
+
+__device__ __forceinline__ float transe_key_64_rt(const float* pe, const float* pf, const float* pr, int D, bool head,
+                                                  float* slab, int lane) {
+    const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
+    const float* ge[8];
+    const float* gf[8];
+    const float* gr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        ge[k] = shfl_ptr(pe, 8 * k + sub_row) + sub_col;
+        gf[k] = shfl_ptr(pf, 8 * k + sub_row) + sub_col;
+        gr[k] = shfl_ptr(pr, 8 * k + sub_row) + sub_col;
+    }
+    float sum = 0.0f;
+    for (int s = 0; s * 32 < D; ++s) {
+        const int cols = D - 32 * s < 32 ? D - 32 * s : 32;
+        float e[32], f[32], r[32];
+        gather_chunk_rt(e, ge, s, cols, slab, lane);
+        gather_chunk_rt(f, gf, s, cols, slab, lane);
+        gather_chunk_rt(r, gr, s, cols, slab, lane);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            float x = (head ? e[k] : f[k]) + r[k];
+            x = x - (head ? f[k] : e[k]);
+            if (k < cols) sum = sum + fabsf(x);
+        }
+    }
+    return -sum;
+}
+
 // ---------------------------------------------------------------- bilinear models: 32 lanes per pair
 // Term i of the reference's sum for candidate row e and query coefficients c: the arithmetic of
 // Scorer<MODEL, SIDE, D>::score (score_core.h) for one summand, addressed at run time.

@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "exact_coop.h"
 #include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
@@ -203,8 +204,13 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int group = blockIdx.x % n_groups;
-    const int64_t q0 = (int64_t)(blockIdx.x / n_groups) * kWChunk;
+    // Consecutive workgroups share the candidate group: its four tile images (64 rows x Dp x 2 B each, 393 KB at
+    // D = 768) are what a workgroup streams chunk by chunk, and with the query chunk as the fast index every one of the
+    // 3 305 query chunks of the FB15k-237 block fetched them again from the fabric (77 GB per launch, 111 x the
+    // algorithmic bytes); now they stay in the L2s while the group's chunks go by.
+    const int n_chunks = (int)(gridDim.x / (unsigned)n_groups);
+    const int group = blockIdx.x / n_chunks;
+    const int64_t q0 = (int64_t)(blockIdx.x % n_chunks) * kWChunk;
     const int nq = (int)(Q - q0 < kWChunk ? Q - q0 : kWChunk);
 
     if (tid < kWChunk) {
@@ -291,22 +297,28 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     for (unsigned i = tid; i < used; i += kSW * 64) pairs[pair_base + i] = pair_s[i];
 }
 
-// Pass 2a: one lane per listed pair.
-__global__ __launch_bounds__(256) void wide_refine_pairs_kernel(const float* __restrict__ table, int64_t ld, int D,
-                                                                const float* __restrict__ q_fixed,
-                                                                const float* __restrict__ q_rel,
-                                                                const float* __restrict__ key_true, int64_t q_head,
-                                                                const uint2* __restrict__ pairs,
-                                                                const SadParams* __restrict__ params,
-                                                                unsigned long long* __restrict__ acc) {
+// Pass 2a: the listed pairs, 64 per single-wave workgroup and step, one lane per pair; the rows are gathered in
+// whole cache lines and transposed through LDS (exact_coop.h: transe_key_64_rt) instead of every lane reading its
+// own three rows 16 bytes at a time.
+__global__ __launch_bounds__(64) void wide_refine_pairs_kernel(const float* __restrict__ table, int64_t ld, int D,
+                                                               const float* __restrict__ q_fixed,
+                                                               const float* __restrict__ q_rel,
+                                                               const float* __restrict__ key_true, int64_t q_head,
+                                                               const uint2* __restrict__ pairs,
+                                                               const SadParams* __restrict__ params,
+                                                               unsigned long long* __restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) float slab[64 * kRefStride];
+    const int lane = threadIdx.x;
     const int64_t n = params->n_pairs;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint2 p = pairs[i];
-        if (p.x == kSNoPair) continue;
-        const int64_t q = p.x;
-        const float key = transe_key_rt(table + (int64_t)p.y * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {  // wave-uniform
+        const int64_t i = base + lane;
+        const uint2 p = i < n ? pairs[i] : make_uint2(kSNoPair, 0u);
+        const bool live = p.x != kSNoPair;
+        const int64_t q = live ? p.x : 0;
+        const float key = transe_key_64_rt(table + (live ? (int64_t)p.y : 0) * ld, q_fixed + q * D, q_rel + q * D, D,
+                                           q < q_head, slab, lane);
         const float kt = key_true[q];
-        const unsigned long long gt = key > kt, ge = key >= kt;
+        const unsigned long long gt = live && key > kt, ge = live && key >= kt;
         if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
     }
 }
@@ -518,8 +530,8 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
         wide_rank_sad_kernel<<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
             w.cimg + (slab0 / 64) * (Dp / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, Dp, words, w.acc,
             w.flags, w.pairs, w.params);
-        const int64_t pair_blocks = (n_blocks * kWQuota + 255) / 256;
-        wide_refine_pairs_kernel<<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 16 ? pair_blocks : (int64_t)n_cu * 16)), 256, 0,
+        const int64_t pair_blocks = (n_blocks * kWQuota + 63) / 64;
+        wide_refine_pairs_kernel<<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 40 ? pair_blocks : (int64_t)n_cu * 40)), 64, 0,
                                    stream>>>(slab, ld, D, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc);
         wide_refine_tiles_kernel<<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
             slab, n_rows, ld, D, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT /tmp/rp && mkdir -p $OUT /tmp/rp
 cd $R
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-sub-results $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp/trace -o trace -- python bench.py $ARGS > $OUT/trace_stdout.log 2>&1
 echo trace rc=$?
 find /tmp/rp/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
@@ -19,7 +19,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/rp/pmc$i -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline $@ > $OUT/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/rp/pmc$i -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sub-results $@ > $OUT/pmc$i.log 2>&1
   echo "pmc$i ($grp) rc=$?"
   f=$(find /tmp/rp/pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" "$OUT/pmc$i.csv" <<'PY'
