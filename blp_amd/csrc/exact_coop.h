@@ -52,33 +52,33 @@ __device__ __forceinline__ void gather_chunk(float (&x)[32], const float* const 
 }
 
 
-// key of lane's pair: pe = its candidate row; head-replacing query: pa = r, pb = t ((e + r) - t); tail-replacing:
-// pa = h + r (hoisted), pb = any readable row ((h + r) - e).  Every lane must pass readable pointers.
+// key of lane's pair straight from the vectors: pe = its candidate row, pf = the query's fixed entity, pr = its
+// relation; head-replacing query (e + r) - f, tail-replacing (f + r) - e (models.py:222-223; Scorer<TRANSE, *, D>
+// computes the same operations, with f + r hoisted).  Every lane must pass readable pointers.
 template <int D>
-__device__ __forceinline__ float transe_key_64(const float* pe, const float* pa, const float* pb, bool head, float* slab, int lane) {
+__device__ __forceinline__ float transe_key_64(const float* pe, const float* pf, const float* pr, bool head, float* slab, int lane) {
     const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
     const float* ge[8];
-    const float* ga[8];
-    const float* gb[8];
+    const float* gf[8];
+    const float* gr[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         ge[k] = shfl_ptr(pe, 8 * k + sub_row) + sub_col;
-        ga[k] = shfl_ptr(pa, 8 * k + sub_row) + sub_col;
-        gb[k] = shfl_ptr(pb, 8 * k + sub_row) + sub_col;
+        gf[k] = shfl_ptr(pf, 8 * k + sub_row) + sub_col;
+        gr[k] = shfl_ptr(pr, 8 * k + sub_row) + sub_col;
     }
     float sum = 0.0f;
 #pragma unroll
     for (int s = 0; s < D / 32; ++s) {
-        float e[32], a[32], b[32];
+        float e[32], f[32], r[32];
         gather_chunk(e, ge, s, slab, lane);
-        gather_chunk(a, ga, s, slab, lane);
-        gather_chunk(b, gb, s, slab, lane);
+        gather_chunk(f, gf, s, slab, lane);
+        gather_chunk(r, gr, s, slab, lane);
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            const float y = e[k] + a[k];  // head: (e + r) - t
-            const float xh = y - b[k];
-            const float xt = a[k] - e[k];  // tail: (h + r) - e
-            sum = sum + fabsf(head ? xh : xt);
+            float x = (head ? e[k] : f[k]) + r[k];
+            x = x - (head ? f[k] : e[k]);
+            sum = sum + fabsf(x);
         }
     }
     return -sum;
@@ -139,46 +139,52 @@ __device__ __forceinline__ float transe_key_64_rt(const float* pe, const float* 
 }
 
 // ---------------------------------------------------------------- bilinear models: 32 lanes per pair
-// Term i of the reference's sum for candidate row e and query coefficients c: the arithmetic of
-// Scorer<MODEL, SIDE, D>::score (score_core.h) for one summand, addressed at run time.
+// Term i of the reference's sum for candidate row e and the query's vectors f (the entity kept fixed) and r (the
+// relation): the arithmetic of Scorer<MODEL, SIDE, D>::score (score_core.h) for one summand with its coefficients
+// (Scorer<>::coef) computed in place, addressed at run time.
 template <int MODEL, int SIDE, int D>
-__device__ __forceinline__ float score_term(const float* __restrict__ e, const float* __restrict__ c, int i) {
+__device__ __forceinline__ float score_term(const float* __restrict__ e, const float* __restrict__ f,
+                                            const float* __restrict__ r, int i) {
     constexpr int H = D / 2;
     if constexpr (MODEL == DISTMULT) {
-        if constexpr (SIDE == TAIL) {
-            return c[i] * e[i];
-        } else {
-            const float x = e[i] * c[i];
-            return x * c[D + i];
+        if constexpr (SIDE == TAIL) {  // (h * r) * e
+            const float c = f[i] * r[i];
+            return c * e[i];
+        } else {                       // (e * r) * t
+            const float x = e[i] * r[i];
+            return x * f[i];
         }
     } else if constexpr (MODEL == COMPLEX) {
-        if constexpr (SIDE == TAIL) {
-            const float a = c[i] * e[i];
-            const float b = c[H + i] * e[H + i];
-            const float cc = c[2 * H + i] * e[H + i];
-            const float d = c[3 * H + i] * e[i];
+        if constexpr (SIDE == TAIL) {  // f = head: the four r * h products are the coefficients
+            const float c0 = r[i] * f[i], c1 = r[i] * f[H + i], c2 = r[H + i] * f[i], c3 = r[H + i] * f[H + i];
+            const float a = c0 * e[i];
+            const float b = c1 * e[H + i];
+            const float cc = c2 * e[H + i];
+            const float d = c3 * e[i];
             float s = a + b;
             s = s + cc;
             return s - d;
-        } else {
-            float a = c[i] * e[i];          a = a * c[D + i];
-            float b = c[i] * e[H + i];      b = b * c[D + H + i];
-            float cc = c[H + i] * e[i];     cc = cc * c[D + H + i];
-            float d = c[H + i] * e[H + i];  d = d * c[D + i];
+        } else {                       // f = tail
+            float a = r[i] * e[i];          a = a * f[i];
+            float b = r[i] * e[H + i];      b = b * f[H + i];
+            float cc = r[H + i] * e[i];     cc = cc * f[H + i];
+            float d = r[H + i] * e[H + i];  d = d * f[i];
             float s = a + b;
             s = s + cc;
             return s - d;
         }
     } else {
-        if constexpr (SIDE == TAIL) {
-            const float a = c[i] * e[H + i];
-            float b = e[i] * c[H + i];
-            b = b * c[2 * H + i];
+        if constexpr (SIDE == TAIL) {  // f = head = [hh | ht], e = tail = [th | tt]
+            const float c0 = f[i] * r[i];
+            const float a = c0 * e[H + i];
+            float b = e[i] * r[H + i];
+            b = b * f[H + i];
             return a + b;
-        } else {
-            float a = e[i] * c[i];
-            a = a * c[H + i];
-            const float b = c[2 * H + i] * e[H + i];
+        } else {                       // f = tail = [th | tt], e = head = [hh | ht]
+            float a = e[i] * r[i];
+            a = a * f[H + i];
+            const float c2 = f[i] * r[H + i];
+            const float b = c2 * e[H + i];
             return a + b;
         }
     }
@@ -190,11 +196,12 @@ __device__ __forceinline__ float score_term(const float* __restrict__ e, const f
 // consecutive floats (one 128-B line) instead of 64 lanes gathering 16 bytes each from 64 different rows.
 // `sub` = lane & 31; both 32-lane halves of a wave work on their own pair.  Result valid in every lane of the half.
 template <int MODEL, int SIDE, int D>
-__device__ __forceinline__ float coop_score(const float* __restrict__ e, const float* __restrict__ c, int sub) {
+__device__ __forceinline__ float coop_score(const float* __restrict__ e, const float* __restrict__ f,
+                                            const float* __restrict__ r, int sub) {
     constexpr int NT = MODEL == DISTMULT ? D : D / 2;
-    float a = score_term<MODEL, SIDE, D>(e, c, sub);
+    float a = score_term<MODEL, SIDE, D>(e, f, r, sub);
 #pragma unroll
-    for (int k = 1; k < NT / 32; ++k) a = a + score_term<MODEL, SIDE, D>(e, c, 32 * k + sub);
+    for (int k = 1; k < NT / 32; ++k) a = a + score_term<MODEL, SIDE, D>(e, f, r, 32 * k + sub);
     float v = a + __shfl_down(a, 8, 32);
     v = v + __shfl_down(a, 16, 32);
     v = v + __shfl_down(a, 24, 32);

@@ -54,14 +54,13 @@ __host__ __device__ constexpr int kMaxCoef(int D) { return 2 * D; }
 template <int MODEL, int D>
 __global__ void prep_coef_kernel(const float* __restrict__ q_fixed, const float* __restrict__ q_rel,
                                  int64_t q_head, int64_t q_tail, float* __restrict__ coef_head,
-                                 float* __restrict__ coef_tail, unsigned long long* __restrict__ acc) {
+                                 float* __restrict__ coef_tail) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
     const int64_t n_head = q_head * SH::C;
     const int64_t total = n_head + q_tail * ST::C;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < q_head + q_tail) acc[i] = 0;  // the rank-count accumulators start here (total >= Q)
         if (i < n_head) {
             const int64_t q = i / SH::C;
             coef_head[i] = SH::coef(q_fixed + q * D, q_rel + q * D, (int)(i % SH::C));
@@ -72,18 +71,23 @@ __global__ void prep_coef_kernel(const float* __restrict__ q_fixed, const float*
     }
 }
 
+// One lane per query: the true entity's key by the same Scorer<> routine as every other exact key (identical
+// rounding by construction), the query's coefficients computed in place; the query's accumulator starts at zero.
 template <int MODEL, int D>
 __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ table, int64_t ld,
                                 const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
-                                const float* __restrict__ coef_head, const float* __restrict__ coef_tail,
-                                int64_t q_head, int64_t q_tail, float* __restrict__ key_true) {
+                                const float* __restrict__ q_fixed, const float* __restrict__ q_rel,
+                                int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
+                                unsigned long long* __restrict__ acc) {
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (q >= q_head + q_tail) return;
+    acc[q] = 0;
     float e[D];
     load_row<D>(e, true_row ? table + true_row[q] * ld : q_true + q * D);
-    key_true[q] = q < q_head
-        ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C})
-        : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
+    const float* f = q_fixed + q * D;
+    const float* r = q_rel + q * D;
+    key_true[q] = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r})
+                             : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,8 +413,8 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_t
 // row-by-row loads: 127 us for the 105 740 queries of the FB15k-237 block, of which 9 % have an entry.)
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void filter_finalize_kernel(
-    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
-    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int64_t q_head,
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ q_fixed,
+    const float* __restrict__ q_rel, const float* __restrict__ key_true, int64_t q_head,
     int64_t q_tail, const FilterSpec filter, const unsigned long long* __restrict__ acc, int32_t* __restrict__ counts) {
     __shared__ int prefix[kSweepQueries + 1];
     __shared__ unsigned removed[kSweepQueries][2];
@@ -452,10 +456,7 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             int slot = 0;
             if (x < total) locate(x, q, row, slot);
             const bool live = row >= 0, head = q < q_head;
-            const float* pe = table + (live ? row : 0) * ld;
-            const float* pa = head ? coef_head + q * (2 * D) : coef_tail + (q - q_head) * D;
-            const float* pb = head ? pa + D : pa;
-            const float key = transe_key_64<D>(pe, pa, pb, head, slab, lane);
+            const float key = transe_key_64<D>(table + (live ? row : 0) * ld, q_fixed + q * D, q_rel + q * D, head, slab, lane);
             const float kt = key_true[q];
             if (live && key > kt) atomicAdd(&removed[slot][0], 1u);
             if (live && key >= kt) atomicAdd(&removed[slot][1], 1u);
@@ -470,8 +471,8 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             const bool live = row >= 0, head = q < q_head;
             const float* e = table + (live ? row : 0) * ld;
             float key;
-            if (head) key = coop_score<MODEL, HEAD, D>(e, coef_head + q * Scorer<MODEL, HEAD, D>::C, sub);
-            else key = coop_score<MODEL, TAIL, D>(e, coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C, sub);
+            if (head) key = coop_score<MODEL, HEAD, D>(e, q_fixed + q * D, q_rel + q * D, sub);
+            else key = coop_score<MODEL, TAIL, D>(e, q_fixed + q * D, q_rel + q * D, sub);
             const float kt = key_true[q];
             if (sub == 0 && live && key > kt) atomicAdd(&removed[slot][0], 1u);
             if (sub == 0 && live && key >= kt) atomicAdd(&removed[slot][1], 1u);
@@ -607,9 +608,9 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
         const int64_t blocks = (total + 255) / 256;
         const int grid = (int)(blocks < 8192 ? blocks : 8192);
-        prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail, w.acc);
+        prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail);
         true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(
-            table, ld, true_row, q_true, w.coef_head, w.coef_tail, q_head, q_tail, w.key_true);
+            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc);
     }
 
     if (N > 0) {
@@ -650,8 +651,8 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
 
-    return launch_filter_finalize(MODEL, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filter,
-                                  w.acc, counts, stream);
+    return launch_filter_finalize(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter, w.acc, counts,
+                                  stream);
 }
 
 template <int MODEL>
@@ -699,27 +700,25 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exact-path building blocks reused by rank_gemm.hip and rank_sad.hip (row-major coefficients, true keys, CSR filter).
+// Building blocks the pre-pass paths (rank_gemm.hip, rank_sad.hip) share with the exact path: true-entity keys (+ zeroed
+// accumulators) and the filter / finalize step.  They read the query vectors directly: no coefficient array.
 template <int MODEL, int D>
-static hipError_t exact_prep_impl(const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
-                                  const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
-                                  float* coef_head, float* coef_tail, float* key_true, unsigned long long* acc,
-                                  hipStream_t stream) {
+static hipError_t true_keys_impl(const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
+                                 const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
+                                 float* key_true, unsigned long long* acc, hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
-    const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
-    const int64_t blocks = (total + 255) / 256;
-    prep_coef_kernel<MODEL, D><<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, coef_head, coef_tail, acc);
-    true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(table, ld, true_row, q_true, coef_head, coef_tail, q_head, q_tail, key_true);
+    true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail,
+                                                                        key_true, acc);
     return hipGetLastError();
 }
 
 template <int MODEL, int D>
-static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const float* coef_head,
-                                       const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                                       const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                        const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
                                        hipStream_t stream) {
     filter_finalize_kernel<MODEL, D><<<(int)((q_head + q_tail + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(
-        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, filter, acc, counts);
+        table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc, counts);
     return hipGetLastError();
 }
 
@@ -740,16 +739,14 @@ static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld
     default: return hipErrorInvalidValue;                                                   \
     }
 
-hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head,
-                             int64_t q_tail, const float* table, int64_t ld, const int64_t* true_row,
-                             const float* q_true, float* coef_head, float* coef_tail, float* key_true,
-                             unsigned long long* acc, hipStream_t stream) {
-    BLP_DISPATCH_MODEL_DIM(exact_prep_impl, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, coef_head,
-                           coef_tail, key_true, acc, stream)
+hipError_t launch_true_keys(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
+                            const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
+                            float* key_true, unsigned long long* acc, hipStream_t stream) {
+    BLP_DISPATCH_MODEL_DIM(true_keys_impl, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, key_true, acc, stream)
 }
 
-hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
-                                  const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                                  const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
                                   hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
@@ -757,7 +754,7 @@ hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t 
         finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(acc, Q, counts);
         return hipGetLastError();
     }
-    BLP_DISPATCH_MODEL_DIM(filter_finalize_impl, table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, filter, acc,
+    BLP_DISPATCH_MODEL_DIM(filter_finalize_impl, table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc,
                            counts, stream)
 }
 

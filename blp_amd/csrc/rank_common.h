@@ -74,17 +74,15 @@ __device__ __forceinline__ int64_t filter_row(const FilterSpec& f, int64_t q, in
 // Last step of every ranking path: counts[q] = {gt, ge, gt - fgt, ge - fge} from the packed 64-bit accumulators,
 // fgt / fge = the filtered candidates that score above / at least the true entity (one wave per query, exact
 // Scorer<> arithmetic).  Without a filter the last two equal the first two.
-hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
-                                  const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                                  const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
                                   hipStream_t stream);
 
-// rank_all.hip: exact-path building blocks (row-major coefficients + true keys, the Q rank-count
-// accumulators `acc` zeroed on the way; CSR filter counts)
-hipError_t launch_exact_prep(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head,
-                             int64_t q_tail, const float* table, int64_t ld, const int64_t* true_row,
-                             const float* q_true, float* coef_head, float* coef_tail, float* key_true,
-                             unsigned long long* acc, hipStream_t stream);
+// rank_all.hip: true-entity keys by the exact routine (and the Q rank-count accumulators `acc` zeroed on the way)
+hipError_t launch_true_keys(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
+                            const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
+                            float* key_true, unsigned long long* acc, hipStream_t stream);
 
 // rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
 void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)

@@ -822,8 +822,8 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
 // (coop_score) and counted.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
-                                                           const float* __restrict__ coef_head,
-                                                           const float* __restrict__ coef_tail,
+                                                           const float* __restrict__ q_fixed,
+                                                           const float* __restrict__ q_rel,
                                                            const float* __restrict__ key_true, int64_t q_head,
                                                            const uint2* __restrict__ pairs,
                                                            const unsigned* __restrict__ n_pairs,
@@ -840,8 +840,8 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
         const int64_t row0 = (int64_t)(p.y >> 16) * kGCT;
         unsigned und = live ? p.y & 0xffffu : 0u;
         const bool is_head = q < q_head;
-        const float* coef = is_head ? coef_head + q * Scorer<MODEL, HEAD, D>::C
-                                    : coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C;
+        const float* f = q_fixed + q * D;
+        const float* r = q_rel + q * D;
         const float kt = key_true[q];
         unsigned gt = 0, ge = 0;
         while (__ballot(und != 0)) {  // the halves walk their own masks; an exhausted half idles
@@ -850,8 +850,8 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
             und &= ~(1u << bit);
             const float* e = table + (row0 + acc_row(15 - bit, half)) * ld;
             float key;
-            if (is_head) key = coop_score<MODEL, HEAD, D>(work ? e : table, coef, sub);
-            else key = coop_score<MODEL, TAIL, D>(work ? e : table, coef, sub);
+            if (is_head) key = coop_score<MODEL, HEAD, D>(work ? e : table, f, r, sub);
+            else key = coop_score<MODEL, TAIL, D>(work ? e : table, f, r, sub);
             gt += work && key > kt;
             ge += work && key >= kt;
         }
@@ -862,8 +862,8 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
 // Pass 2a of the f32-chain kernel: one lane per slot of the workgroups' fixed (query, row) pair regions.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __restrict__ table, int64_t ld,
-                                                                const float* __restrict__ coef_head,
-                                                                const float* __restrict__ coef_tail,
+                                                                const float* __restrict__ q_fixed,
+                                                                const float* __restrict__ q_rel,
                                                                 const float* __restrict__ key_true, int64_t q_head,
                                                                 const uint2* __restrict__ pairs, int64_t n_entries,
                                                                 unsigned long long* __restrict__ acc) {
@@ -875,8 +875,10 @@ __global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __r
     float e[D];
     load_row<D>(e, table + (int64_t)p.y * ld);
     float key;
-    if (q < q_head) key = Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef_head + q * Scorer<MODEL, HEAD, D>::C});
-    else key = Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C});
+    const float* f = q_fixed + q * D;
+    const float* r = q_rel + q * D;
+    if (q < q_head) key = Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r});
+    else key = Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
     const float kt = key_true[q];
     const unsigned long long gt = key > kt, ge = key >= kt;
     if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
@@ -886,8 +888,8 @@ __global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __r
 // (query, 16-candidate) half-segment is re-scored exactly, four half-segments per iteration.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
-                                                     const float* __restrict__ coef_head,
-                                                     const float* __restrict__ coef_tail,
+                                                     const float* __restrict__ q_fixed,
+                                                     const float* __restrict__ q_rel,
                                                      const float* __restrict__ key_true, int64_t q_head, int64_t Q,
                                                      int words_per_query, const unsigned* __restrict__ flags,
                                                      unsigned long long* __restrict__ acc) {
@@ -899,8 +901,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
     const int64_t q = q_base + list[i];
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
-    const float* coef = q < q_head ? coef_head + q * Scorer<MODEL, HEAD, D>::C
-                                   : coef_tail + (q - q_head) * Scorer<MODEL, TAIL, D>::C;
+    const float* f = q_fixed + q * D;
+    const float* rl = q_rel + q * D;
     unsigned gt = 0, ge = 0;
     for (int w0 = 0; w0 < words_per_query; w0 += 64) {
         const unsigned mine = w0 + lane < words_per_query ? row[w0 + lane] : 0u;
@@ -923,8 +925,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
                 const bool ok = b >= 0 && r < N;
                 float e[D];
                 load_row<D>(e, table + (ok ? r : 0) * ld);
-                const float key = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, PtrCoef{coef})
-                                             : Scorer<MODEL, TAIL, D>::template score<false>(e, PtrCoef{coef});
+                const float key = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, rl})
+                                             : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, rl});
                 gt += ok && key > kt;
                 ge += ok && key >= kt;
             }
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
 
 // ------------------------------------------------------------------------------------------------
 struct GemmWorkspace {
-    float* coef_head; float* coef_tail; float* key_true; float* eps_q;
+    float* key_true; float* eps_q;
     float4* img_head; float4* img_tail;
     uint4* cimg; float* cnmax;  // bf16 candidate image (whole table) and its per-half-tile band factors
     unsigned long long* acc; unsigned* n_pairs; unsigned* flags; uint2* pairs;
@@ -990,8 +992,6 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     char* p = static_cast<char*>(base);
     size_t off = 0;
     const size_t tile_bytes = (size_t)(D / 8) * 64 * 16;
-    w.coef_head = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_head * max_coef(D) * 4, 256);
-    w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * max_coef(D) * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
     w.eps_q = reinterpret_cast<float*>(p + off);     off = align_up(off + (size_t)Q * 4, 256);
     w.img_head = reinterpret_cast<float4*>(p + off); off = align_up(off + (size_t)((q_head + kGQT - 1) / kGQT) * tile_bytes, 256);
@@ -1036,8 +1036,8 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     const int64_t Q = q_head + q_tail;
     GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
     const int64_t pass_tiles = w.pass_ctiles;
-    hipError_t err = launch_exact_prep(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.coef_head,
-                                       w.coef_tail, w.key_true, w.acc, stream);
+    hipError_t err = launch_true_keys(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.key_true, w.acc,
+                                      stream);
     if (err != hipSuccess) return err;
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
     const bool f32_kernel = gemm_use_f32();
@@ -1094,7 +1094,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                 slab, n_rows, ld, w.img_head, w.img_tail, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups,
                 (int)chunks_head, words, w.acc, w.flags, w.pairs);
             refine_pair_slots_kernel<MODEL, D><<<dim3((unsigned)((n_entries + 255) / 256)), 256, 0, stream>>>(
-                slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, n_entries, w.acc);
+                slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs, n_entries, w.acc);
         } else {
             const uint4* cimg = w.cimg + (size_t)(slab0 / kGCT) * (D / 8) * 64;  // 2 parts x D/16 steps x 64 lanes per tile
             const float* cnmax = w.cnmax + (slab0 / kGCT) * 2;
@@ -1111,14 +1111,14 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             rank_gemm_bf16_kernel<MODEL, D, false><<<dim3((unsigned)n_blocks), kBfW * 64, lds_bf16, stream>>>(
                 cimg, cnmax, n_rows, ih, it, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head,
                 tiles_per_chunk, words, w.acc, w.flags, w.pairs, w.n_pairs, nullptr, nullptr);
-            refine_pairs_kernel<MODEL, D><<<dim3(2048), 256, 0, stream>>>(slab, ld, w.coef_head, w.coef_tail, w.key_true,
-                                                                        q_head, w.pairs, w.n_pairs, w.acc);
+            refine_pairs_kernel<MODEL, D><<<dim3(2048), 256, 0, stream>>>(slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs,
+                                                                        w.n_pairs, w.acc);
         }
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
-            slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.acc);
+            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-    err = launch_filter_finalize(MODEL, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filter,
+    err = launch_filter_finalize(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter,
                                  w.acc, counts, stream);
     return err != hipSuccess ? err : hipGetLastError();
 }

@@ -310,8 +310,8 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
 // gathered through per-lane pointers instead of being consecutive.  Same arithmetic as Scorer<TRANSE, *, D>::score.
 template <int D>
 __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
-                                                              const float* __restrict__ coef_head,
-                                                              const float* __restrict__ coef_tail,
+                                                              const float* __restrict__ q_fixed,
+                                                              const float* __restrict__ q_rel,
                                                               const float* __restrict__ key_true, int64_t q_head,
                                                               const uint2* __restrict__ pairs,
                                                               const SadParams* __restrict__ params,
@@ -325,11 +325,7 @@ __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __res
         const bool live = p.x != kSNoPair;
         const int64_t q = live ? p.x : 0;
         const bool head = q < q_head;
-        // candidate row; a = r (head) | h + r (tail); b = t (head) | unused (tail: any readable row)
-        const float* pe = table + (live ? (int64_t)p.y : 0) * ld;
-        const float* pa = head ? coef_head + q * (2 * D) : coef_tail + (q - q_head) * D;
-        const float* pb = head ? pa + D : pa;
-        const float key = transe_key_64<D>(pe, pa, pb, head, slab, lane);
+        const float key = transe_key_64<D>(table + (live ? (int64_t)p.y : 0) * ld, q_fixed + q * D, q_rel + q * D, head, slab, lane);
         const float kt = key_true[q];
         const unsigned long long gt = live && key > kt, ge_ = live && key >= kt;
         if (gt | ge_) atomicAdd(acc + q, gt | (ge_ << 32));
@@ -340,8 +336,8 @@ __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __res
 // re-scored exactly.  When the pre-pass did not run (non-finite input, degenerate range) all tiles are.
 template <int D>
 __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __restrict__ table, int64_t n_rows,
-                                                               int64_t ld, const float* __restrict__ coef_head,
-                                                               const float* __restrict__ coef_tail,
+                                                               int64_t ld, const float* __restrict__ q_fixed,
+                                                               const float* __restrict__ q_rel,
                                                                const float* __restrict__ key_true, int64_t q_head,
                                                                int64_t Q, int words_per_query,
                                                                const unsigned* __restrict__ flags,
@@ -356,8 +352,8 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
     const int64_t q = q_base + list[i];
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
-    const float* coef = q < q_head ? coef_head + q * Scorer<TRANSE, HEAD, D>::C
-                                   : coef_tail + (q - q_head) * Scorer<TRANSE, TAIL, D>::C;
+    const float* f = q_fixed + q * D;
+    const float* rl = q_rel + q * D;
     unsigned gt = 0, ge = 0;
     for (int w0 = 0; w0 < words_per_query; w0 += 64) {
         const unsigned mine = w0 + lane < words_per_query ? (all ? 0xFFFFFFFFu : row[w0 + lane]) : 0u;
@@ -375,8 +371,8 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
                 if (__ballot(ok) == 0) continue;
                 float e[D];
                 load_row<D>(e, table + (ok ? r : 0) * ld);
-                const float key = q < q_head ? Scorer<TRANSE, HEAD, D>::template score<false>(e, PtrCoef{coef})
-                                             : Scorer<TRANSE, TAIL, D>::template score<false>(e, PtrCoef{coef});
+                const float key = q < q_head ? Scorer<TRANSE, HEAD, D>::template score<false>(e, LazyCoef<TRANSE, HEAD, D>{f, rl})
+                                             : Scorer<TRANSE, TAIL, D>::template score<false>(e, LazyCoef<TRANSE, TAIL, D>{f, rl});
                 gt += ok && key > kt;
                 ge += ok && key >= kt;
             }
@@ -396,7 +392,7 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
 static constexpr int sad_tiles_per_wave(int D) { return D <= 64 ? 2 : 1; }
 
 struct SadWorkspace {
-    float* coef_head; float* coef_tail; float* key_true;
+    float* key_true;
     unsigned long long* acc;
     SadParams* params; SadParams* partial; int2* thr; unsigned* qimg; uint4* cimg; unsigned* resid; unsigned* flags;
     uint2* pairs;
@@ -451,8 +447,6 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     const int64_t Q = q_head + q_tail;
     char* p = static_cast<char*>(base);
     size_t off = 0;
-    w.coef_head = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_head * 2 * D * 4, 256);
-    w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * 2 * D * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
     w.params = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams), 256);
@@ -493,8 +487,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     constexpr int TPW = sad_tiles_per_wave(D);
     const int64_t Q = q_head + q_tail;
     SadWorkspace w = carve_sad(workspace, D, N, q_head, q_tail);
-    hipError_t err = launch_exact_prep(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true,
-                                       w.coef_head, w.coef_tail, w.key_true, w.acc, stream);
+    hipError_t err = launch_true_keys(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.key_true, w.acc,
+                                      stream);
     if (err != hipSuccess) return err;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     const int64_t n_tiles = (N + 63) / 64;
@@ -536,12 +530,12 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
             w.flags, w.pairs, w.params);
         const int64_t pair_blocks = (n_blocks * kSQuota + 63) / 64;  // 64 pairs per single-wave workgroup and iteration
         sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 40 ? pair_blocks : (int64_t)n_cu * 40)), 64, 0, stream>>>(
-            slab, ld, w.coef_head, w.coef_tail, w.key_true, q_head, w.pairs, w.params, w.acc);
+            slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc);
         sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
-            slab, n_rows, ld, w.coef_head, w.coef_tail, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
+            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-    err = launch_filter_finalize(TRANSE, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail, filter,
+    err = launch_filter_finalize(TRANSE, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter,
                                  w.acc, counts, stream);
     return err != hipSuccess ? err : hipGetLastError();
 }

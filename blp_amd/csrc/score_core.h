@@ -255,6 +255,18 @@ struct PtrCoef {
     __device__ __forceinline__ float operator()(ic<I>) const { return p[I]; }
 };
 
+// LazyCoef: coefficient i computed on use from the query's two vectors (f = the entity kept fixed, r = the relation),
+// by the same Scorer<>::coef expression the prep kernel materialises -- so a key scored through it is bit-identical to
+// one scored from the materialised row.  Used wherever single pairs are re-scored (true-entity keys, refinement,
+// flag sweeps, filter): those paths then need no (Q, C) coefficient array at all.
+template <int MODEL, int SIDE, int D>
+struct LazyCoef {
+    const float* __restrict__ f;
+    const float* __restrict__ r;
+    template <int I>
+    __device__ __forceinline__ float operator()(ic<I>) const { return Scorer<MODEL, SIDE, D>::coef(f, r, I); }
+};
+
 template <int K>
 __device__ __forceinline__ float quad_bcast(float x) {  // lane K of each quad -> the whole quad
     constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
