@@ -26,9 +26,9 @@ python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/tg/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# last call = from the last prep_coef launch on
-starts = [i for i, r in enumerate(rows) if "prep_coef" in r["Kernel_Name"]]
-seg = rows[starts[-1] - 1:]  # include the memset before it if it is a kernel
+# last call = from the last true_key launch on (the first kernel of a pre-pass call)
+starts = [i for i, r in enumerate(rows) if "true_key" in r["Kernel_Name"]]
+seg = rows[starts[-1]:]
 prev_end = None; busy = 0; gaps = 0
 for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
