@@ -300,16 +300,19 @@ __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
 // hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|, and W . e is taken as w_hi e_hi + w_hi e_lo + w_lo e_hi
 // on v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in f32, the accumulator is f32).  Three
 // bf16 MFMAs of K = 16 replace eight f32 MFMAs of K = 2: 5.3x less matrix-pipe time per tile.  The price
-// is a wider band (kBandCBf16): dropped terms 3.02 * 2^-18 = 194 u, accumulation of 3 D products at one
-// ulp each (the matrix pipe's internal rounding is not documented; one ulp = 2 u per addition covers
-// round-to-nearest and truncation) 775 u, reference side (n + 2) u = 130 u  ->  1100 u, taken as 1150 u.
+// is a wider band (kBandCBf16 u ||B_q|| ||e_c||): dropped terms 3.02 * 2^-18 = 194 u; the reference's
+// own (n + 2) u = 130 u; operand rounding 3 u; and the accumulation inside the matrix pipe, whose internal
+// rounding is not documented -- ASSUMED no worse than adding the products one at a time with a truncating f32
+// addition (2 u each).  The MFMAs of a tile are ordered cross terms first (256 additions while the partial sum is
+// <= 2^-7 of the final magnitude: 4 u), main products last (128 additions: 258 u): 262 u instead of the 775 u of an
+// interleaved order.  Sum 589 u, taken as 620 u.
 // Operands whose magnitudes would break the relative bounds (bf16 denormal flush below 1e-18, bf16
 // overflow above 3e38, non-finite) get an infinite band factor and so take the exact path.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr float kBandCBf16 = 1150.0f;
+constexpr float kBandCBf16 = 620.0f;
 constexpr int kBfW = 4;          // waves per workgroup
 constexpr int kBfTPW = 2;        // candidate tiles per wave (4 at one wave/SIMD spills and runs 1.8x slower)
 constexpr int kBfWavesPerSimd = 2;  // launch bound: <= 256 VGPRs (128 of them hold the A operands)
@@ -455,9 +458,10 @@ __global__ __launch_bounds__(64) void prep_cand_bf16_kernel(const float* __restr
 template <int D>
 struct BfTile {
     uint4 hi[D / 16], lo[D / 16];  // A operands of the D/16 K-steps
-    float nmax;                    // largest band factor among the 16 candidates this lane's accumulators hold
-    unsigned row_mask;             // bit 15 - r: the candidate of accumulator register r exists (row < N)
 };
+// per (wave, candidate tile, half), kept in LDS (the registers are all taken): nmax = the largest band factor among the
+// 16 candidates a lane's accumulators hold; row_mask bit 15 - r = the candidate of accumulator register r exists
+struct BfHalfInfo { float nmax; unsigned row_mask; };
 
 // -DBLP_TIMING: per-phase cycle counts of the kernel below, summed over waves (tools/gemm_phase_timing.py)
 #ifdef BLP_TIMING
@@ -487,65 +491,74 @@ __device__ __forceinline__ void decide_pair(unsigned& gm, unsigned& lm, float s0
         : "v"(s0), "v"(s1), "v"(hi), "v"(lo));
 }
 
-// One K-step of the pipelined stage with the instruction order fixed by hand: the six MFMAs of the NEXT query
-// tile (both candidate tiles: n += lo x bh, then hi x bl, then hi x bh -- bf16 products are exact in f32 -- the two
-// accumulator chains alternating so that no MFMA reads the accumulator the previous one writes) with the decision of
-// two accumulator registers per candidate tile of the CURRENT query tile (decide_pair's instructions) in their
-// shadow: 16 VALU behind 6 MFMAs, 3 + 3 + 3 + 3 + 2 + 2.  Left to itself the compiler issues a tile's 48 MFMAs back
-// to back and the 128 decision instructions after them, so within a wave neither hides behind the other.
-// Carries live in s[84:99] (clobbered): every carry is read >= 2 instructions after the compare that wrote it.
-// A and B operands are register quadruples of four packed bf16 pairs.  FIRST: the K-step that starts the
-// accumulation (SrcC = 0: no register zeroing).  BLP_GEMM_ASM_STAGE=0 builds the compiler-scheduled variant (A/B).
+// The pipelined stage with the instruction order fixed by hand.  A query tile's 48 MFMAs (two candidate tiles, two
+// accumulator chains alternating so that no MFMA reads the accumulator the previous one writes; bf16 products are
+// exact in f32) are issued in TWO PHASES: first the 32 cross-term MFMAs (n += lo x bh, n += hi x bl for the eight
+// K-steps), then the 16 main ones (n += hi x bh).  The cross terms are 2^-8 of the main ones, so the accumulator stays
+// small while they are added and the matrix pipe's internal rounding of those 256 additions is negligible; only the
+// 128 additions of the main phase see the full magnitude (this order is what the band constant kBandCBf16 prices).
+// Behind the MFMAs, in their shadow, runs the decision of the CURRENT query tile's accumulators (decide_pair's eight
+// instructions per register pair): a cross K-step decides one pair of candidate tile 0 (8 VALU behind 4 MFMAs), a
+// main K-step one pair of candidate tile 1 (8 VALU behind 2 MFMAs).  Left to itself the compiler issues the 48
+// MFMAs back to back and the 128 decision instructions after them.  Carries live in s[84:91] (clobbered): every
+// carry is read >= 2 instructions after the compare that wrote it.  A and B operands are register quadruples of four
+// packed bf16 pairs.  FIRST: the K-step that starts the accumulation (SrcC = 0: no register zeroing).
+// BLP_GEMM_ASM_STAGE=0 builds the compiler-scheduled variant (A/B measurements).
 #ifndef BLP_GEMM_ASM_STAGE
 #define BLP_GEMM_ASM_STAGE 1
 #endif
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));  // (HIP's uint4 is a struct: not an asm operand)
 __device__ __forceinline__ u32x4_t as_quad(const uint4& x) { return __builtin_bit_cast(u32x4_t, x); }
-#define BLP_KSTEP_BODY(C0, C1)                                                                              \
-    asm("v_mfma_f32_32x32x16_bf16 %0, %6, %10, " C0 "\n\t"                                                   \
-        "v_cmp_gt_f32_e64 s[84:85], %12, %16\n\t"                                                           \
-        "v_cmp_lt_f32_e64 s[86:87], %12, %17\n\t"                                                           \
-        "v_cmp_gt_f32_e64 s[88:89], %13, %16\n\t"                                                           \
-        "v_mfma_f32_32x32x16_bf16 %1, %8, %10, " C1 "\n\t"                                                   \
-        "v_cmp_lt_f32_e64 s[90:91], %13, %17\n\t"                                                           \
-        "v_cmp_gt_f32_e64 s[92:93], %14, %18\n\t"                                                           \
-        "v_cmp_lt_f32_e64 s[94:95], %14, %19\n\t"                                                           \
-        "v_mfma_f32_32x32x16_bf16 %0, %7, %11, %0\n\t"                                                      \
+#define BLP_KSTEP_CLOBBERS "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"
+#define BLP_KCROSS_BODY(C0, C1)                                                                             \
+    asm("v_mfma_f32_32x32x16_bf16 %0, %4, %8, " C0 "\n\t"                                                    \
+        "v_cmp_gt_f32_e64 s[84:85], %10, %12\n\t"                                                           \
+        "v_cmp_lt_f32_e64 s[86:87], %10, %13\n\t"                                                           \
+        "v_mfma_f32_32x32x16_bf16 %1, %6, %8, " C1 "\n\t"                                                    \
+        "v_cmp_gt_f32_e64 s[88:89], %11, %12\n\t"                                                           \
+        "v_cmp_lt_f32_e64 s[90:91], %11, %13\n\t"                                                           \
+        "v_mfma_f32_32x32x16_bf16 %0, %5, %9, %0\n\t"                                                       \
         "v_addc_co_u32_e64 %2, s[84:85], %2, %2, s[84:85]\n\t"                                              \
         "v_addc_co_u32_e64 %3, s[86:87], %3, %3, s[86:87]\n\t"                                              \
-        "v_cmp_gt_f32_e64 s[96:97], %15, %18\n\t"                                                           \
-        "v_mfma_f32_32x32x16_bf16 %1, %9, %11, %1\n\t"                                                      \
-        "v_cmp_lt_f32_e64 s[98:99], %15, %19\n\t"                                                           \
+        "v_mfma_f32_32x32x16_bf16 %1, %7, %9, %1\n\t"                                                       \
         "v_addc_co_u32_e64 %2, s[88:89], %2, %2, s[88:89]\n\t"                                              \
-        "v_addc_co_u32_e64 %3, s[90:91], %3, %3, s[90:91]\n\t"                                              \
-        "v_mfma_f32_32x32x16_bf16 %0, %7, %10, %0\n\t"                                                      \
-        "v_addc_co_u32_e64 %4, s[92:93], %4, %4, s[92:93]\n\t"                                              \
-        "v_addc_co_u32_e64 %5, s[94:95], %5, %5, s[94:95]\n\t"                                              \
-        "v_mfma_f32_32x32x16_bf16 %1, %9, %10, %1\n\t"                                                      \
-        "v_addc_co_u32_e64 %4, s[96:97], %4, %4, s[96:97]\n\t"                                              \
-        "v_addc_co_u32_e64 %5, s[98:99], %5, %5, s[98:99]"
-#define BLP_KSTEP_CLOBBERS "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+        "v_addc_co_u32_e64 %3, s[90:91], %3, %3, s[90:91]"
+// cross K-step: n0 += lo0 x bh, n1 += lo1 x bh, n0 += hi0 x bl, n1 += hi1 x bl; decides (c0, c1) of candidate tile 0
 template <bool FIRST>
-__device__ __forceinline__ void kstep_pair(f32x16_t& n0, f32x16_t& n1, u32x4_t lo0, u32x4_t hi0, u32x4_t lo1, u32x4_t hi1,
-                                           u32x4_t bh, u32x4_t bl, float c00, float c01, float c10, float c11, float th0,
-                                           float tl0, float th1, float tl1, unsigned& gm0, unsigned& lm0, unsigned& gm1,
-                                           unsigned& lm1) {
+__device__ __forceinline__ void kstep_cross(f32x16_t& n0, f32x16_t& n1, u32x4_t lo0, u32x4_t hi0, u32x4_t lo1, u32x4_t hi1,
+                                            u32x4_t bh, u32x4_t bl, float c0, float c1, float th, float tl, unsigned& gm,
+                                            unsigned& lm) {
     if constexpr (FIRST) {
-        BLP_KSTEP_BODY("0", "0")
-            : "=&v"(n0), "=&v"(n1), "+v"(gm0), "+v"(lm0), "+v"(gm1), "+v"(lm1)
-            : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(bh), "v"(bl), "v"(c00), "v"(c01), "v"(c10), "v"(c11), "v"(th0),
-              "v"(tl0), "v"(th1), "v"(tl1)
+        BLP_KCROSS_BODY("0", "0")
+            : "=&v"(n0), "=&v"(n1), "+v"(gm), "+v"(lm)
+            : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(bh), "v"(bl), "v"(c0), "v"(c1), "v"(th), "v"(tl)
             : BLP_KSTEP_CLOBBERS);
     } else {
-        BLP_KSTEP_BODY("%0", "%1")
-            : "+v"(n0), "+v"(n1), "+v"(gm0), "+v"(lm0), "+v"(gm1), "+v"(lm1)
-            : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(bh), "v"(bl), "v"(c00), "v"(c01), "v"(c10), "v"(c11), "v"(th0),
-              "v"(tl0), "v"(th1), "v"(tl1)
+        BLP_KCROSS_BODY("%0", "%1")
+            : "+v"(n0), "+v"(n1), "+v"(gm), "+v"(lm)
+            : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(bh), "v"(bl), "v"(c0), "v"(c1), "v"(th), "v"(tl)
             : BLP_KSTEP_CLOBBERS);
     }
 }
-#undef BLP_KSTEP_BODY
+// main K-step: n0 += hi0 x bh, n1 += hi1 x bh; decides (c0, c1) of candidate tile 1
+__device__ __forceinline__ void kstep_main(f32x16_t& n0, f32x16_t& n1, u32x4_t hi0, u32x4_t hi1, u32x4_t bh, float c0,
+                                           float c1, float th, float tl, unsigned& gm, unsigned& lm) {
+    asm("v_mfma_f32_32x32x16_bf16 %0, %4, %6, %0\n\t"
+        "v_cmp_gt_f32_e64 s[84:85], %7, %9\n\t"
+        "v_cmp_lt_f32_e64 s[86:87], %7, %10\n\t"
+        "v_cmp_gt_f32_e64 s[88:89], %8, %9\n\t"
+        "v_cmp_lt_f32_e64 s[90:91], %8, %10\n\t"
+        "v_mfma_f32_32x32x16_bf16 %1, %5, %6, %1\n\t"
+        "v_addc_co_u32_e64 %2, s[84:85], %2, %2, s[84:85]\n\t"
+        "v_addc_co_u32_e64 %3, s[86:87], %3, %3, s[86:87]\n\t"
+        "v_addc_co_u32_e64 %2, s[88:89], %2, %2, s[88:89]\n\t"
+        "v_addc_co_u32_e64 %3, s[90:91], %3, %3, s[90:91]"
+        : "+v"(n0), "+v"(n1), "+v"(gm), "+v"(lm)
+        : "v"(hi0), "v"(hi1), "v"(bh), "v"(c0), "v"(c1), "v"(th), "v"(tl)
+        : BLP_KSTEP_CLOBBERS);
+}
+#undef BLP_KCROSS_BODY
 #undef BLP_KSTEP_CLOBBERS
 
 // Undecided entries of the bf16 kernel: one per (query, 16-candidate half-tile) with at least one undecided pair.
@@ -571,6 +584,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * (TILE_BYTES / 4));   // [tiles_per_chunk * 32]
     uint2* pair_s = reinterpret_cast<uint2*>(cnt + tiles_per_chunk * kGQT);     // [quota]
     float2* kq_s = reinterpret_cast<float2*>(pair_s + quota);                    // [tiles_per_chunk * 32] {s_true, eps_q}
+    BfHalfInfo* half_info = reinterpret_cast<BfHalfInfo*>(kq_s + tiles_per_chunk * kGQT);  // [kBfW][kBfTPW][2]
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, half = lane >> 5;
@@ -607,12 +621,15 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
             c[t].hi[st] = src[st * 64];
             c[t].lo[st] = src[(STEPS + st) * 64];
         });
-        c[t].nmax = cnmax[(ctile0 + t) * 2 + half];
-        const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
-        c[t].row_mask = 0;
+        if ((lane & 31) == 0) {
+            const int64_t row0 = (int64_t)(ctile0 + t) * kGCT;
+            unsigned mask = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[t].row_mask |= (unsigned)(row0 + acc_row(r, half) < n_rows) << (15 - r);
+            for (int r = 0; r < 16; ++r) mask |= (unsigned)(row0 + acc_row(r, half) < n_rows) << (15 - r);
+            half_info[(wave * kBfTPW + t) * 2 + half] = BfHalfInfo{cnmax[(ctile0 + t) * 2 + half], mask};
+        }
     });
+    const BfHalfInfo* my_info = half_info + wave * kBfTPW * 2 + half;  // [ti * 2]; written by this wave's own lanes
 
     const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
     unsigned my_pairs = 0;  // entries this wave has listed (wave-uniform)
@@ -625,30 +642,31 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         bh = __builtin_bit_cast(bf16x8, bp[st * 64]);
         bl = __builtin_bit_cast(bf16x8, bp[(STEPS + st) * 64]);
     };
-    auto mfma_step = [&](auto kk, f32x16 (&s)[kBfTPW], const bf16x8& bh, const bf16x8& bl) {
-        constexpr int st = decltype(kk)::value;
-        static_for<kBfTPW>([&](auto tt) {
-            constexpr int ti = decltype(tt)::value;
-            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].lo[st]), bh, s[ti], 0, 0, 0);
-        });
-        static_for<kBfTPW>([&](auto tt) {
-            constexpr int ti = decltype(tt)::value;
-            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bl, s[ti], 0, 0, 0);
-        });
-        static_for<kBfTPW>([&](auto tt) {
-            constexpr int ti = decltype(tt)::value;
-            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bh, s[ti], 0, 0, 0);
-        });
-    };
-    // all K-steps of one query tile; the B operands of step st + 1 are requested before step st's MFMAs
-    auto mfma_tile = [&](f32x16 (&s)[kBfTPW], const float* buf, auto&& between) {
-        bf16x8 bh[2], bl[2];
-        load_b(ic<0>{}, buf, bh[0], bl[0]);
+    // A query tile without anything in the MFMAs' shadow (the first tile of a workgroup, dump mode, the
+    // compiler-scheduled variant): the same two-phase order as kstep_cross / kstep_main -- all cross terms, then the
+    // main products -- so that every accumulator sees the same sequence of additions whichever routine filled it.
+    auto mfma_tile = [&](f32x16 (&s)[kBfTPW], const float* buf) {
         static_for<STEPS>([&](auto kk) {
             constexpr int st = decltype(kk)::value;
-            if constexpr (st + 1 < STEPS) load_b(ic<st + 1>{}, buf, bh[(st + 1) & 1], bl[(st + 1) & 1]);
-            mfma_step(kk, s, bh[st & 1], bl[st & 1]);
-            between(kk);
+            bf16x8 bh, bl;
+            load_b(kk, buf, bh, bl);
+            static_for<kBfTPW>([&](auto tt) {
+                constexpr int ti = decltype(tt)::value;
+                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].lo[st]), bh, s[ti], 0, 0, 0);
+            });
+            static_for<kBfTPW>([&](auto tt) {
+                constexpr int ti = decltype(tt)::value;
+                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bl, s[ti], 0, 0, 0);
+            });
+        });
+        static_for<STEPS>([&](auto kk) {
+            constexpr int st = decltype(kk)::value;
+            bf16x8 bh, bl;
+            load_b(kk, buf, bh, bl);
+            static_for<kBfTPW>([&](auto tt) {
+                constexpr int ti = decltype(tt)::value;
+                s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[ti].hi[st]), bh, s[ti], 0, 0, 0);
+            });
         });
     };
     // Decision for accumulator registers [R0, R0 + NR) of both tiles against the two thresholds of this
@@ -677,7 +695,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
             unsigned above = q_ok ? __popc(gm[ti]) : 0u;  // rows that do not exist score NaN: never above
-            const unsigned und = q_ok ? ~(gm[ti] | lm[ti]) & c[ti].row_mask : 0u;
+            const unsigned und = q_ok ? ~(gm[ti] | lm[ti]) & my_info[ti * 2].row_mask : 0u;
             const unsigned long long listing = __ballot(und != 0);
             if (listing) {  // wave-uniform
                 const unsigned n = __popcll(listing);
@@ -725,7 +743,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         float thr_hi[kBfTPW], thr_lo[kBfTPW], eps[kBfTPW];
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            eps[ti] = __builtin_fmaf(eq, c[ti].nmax, guard);
+            eps[ti] = __builtin_fmaf(eq, my_info[ti * 2].nmax, guard);
             thr_hi[ti] = kt + eps[ti];
             thr_lo[ti] = kt - eps[ti];
             gm[ti] = 0;
@@ -733,29 +751,34 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         });
         if (more) {
             const float* nbuf = ((t + 1) & 1) ? buf1 : buf0;
-            if constexpr (!DUMP && BLP_GEMM_ASM_STAGE && STEPS == 8) {  // two registers per K-step: 16 = 2 x 8
-                u32x4_t bh[2], bl[2];
+            if constexpr (!DUMP && BLP_GEMM_ASM_STAGE && STEPS == 8) {  // one register pair per K-step and phase: 16 = 2 x 8
+                static_assert(kBfTPW == 2, "kstep_cross / kstep_main are written for two candidate tiles per wave");
                 const u32x4_t* bp = reinterpret_cast<const u32x4_t*>(nbuf) + lane;
+                u32x4_t bh[2], bl[2];
                 bh[0] = bp[0];
                 bl[0] = bp[STEPS * 64];
-                static_for<STEPS>([&](auto kk) {
+                static_for<STEPS>([&](auto kk) {  // cross terms; candidate tile 0 is decided
                     constexpr int st = decltype(kk)::value;
                     if constexpr (st + 1 < STEPS) {
                         bh[(st + 1) & 1] = bp[(st + 1) * 64];
                         bl[(st + 1) & 1] = bp[(STEPS + st + 1) * 64];
+                    } else {
+                        bh[(st + 1) & 1] = bp[0];  // the main phase starts over at K-step 0
                     }
-                    static_assert(kBfTPW == 2, "kstep_pair is written for two candidate tiles per wave");
-                    kstep_pair<st == 0>(nxt[0], nxt[1], as_quad(c[0].lo[st]), as_quad(c[0].hi[st]), as_quad(c[1].lo[st]),
-                                        as_quad(c[1].hi[st]), bh[st & 1], bl[st & 1], cur[0][2 * st], cur[0][2 * st + 1],
-                                        cur[1][2 * st], cur[1][2 * st + 1], thr_hi[0], thr_lo[0], thr_hi[1], thr_lo[1], gm[0],
-                                        lm[0], gm[1], lm[1]);
+                    kstep_cross<st == 0>(nxt[0], nxt[1], as_quad(c[0].lo[st]), as_quad(c[0].hi[st]), as_quad(c[1].lo[st]),
+                                         as_quad(c[1].hi[st]), bh[st & 1], bl[st & 1], cur[0][2 * st], cur[0][2 * st + 1],
+                                         thr_hi[0], thr_lo[0], gm[0], lm[0]);
+                });
+                static_for<STEPS>([&](auto kk) {  // main products; candidate tile 1 is decided
+                    constexpr int st = decltype(kk)::value;
+                    if constexpr (st + 1 < STEPS) bh[(st + 1) & 1] = bp[(st + 1) * 64];
+                    kstep_main(nxt[0], nxt[1], as_quad(c[0].hi[st]), as_quad(c[1].hi[st]), bh[st & 1], cur[1][2 * st],
+                               cur[1][2 * st + 1], thr_hi[1], thr_lo[1], gm[1], lm[1]);
                 });
             } else {
                 zero_acc(nxt);
-                mfma_tile(nxt, nbuf, [&](auto kk) {
-                    constexpr int st = decltype(kk)::value;
-                    if constexpr (!DUMP) decide_chunk(ic<st * (16 / STEPS)>{}, ic<16 / STEPS>{}, cur, thr_hi, thr_lo, gm, lm);
-                });
+                mfma_tile(nxt, nbuf);
+                if constexpr (!DUMP) decide_chunk(ic<0>{}, ic<16>{}, cur, thr_hi, thr_lo, gm, lm);
             }
         } else if constexpr (!DUMP) {
             decide_chunk(ic<0>{}, ic<16>{}, cur, thr_hi, thr_lo, gm, lm);
@@ -790,7 +813,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     __syncthreads();
     f32x16 acc_a[kBfTPW], acc_b[kBfTPW];
     zero_acc(acc_a);
-    mfma_tile(acc_a, buf0, [](auto) {});
+    mfma_tile(acc_a, buf0);
     __syncthreads();  // buf0 is read: stage(0) may overwrite it with tile 2
     for (int t = 0; t < n_tiles; t += 2) {
         stage(t, acc_a, acc_b);
@@ -1083,7 +1106,8 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         const int64_t chunks_head = (th + tiles_per_chunk - 1) / tiles_per_chunk;
         const int64_t chunks_tail = (tt + tiles_per_chunk - 1) / tiles_per_chunk;
         const size_t lds_bf16 = (size_t)2 * (2 * (D / 16) * 64 * 16) + (size_t)tiles_per_chunk * kGQT * 4 +
-                                (size_t)kBfQuotaPerTile * tiles_per_chunk * 8 + (size_t)tiles_per_chunk * kGQT * 8 + 16;
+                                (size_t)kBfQuotaPerTile * tiles_per_chunk * 8 + (size_t)tiles_per_chunk * kGQT * 8 +
+                                (size_t)kBfW * kBfTPW * 2 * 8 + 16;
         const int64_t n_blocks = n_groups * (chunks_head + chunks_tail);
         err = hipMemsetAsync(w.n_pairs, 0, 256 + (size_t)Q * words * 4, stream);  // the entry counter and the flag bitmap
         if (err != hipSuccess) return err;
