@@ -344,7 +344,7 @@ template <int MODEL, int D, bool STATIC>
 __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_tiles_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
-    int n_tiles, int n_quad_groups, int n_chunks, const int64_t* __restrict__ q_rel_id,
+    int n_tiles, int n_quad_groups, int q_chunk, const int64_t* __restrict__ q_rel_id,
     unsigned long long* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_t
     const int chunk = blockIdx.x / n_quad_groups;
     const int qg = blockIdx.x % n_quad_groups;
     const int Q = q_head + q_tail;
-    const int qa = chunk * kQueryChunk;
-    const int qb = qa + kQueryChunk < Q ? qa + kQueryChunk : Q;
+    const int qa = chunk * q_chunk;  // q_chunk <= kQueryChunk: short chunks spread a small block over the chip
+    const int qb = qa + q_chunk < Q ? qa + q_chunk : Q;
     // [qa, qb) split at q_head: head-replacing queries first (train.py:149 order)
     const int h_lo = qa < q_head ? qa : q_head, h_hi = qb < q_head ? qb : q_head;
     const int t_lo = qa > q_head ? qa : q_head, t_hi = qb > q_head ? qb : q_head;
@@ -616,7 +616,12 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
     if (N > 0) {
         const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
         const int64_t n_quads = (n_tiles + kWaves - 1) / kWaves;
-        const int64_t n_chunks = (Q + kQueryChunk - 1) / kQueryChunk;
+        // Queries per workgroup: kQueryChunk amortises a tile fetch best, but a small block then occupies only
+        // n_quads workgroups (57 for the FB15k-237 table: a fifth of the chip, one wave per SIMD): halve the chunk
+        // while the grid would not even fill the resident set once.
+        int q_chunk = kQueryChunk;
+        while (q_chunk > 16 && n_quads * ((Q + q_chunk - 1) / q_chunk) < (int64_t)n_cu * 3) q_chunk >>= 1;
+        const int64_t n_chunks = (Q + q_chunk - 1) / q_chunk;
         // Resident workgroups: 3 per CU (12 waves at <= 168 VGPRs, ~48 KB of LDS each).  With plenty
         // of (tile quad, chunk) pairs give every workgroup one quad (many short workgroups -> no
         // tail); otherwise grid-stride ~2 resident sets of workgroups over the quads.
@@ -643,11 +648,11 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         if (static_mode)
             rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-                (int)groups, (int)n_chunks, q_rel_id, w.acc);
+                (int)groups, q_chunk, q_rel_id, w.acc);
         else
             rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-                (int)groups, (int)n_chunks, q_rel_id, w.acc);
+                (int)groups, q_chunk, q_rel_id, w.acc);
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
 
@@ -686,7 +691,7 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
     if (rank_sad_wide_applicable(model, D, q_head, q_tail))
         return launch_rank_all_sad_wide(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
                                         counts, workspace, n_cu, stream, ev_start, ev_stop);
-    if (rank_sad_applicable(model, D, q_head, q_tail))
+    if (rank_sad_applicable(model, D, N, q_head, q_tail))
         return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
                                    counts, workspace, n_cu, stream, ev_start, ev_stop);
     // everything else: the exact f32 kernels (few queries, D = 256 bilinear, or the rank_kernel knob)

@@ -97,7 +97,7 @@ hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N,
 
 // rank_sad.hip: TransE with many queries as a 16-bit fixed-point v_sad_u16 pre-pass + error band +
 // exact refinement.
-bool rank_sad_applicable(int model, int D, int64_t q_head, int64_t q_tail);
+bool rank_sad_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,

@@ -466,16 +466,22 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     return w;
 }
 
-// Worth it once the quantisation passes over the table (~2.5 table reads) are amortised.
-bool rank_sad_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
+// Worth it once its longer launch chain (range, quantisation, pre-pass, two refinement kernels: 9 launches against
+// the exact path's 4) is paid for by the 2.3x cheaper pair-element: measured on the FB15k-237 table (14 541 rows) the
+// exact f32 kernels win up to ~256 queries (128 queries: 42 vs 59 us), on the 4.6 M-row table the pre-pass wins from 64
+// queries on -- i.e. from about 4 million (query, candidate) pairs (tools/bench_small_blocks.py).
+bool rank_sad_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
     if (knob(KNOB_RANK_KERNEL) == 1) return false;  // test knob: the exact f32 kernels
+    const int64_t Q = q_head + q_tail;
     int64_t min_queries = kSadMinQueries;
-    if (const int64_t v = knob(KNOB_SAD_MIN_QUERIES)) min_queries = v > 0 ? v : 1;  // A/B knob
-    return model == TRANSE && (D == 64 || D == 128 || D == 256) && q_head + q_tail >= min_queries;
+    bool forced = false;
+    if (const int64_t v = knob(KNOB_SAD_MIN_QUERIES)) { min_queries = v > 0 ? v : 1; forced = true; }  // A/B knob
+    if (model != TRANSE || !(D == 64 || D == 128 || D == 256) || Q < min_queries) return false;
+    return forced || Q * N >= kSadMinPairs;
 }
 
 size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
-    if (!rank_sad_applicable(model, D, q_head, q_tail)) return 0;
+    if (!rank_sad_applicable(model, D, N, q_head, q_tail)) return 0;
     return carve_sad(nullptr, D, N, q_head, q_tail).bytes;
 }
 

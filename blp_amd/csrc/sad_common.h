@@ -11,7 +11,8 @@ namespace blp {
 
 constexpr int kSW = 4;                       // waves per workgroup
 constexpr int kSChunk = 256;                 // queries per workgroup at most (3.75 ms; 128: 3.79, 512: 3.82)
-constexpr int kSadMinQueries = 64;          // below this the exact f32 kernels win (tools/bench_small_blocks.py)
+constexpr int kSadMinQueries = 64;          // below this, or below kSadMinPairs (query, candidate) pairs, the exact
+constexpr long long kSadMinPairs = 4000000;  // f32 kernels win (tools/bench_small_blocks.py)
 constexpr int kSQuota = 1024;                // undecided pairs a workgroup can list
 constexpr unsigned kSInvalid = 0x40001000u;  // accumulator bias of padding rows: beyond every T_hi + E_c
 constexpr unsigned kSThrMax = 0x3fffffffu;

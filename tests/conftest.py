@@ -15,6 +15,7 @@ REL_MODELS = ("transe", "distmult", "complex", "simple")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "default_routing: keep the library's own choice of TransE kernel (no sad_min_queries knob)")
 
 
 def golden(name):

@@ -11,6 +11,15 @@ from conftest import REL_MODELS, golden, golden_names
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def prepass_from_64_queries():
+    """Small tables on purpose: keep the TransE pre-pass in play from 64 queries on (see tests/test_gpu_parity.py)."""
+    from blp_amd import _lib
+    _lib.set_knob("sad_min_queries", 64)
+    yield
+    _lib.reset_knobs()
+
+
 @pytest.mark.parametrize("rel_model", REL_MODELS)
 def test_eval_link_prediction_on_gpu_matches_reference(rel_model):
     from blp_amd import ranking

@@ -17,6 +17,19 @@ def ops():
     return _ops
 
 
+@pytest.fixture(autouse=True)
+def prepass_from_64_queries(request):
+    """The library sends TransE blocks below ~4 million (query, candidate) pairs to the exact f32 kernels (their shorter
+    launch chain wins there).  These tests use small tables on purpose, so the fixed-point pre-pass is made to take
+    every block of >= 64 queries, as it does at evaluation sizes; tests marked `default_routing` keep the library's
+    own choice."""
+    from blp_amd import _lib
+    if "default_routing" not in request.keywords:
+        _lib.set_knob("sad_min_queries", 64)
+    yield
+    _lib.reset_knobs()
+
+
 def dev(x, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(x))
     if dtype is not None:
@@ -107,6 +120,24 @@ def test_random_vs_oracle_ragged(ops, oracle, model, D):
     rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D)
     want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
     got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.default_routing
+@pytest.mark.parametrize("q_head,q_tail", [(70, 58), (300, 41), (1, 180)])
+def test_transe_small_blocks_take_the_exact_kernels(ops, oracle, q_head, q_tail):
+    """The library's own routing (no knob): 128 .. 341 TransE queries against a 2 000-row table are below the
+    pre-pass's break-even and go to the exact f32 kernels with short query chunks (16 .. 128 queries per workgroup so
+    that a small block still fills the chip).  Counts against the oracle, with a filter."""
+    from blp_amd import _lib
+    L = _lib.lib()
+    N, D = 2000, 128
+    assert L.blp_rank_all_workspace_bytes(0, N, D, q_head, q_tail) < (q_head + q_tail) * 2 * D * 4 + N * D  # no table image
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=q_head)
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=q_tail)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
                        filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
     assert np.array_equal(got, want)
 

@@ -81,6 +81,8 @@ def make_case(rng):
         env["gemm_kernel"] = 1
     if rng.random() < 0.15:
         env["rank_kernel"] = 1
+    if rng.random() < 0.6:
+        env["sad_min_queries"] = 64  # the tables here are small: without it TransE blocks take the exact kernels
     return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids
 
 
