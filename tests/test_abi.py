@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     assert L.blp_version() == 200
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
-    assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 16)
+    assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 8)  # coefficients, key, accumulator
     # blocks blp_rank_all takes: the compiled widths always; TransE with >= 256 queries at any D % 4 == 0
     assert L.blp_rank_all_supported(0, 128, 1, 1) == 1 and L.blp_rank_all_supported(2, 128, 1, 1) == 1
     assert L.blp_rank_all_supported(0, 300, 150, 170) == 1 and L.blp_rank_all_supported(0, 768, 256, 0) == 1
