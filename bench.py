@@ -6,7 +6,7 @@
 
 A "step" is ONE WHOLE EVALUATION of the workload's test triples against the entity table, exactly what
 blp_amd.ranking.eval_link_prediction runs after the table build (it is the same function,
-ranking.rank_triples): relation sort, id -> row lookups, query gathers (train.py:132-150), the filter
+ranking.rank_triples): id -> row lookups, query gathers (train.py:132-150), the filter
 of every query from the sorted index of the filtering graph (utils.py:46-83), the ranking pass -- every
 query scored against every candidate and counted, raw AND filtered (train.py:146-171) -- and the metric
 sums (utils.py:86-111, train.py:152-157).  Inputs resident in HBM when the clock starts: the entity table,
@@ -482,7 +482,7 @@ def main():
             "config": {"workload": args.workload, "rel_model": cfg["model"], "entities": cfg["N"], "dim": cfg["D"],
                        "queries_per_step": 2 * cfg["triples"], "triples_per_ranking_call": min(cfg["triples"], cfg["block"]),
                        "filter_graph_edges": job.index.num_edges,
-                       "step": "whole evaluation: relation sort + id lookups + query gathers + filter segments + raw and "
+                       "step": "whole evaluation: id lookups + query gathers + filter segments + raw and "
                                "filtered ranking + metric sums",
                        "parallelism": f"{job.axis}-axis shards x{world}" if world > 1 else "single GPU",
                        "shard_axis": job.axis, "ranks_in_process_group": ranks_seen, "backend": backend if world > 1 else None},

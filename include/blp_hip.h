@@ -12,8 +12,9 @@
  *   - `device` is the HIP device ordinal the pointers live on, `stream` a hipStream_t (torch:
  *     torch.cuda.current_stream().cuda_stream; NULL = the legacy default stream).  Calls only
  *     enqueue work on `stream`: no host synchronisation, safe to capture in a hipGraph;
- *   - re-entrant: no global mutable state; one thread per device (nn.DataParallel replicas) may
- *     call concurrently.  ctypes releases the GIL for the duration of the call;
+ *   - re-entrant: the only process-wide state is the set of test knobs behind blp_debug_set_knob
+ *     (atomic integers, all 0 = automatic in production); one thread per device (nn.DataParallel
+ *     replicas) may call concurrently.  ctypes releases the GIL for the duration of the call;
  *   - return 0 (BLP_OK) or a negative blp_status; blp_last_error() gives the thread-local message;
  *   - f32 tensors, int64 indices exactly as the reference produces them (neg_idx, true_idx);
  *   - arithmetic follows the torch-CPU evaluation order of the reference expressions (see
