@@ -25,7 +25,8 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supporte
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t", "blp_debug_set_knob", "blp_debug_gemm_dump")
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
-         "gemm_pass_words", "gemm_tiles_per_chunk")  # blp_amd/csrc/knobs.h
+         "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
+         "small_kernel")  # blp_amd/csrc/knobs.h
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h

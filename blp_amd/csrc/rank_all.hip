@@ -36,18 +36,14 @@
 #include "launch.h"
 #include "rank_common.h"
 #include "score_core.h"
+#include "tile.h"
 
 #pragma clang fp contract(off)
 
 namespace blp {
 
-constexpr int kWaves = 4;            // waves per workgroup
-constexpr int kTileRows = 64;        // candidates per wave tile (one per lane)
-constexpr int kSubCols = 32;         // floats per row per LDS pass (128 B = one cache line)
-constexpr int kLdsStride = 36;       // dwords; 36*l mod 64 is conflict-free for ds_read_b128
 constexpr int kQueryChunk = 128;     // queries per workgroup pass over its tiles
 constexpr int kQB = 4;               // queries staged per LDS coefficient batch
-constexpr int kSlabFloats = kTileRows * kLdsStride;
 __host__ __device__ constexpr int kMaxCoef(int D) { return 2 * D; }
 
 // ------------------------------------------------------------------------------------------------
@@ -88,51 +84,6 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
     const float* r = q_rel + q * D;
     key_true[q] = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r})
                              : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fetch rows [row0, row0 + 64) of the table into e[] (lane l <- row row0 + l) through the wave's LDS
-// slab.  Rows past the table end are clamped to the last row (their counts are masked by `valid`).
-template <int D, bool NT>
-__device__ __forceinline__ void load_tile(float (&e)[D], const float* __restrict__ table, int64_t N,
-                                          int64_t ld, int64_t row0, float* slab, int lane) {
-    const int sub_row = lane >> 3;        // 8 rows per wave instruction
-    const int sub_col = (lane & 7) * 4;   // 8 x 16 B = one 128-B line per row
-    // 1. every global load of the tile up front (D/4 x 1 KiB in flight per wave), landing in e[] in
-    //    the coalesced layout: e[32s + 4i .. +3] = row (row0 + 8i + sub_row), cols 32s + sub_col .. +3
-    static_for<8>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        int64_t row = row0 + 8 * i + sub_row;
-        row = row < N ? row : N - 1;
-        const float* src = table + row * ld + sub_col;
-        static_for<D / kSubCols>([&](auto ss) {
-            constexpr int s = decltype(ss)::value;
-            typedef float floatx4 __attribute__((ext_vector_type(4)));
-            const floatx4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(src + s * kSubCols))
-                                 : *reinterpret_cast<const floatx4*>(src + s * kSubCols);
-            e[32 * s + 4 * i] = v.x; e[32 * s + 4 * i + 1] = v.y;
-            e[32 * s + 4 * i + 2] = v.z; e[32 * s + 4 * i + 3] = v.w;
-        });
-    });
-    // 2. transpose 32 columns at a time through the wave's slab, in place in e[]
-    float* wr = slab + sub_row * kLdsStride + sub_col;
-    const float* rd = slab + lane * kLdsStride;
-    static_for<D / kSubCols>([&](auto ss) {
-        constexpr int s = decltype(ss)::value;
-        if (s > 0) wave_lds_sync();  // previous pass' reads are done before the slab is rewritten
-        static_for<8>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            *reinterpret_cast<float4*>(wr + 8 * i * kLdsStride) =
-                make_float4(e[32 * s + 4 * i], e[32 * s + 4 * i + 1], e[32 * s + 4 * i + 2], e[32 * s + 4 * i + 3]);
-        });
-        wave_lds_sync();
-        static_for<8>([&](auto jj) {
-            constexpr int j = decltype(jj)::value;
-            const float4 w = *reinterpret_cast<const float4*>(rd + 4 * j);
-            e[32 * s + 4 * j] = w.x; e[32 * s + 4 * j + 1] = w.y;
-            e[32 * s + 4 * j + 2] = w.z; e[32 * s + 4 * j + 3] = w.w;
-        });
-    });
 }
 
 // Stage `count` floats (a multiple of 4, at most 2 * 4 * 256) from global memory into LDS with
@@ -403,6 +354,33 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Packed counts of query q_base + (threadIdx.x & 63) summed over the n_partials slots acc[p * Q + q] -- workgroup of four
+// waves: wave w adds the slots p = w (mod 4), the first wave gets the total (the others: garbage).  Ends with a barrier.
+__device__ __forceinline__ unsigned long long sum_partials(const unsigned long long* __restrict__ acc, int n_partials,
+                                                           int64_t Q, int64_t q_base,
+                                                           unsigned long long (&sums)[3][kSweepQueries]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = q_base + lane;
+    unsigned long long a = 0;
+    if (q < Q) {
+        int p = wave;
+#pragma unroll 1
+        for (; p + 28 < n_partials; p += 32) {  // eight independent loads in flight
+            unsigned long long v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = acc[(int64_t)(p + 4 * k) * Q + q];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += v[k];
+        }
+        for (; p < n_partials; p += 4) a += acc[(int64_t)p * Q + q];
+    }
+    if (wave > 0) sums[wave - 1][lane] = a;
+    __syncthreads();
+    if (wave == 0) a += sums[0][lane] + sums[1][lane] + sums[2][lane];
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Last kernel of a call.  Filtered setting (train.py:159-171): a workgroup of four waves owns 64 consecutive queries.
 // Its first wave reads their filter segments and scans the segment lengths; the workgroup's entries -- the rows the
 // filter removes, usually few: most evaluation queries have none -- are then numbered 0 .. total - 1 across the 64
@@ -415,7 +393,9 @@ template <int MODEL, int D>
 __global__ __launch_bounds__(256) void filter_finalize_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ q_fixed,
     const float* __restrict__ q_rel, const float* __restrict__ key_true, int64_t q_head,
-    int64_t q_tail, const FilterSpec filter, const unsigned long long* __restrict__ acc, int32_t* __restrict__ counts) {
+    int64_t q_tail, const FilterSpec filter, const unsigned long long* __restrict__ acc, int n_partials,
+    int32_t* __restrict__ counts) {
+    __shared__ unsigned long long partial_sums[3][kSweepQueries];
     __shared__ int prefix[kSweepQueries + 1];
     __shared__ unsigned removed[kSweepQueries][2];
     __shared__ __attribute__((aligned(16))) float slabs[MODEL == TRANSE ? 4 * 64 * kRefStride : 4];
@@ -478,23 +458,24 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             if (sub == 0 && live && key >= kt) atomicAdd(&removed[slot][1], 1u);
         }
     }
-    __syncthreads();
+    const unsigned long long a = sum_partials(acc, n_partials, Q, q_base, partial_sums);  // ends with a barrier
     if (threadIdx.x < 64 && q_base + lane < Q) {
         const int64_t q = q_base + lane;
-        const unsigned long long a = acc[q];
         const int32_t all_gt = (int32_t)(a & 0xffffffffull), all_ge = (int32_t)(a >> 32);
         reinterpret_cast<int4*>(counts)[q] =
             make_int4(all_gt, all_ge, all_gt - (int32_t)removed[lane][0], all_ge - (int32_t)removed[lane][1]);
     }
 }
 
-__global__ void finalize_counts_kernel(const unsigned long long* __restrict__ acc, int64_t Q,
-                                       int32_t* __restrict__ counts) {
-    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    const unsigned long long a = acc[q];
-    const int32_t gt = (int32_t)(a & 0xffffffffull), ge = (int32_t)(a >> 32);
-    reinterpret_cast<int4*>(counts)[q] = make_int4(gt, ge, gt, ge);
+__global__ __launch_bounds__(256) void finalize_counts_kernel(const unsigned long long* __restrict__ acc, int n_partials,
+                                                              int64_t Q, int32_t* __restrict__ counts) {
+    __shared__ unsigned long long partial_sums[3][kSweepQueries];
+    const int64_t q_base = (int64_t)blockIdx.x * kSweepQueries, q = q_base + threadIdx.x;
+    const unsigned long long a = sum_partials(acc, n_partials, Q, q_base, partial_sums);
+    if (threadIdx.x < 64 && q < Q) {
+        const int32_t gt = (int32_t)(a & 0xffffffffull), ge = (int32_t)(a >> 32);
+        reinterpret_cast<int4*>(counts)[q] = make_int4(gt, ge, gt, ge);
+    }
 }
 
 // utils.py:104-109 from the counts
@@ -573,7 +554,8 @@ struct RankWorkspace {
     size_t bytes;
 };
 
-static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t q_tail) {
+// partial_slots > 1: the small-block kernel's per-slot partial counts, partial_slots x Q accumulators
+static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t q_tail, int partial_slots = 1) {
     // Both sides are sized for the larger coefficient layout (2 * D floats per query).
     RankWorkspace w;
     const int64_t Q = q_head + q_tail;
@@ -582,14 +564,15 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
     w.coef_head = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_head * max_coef(D) * 4, 256);
     w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * max_coef(D) * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
-    w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8, 256);
+    w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8 * partial_slots, 256);
     w.bytes = off;
     return w;
 }
 
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
     if (rank_sad_wide_applicable(model, D, q_head, q_tail)) return rank_sad_wide_workspace_bytes(model, D, N, q_head, q_tail);
-    size_t bytes = carve_workspace(nullptr, D, q_head, q_tail).bytes;
+    const int slots = rank_small_applicable(model, D, N, q_head, q_tail) ? rank_small_slots(N) : 1;
+    size_t bytes = carve_workspace(nullptr, D, q_head, q_tail, slots).bytes;
     const size_t alt[2] = {rank_gemm_workspace_bytes(model, D, N, q_head, q_tail),
                            rank_sad_workspace_bytes(model, D, N, q_head, q_tail)};
     for (size_t a : alt) bytes = a > bytes ? a : bytes;
@@ -603,6 +586,18 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
     if (Q == 0) return hipSuccess;
+    if (rank_small_applicable(MODEL, D, N, q_head, q_tail)) {  // small block: 3 launches, no coefficient array
+        const int slots = rank_small_slots(N);
+        RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail, slots);
+        true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(
+            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc);
+        if (ev_start) (void)hipEventRecord(ev_start, stream);
+        const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, w.acc, n_cu, stream);
+        if (err != hipSuccess) return err;
+        if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+        return launch_filter_finalize(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter, w.acc, counts,
+                                      stream, slots);
+    }
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
     {
         const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
@@ -621,6 +616,8 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         // while the grid would not even fill the resident set once.
         int q_chunk = kQueryChunk;
         while (q_chunk > 16 && n_quads * ((Q + q_chunk - 1) / q_chunk) < (int64_t)n_cu * 3) q_chunk >>= 1;
+        if (const long long forced = knob(KNOB_EXACT_QUERY_CHUNK); forced == 16 || forced == 32 || forced == 64 || forced == 128)
+            q_chunk = (int)forced;
         const int64_t n_chunks = (Q + q_chunk - 1) / q_chunk;
         // Resident workgroups: 3 per CU (12 waves at <= 168 VGPRs, ~48 KB of LDS each).  With plenty
         // of (tile quad, chunk) pairs give every workgroup one quad (many short workgroups -> no
@@ -685,13 +682,14 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                            hipEvent_t ev_stop) {
-    if (rank_gemm_applicable(model, D, q_head, q_tail))
+    const bool small = rank_small_applicable(model, D, N, q_head, q_tail);  // a small block: rank_small.hip, below
+    if (!small && rank_gemm_applicable(model, D, q_head, q_tail))
         return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
                                     filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    if (rank_sad_wide_applicable(model, D, q_head, q_tail))
+    if (!small && rank_sad_wide_applicable(model, D, q_head, q_tail))
         return launch_rank_all_sad_wide(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
                                         counts, workspace, n_cu, stream, ev_start, ev_stop);
-    if (rank_sad_applicable(model, D, N, q_head, q_tail))
+    if (!small && rank_sad_applicable(model, D, N, q_head, q_tail))
         return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
                                    counts, workspace, n_cu, stream, ev_start, ev_stop);
     // everything else: the exact f32 kernels (few queries, D = 256 bilinear, or the rank_kernel knob)
@@ -720,10 +718,10 @@ static hipError_t true_keys_impl(const float* q_fixed, const float* q_rel, int64
 template <int MODEL, int D>
 static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                        const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
-                                       const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
-                                       hipStream_t stream) {
+                                       const FilterSpec& filter, const unsigned long long* acc, int n_partials,
+                                       int32_t* counts, hipStream_t stream) {
     filter_finalize_kernel<MODEL, D><<<(int)((q_head + q_tail + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(
-        table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc, counts);
+        table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc, n_partials, counts);
     return hipGetLastError();
 }
 
@@ -753,14 +751,14 @@ hipError_t launch_true_keys(int model, int D, const float* q_fixed, const float*
 hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                   const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int n_partials) {
     const int64_t Q = q_head + q_tail;
     if (!filter.on()) {
-        finalize_counts_kernel<<<(int)((Q + 255) / 256), 256, 0, stream>>>(acc, Q, counts);
+        finalize_counts_kernel<<<(int)((Q + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(acc, n_partials, Q, counts);
         return hipGetLastError();
     }
     BLP_DISPATCH_MODEL_DIM(filter_finalize_impl, table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc,
-                           counts, stream)
+                           n_partials, counts, stream)
 }
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,

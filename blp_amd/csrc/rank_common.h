@@ -71,18 +71,31 @@ __device__ __forceinline__ int64_t filter_row(const FilterSpec& f, int64_t q, in
     return (uint64_t)v < (uint64_t)N ? v : -1;
 }
 
-// Last step of every ranking path: counts[q] = {gt, ge, gt - fgt, ge - fge} from the packed 64-bit accumulators,
+// Last step of every ranking path: counts[q] = {gt, ge, gt - fgt, ge - fge} from the packed 64-bit accumulators
+// (query q's is the sum of acc[p * Q + q] over p < n_partials: the small-block kernel leaves one partial per tile slot),
 // fgt / fge = the filtered candidates that score above / at least the true entity (one wave per query, exact
 // Scorer<> arithmetic).  Without a filter the last two equal the first two.
 hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
                                   const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int n_partials = 1);
 
 // rank_all.hip: true-entity keys by the exact routine (and the Q rank-count accumulators `acc` zeroed on the way)
 hipError_t launch_true_keys(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
                             const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
                             float* key_true, unsigned long long* acc, hipStream_t stream);
+
+// rank_small.hip: the exact f32 kernel for small blocks (coefficients computed in the kernel, LDS broadcasts, TransE
+// chains interleaved): the ranking pass only, between launch_true_keys and launch_filter_finalize.
+constexpr long long kSmallMaxPairsTransE = 2400000;    // above: rank_tiles, then (kSadMinPairs) the fixed-point pre-pass
+constexpr long long kSmallMaxPairsBilinear = 1500000;  // above: the bf16 x 3 MFMA pre-pass (tools/exact_small_probe.py)
+constexpr int kSmallMaxSlots = 256;                    // partial counts per query it leaves (one per tile slot)
+constexpr long long kSmallMaxQueries = 4096;           // whatever the knob says
+bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
+int rank_small_slots(int64_t N);  // partial[slot * Q + q], slot < rank_small_slots(N): what the kernel writes (every entry)
+hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
+                             const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
+                             unsigned long long* partial, int n_cu, hipStream_t stream);
 
 // rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
 void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)

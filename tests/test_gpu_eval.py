@@ -16,6 +16,7 @@ def prepass_from_64_queries():
     """Small tables on purpose: keep the TransE pre-pass in play from 64 queries on (see tests/test_gpu_parity.py)."""
     from blp_amd import _lib
     _lib.set_knob("sad_min_queries", 64)
+    _lib.set_knob("small_kernel", 2)
     yield
     _lib.reset_knobs()
 

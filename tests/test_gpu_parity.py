@@ -19,13 +19,14 @@ def ops():
 
 @pytest.fixture(autouse=True)
 def prepass_from_64_queries(request):
-    """The library sends TransE blocks below ~4 million (query, candidate) pairs to the exact f32 kernels (their shorter
-    launch chain wins there).  These tests use small tables on purpose, so the fixed-point pre-pass is made to take
-    every block of >= 64 queries, as it does at evaluation sizes; tests marked `default_routing` keep the library's
+    """The library sends blocks below ~4 million (query, candidate) pairs to the small-block exact f32 kernel (its short
+    launch chain wins there).  These tests use small tables on purpose, so the pre-pass paths are made to take
+    every block of >= 64 queries, as they do at evaluation sizes; tests marked `default_routing` keep the library's
     own choice."""
     from blp_amd import _lib
     if "default_routing" not in request.keywords:
         _lib.set_knob("sad_min_queries", 64)
+        _lib.set_knob("small_kernel", 2)  # same reason: the MFMA pre-pass, not the small-block kernel, from 64 queries on
     yield
     _lib.reset_knobs()
 
@@ -128,8 +129,8 @@ def test_random_vs_oracle_ragged(ops, oracle, model, D):
 @pytest.mark.parametrize("q_head,q_tail", [(70, 58), (300, 41), (1, 180)])
 def test_transe_small_blocks_take_the_exact_kernels(ops, oracle, q_head, q_tail):
     """The library's own routing (no knob): 128 .. 341 TransE queries against a 2 000-row table are below the
-    pre-pass's break-even and go to the exact f32 kernels with short query chunks (16 .. 128 queries per workgroup so
-    that a small block still fills the chip).  Counts against the oracle, with a filter."""
+    pre-pass's break-even and go to the small-block exact f32 kernel (rank_small.hip).  Counts against the oracle,
+    with a filter."""
     from blp_amd import _lib
     L = _lib.lib()
     N, D = 2000, 128
@@ -140,6 +141,94 @@ def test_transe_small_blocks_take_the_exact_kernels(ops, oracle, q_head, q_tail)
     got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
                        filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+SMALL_SHAPES = [(5, 7), (64, 64), (0, 33), (37, 0), (130, 129)]
+
+
+@pytest.mark.default_routing
+@pytest.mark.parametrize("model", REL_MODELS)
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("q_head,q_tail", SMALL_SHAPES)
+def test_small_block_kernel_vs_oracle(ops, oracle, knobs, model, D, q_head, q_tail):
+    """rank_small.hip (coefficients computed in the kernel, LDS broadcasts, four TransE chains interleaved) on every
+    block it can take: both sides, one side only, query counts that are no multiple of its group of four, a table that
+    is no multiple of a workgroup's 256 rows (the last quad has an empty tile), CSR filter.  == oracle."""
+    knobs("small_kernel", 1)
+    N = 1000 + D // 64 if q_head != 37 else 300
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=D + q_head + len(model))
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + q_tail)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.default_routing
+@pytest.mark.parametrize("model", ["transe", "complex"])
+@pytest.mark.parametrize("chunk", [1, 5, 12, 32, 50, 96])
+def test_small_block_kernel_query_chunks(ops, oracle, knobs, model, chunk):
+    """Any number of queries per workgroup (the host picks a multiple of 32 by the size of the block): partial rounds,
+    waves with no query, chunks that straddle the head / tail boundary."""
+    knobs("small_kernel", 1)
+    knobs("exact_query_chunk", chunk)
+    N, D, q_head, q_tail = 777, 128, 45, 38
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=chunk)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda()).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.default_routing
+@pytest.mark.parametrize("model,q_head,q_tail", [("transe", 40, 50), ("distmult", 3, 9), ("simple", 70, 0)])
+def test_small_block_kernel_table_of_more_tiles_than_slots(ops, oracle, knobs, model, q_head, q_tail):
+    """A table of more than 256 tiles: a workgroup then walks several tiles (coefficients staged once for up to two
+    rounds, again per tile otherwise) and its slot's partial counts add them up."""
+    knobs("small_kernel", 1)
+    N, D = 256 * 64 * 2 + 777, 64
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=q_head)
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=q_tail)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.default_routing
+@pytest.mark.parametrize("model", REL_MODELS)
+def test_small_block_kernel_ties_and_nonfinite(ops, oracle, knobs, model):
+    """Duplicated rows (ties with the true entity: > vs >=), a NaN row, an infinite value, true entity given as a
+    vector (candidate shards): the small-block kernel keeps the reference's counts."""
+    knobs("small_kernel", 1)
+    N, D, q_head, q_tail = 600, 128, 21, 22
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=len(model))
+    table[100:140] = table[true_row[:40]]           # exact duplicates of true entities
+    table[7, 3] = float("nan")
+    table[9, 5] = float("inf")
+    table[11] = 0.0
+    q_true = table[true_row].clone()
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, q_true=q_true)
+    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, q_true=q_true.cuda()).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert (want[:40, 1] > want[:40, 0]).all()      # the ties are really there
+
+
+@pytest.mark.default_routing
+@pytest.mark.parametrize("model", REL_MODELS)
+def test_small_blocks_default_routing_equals_the_other_kernels(ops, model, knobs):
+    """A reference-sized batch (64 triples = 128 queries) against an FB15k-237-sized table, the library's own routing
+    (the small-block kernel) == the exact tile kernel == the pre-pass path."""
+    N, D, q_head, q_tail = 14541, 128, 64, 64
+    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=5)
+    args = (model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+    auto = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+    knobs("rank_kernel", 1)
+    tiles = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+    knobs("rank_kernel", 0)
+    knobs("small_kernel", 2)
+    knobs("sad_min_queries", 64)
+    prepass = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+    assert np.array_equal(auto, tiles) and np.array_equal(auto, prepass)
 
 
 @pytest.mark.parametrize("D", [64, 128, 256])
