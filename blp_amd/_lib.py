@@ -23,7 +23,8 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supporte
            "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex",
            "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
-           "blp_inbatch_loss_bwd_t", "blp_debug_set_knob", "blp_debug_gemm_dump")
+           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_debug_set_knob",
+           "blp_debug_gemm_dump")
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
          "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
          "small_kernel")  # blp_amd/csrc/knobs.h
@@ -113,6 +114,10 @@ def lib():
     L.blp_inbatch_loss_bwd_t.restype = _i
     L.blp_inbatch_loss_bwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                          _i, _vp]
+    L.blp_project_rows_supported.restype = _i
+    L.blp_project_rows_supported.argtypes = [_i, _i]
+    L.blp_project_rows.restype = _i
+    L.blp_project_rows.argtypes = [_vp, _i64, _i64, _vp, _i, _i, _i, _vp, _i64, _i, _vp]
     L.blp_debug_gemm_dump.restype = _i
     L.blp_debug_gemm_dump.argtypes = [_vp, _vp]
     L.blp_debug_set_knob.restype = _i

@@ -112,6 +112,24 @@ int blp_debug_gemm_dump(float* scores, float* eps) {
     return BLP_OK;
 }
 
+int blp_project_rows_supported(int E, int D) { return blp::project_rows_supported(E, D) ? 1 : 0; }
+
+int blp_project_rows(const float* x, int64_t n, int64_t ldx, const float* w, int E, int D, int normalize, float* out,
+                     int64_t ldo, int device, void* stream) {
+    if (n < 0) return fail(BLP_ERR_BAD_ARG, "blp_project_rows: negative row count");
+    if (!blp::project_rows_supported(E, D))
+        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_project_rows: E=%d (needs E %% 4 == 0), D=%d (needs 64 / 128 / 256)", E, D);
+    if (n == 0) return BLP_OK;
+    if (!x || !w || !out) return fail(BLP_ERR_BAD_ARG, "blp_project_rows: NULL pointer");
+    if (!aligned16(x) || !aligned16(w) || !aligned16(out) || (ldx & 3) || ldx < E || ldo < D)
+        return fail(BLP_ERR_BAD_ARG, "blp_project_rows: x / w / out must be 16-byte aligned, ldx %% 4 == 0, ldx >= E, ldo >= D");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_project_rows(x, n, ldx, w, E, D, normalize, out, ldo, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_project_rows launch");
+    return BLP_OK;
+}
+
 int blp_version(void) { return BLP_HIP_VERSION; }
 
 const char* blp_last_error(void) { return g_error; }

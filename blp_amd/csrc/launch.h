@@ -41,6 +41,10 @@ hipError_t launch_rank_from_scores(const float* scores, int64_t Q, int64_t N, in
                                    const float* true_score, const int64_t* rowptr, const int64_t* col,
                                    int32_t* counts, hipStream_t stream);
 
+bool project_rows_supported(int E, int D);
+hipError_t launch_project_rows(const float* x, int64_t n, int64_t ldx, const float* w, int E, int D, int normalize,
+                               float* out, int64_t ldo, hipStream_t stream);
+
 struct StridedRows {  // row(i0, i1) = base + i0 * s0 + i1 * s1   (strides in floats)
     const float* base;
     int64_t s0, s1;

@@ -138,10 +138,16 @@ class LinkPrediction(nn.Module):
         self.loss_name = loss_fn
 
     def encode(self, *args, **kwargs):
-        ent_emb = self._encode_entity(*args, **kwargs)
+        return self._finish(self._encode_entity(*args, **kwargs))
+
+    def _finish(self, ent_emb):
         if self.normalize_embs:
             ent_emb = F.normalize(ent_emb, dim=-1)
         return ent_emb
+
+    def encode_into(self, out, *args, **kwargs):
+        """Encode straight into rows ``out`` of an entity table (train.py:109-113); subclasses may fuse the last steps."""
+        return out.copy_(self.encode(*args, **kwargs))
 
     def _encode_entity(self, *args, **kwargs):
         raise NotImplementedError
@@ -212,6 +218,18 @@ class BertEmbeddingsLP(InductiveLinkPrediction):
     def _encode_entity(self, text_tok, text_mask):
         embs = self.encoder(text_tok, text_mask)[0][:, 0]
         return self.enc_linear(embs)
+
+    def encode_into(self, out, text_tok, text_mask):
+        """Table build (train.py:96-121): on a HIP device and outside autograd, enc_linear + F.normalize + the row
+        assignment are one kernel that reads the [CLS] rows in place and writes the table rows (ops.project_rows)."""
+        if out.is_cuda and not torch.is_grad_enabled() and out.dtype == torch.float32 and \
+                self.enc_linear.weight.dtype == torch.float32 and \
+                ops.project_rows_supported(self.enc_linear.in_features, self.dim):
+            cls = self.encoder(text_tok, text_mask)[0][:, 0]
+            if cls.dtype == torch.float32:
+                return ops.project_rows(cls, self.enc_linear.weight, out, self.normalize_embs)
+            return out.copy_(self._finish(self.enc_linear(cls)))
+        return super().encode_into(out, text_tok, text_mask)
 
 
 class WordEmbeddingsLP(InductiveLinkPrediction):

@@ -195,6 +195,36 @@ def rank_metric_sums(counts, k_values=(1, 3, 10)):
     return sums[:8]
 
 
+# ------------------------------------------------------------------------------- table build epilogue
+def project_rows_supported(hidden_size, dim):
+    """True if blp_project_rows takes an (n, hidden_size) -> (n, dim) projection."""
+    return bool(_lib.lib().blp_project_rows_supported(int(hidden_size), int(dim)))
+
+
+def project_rows(x, weight, out, normalize):
+    """out[i] = x[i] @ weight.T, L2-normalised if ``normalize`` -- enc_linear (models.py:110-111) + F.normalize
+    (models.py:40-41) + the row assignment into the entity table (train.py:109-113) in one kernel.  ``x`` (n, E) f32
+    may be a strided view (the [CLS] rows of an encoder output), ``out`` (n, D) f32 rows of the table (shard).
+    Inference only (no autograd)."""
+    _require_device(x, weight, out)
+    if x.dtype != torch.float32 or weight.dtype != torch.float32 or out.dtype != torch.float32:
+        raise TypeError("project_rows works on float32 tensors")
+    if x.dim() != 2 or weight.dim() != 2 or out.dim() != 2 or x.shape[1] != weight.shape[1] or \
+            out.shape != (x.shape[0], weight.shape[0]):
+        raise ValueError(f"shapes do not match: x {tuple(x.shape)}, weight {tuple(weight.shape)}, out {tuple(out.shape)}")
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if out.stride(1) != 1:
+        raise ValueError("out must have contiguous rows")
+    weight = weight.contiguous()
+    status = _lib.lib().blp_project_rows(_ptr(x), x.shape[0], x.stride(0) if x.shape[0] > 1 else x.shape[1], _ptr(weight),
+                                         x.shape[1], weight.shape[0], int(bool(normalize)), _ptr(out),
+                                         out.stride(0) if out.shape[0] > 1 else out.shape[1], out.device.index,
+                                         _stream(out.device))
+    _lib.check(status, "blp_project_rows")
+    return out
+
+
 # ------------------------------------------------------------------------------------- score_fn
 def _collapse(sizes, strides):
     """Collapse a group of dims into (size, stride) or None if not expressible with one stride."""

@@ -406,10 +406,11 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
         batch_ents = entities[lo + idx: lo + min(idx + emb_batch_size, n)]
         if isinstance(model, models.InductiveLinkPrediction):
             text_tok, text_mask, _ = text_dataset.get_entity_description(batch_ents)
-            batch_emb = model(text_tok.unsqueeze(1).to(device), text_mask.unsqueeze(1).to(device))
+            # the model writes its rows itself: the BERT encoders fuse enc_linear + normalise + this assignment
+            # (models.BertEmbeddingsLP.encode_into -> blp_project_rows); same values as model(tok, mask), train.py:109
+            model.encode_into(table[idx: idx + batch_ents.shape[0]], text_tok.to(device), text_mask.to(device))
         else:
-            batch_emb = model(batch_ents.to(device))
-        table[idx: idx + batch_ents.shape[0]] = batch_emb
+            table[idx: idx + batch_ents.shape[0]] = model(batch_ents.to(device))
         if log is not None and (it + 1) % report == 0:
             log.info(f"[{idx + batch_ents.shape[0]:,}/{n:,}]")
     return table

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 200 /* major*10000 + minor*100 + patch */
+#define BLP_HIP_VERSION 201 /* major*10000 + minor*100 + patch */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -235,6 +235,25 @@ int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, co
                            float regularizer, const float *grad_loss, const float *save_pos,
                            const float *save_neg, void *grad_ent, void *grad_rel, int device,
                            void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Entity-table build, last step (the producer of blp_rank_all's `table`), for the BERT encoders:
+ *
+ *   embs = self.enc_linear(embs)              models.py:110-111 (nn.Linear(hidden, dim, bias=False), :104)
+ *   ent_emb = F.normalize(ent_emb, dim=-1)    models.py:40-41   (iff normalize != 0: TransE)
+ *   ent_emb[idx:idx + batch] = batch_emb      train.py:109-113
+ *
+ *   out[i, :] = x[i, :] . w^T  [ / max(||.||_2, 1e-12) ]      i < n
+ *
+ *   x    (n, E) f32, row stride ldx floats (the [CLS] rows of the encoder output are strided: pass the view);
+ *   w    (D, E) f32 row-major (enc_linear.weight);  out  (n, D) f32, row stride ldo: rows of the table shard.
+ * f32 operands and accumulation on the matrix cores (v_mfma_f32_32x32x2_f32); a floating-point GEMM: results agree
+ * with the torch expression to ~1e-6 relative, not bit for bit (the K-reduction order is the kernel's own).
+ * blp_project_rows_supported: E % 4 == 0 and D in {64, 128, 256}; x, w, out 16-byte aligned, ldx % 4 == 0.
+ * -------------------------------------------------------------------------------------------- */
+int blp_project_rows_supported(int E, int D);
+int blp_project_rows(const float *x, int64_t n, int64_t ldx, const float *w, int E, int D, int normalize,
+                     float *out, int64_t ldo, int device, void *stream);
 
 /* --------------------------------------------------------------------------------------------
  * Test / A-B hook.  The library never reads the environment; the kernel-selection and slab-size

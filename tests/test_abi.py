@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     L = _lib.lib()
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.blp_version() == 200
+    assert L.blp_version() == 201
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 8)  # coefficients, key, accumulator
@@ -67,6 +67,18 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     rc = L.blp_rank_all(0, one, 10, 128, 128, ctypes.c_void_p(20), one, None, one, None, 1, 1, None, None, one, one,
                         1 << 40, 0, None)
     assert rc == -1 and b"aligned" in L.blp_last_error()
+
+
+def test_project_rows_argument_checks(built_lib):
+    from blp_amd import _lib
+    L = _lib.lib()
+    assert L.blp_project_rows_supported(768, 128) == 1 and L.blp_project_rows_supported(770, 128) == 0
+    assert L.blp_project_rows_supported(768, 100) == 0
+    assert L.blp_project_rows(None, 0, 768, None, 768, 128, 1, None, 128, 0, None) == _lib.BLP_OK      # nothing to do
+    assert L.blp_project_rows(None, 4, 768, None, 768, 128, 1, None, 128, 0, None) == -1
+    assert L.blp_project_rows(None, 4, 768, None, 768, 96, 1, None, 96, 0, None) == -2
+    assert L.blp_project_rows(None, -1, 768, None, 768, 128, 1, None, 128, 0, None) == -1
+    assert b"blp_project_rows" in L.blp_last_error()
 
 
 def test_knobs_are_named_and_reset(built_lib):

@@ -292,6 +292,12 @@ def test_model_interface_and_errors():
                                   num_attention_heads=2, intermediate_size=64, vocab_size=50), 0)
     assert blp.enc_linear.bias is None and blp(tok, mask).shape == (10, 16)
     assert any(k.startswith("encoder.") for k in blp.state_dict()) and "enc_linear.weight" in blp.state_dict()
+    # encode_into (the table build's per-chunk call): on CPU tensors it is encode + a row copy for every model
+    for m in (bow, dkrl, blp.eval()):
+        rows = torch.full((7, m.dim), 3.0)
+        with torch.no_grad():
+            m.encode_into(rows[1:6], tok[:, 0], mask[:, 0])
+            assert torch.equal(rows[1:6], m.encode(tok[:, 0], mask[:, 0])) and (rows[0] == 3).all() and (rows[6] == 3).all()
 
 
 def test_sacred_shim_cli_semantics():
