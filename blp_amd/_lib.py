@@ -23,7 +23,7 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supporte
            "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex",
            "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
-           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_debug_set_knob",
+           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_build_queries", "blp_debug_set_knob",
            "blp_debug_gemm_dump")
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
          "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
@@ -48,6 +48,18 @@ class BlpFilter(ctypes.Structure):  # blp_filter of include/blp_hip.h
     _fields_ = [("seg_lo", ctypes.c_void_p), ("seg_hi", ctypes.c_void_p), ("values", ctypes.c_void_p),
                 ("exclude", ctypes.c_void_p), ("ent2idx", ctypes.c_void_p), ("ent2idx_len", ctypes.c_int64),
                 ("row_base", ctypes.c_int64)]
+
+
+class BlpQueries(ctypes.Structure):  # blp_queries of include/blp_hip.h
+    _fields_ = [("triples", ctypes.c_void_p), ("n", ctypes.c_int64), ("block", ctypes.c_int64),
+                ("ent2idx", ctypes.c_void_p), ("ent2idx_len", ctypes.c_int64),
+                ("source", ctypes.c_void_p), ("src_rows", ctypes.c_int64), ("ld", ctypes.c_int64), ("D", ctypes.c_int),
+                ("rel_emb", ctypes.c_void_p), ("R", ctypes.c_int64),
+                ("heads_key", ctypes.c_void_p), ("n_heads", ctypes.c_int64),
+                ("tails_key", ctypes.c_void_p), ("n_tails", ctypes.c_int64), ("index_R", ctypes.c_int64),
+                ("q_fixed", ctypes.c_void_p), ("q_rel", ctypes.c_void_p), ("true_row", ctypes.c_void_p),
+                ("rel_ids", ctypes.c_void_p), ("ids_min", ctypes.c_void_p),
+                ("seg_lo", ctypes.c_void_p), ("seg_hi", ctypes.c_void_p), ("exclude", ctypes.c_void_p)]
 
 
 _lib = None
@@ -114,6 +126,8 @@ def lib():
     L.blp_inbatch_loss_bwd_t.restype = _i
     L.blp_inbatch_loss_bwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                          _i, _vp]
+    L.blp_build_queries.restype = _i
+    L.blp_build_queries.argtypes = [ctypes.POINTER(BlpQueries), _i, _vp]
     L.blp_project_rows_supported.restype = _i
     L.blp_project_rows_supported.argtypes = [_i, _i]
     L.blp_project_rows.restype = _i

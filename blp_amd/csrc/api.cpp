@@ -112,6 +112,29 @@ int blp_debug_gemm_dump(float* scores, float* eps) {
     return BLP_OK;
 }
 
+int blp_build_queries(const blp_queries* q, int device, void* stream) {
+    if (!q) return fail(BLP_ERR_BAD_ARG, "blp_build_queries: NULL argument block");
+    if (q->n < 0 || q->block <= 0 || q->D <= 0 || (q->D & 3) || q->src_rows < 0 || q->R < 0 || q->n > (1ll << 40))
+        return fail(BLP_ERR_BAD_ARG, "blp_build_queries: bad sizes (n=%lld block=%lld D=%d)", (long long)q->n, (long long)q->block, q->D);
+    if (!q->ids_min) return fail(BLP_ERR_BAD_ARG, "blp_build_queries: ids_min is NULL");
+    if (q->n > 0 && (!q->triples || !q->source || !q->rel_emb || !q->q_fixed || !q->q_rel || !q->true_row || !q->rel_ids))
+        return fail(BLP_ERR_BAD_ARG, "blp_build_queries: NULL pointer");
+    if (!aligned16(q->source) || !aligned16(q->rel_emb) || !aligned16(q->q_fixed) || !aligned16(q->q_rel) || (q->ld & 3) || q->ld < q->D)
+        return fail(BLP_ERR_BAD_ARG, "blp_build_queries: source / rel_emb / q_fixed / q_rel must be 16-byte aligned, ld %% 4 == 0, ld >= D");
+    const bool with_index = q->heads_key || q->tails_key || q->seg_lo || q->seg_hi || q->exclude;
+    if (with_index && (!q->seg_lo || !q->seg_hi || !q->exclude || q->index_R <= 0 || q->n_heads < 0 || q->n_tails < 0 ||
+                       (q->n_heads > 0 && !q->heads_key) || (q->n_tails > 0 && !q->tails_key)))
+        return fail(BLP_ERR_BAD_ARG, "blp_build_queries: a filter index needs both key arrays, index_R > 0 and all three segment outputs");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    blp::QueryBuild a{q->triples, q->n, q->block, q->ent2idx, q->ent2idx_len, q->source, q->src_rows, q->ld, q->D,
+                      q->rel_emb, q->R, q->heads_key, q->n_heads, q->tails_key, q->n_tails, q->index_R, q->q_fixed, q->q_rel,
+                      q->true_row, q->rel_ids, q->ids_min, with_index ? q->seg_lo : nullptr, q->seg_hi, q->exclude};
+    hipError_t err = blp::launch_build_queries(a, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_build_queries launch");
+    return BLP_OK;
+}
+
 int blp_project_rows_supported(int E, int D) { return blp::project_rows_supported(E, D) ? 1 : 0; }
 
 int blp_project_rows(const float* x, int64_t n, int64_t ldx, const float* w, int E, int D, int normalize, float* out,

@@ -41,6 +41,20 @@ hipError_t launch_rank_from_scores(const float* scores, int64_t Q, int64_t N, in
                                    const float* true_score, const int64_t* rowptr, const int64_t* col,
                                    int32_t* counts, hipStream_t stream);
 
+// queries.hip: blp_build_queries (include/blp_hip.h: blp_queries, same fields)
+struct QueryBuild {
+    const int64_t* triples; int64_t n, block;
+    const int64_t* ent2idx; int64_t ent2idx_len;
+    const float* source; int64_t src_rows, ld; int D;
+    const float* rel_emb; int64_t R;
+    const int64_t* heads_key; int64_t n_heads;
+    const int64_t* tails_key; int64_t n_tails;
+    int64_t index_R;
+    float* q_fixed; float* q_rel; int64_t* true_row; int64_t* rel_ids; int* ids_min;
+    int64_t* seg_lo; int64_t* seg_hi; int64_t* exclude;
+};
+hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream);
+
 bool project_rows_supported(int E, int D);
 hipError_t launch_project_rows(const float* x, int64_t n, int64_t ldx, const float* w, int E, int D, int normalize,
                                float* out, int64_t ldo, hipStream_t stream);

@@ -1,0 +1,93 @@
+// queries.hip -- the evaluation loop's per-batch prelude (train.py:132-145, utils.py:46-83) for a whole set of triples
+// in ONE kernel: what blp_amd.ranking.rank_triples otherwise does with ~35 small torch kernels per evaluation (index,
+// gather, cat, searchsorted, reduce: 250 us of an FB15k-237 evaluation whose ranking pass takes 1.05 ms for DistMult).
+//
+//   heads = ent2idx[triples[:, 0]]; tails = ent2idx[triples[:, 1]]; assert min >= 0       train.py:134-138
+//   head queries: fixed = ent_emb[tails], true = heads;  tail queries: fixed = ent_emb[heads], true = tails
+//   rel_embs = model.rel_emb(rels)                                                          train.py:141-145
+//   the filter of a query = the slice of the sorted (entity, relation) index its key selects  utils.py:46-83
+//
+// Layout of the 2n queries: block after block of `block` triples, each block as [its head-replacing queries | its
+// tail-replacing queries] (train.py:149 order inside a block), so that a block is a contiguous range of every output.
+// 32 lanes per query: each moves 16 bytes of the fixed-entity row and of the relation row (D <= 128 floats per
+// sweep; wider rows: more sweeps); lanes 0 and 1 also run the lower / upper bound searches of the query's key.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch.h"
+
+namespace blp {
+
+__device__ __forceinline__ int64_t bound(const int64_t* __restrict__ keys, int64_t n, int64_t key, bool upper) {
+    int64_t lo = 0, hi = n;  // first index with keys[i] >= key (lower) / > key (upper)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t k = keys[mid];
+        if (upper ? k <= key : k < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a) {
+    const int sub = threadIdx.x & 31;
+    const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);  // query position
+    if (p >= 2 * a.n) return;
+    // position -> (block, side, triple)
+    const int64_t bi = p / (2 * a.block), first = bi * a.block;
+    const int64_t nb = a.n - first < a.block ? a.n - first : a.block;  // triples in this block
+    const int64_t o = p - 2 * first;
+    const bool head_side = o < nb;
+    const int64_t t = first + (head_side ? o : o - nb);
+    const int64_t h_id = a.triples[3 * t], t_id = a.triples[3 * t + 1], r_id = a.triples[3 * t + 2];
+    auto row_of = [&](int64_t id) -> int64_t {
+        if (!a.ent2idx) return (uint64_t)id < (uint64_t)a.src_rows ? id : -1;
+        const int64_t r = (uint64_t)id < (uint64_t)a.ent2idx_len ? a.ent2idx[id] : -1;
+        return (uint64_t)r < (uint64_t)a.src_rows ? r : -1;
+    };
+    const int64_t h_row = row_of(h_id), t_row = row_of(t_id);
+    const int64_t fixed_row = head_side ? t_row : h_row, true_row = head_side ? h_row : t_row;
+    const bool rel_ok = (uint64_t)r_id < (uint64_t)a.R;
+    if (sub == 0) {
+        a.true_row[p] = true_row;
+        a.rel_ids[p] = r_id;
+        if (h_row < 0 || t_row < 0 || !rel_ok) atomicMin(a.ids_min, -1);  // train.py:137-138's assertion, left on the device
+    }
+    // the two vectors: fixed entity and relation (an id that is no row: zeros -- the caller checks ids_min)
+    const float* fsrc = a.source + (fixed_row >= 0 ? fixed_row : 0) * a.ld;
+    const float* rsrc = a.rel_emb + (rel_ok ? r_id : 0) * (int64_t)a.D;
+    float* fdst = a.q_fixed + p * a.D;
+    float* rdst = a.q_rel + p * a.D;
+    for (int c = 4 * sub; c < a.D; c += 128) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f), r = f;
+        if (fixed_row >= 0) f = *reinterpret_cast<const float4*>(fsrc + c);
+        if (rel_ok) r = *reinterpret_cast<const float4*>(rsrc + c);
+        *reinterpret_cast<float4*>(fdst + c) = f;
+        *reinterpret_cast<float4*>(rdst + c) = r;
+    }
+    // the filter segment: head side key (tail, rel) in heads_key, tail side key (head, rel) in tails_key, whose values
+    // follow the head side's in the caller's concatenated value array
+    if (a.seg_lo && sub < 2) {
+        const int64_t* keys = head_side ? a.heads_key : a.tails_key;
+        const int64_t nk = head_side ? a.n_heads : a.n_tails, base = head_side ? 0 : a.n_heads;
+        const bool known = r_id >= 0 && r_id < a.index_R;  // a relation the index never saw matches nothing
+        const int64_t key = (head_side ? t_id : h_id) * a.index_R + r_id;
+        const int64_t b = known ? bound(keys, nk, key, sub == 1) : 0;
+        if (sub == 0) {
+            a.seg_lo[p] = base + b;
+            a.exclude[p] = head_side ? h_id : t_id;  // the triple's own entity is never filtered (utils.py:71,78)
+        } else {
+            a.seg_hi[p] = base + b;
+        }
+    }
+}
+
+hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(a.ids_min, 0, sizeof(int), stream);
+    if (err != hipSuccess || a.n == 0) return err;
+    const int64_t blocks = (2 * a.n + 7) / 8;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    build_queries_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace blp

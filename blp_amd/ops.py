@@ -195,6 +195,55 @@ def rank_metric_sums(counts, k_values=(1, 3, 10)):
     return sums[:8]
 
 
+# ------------------------------------------------------------------------------- evaluation prelude
+QueryBlock = collections.namedtuple("QueryBlock", "q_fixed q_rel true_row rel_ids ids_min filter")
+
+
+def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_base=0):
+    """train.py:132-145 (+ utils.py:46-83 with ``index``) for a whole set of triples in one kernel (blp_build_queries).
+
+    triples (n, 3) int64 rows (head id, tail id, relation id) on the table's device; ent2idx: id -> table row (-1: not a
+    candidate) or None (ids are rows); table (N, D) f32; rel_emb (R, D) f32 (model.rel_emb.weight); queries come out
+    block after block of ``block_size`` triples, each block as [head-replacing | tail-replacing] queries.
+    index: a utils.FilterIndex -> ``filter`` is the SegmentFilter of all 2n queries (slice it per block).
+    Returns QueryBlock(q_fixed (2n, D), q_rel (2n, D), true_row (2n,), rel_ids (2n,), ids_min (0-dim int32: -1 if any
+    id had no row -- the reference's assertion train.py:137-138, left on the device), filter or None)."""
+    _require_device(triples, ent2idx, table, rel_emb)
+    dev = table.device
+    table = _f32_rows(table, "table")
+    rel_emb = _f32_rows(rel_emb, "rel_emb").contiguous()
+    triples = triples.to(torch.int64).contiguous()
+    n, D = triples.shape[0], table.shape[1]
+    q_fixed = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
+    q_rel = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
+    true_row = torch.empty(2 * n, dtype=torch.int64, device=dev)
+    rel_ids = torch.empty(2 * n, dtype=torch.int64, device=dev)
+    ids_min = torch.empty((), dtype=torch.int32, device=dev)
+    a = _lib.BlpQueries()
+    a.triples, a.n, a.block = triples.data_ptr(), n, int(block_size)
+    if ent2idx is not None:
+        ent2idx = ent2idx.to(torch.int64).contiguous()
+        a.ent2idx, a.ent2idx_len = ent2idx.data_ptr(), ent2idx.shape[0]
+    a.source, a.src_rows, a.ld, a.D = table.data_ptr(), table.shape[0], table.stride(0) if table.shape[0] > 1 else D, D
+    a.rel_emb, a.R = rel_emb.data_ptr(), rel_emb.shape[0]
+    a.q_fixed, a.q_rel, a.true_row, a.rel_ids, a.ids_min = (q_fixed.data_ptr(), q_rel.data_ptr(), true_row.data_ptr(),
+                                                            rel_ids.data_ptr(), ids_min.data_ptr())
+    filt = None
+    if index is not None:
+        heads_key, tails_key, values, n_head_vals = index.device_arrays(dev)
+        seg_lo = torch.empty(2 * n, dtype=torch.int64, device=dev)
+        seg_hi = torch.empty_like(seg_lo)
+        exclude = torch.empty_like(seg_lo)
+        a.heads_key, a.n_heads, a.tails_key, a.n_tails, a.index_R = (heads_key.data_ptr(), heads_key.shape[0],
+                                                                     tails_key.data_ptr(), tails_key.shape[0], index.R)
+        a.seg_lo, a.seg_hi, a.exclude = seg_lo.data_ptr(), seg_hi.data_ptr(), exclude.data_ptr()
+        assert n_head_vals == heads_key.shape[0]
+        filt = SegmentFilter(seg_lo, seg_hi, values, exclude, ent2idx, row_base)
+    status = _lib.lib().blp_build_queries(ctypes.byref(a), dev.index, _stream(dev))
+    _lib.check(status, "blp_build_queries")
+    return QueryBlock(q_fixed, q_rel, true_row, rel_ids, ids_min, filt)
+
+
 # ------------------------------------------------------------------------------- table build epilogue
 def project_rows_supported(hidden_size, dim):
     """True if blp_project_rows takes an (n, hidden_size) -> (n, dim) projection."""

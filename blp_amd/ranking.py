@@ -286,55 +286,63 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     # bilinear models' kernels); elsewhere the sort would be 50 us of wasted device time per evaluation.
     if model.rel_model == "transe" and 2 * min(block_size, triples.shape[0]) * num_entities < EXACT_TRANSE_MAX_PAIRS:
         triples = triples[torch.argsort(triples[:, 2], stable=True)]
-    heads = ent2idx[triples[:, 0]]
-    tails = ent2idx[triples[:, 1]]
     num_triples = triples.shape[0]
-    ids_ok = torch.minimum(heads.min(), tails.min()) >= 0 if num_triples else None
     by_query = world > 1 and axis == "query"
     by_candidate = world > 1 and not by_query
     t_lo, t_hi = shard_bounds(num_triples, world, rank) if by_query else (0, num_triples)
+    n = t_hi - t_lo
+    mine = slice(t_lo, t_hi)
+    fused = n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n))
     ranker = ShardedRanker(model, table, num_entities, group) if by_candidate else None
-    if by_candidate:  # replicate the vectors of every entity that occurs in a triple: one exchange
-        if num_triples > 512:
-            uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
-            vectors = ranker.gather_rows(uniq)
-            head_pos_v, tail_pos_v = inverse[:num_triples], inverse[num_triples:]
-        else:  # a reference-sized batch: no host decision at all (torch.unique sizes its output on the host)
-            vectors = ranker.gather_rows(torch.cat((heads, tails)))
-            head_pos_v = torch.arange(num_triples, device=device)
-            tail_pos_v = head_pos_v + num_triples
+    head_pos = tail_pos = None
+
+    def block_positions():
+        idx = torch.arange(n, device=device)
+        first = torch.div(idx, block_size, rounding_mode="floor") * block_size       # first triple of the block
+        hp = first + idx                                                                # = 2 * first + (idx - first)
+        return idx, hp, hp + torch.clamp(n - first, max=block_size)
 
     # Everything a block needs is laid out ONCE for the whole set, block after block, each block as [its head
-    # queries | its tail queries] (train.py:149 order): one gather of the fixed-entity vectors, one of the relation
-    # vectors, one pass of binary searches for the filter segments.  A block is then a set of contiguous views --
-    # no per-block gather / cat kernels, which at the reference's Wikidata5M batching (2 triples per table pass) cost
-    # more than a sixth of the pass.
-    n = t_hi - t_lo
-    idx = torch.arange(n, device=device)
-    first = torch.div(idx, block_size, rounding_mode="floor") * block_size       # first triple of the block
-    head_pos = first + idx                                                          # = 2 * first + (idx - first)
-    tail_pos = head_pos + torch.clamp(n - first, max=block_size)
-    mine = slice(t_lo, t_hi)
-    if by_candidate:
-        source, head_ref, tail_ref = vectors, head_pos_v[mine], tail_pos_v[mine]
+    # queries | its tail queries] (train.py:149 order): the fixed-entity vectors, the relation vectors, the true rows
+    # and the filter segments.  A block is then a set of contiguous views -- no per-block gather / cat kernels, which
+    # at the reference's Wikidata5M batching (2 triples per table pass) cost more than a sixth of the pass.
+    if fused and not by_candidate and model.rel_emb.weight.dtype == torch.float32:
+        # one kernel (blp_build_queries) instead of ~35 small torch kernels: lookups, gathers, binary searches
+        qb = ops.build_queries(triples[mine], ent2idx, table, model.rel_emb.weight, block_size, index=index)
+        q_fixed, q_rel, true_src, rel_ids, seg, q_true = qb.q_fixed, qb.q_rel, qb.true_row, qb.rel_ids, qb.filter, None
+        ids_ok = qb.ids_min >= 0
     else:
-        source, head_ref, tail_ref = table, heads[mine], tails[mine]
-    fixed_src = torch.empty(2 * n, dtype=torch.long, device=device)
-    true_src = torch.empty_like(fixed_src)
-    rel_ids = torch.empty_like(fixed_src)
-    order_src = torch.empty_like(fixed_src)  # position in the [all heads | all tails] order of utils.FilterIndex
-    fixed_src[head_pos], fixed_src[tail_pos] = tail_ref, head_ref
-    true_src[head_pos], true_src[tail_pos] = head_ref, tail_ref
-    rel_ids[head_pos] = rel_ids[tail_pos] = triples[mine, 2]
-    order_src[head_pos], order_src[tail_pos] = idx, idx + n
-    q_fixed = source[fixed_src]
-    q_rel = model.rel_emb(rel_ids)
-    q_true = source[true_src] if by_candidate else None
-    fused = n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n))
-    seg = None
-    if index is not None and fused:  # slices of the sorted index: nothing is listed per batch
-        seg = index.segments(triples[mine], ent2idx, device)
-        seg = seg._replace(seg_lo=seg.seg_lo[order_src], seg_hi=seg.seg_hi[order_src], exclude=seg.exclude[order_src])
+        heads = ent2idx[triples[:, 0]]
+        tails = ent2idx[triples[:, 1]]
+        ids_ok = torch.minimum(heads.min(), tails.min()) >= 0 if num_triples else None
+        if by_candidate:  # replicate the vectors of every entity that occurs in a triple: one exchange
+            if num_triples > 512:
+                uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
+                vectors = ranker.gather_rows(uniq)
+                head_pos_v, tail_pos_v = inverse[:num_triples], inverse[num_triples:]
+            else:  # a reference-sized batch: no host decision at all (torch.unique sizes its output on the host)
+                vectors = ranker.gather_rows(torch.cat((heads, tails)))
+                head_pos_v = torch.arange(num_triples, device=device)
+                tail_pos_v = head_pos_v + num_triples
+            source, head_ref, tail_ref = vectors, head_pos_v[mine], tail_pos_v[mine]
+        else:
+            source, head_ref, tail_ref = table, heads[mine], tails[mine]
+        idx, head_pos, tail_pos = block_positions()
+        fixed_src = torch.empty(2 * n, dtype=torch.long, device=device)
+        true_src = torch.empty_like(fixed_src)
+        rel_ids = torch.empty_like(fixed_src)
+        order_src = torch.empty_like(fixed_src)  # position in the [all heads | all tails] order of utils.FilterIndex
+        fixed_src[head_pos], fixed_src[tail_pos] = tail_ref, head_ref
+        true_src[head_pos], true_src[tail_pos] = head_ref, tail_ref
+        rel_ids[head_pos] = rel_ids[tail_pos] = triples[mine, 2]
+        order_src[head_pos], order_src[tail_pos] = idx, idx + n
+        q_fixed = source[fixed_src]
+        q_rel = model.rel_emb(rel_ids)
+        q_true = source[true_src] if by_candidate else None
+        seg = None
+        if index is not None and fused:  # slices of the sorted index: nothing is listed per batch
+            seg = index.segments(triples[mine], ent2idx, device)
+            seg = seg._replace(seg_lo=seg.seg_lo[order_src], seg_hi=seg.seg_hi[order_src], exclude=seg.exclude[order_src])
     counts = torch.empty((2 * n, 4), dtype=torch.int32, device=device)
 
     for start in range(0, n, block_size):
@@ -354,6 +362,8 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     if by_candidate:
         counts = ranker.finish()  # ONE all-gather for the whole set; blocks in the order they were queued
     if n > block_size:  # every head query first, like one big batch
+        if head_pos is None:
+            _, head_pos, tail_pos = block_positions()
         counts = counts[torch.cat((head_pos, tail_pos))]
     if by_query:  # per-triple counts of every rank's slice: ONE all-gather for the whole set
         both = all_gather_rows(torch.cat((counts[:n], counts[n:]), dim=1), num_triples, world, group)

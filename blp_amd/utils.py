@@ -116,13 +116,8 @@ class FilterIndex:
         replacing, then B tail-replacing): four binary searches on the device, no list is built and the host
         never waits.  ``ent2idx`` should already live on ``device`` (it is moved if not)."""
         from .ops import SegmentFilter
-        cache = self.__dict__.setdefault("_segment_cache", {})
         device = torch.device(device)
-        if device not in cache:
-            heads_key, heads_val, tails_key, tails_val = self._on(device)
-            cache[device] = (heads_key.contiguous(), tails_key.contiguous(), torch.cat((heads_val, tails_val)).contiguous(),
-                             heads_val.shape[0])
-        heads_key, tails_key, values, n_head_vals = cache[device]
+        heads_key, tails_key, values, n_head_vals = self.device_arrays(device)
         triples = triples.to(device=device, dtype=torch.long)
         key_head, key_tail = self._keys(triples)
         lo = torch.cat((torch.searchsorted(heads_key, key_head, right=False),
@@ -131,6 +126,17 @@ class FilterIndex:
                         torch.searchsorted(tails_key, key_tail, right=True) + n_head_vals))
         exclude = torch.cat((triples[:, 0], triples[:, 1]))
         return SegmentFilter(lo, hi, values, exclude, ent2idx.to(device), row_base)
+
+    def device_arrays(self, device):
+        """(heads_key, tails_key, [heads' values | tails' values], number of head values) on ``device``, cached: what
+        the segment form of the filter indexes (ops.SegmentFilter, blp_build_queries)."""
+        cache = self.__dict__.setdefault("_segment_cache", {})
+        device = torch.device(device)
+        if device not in cache:
+            heads_key, heads_val, tails_key, tails_val = self._on(device)
+            cache[device] = (heads_key.contiguous(), tails_key.contiguous(), torch.cat((heads_val, tails_val)).contiguous(),
+                             heads_val.shape[0])
+        return cache[device]
 
     def _on(self, device):
         """The four sorted arrays on ``device`` (moved once, cached)."""

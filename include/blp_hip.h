@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 201 /* major*10000 + minor*100 + patch */
+#define BLP_HIP_VERSION 202 /* major*10000 + minor*100 + patch */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -235,6 +235,40 @@ int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, co
                            float regularizer, const float *grad_loss, const float *save_pos,
                            const float *save_neg, void *grad_ent, void *grad_rel, int device,
                            void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * The evaluation loop's per-batch prelude for a whole set of n triples, in one kernel (the producer of blp_rank_all's
+ * query arguments and of blp_rank_all_ex's filter segments):
+ *
+ *   heads = [ent2idx[ent] for ent in triples[:, 0]], tails likewise, assert min >= 0        train.py:134-138
+ *   head_embs = ent_emb[heads], tail_embs = ent_emb[tails], rel_embs = rel_emb(rels)       train.py:141-145
+ *   utils.get_triple_filters(triples, graph, ...)                                           utils.py:46-83
+ *
+ * Query order: blocks of `block` triples, each block as [its head-replacing queries | its tail-replacing queries]
+ * (train.py:149), so that block b is rows [2 b block, ...) of every output and can be handed to blp_rank_all(_ex) as is.
+ *   triples      (n, 3) int64 rows (head id, tail id, relation id) -- data.py:128 column order
+ *   ent2idx      id -> row of `source`, -1 = not a candidate (utils.make_ent2idx); NULL: ids are rows
+ *   source       (src_rows, D) f32, row stride ld: the entity table;  rel_emb (R, D) f32 contiguous
+ *   heads_key / tails_key  sorted keys entity * index_R + relation of the filtering graph's (tail, rel) -> heads and
+ *                (head, rel) -> tails indices (blp_amd.utils.FilterIndex); both NULL: no filter outputs
+ * Outputs (2n rows each): q_fixed, q_rel (2n, D) f32; true_row, rel_ids int64; seg_lo / seg_hi: the query's slice of
+ * the caller's value array [heads' values | tails' values] (tail-side slices are offset by n_heads); exclude: the
+ * triple's own entity id; *ids_min: 0, or -1 if any id has no row / any relation is outside [0, R) (such queries get
+ * zero vectors and true_row -1: the caller must check before ranking, as train.py:137-138 asserts).
+ * D % 4 == 0; 16-byte aligned source / rel_emb / q_fixed / q_rel; ld % 4 == 0.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct blp_queries {
+    const int64_t *triples; int64_t n, block;
+    const int64_t *ent2idx; int64_t ent2idx_len;
+    const float *source; int64_t src_rows, ld; int D;
+    const float *rel_emb; int64_t R;
+    const int64_t *heads_key; int64_t n_heads;
+    const int64_t *tails_key; int64_t n_tails;
+    int64_t index_R;
+    float *q_fixed; float *q_rel; int64_t *true_row; int64_t *rel_ids; int32_t *ids_min;
+    int64_t *seg_lo; int64_t *seg_hi; int64_t *exclude;
+} blp_queries;
+int blp_build_queries(const blp_queries *q, int device, void *stream);
 
 /* --------------------------------------------------------------------------------------------
  * Entity-table build, last step (the producer of blp_rank_all's `table`), for the BERT encoders:

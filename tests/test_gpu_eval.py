@@ -377,3 +377,54 @@ def test_bert_table_build_uses_the_fused_epilogue(rel_model, monkeypatch):
         n_before = len(calls)
         model.encode_into(out, text.tok[:4].cuda(), text.mask[:4].cuda())
         assert len(calls) == n_before
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,block,D", [(1, 64, 128), (100, 64, 128), (128, 64, 64), (333, 50, 300), (70, 1000, 768)])
+def test_build_queries_equals_the_torch_prelude(n, block, D):
+    """blp_build_queries (train.py:132-145 + utils.py:46-83 for a whole set of triples, one kernel) against the same
+    layout built from torch indexing / searchsorted: identical vectors, rows, ids and filter segments, block by block
+    ([head-replacing | tail-replacing] per block, the last block short).  An id without a row or an unknown relation
+    sets ids_min to -1 (the reference's assertion, train.py:137-138)."""
+    from blp_amd import ops, utils
+    g = torch.Generator().manual_seed(n + D)
+    num_ids, N, R = 500, 300, 11
+    entities = torch.randperm(num_ids, generator=g)[:N]
+    ent2idx = utils.make_ent2idx(entities, num_ids - 1).cuda()
+    table = torch.randn(N, D, generator=g).cuda()
+    rel_emb = torch.randn(R, D, generator=g).cuda()
+    triples = torch.stack((entities[torch.randint(0, N, (n,), generator=g)], entities[torch.randint(0, N, (n,), generator=g)],
+                           torch.randint(0, R, (n,), generator=g)), dim=1)
+    edges = torch.cat((triples, torch.stack((entities[torch.randint(0, N, (4000,), generator=g)],
+                                             entities[torch.randint(0, N, (4000,), generator=g)],
+                                             torch.randint(0, R - 2, (4000,), generator=g)), dim=1)))
+    index = utils.FilterIndex(edges, num_relations=R)
+    qb = ops.build_queries(triples.cuda(), ent2idx, table, rel_emb, block, index=index)
+    assert int(qb.ids_min) == 0
+    seg_all = index.segments(triples, ent2idx, "cuda")          # order [all heads | all tails]
+    heads, tails = ent2idx[triples[:, 0].cuda()], ent2idx[triples[:, 1].cuda()]
+    pos = 0
+    for first in range(0, n, block):
+        nb = min(block, n - first)
+        t = slice(first, first + nb)
+        hs, ts = slice(pos, pos + nb), slice(pos + nb, pos + 2 * nb)
+        assert torch.equal(qb.q_fixed[hs], table[tails[t]]) and torch.equal(qb.q_fixed[ts], table[heads[t]])
+        rel = rel_emb[triples[t, 2].cuda()]
+        assert torch.equal(qb.q_rel[hs], rel) and torch.equal(qb.q_rel[ts], rel)
+        assert torch.equal(qb.true_row[hs], heads[t]) and torch.equal(qb.true_row[ts], tails[t])
+        assert torch.equal(qb.rel_ids[hs].cpu(), triples[t, 2]) and torch.equal(qb.rel_ids[ts].cpu(), triples[t, 2])
+        for name in ("seg_lo", "seg_hi", "exclude"):
+            want = getattr(seg_all, name)
+            got = getattr(qb.filter, name)
+            assert torch.equal(got[hs], want[first: first + nb]) and torch.equal(got[ts], want[n + first: n + first + nb]), name
+        pos += 2 * nb
+    assert torch.equal(qb.filter.values, seg_all.values)
+    bad = triples.clone()
+    bad[n // 2, 0] = int((ent2idx < 0).nonzero()[0])            # an entity id that is not a candidate
+    assert int(ops.build_queries(bad.cuda(), ent2idx, table, rel_emb, block).ids_min) == -1
+    bad = triples.clone()
+    bad[n // 2, 1] = num_ids + 7                               # beyond the map
+    assert int(ops.build_queries(bad.cuda(), ent2idx, table, rel_emb, block).ids_min) == -1
+    bad = triples.clone()
+    bad[0, 2] = R
+    assert int(ops.build_queries(bad.cuda(), ent2idx, table, rel_emb, block).ids_min) == -1
