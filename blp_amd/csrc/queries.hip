@@ -10,7 +10,7 @@
 // Layout of the 2n queries: block after block of `block` triples, each block as [its head-replacing queries | its
 // tail-replacing queries] (train.py:149 order inside a block), so that a block is a contiguous range of every output.
 // 32 lanes per query: each moves 16 bytes of the fixed-entity row and of the relation row (D <= 128 floats per
-// sweep; wider rows: more sweeps); lanes 0 and 1 also run the lower / upper bound searches of the query's key.
+// sweep; wider rows: more sweeps); the lower / upper bound searches of the queries' keys run in workgroups of their own.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,16 +28,49 @@ __device__ __forceinline__ int64_t bound(const int64_t* __restrict__ keys, int64
     return lo;
 }
 
-__global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a) {
-    const int sub = threadIdx.x & 31;
-    const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);  // query position
-    if (p >= 2 * a.n) return;
-    // position -> (block, side, triple)
+// position p of the layout -> (head side?, triple)
+__device__ __forceinline__ void query_at(const QueryBuild& a, int64_t p, bool& head_side, int64_t& t) {
     const int64_t bi = p / (2 * a.block), first = bi * a.block;
     const int64_t nb = a.n - first < a.block ? a.n - first : a.block;  // triples in this block
     const int64_t o = p - 2 * first;
-    const bool head_side = o < nb;
-    const int64_t t = first + (head_side ? o : o - nb);
+    head_side = o < nb;
+    t = first + (head_side ? o : o - nb);
+}
+
+// Workgroups [0, gather_blocks): 8 queries each, 32 lanes per query (16 bytes of each row per lane and sweep).
+// Workgroups after them: the filter segments, one thread per (query, bound) -- 18 dependent loads per search, so they
+// get threads of their own instead of stalling a gathering wave (72 -> 35 us for the FB15k-237 test set).
+__global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a, unsigned gather_blocks) {
+    if (blockIdx.x >= gather_blocks) {
+        const int64_t i = (int64_t)(blockIdx.x - gather_blocks) * 256 + threadIdx.x;
+        const int64_t p = i >> 1;
+        if (p >= 2 * a.n) return;
+        const bool upper = i & 1;
+        bool head_side;
+        int64_t t;
+        query_at(a, p, head_side, t);
+        const int64_t h_id = a.triples[3 * t], t_id = a.triples[3 * t + 1], r_id = a.triples[3 * t + 2];
+        // head side: key (tail, rel) in heads_key; tail side: key (head, rel) in tails_key, whose values follow the head
+        // side's in the caller's concatenated value array
+        const int64_t* keys = head_side ? a.heads_key : a.tails_key;
+        const int64_t nk = head_side ? a.n_heads : a.n_tails, base = head_side ? 0 : a.n_heads;
+        const bool known = r_id >= 0 && r_id < a.index_R;  // a relation the index never saw matches nothing
+        const int64_t key = (head_side ? t_id : h_id) * a.index_R + r_id;
+        const int64_t b = known ? bound(keys, nk, key, upper) : 0;
+        if (upper) {
+            a.seg_hi[p] = base + b;
+        } else {
+            a.seg_lo[p] = base + b;
+            a.exclude[p] = head_side ? h_id : t_id;  // the triple's own entity is never filtered (utils.py:71,78)
+        }
+        return;
+    }
+    const int sub = threadIdx.x & 31;
+    const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);  // query position
+    if (p >= 2 * a.n) return;
+    bool head_side;
+    int64_t t;
+    query_at(a, p, head_side, t);
     const int64_t h_id = a.triples[3 * t], t_id = a.triples[3 * t + 1], r_id = a.triples[3 * t + 2];
     auto row_of = [&](int64_t id) -> int64_t {
         if (!a.ent2idx) return (uint64_t)id < (uint64_t)a.src_rows ? id : -1;
@@ -64,29 +97,14 @@ __global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a) {
         *reinterpret_cast<float4*>(fdst + c) = f;
         *reinterpret_cast<float4*>(rdst + c) = r;
     }
-    // the filter segment: head side key (tail, rel) in heads_key, tail side key (head, rel) in tails_key, whose values
-    // follow the head side's in the caller's concatenated value array
-    if (a.seg_lo && sub < 2) {
-        const int64_t* keys = head_side ? a.heads_key : a.tails_key;
-        const int64_t nk = head_side ? a.n_heads : a.n_tails, base = head_side ? 0 : a.n_heads;
-        const bool known = r_id >= 0 && r_id < a.index_R;  // a relation the index never saw matches nothing
-        const int64_t key = (head_side ? t_id : h_id) * a.index_R + r_id;
-        const int64_t b = known ? bound(keys, nk, key, sub == 1) : 0;
-        if (sub == 0) {
-            a.seg_lo[p] = base + b;
-            a.exclude[p] = head_side ? h_id : t_id;  // the triple's own entity is never filtered (utils.py:71,78)
-        } else {
-            a.seg_hi[p] = base + b;
-        }
-    }
 }
 
 hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream) {
     hipError_t err = hipMemsetAsync(a.ids_min, 0, sizeof(int), stream);
     if (err != hipSuccess || a.n == 0) return err;
-    const int64_t blocks = (2 * a.n + 7) / 8;
-    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    build_queries_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(a);
+    const int64_t gather_blocks = (2 * a.n + 7) / 8, search_blocks = a.seg_lo ? (4 * a.n + 255) / 256 : 0;
+    if (gather_blocks + search_blocks > 0x7fffffff) return hipErrorInvalidValue;
+    build_queries_kernel<<<dim3((unsigned)(gather_blocks + search_blocks)), 256, 0, stream>>>(a, (unsigned)gather_blocks);
     return hipGetLastError();
 }
 
