@@ -83,6 +83,13 @@ def make_case(rng):
         env["rank_kernel"] = 1
     if rng.random() < 0.6:
         env["sad_min_queries"] = 64  # the tables here are small: without it TransE blocks take the exact kernels
+    u = rng.random()
+    if u < 0.35:
+        env["small_kernel"] = 2      # ... and every small block the small-block kernel
+    elif u < 0.6:
+        env["small_kernel"] = 1      # wherever it can run (D = 64 / 128, up to 4 096 queries), whatever the block size
+        if rng.random() < 0.5:
+            env["exact_query_chunk"] = int(rng.integers(1, 200))
     return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids
 
 
