@@ -231,15 +231,22 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     }
     __syncthreads();
 
+    // The query loop.  A CU has ONE scalar ALU for its four SIMDs: with five waves per SIMD walking 64 v_sad_u16 per
+    // query, ~70 scalar instructions per query (64-bit address arithmetic for three row pointers with end-of-block
+    // clamps, the atomic optimiser's lane loop around the LDS count) kept the scalar pipe as busy as the SAD pipe and
+    // the kernel at 78 % of the SAD rate.  So: pointers advance by a constant (the image is padded by four rows, no
+    // clamps), and a query's count goes to lane j % 64 of a register with one masked add; the register is flushed to
+    // the LDS counters once per 64 queries by all lanes.
     unsigned my_pairs = 0;  // entries in this wave's slice of pair_s (wave-uniform)
-    const float* rows = reinterpret_cast<const float*>(qimg + q0 * (D / 2));
-    sf16 cur = sload16<0>(rows);
+    const float* row = reinterpret_cast<const float*>(qimg + q0 * (D / 2));
+    sf16 cur = sload16<0>(row);
     sdrain(cur);
-    for (int j = 0; j < nq; ++j) {
-        const float* row = rows + (size_t)j * (D / 2);
-        const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * (D / 2);
-        // the four waves walk the same rows: they take turns touching the lines of the query three ahead
-        const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * (D / 2) : row;
+    for (int jb = 0; jb < nq; jb += 64) {  // 64 queries per flush of the count register
+    const int jn = nq - jb < 64 ? nq - jb : 64;
+    unsigned cnt_reg = 0;  // lane l: certainly-above count of query jb + l
+    unsigned long long bit = 1;
+    for (int j = jb; j < jb + jn; ++j, row += D / 2, bit <<= 1) {
+        const float* next_row = row + D / 2;  // rows past the block's last query: the next block's, or the padding
         const int2 th = thr_s[j];
         unsigned sad[TPW];
         static_for<TPW>([&](auto tt) { sad[decltype(tt)::value] = c.bias[decltype(tt)::value]; });
@@ -247,7 +254,8 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
             constexpr int k = decltype(kk)::value;
             sf16 nxt;
             if constexpr (k + 1 < D / 32) nxt = sload16<(k + 1) * 64>(row); else nxt = sload16<0>(next_row);
-            if constexpr (k == 0) stouch<D * 2>(touch_row);
+            // the four waves walk the same rows: they take turns touching the lines of the query three ahead
+            if constexpr (k == 0) { if ((j & 3) == wave) stouch<D * 2>(row + 3 * (D / 2)); }
             static_for<16>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
                 const float qf = cur[i];  // (bit_cast straight from the vector element reads element 0)
@@ -281,7 +289,13 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
             }
             n_above += n_t;
         });
-        if (lane == 0 && n_above) atomicAdd(&cnt[j], n_above);
+        {   // cnt_reg[lane j - jb] += n_above: one VALU instruction under a one-lane exec mask
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\tv_add_u32 %0, %0, %2\n\ts_mov_b64 exec, %1"
+                         : "+v"(cnt_reg), "=&s"(saved) : "s"(n_above), "s"(bit));
+        }
+    }
+    if (cnt_reg) atomicAdd(&cnt[jb + lane], cnt_reg);  // all lanes: distinct counters, plain ds_add_u32
     }
     __syncthreads();
     for (int i = tid; i < nq; i += kSW * 64) {
@@ -452,7 +466,8 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     w.params = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams), 256);
     w.partial = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams) * kSRangeBlocks, 256);
     w.thr = reinterpret_cast<int2*>(p + off);         off = align_up(off + (size_t)Q * 8, 256);
-    w.qimg = reinterpret_cast<unsigned*>(p + off);    off = align_up(off + (size_t)Q * (D / 2) * 4 + 64, 256);
+    // + 4 rows: the pre-pass reads ahead of its query (next row, the row three ahead) without clamping at the end
+    w.qimg = reinterpret_cast<unsigned*>(p + off);    off = align_up(off + (size_t)(Q + 4) * (D / 2) * 4 + 64, 256);
     w.cimg = reinterpret_cast<uint4*>(p + off);       off = align_up(off + (size_t)((N + 63) / 64) * 64 * (D / 2) * 4, 256);
     w.resid = reinterpret_cast<unsigned*>(p + off);   off = align_up(off + (size_t)((N + 63) / 64) * 64 * 4, 256);
     w.pass_groups = sad_groups_per_pass(D, N, Q);
