@@ -239,19 +239,21 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
             v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
         });
         const bool first = ch == 0, last = ch + 1 == n_ch;
-        const float* rows = reinterpret_cast<const float*>(qimg + q0 * row_dwords + ch * 64);
-        sf16 cur = sload16<0>(rows);
+        // (scalar work per query kept small -- a CU has one scalar ALU for four SIMDs, see rank_sad.hip: pointers step
+        //  by a constant over an image padded by four rows, counts go to lane j of a register)
+        const float* row = reinterpret_cast<const float*>(qimg + q0 * row_dwords + ch * 64);
+        sf16 cur = sload16<0>(row);
         sdrain(cur);
-        for (int j = 0; j < nq; ++j) {
-            const float* row = rows + (size_t)j * row_dwords;
-            const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * row_dwords;
-            const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * row_dwords : row;
+        unsigned cnt_reg = 0;  // lane j: certainly-above count of query q0 + j for this wave's tile
+        unsigned long long bit = 1;
+        for (int j = 0; j < nq; ++j, row += row_dwords, bit <<= 1) {
+            const float* next_row = row + row_dwords;
             unsigned sad = first ? bias : psum[wave][j][lane];
             static_for<4>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
                 sf16 nxt;
                 if constexpr (k + 1 < 4) nxt = sload16<(k + 1) * 64>(row); else nxt = sload16<0>(next_row);
-                if constexpr (k == 0) stouch<256>(touch_row);
+                if constexpr (k == 0) { if ((j & 3) == wave) stouch<256>(row + 3 * (size_t)row_dwords); }
                 static_for<16>([&](auto ii) {
                     constexpr int i = decltype(ii)::value;
                     const float qf = cur[i];
@@ -283,8 +285,11 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
                     n_above = 0;
                 }
             }
-            if (lane == 0 && n_above) atomicAdd(&cnt[j], n_above);
+            unsigned long long saved;  // cnt_reg[lane j] += n_above: one VALU instruction under a one-lane exec mask
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\tv_add_u32 %0, %0, %2\n\ts_mov_b64 exec, %1"
+                         : "+v"(cnt_reg), "=&s"(saved) : "s"(n_above), "s"(bit));
         }
+        if (last && lane < kWChunk && cnt_reg) atomicAdd(&cnt[lane], cnt_reg);
     }
     __syncthreads();
     if (tid < nq) {
@@ -462,7 +467,8 @@ static WideWorkspace carve_wide(void* base, int D, int64_t N, int64_t Q) {
     w.params = reinterpret_cast<SadParams*>(p + off);  off = align_up(off + sizeof(SadParams), 256);
     w.partial = reinterpret_cast<SadParams*>(p + off); off = align_up(off + sizeof(SadParams) * kSRangeBlocks, 256);
     w.thr = reinterpret_cast<int2*>(p + off);          off = align_up(off + (size_t)Q * 8, 256);
-    w.qimg = reinterpret_cast<unsigned*>(p + off);     off = align_up(off + (size_t)Q * (Dp / 2) * 4 + 64, 256);
+    // + 4 rows: the pre-pass reads ahead of its query (next row, the row three ahead) without clamping at the end
+    w.qimg = reinterpret_cast<unsigned*>(p + off);     off = align_up(off + (size_t)(Q + 4) * (Dp / 2) * 4 + 64, 256);
     w.cimg = reinterpret_cast<uint4*>(p + off);        off = align_up(off + (size_t)((N + 63) / 64) * 64 * (Dp / 2) * 4, 256);
     w.resid = reinterpret_cast<unsigned*>(p + off);    off = align_up(off + (size_t)((N + 63) / 64) * 64 * 4, 256);
     w.pass_groups = wide_groups_per_pass(N, Q);
