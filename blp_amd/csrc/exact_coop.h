@@ -87,7 +87,7 @@ __device__ __forceinline__ float transe_key_64(const float* pe, const float* pf,
 // The same at a run-time width D (D % 4 == 0; the bag-of-words / DKRL widths 300, 768), straight from the entity and
 // relation vectors: head-replacing query (e + r) - f with f = the tail, tail-replacing (f + r) - e with f = the head
 // (models.py:222-223).  The last chunk of a width that is not a multiple of 32 loads only the columns that exist.
-__device__ __forceinline__ void gather_chunk_rt(float (&x)[32], const float* const (&g)[8], int s, int cols, float* slab, int lane) {
+__device__ __forceinline__ void gather_issue_rt(float (&x)[32], const float* const (&g)[8], int s, int cols, int lane) {
     const bool mine = (lane & 7) * 4 < cols;  // cols is a multiple of 4: a lane's four columns exist together
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -95,8 +95,10 @@ __device__ __forceinline__ void gather_chunk_rt(float (&x)[32], const float* con
         if (mine) v = *reinterpret_cast<const float4*>(g[i] + 32 * s);
         x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
     }
+}
+__device__ __forceinline__ void gather_transpose(float (&x)[32], float* slab, int lane) {
     float* wr = slab + (lane >> 3) * kRefStride + (lane & 7) * 4;
-    wave_lds_sync();
+    wave_lds_sync();  // the previous trip's reads are done before the slab is rewritten
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         *reinterpret_cast<float4*>(wr + 8 * i * kRefStride) = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
@@ -124,10 +126,16 @@ __device__ __forceinline__ float transe_key_64_rt(const float* pe, const float* 
     float sum = 0.0f;
     for (int s = 0; s * 32 < D; ++s) {
         const int cols = D - 32 * s < 32 ? D - 32 * s : 32;
+        // the 24 row loads of the chunk go out together, then the three trips through the slab: one memory round trip
+        // per chunk instead of three (each gather's loads otherwise wait behind the previous one's LDS fences); at
+        // D = 768 that is worth 7 %, at D <= 256 the extra live registers cost more occupancy than the round trips
         float e[32], f[32], r[32];
-        gather_chunk_rt(e, ge, s, cols, slab, lane);
-        gather_chunk_rt(f, gf, s, cols, slab, lane);
-        gather_chunk_rt(r, gr, s, cols, slab, lane);
+        gather_issue_rt(e, ge, s, cols, lane);
+        gather_issue_rt(f, gf, s, cols, lane);
+        gather_issue_rt(r, gr, s, cols, lane);
+        gather_transpose(e, slab, lane);
+        gather_transpose(f, slab, lane);
+        gather_transpose(r, slab, lane);
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             float x = (head ? e[k] : f[k]) + r[k];
