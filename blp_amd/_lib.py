@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 
 # every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
-           "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex",
+           "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex", "blp_rank_all_idx",
            "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_build_queries", "blp_debug_set_knob",
@@ -59,7 +59,8 @@ class BlpQueries(ctypes.Structure):  # blp_queries of include/blp_hip.h
                 ("tails_key", ctypes.c_void_p), ("n_tails", ctypes.c_int64), ("index_R", ctypes.c_int64),
                 ("q_fixed", ctypes.c_void_p), ("q_rel", ctypes.c_void_p), ("true_row", ctypes.c_void_p),
                 ("rel_ids", ctypes.c_void_p), ("ids_min", ctypes.c_void_p),
-                ("seg_lo", ctypes.c_void_p), ("seg_hi", ctypes.c_void_p), ("exclude", ctypes.c_void_p)]
+                ("seg_lo", ctypes.c_void_p), ("seg_hi", ctypes.c_void_p), ("exclude", ctypes.c_void_p),
+                ("fixed_row", ctypes.c_void_p)]
 
 
 _lib = None
@@ -102,6 +103,9 @@ def lib():
     L.blp_rank_all_ex.restype = _i
     L.blp_rank_all_ex.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.POINTER(BlpFilter),
                                   _vp, _vp, _sz, _i, _vp]
+    L.blp_rank_all_idx.restype = _i
+    L.blp_rank_all_idx.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, ctypes.POINTER(BlpFilter),
+                                   _vp, _vp, _sz, _i, _vp]
     L.blp_profile_next_rank_kernel.restype = _i
     L.blp_profile_next_rank_kernel.argtypes = [_vp, _vp]
     L.blp_rank_from_scores.restype = _i

@@ -117,8 +117,10 @@ int blp_build_queries(const blp_queries* q, int device, void* stream) {
     if (q->n < 0 || q->block <= 0 || q->D <= 0 || (q->D & 3) || q->src_rows < 0 || q->R < 0 || q->n > (1ll << 40))
         return fail(BLP_ERR_BAD_ARG, "blp_build_queries: bad sizes (n=%lld block=%lld D=%d)", (long long)q->n, (long long)q->block, q->D);
     if (!q->ids_min) return fail(BLP_ERR_BAD_ARG, "blp_build_queries: ids_min is NULL");
-    if (q->n > 0 && (!q->triples || !q->source || !q->rel_emb || !q->q_fixed || !q->q_rel || !q->true_row || !q->rel_ids))
+    if (q->n > 0 && (!q->triples || !q->source || !q->rel_emb || !q->true_row || !q->rel_ids))
         return fail(BLP_ERR_BAD_ARG, "blp_build_queries: NULL pointer");
+    if ((q->q_fixed == nullptr) != (q->q_rel == nullptr))
+        return fail(BLP_ERR_BAD_ARG, "blp_build_queries: q_fixed and q_rel are given together or not at all");
     if (!aligned16(q->source) || !aligned16(q->rel_emb) || !aligned16(q->q_fixed) || !aligned16(q->q_rel) || (q->ld & 3) || q->ld < q->D)
         return fail(BLP_ERR_BAD_ARG, "blp_build_queries: source / rel_emb / q_fixed / q_rel must be 16-byte aligned, ld %% 4 == 0, ld >= D");
     const bool with_index = q->heads_key || q->tails_key || q->seg_lo || q->seg_hi || q->exclude;
@@ -129,7 +131,7 @@ int blp_build_queries(const blp_queries* q, int device, void* stream) {
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
     blp::QueryBuild a{q->triples, q->n, q->block, q->ent2idx, q->ent2idx_len, q->source, q->src_rows, q->ld, q->D,
                       q->rel_emb, q->R, q->heads_key, q->n_heads, q->tails_key, q->n_tails, q->index_R, q->q_fixed, q->q_rel,
-                      q->true_row, q->rel_ids, q->ids_min, with_index ? q->seg_lo : nullptr, q->seg_hi, q->exclude};
+                      q->true_row, q->rel_ids, q->ids_min, with_index ? q->seg_lo : nullptr, q->seg_hi, q->exclude, q->fixed_row};
     hipError_t err = blp::launch_build_queries(a, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_build_queries launch");
     return BLP_OK;
@@ -188,10 +190,13 @@ size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head,
     return blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
 }
 
-int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
-                    const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
-                    int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
-                    size_t workspace_bytes, int device, void* stream) {
+}  // extern "C"
+
+// Shared by blp_rank_all / _ex (dense query vectors) and blp_rank_all_idx (queries as rows of the table / of rel_emb)
+static int rank_all_checked(int model, const float* table, int64_t N, int D, int64_t ld, const blp::QRows& q_fixed,
+                            const blp::QRows& q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+                            int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
+                            size_t workspace_bytes, int device, void* stream) {
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
     if (!blp_rank_all_supported(model, D, q_head, q_tail))
         return fail(BLP_ERR_UNSUPPORTED_DIM,
@@ -206,7 +211,7 @@ int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld,
     if (Q > (1ll << 30) || N >= (1ll << 31))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: Q > 2^30 or N >= 2^31 (counts are int32): split the query block / "
                                      "shard the candidate axis");
-    if (!q_fixed || !q_rel || !counts) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL q_fixed / q_rel / counts");
+    if (!q_fixed.base || !q_rel.base || !counts) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL q_fixed / q_rel / counts");
     if (N > 0 && !table) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL table");
     if ((true_row == nullptr) == (q_true == nullptr))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: exactly one of true_row / q_true must be given");
@@ -220,8 +225,8 @@ int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld,
         spec.ent2idx = filter->ent2idx; spec.ent2idx_len = filter->ent2idx ? filter->ent2idx_len : 0;
         spec.row_base = filter->row_base;
     }
-    if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts) || !aligned16(q_fixed) ||
-        !aligned16(q_rel) || (D & 3))
+    if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts) || !aligned16(q_fixed.base) ||
+        !aligned16(q_rel.base) || (q_fixed.ld & 3) || (q_rel.ld & 3) || (D & 3))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: table / q_fixed / q_rel / q_true / counts must be 16-byte aligned, "
                                      "ld %% 4 == 0 and D %% 4 == 0");
     const size_t need = blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
@@ -238,6 +243,27 @@ int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld,
                                           spec, counts, workspace, cu, static_cast<hipStream_t>(stream), ev0, ev1);
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all launch");
     return BLP_OK;
+}
+
+extern "C" {
+
+int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
+                    const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+                    int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
+                    size_t workspace_bytes, int device, void* stream) {
+    return rank_all_checked(model, table, N, D, ld, blp::QRows::dense(q_fixed, D), blp::QRows::dense(q_rel, D), q_rel_id,
+                            true_row, q_true, q_head, q_tail, filter, counts, workspace, workspace_bytes, device, stream);
+}
+
+int blp_rank_all_idx(int model, const float* table, int64_t N, int D, int64_t ld, const int64_t* fixed_row,
+                     const float* rel_emb, int64_t R, const int64_t* rel_id, const int64_t* true_row, int64_t q_head,
+                     int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace, size_t workspace_bytes,
+                     int device, void* stream) {
+    if (q_head + q_tail > 0 && (!fixed_row || !rel_id || !rel_emb || !true_row || R <= 0))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_idx: NULL fixed_row / rel_id / rel_emb / true_row or R <= 0");
+    return rank_all_checked(model, table, N, D, ld, blp::QRows::rows_of(table, fixed_row, ld, D),
+                            blp::QRows::rows_of(rel_emb, rel_id, D, D), rel_id, true_row, nullptr, q_head, q_tail, filter,
+                            counts, workspace, workspace_bytes, device, stream);
 }
 
 int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,

@@ -13,6 +13,32 @@ namespace blp {
 //             val = entity ids, exclude[q] = the triple's own entity (never filtered, utils.py:71,78), ent2idx maps
 //             ids to table rows (-1 or beyond its length: not a candidate, utils.py:72,79).
 // row_base is subtracted from every row and rows outside [0, N) are skipped (candidate shards).
+// The query vectors of a block, q_fixed / q_rel, are (Q, D) row arrays -- either DENSE (row q = base + q * D) or INDEXED
+// (row q = base + idx[q] * ld: the fixed-entity vector is a row of the entity table, the relation vector a row of
+// rel_emb).  Indexed queries cost no gather and no 2 x Q x D x 4 bytes that every prep / true-key / refinement /
+// filter kernel would stream again; their rows come out of L2 instead.  Kernels address both forms as
+// `q_fixed + q * D` (and flat `q_fixed[q * D + c]`): operator+ takes the FLAT offset of the dense form.
+struct QRows {
+    const float* base = nullptr;
+    const int64_t* idx = nullptr;  // NULL: dense
+    int64_t ld = 0;                // row stride in floats (dense: D)
+    int D = 0, shift = -1;         // shift: log2(D) if D is a power of two (the division below is then a shift)
+    __host__ __device__ const float* operator+(int64_t off) const {
+        const int64_t q = shift >= 0 ? off >> shift : off / D;
+        return base + (idx ? idx[q] : q) * ld + (off - q * D);
+    }
+    __host__ __device__ float operator[](int64_t off) const { return *(*this + off); }
+    static QRows dense(const float* p, int D) { return make(p, nullptr, D, D); }
+    static QRows rows_of(const float* table, const int64_t* idx, int64_t ld, int D) { return make(table, idx, ld, D); }
+    static QRows make(const float* p, const int64_t* idx, int64_t ld, int D) {
+        QRows r;
+        r.base = p; r.idx = idx; r.ld = ld; r.D = D;
+        r.shift = -1;
+        for (int s = 0; s < 31; ++s) if ((1 << s) == D) r.shift = s;
+        return r;
+    }
+};
+
 struct FilterSpec {
     const int64_t* lo = nullptr;
     const int64_t* hi = nullptr;
@@ -28,7 +54,7 @@ bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
-                           const float* q_fixed, const float* q_rel, const int64_t* q_rel_id,
+                           const QRows q_fixed, const QRows q_rel, const int64_t* q_rel_id,
                            const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
@@ -52,6 +78,7 @@ struct QueryBuild {
     int64_t index_R;
     float* q_fixed; float* q_rel; int64_t* true_row; int64_t* rel_ids; int* ids_min;
     int64_t* seg_lo; int64_t* seg_hi; int64_t* exclude;
+    int64_t* fixed_row;
 };
 hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream);
 

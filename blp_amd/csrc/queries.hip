@@ -80,11 +80,13 @@ __global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a, unsign
     const int64_t h_row = row_of(h_id), t_row = row_of(t_id);
     const int64_t fixed_row = head_side ? t_row : h_row, true_row = head_side ? h_row : t_row;
     const bool rel_ok = (uint64_t)r_id < (uint64_t)a.R;
-    if (sub == 0) {
-        a.true_row[p] = true_row;
-        a.rel_ids[p] = r_id;
+    if (sub == 0) {  // (a bad id: row / relation 0, so that nothing downstream reads out of bounds; ids_min tells)
+        a.true_row[p] = true_row >= 0 ? true_row : 0;
+        a.rel_ids[p] = rel_ok ? r_id : 0;
+        if (a.fixed_row) a.fixed_row[p] = fixed_row >= 0 ? fixed_row : 0;
         if (h_row < 0 || t_row < 0 || !rel_ok) atomicMin(a.ids_min, -1);  // train.py:137-138's assertion, left on the device
     }
+    if (!a.q_fixed) return;  // index form only (blp_rank_all_idx): no vectors
     // the two vectors: fixed entity and relation (an id that is no row: zeros -- the caller checks ids_min)
     const float* fsrc = a.source + (fixed_row >= 0 ? fixed_row : 0) * a.ld;
     const float* rsrc = a.rel_emb + (rel_ok ? r_id : 0) * (int64_t)a.D;

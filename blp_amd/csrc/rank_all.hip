@@ -48,7 +48,7 @@ __host__ __device__ constexpr int kMaxCoef(int D) { return 2 * D; }
 
 // ------------------------------------------------------------------------------------------------
 template <int MODEL, int D>
-__global__ void prep_coef_kernel(const float* __restrict__ q_fixed, const float* __restrict__ q_rel,
+__global__ void prep_coef_kernel(const QRows q_fixed, const QRows q_rel,
                                  int64_t q_head, int64_t q_tail, float* __restrict__ coef_head,
                                  float* __restrict__ coef_tail) {
     using SH = Scorer<MODEL, HEAD, D>;
@@ -72,7 +72,7 @@ __global__ void prep_coef_kernel(const float* __restrict__ q_fixed, const float*
 template <int MODEL, int D>
 __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ table, int64_t ld,
                                 const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
-                                const float* __restrict__ q_fixed, const float* __restrict__ q_rel,
+                                const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc) {
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -391,8 +391,8 @@ __device__ __forceinline__ unsigned long long sum_partials(const unsigned long l
 // row-by-row loads: 127 us for the 105 740 queries of the FB15k-237 block, of which 9 % have an entry.)
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void filter_finalize_kernel(
-    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ q_fixed,
-    const float* __restrict__ q_rel, const float* __restrict__ key_true, int64_t q_head,
+    const float* __restrict__ table, int64_t N, int64_t ld, const QRows q_fixed,
+    const QRows q_rel, const float* __restrict__ key_true, int64_t q_head,
     int64_t q_tail, const FilterSpec filter, const unsigned long long* __restrict__ acc, int n_partials,
     int32_t* __restrict__ counts) {
     __shared__ unsigned long long partial_sums[3][kSweepQueries];
@@ -580,8 +580,8 @@ size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
 }
 
 template <int MODEL, int D>
-static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                                const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                                const QRows q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
                                 int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
@@ -658,8 +658,8 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
 }
 
 template <int MODEL>
-static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                               const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                               const QRows q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
                                int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace, int n_cu,
                                hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define BLP_RANK_CASE(DD)                                                                              \
@@ -677,7 +677,7 @@ static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld,
 }
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
-                           const float* q_fixed, const float* q_rel, const int64_t* q_rel_id,
+                           const QRows q_fixed, const QRows q_rel, const int64_t* q_rel_id,
                            const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
@@ -706,7 +706,7 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 // Building blocks the pre-pass paths (rank_gemm.hip, rank_sad.hip) share with the exact path: true-entity keys (+ zeroed
 // accumulators) and the filter / finalize step.  They read the query vectors directly: no coefficient array.
 template <int MODEL, int D>
-static hipError_t true_keys_impl(const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
+static hipError_t true_keys_impl(const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
                                  const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
                                  float* key_true, unsigned long long* acc, hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
@@ -716,8 +716,8 @@ static hipError_t true_keys_impl(const float* q_fixed, const float* q_rel, int64
 }
 
 template <int MODEL, int D>
-static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                                       const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
+static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                                       const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                        const FilterSpec& filter, const unsigned long long* acc, int n_partials,
                                        int32_t* counts, hipStream_t stream) {
     filter_finalize_kernel<MODEL, D><<<(int)((q_head + q_tail + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(
@@ -742,14 +742,14 @@ static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld
     default: return hipErrorInvalidValue;                                                   \
     }
 
-hipError_t launch_true_keys(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
+hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
                             const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
                             float* key_true, unsigned long long* acc, hipStream_t stream) {
     BLP_DISPATCH_MODEL_DIM(true_keys_impl, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, key_true, acc, stream)
 }
 
-hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                                  const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
+hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                                  const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
                                   hipStream_t stream, int n_partials) {
     const int64_t Q = q_head + q_tail;

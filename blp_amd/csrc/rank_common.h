@@ -75,13 +75,13 @@ __device__ __forceinline__ int64_t filter_row(const FilterSpec& f, int64_t q, in
 // (query q's is the sum of acc[p * Q + q] over p < n_partials: the small-block kernel leaves one partial per tile slot),
 // fgt / fge = the filtered candidates that score above / at least the true entity (one wave per query, exact
 // Scorer<> arithmetic).  Without a filter the last two equal the first two.
-hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                                  const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
+hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                                  const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
                                   hipStream_t stream, int n_partials = 1);
 
 // rank_all.hip: true-entity keys by the exact routine (and the Q rank-count accumulators `acc` zeroed on the way)
-hipError_t launch_true_keys(int model, int D, const float* q_fixed, const float* q_rel, int64_t q_head, int64_t q_tail,
+hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
                             const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
                             float* key_true, unsigned long long* acc, hipStream_t stream);
 
@@ -93,8 +93,8 @@ constexpr int kSmallMaxSlots = 256;                    // partial counts per que
 constexpr long long kSmallMaxQueries = 4096;           // whatever the knob says
 bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 int rank_small_slots(int64_t N);  // partial[slot * Q + q], slot < rank_small_slots(N): what the kernel writes (every entry)
-hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                             const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
+hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                             const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                              unsigned long long* partial, int n_cu, hipStream_t stream);
 
 // rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
@@ -102,7 +102,7 @@ void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,
-                                const float* q_fixed, const float* q_rel, const int64_t* true_row,
+                                const QRows q_fixed, const QRows q_rel, const int64_t* true_row,
                                 const float* q_true, int64_t q_head, int64_t q_tail,
                                 const FilterSpec& filter, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
@@ -112,8 +112,8 @@ hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N,
 // exact refinement.
 bool rank_sad_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
-hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                               const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                               const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
                                int64_t q_tail, const FilterSpec& filter, int32_t* counts,
                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                hipEvent_t ev_stop);
@@ -122,8 +122,8 @@ hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld,
 // encoders' 300 and 768), 128 elements of the candidate row in registers at a time.
 bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
-hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                                    const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                                    const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
                                     int64_t q_tail, const FilterSpec& filter,
                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
                                     hipEvent_t ev_start, hipEvent_t ev_stop);

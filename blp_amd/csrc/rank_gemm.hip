@@ -91,8 +91,8 @@ __device__ __forceinline__ void gemm_operand(const float* __restrict__ f, const 
 // One workgroup per query tile: 8 threads per query build W (and the band factor C u ||B_q||, rounded
 // up) from coalesced reads, the image goes out through LDS so that the stores are linear too.
 template <int MODEL, int D>
-__global__ __launch_bounds__(256) void prep_gemm_kernel(const float* __restrict__ q_fixed,
-                                                        const float* __restrict__ q_rel, int64_t q_head,
+__global__ __launch_bounds__(256) void prep_gemm_kernel(const QRows q_fixed,
+                                                        const QRows q_rel, int64_t q_head,
                                                         int64_t q_tail, float4* __restrict__ img_head,
                                                         float4* __restrict__ img_tail, float* __restrict__ eps_q) {
     constexpr int F4 = (D / 8) * 64;  // float4 per tile
@@ -342,8 +342,8 @@ __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, uns
 // Query tile image for the bf16 kernel: uint4 index (s * 64 + l) of the hi part, then of the lo part,
 // holds W_{q = l & 31}[16 s + 8 (l >> 5) + j], j = 0..7, as four packed bf16 pairs.
 template <int MODEL, int D>
-__global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const float* __restrict__ q_fixed,
-                                                             const float* __restrict__ q_rel, int64_t q_head,
+__global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const QRows q_fixed,
+                                                             const QRows q_rel, int64_t q_head,
                                                              int64_t q_tail, uint4* __restrict__ img_head,
                                                              uint4* __restrict__ img_tail, float* __restrict__ eps_q) {
     constexpr int STEPS = D / 16, U4 = STEPS * 64;  // uint4 per part
@@ -845,8 +845,8 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
 // (coop_score) and counted.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
-                                                           const float* __restrict__ q_fixed,
-                                                           const float* __restrict__ q_rel,
+                                                           const QRows q_fixed,
+                                                           const QRows q_rel,
                                                            const float* __restrict__ key_true, int64_t q_head,
                                                            const uint2* __restrict__ pairs,
                                                            const unsigned* __restrict__ n_pairs,
@@ -885,8 +885,8 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
 // Pass 2a of the f32-chain kernel: one lane per slot of the workgroups' fixed (query, row) pair regions.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __restrict__ table, int64_t ld,
-                                                                const float* __restrict__ q_fixed,
-                                                                const float* __restrict__ q_rel,
+                                                                const QRows q_fixed,
+                                                                const QRows q_rel,
                                                                 const float* __restrict__ key_true, int64_t q_head,
                                                                 const uint2* __restrict__ pairs, int64_t n_entries,
                                                                 unsigned long long* __restrict__ acc) {
@@ -911,8 +911,8 @@ __global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __r
 // (query, 16-candidate) half-segment is re-scored exactly, four half-segments per iteration.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
-                                                     const float* __restrict__ q_fixed,
-                                                     const float* __restrict__ q_rel,
+                                                     const QRows q_fixed,
+                                                     const QRows q_rel,
                                                      const float* __restrict__ key_true, int64_t q_head, int64_t Q,
                                                      int words_per_query, const unsigned* __restrict__ flags,
                                                      unsigned long long* __restrict__ acc) {
@@ -1052,7 +1052,7 @@ static thread_local float* g_dump_eps = nullptr;
 void gemm_set_dump(float* s, float* eps) { g_dump_s = s; g_dump_eps = eps; }
 
 template <int MODEL, int D>
-static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
+static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
                                  const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
                                  const FilterSpec& filter, int32_t* counts, void* workspace,
                                  hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -1148,7 +1148,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
 }
 
 hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,
-                                const float* q_fixed, const float* q_rel, const int64_t* true_row,
+                                const QRows q_fixed, const QRows q_rel, const int64_t* true_row,
                                 const float* q_true, int64_t q_head, int64_t q_tail,
                                 const FilterSpec& filter, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,

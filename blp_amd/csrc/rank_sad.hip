@@ -46,8 +46,8 @@ namespace blp {
 
 template <int D>
 __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
-                                                        const float* __restrict__ q_fixed,
-                                                        const float* __restrict__ q_rel, int64_t q_head, int64_t Q,
+                                                        const QRows q_fixed,
+                                                        const QRows q_rel, int64_t q_head, int64_t Q,
                                                         SadParams* __restrict__ partial) {
     SadRange range;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __
 // Query image (D/2 dwords per query, same packing) and the two signed thresholds {T_lo, T_hi}.
 // D/2 consecutive threads per query (32, 64 or 128: whole waves or half-waves).
 template <int D>
-__global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const float* __restrict__ q_fixed,
-                                                                   const float* __restrict__ q_rel, int64_t q_head,
+__global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const QRows q_fixed,
+                                                                   const QRows q_rel, int64_t q_head,
                                                                    int64_t Q, const float* __restrict__ key_true,
                                                                    const SadParams* __restrict__ p,
                                                                    unsigned* __restrict__ qimg,
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
 // gathered through per-lane pointers instead of being consecutive.  Same arithmetic as Scorer<TRANSE, *, D>::score.
 template <int D>
 __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __restrict__ table, int64_t ld,
-                                                              const float* __restrict__ q_fixed,
-                                                              const float* __restrict__ q_rel,
+                                                              const QRows q_fixed,
+                                                              const QRows q_rel,
                                                               const float* __restrict__ key_true, int64_t q_head,
                                                               const uint2* __restrict__ pairs,
                                                               const SadParams* __restrict__ params,
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __res
 // re-scored exactly.  When the pre-pass did not run (non-finite input, degenerate range) all tiles are.
 template <int D>
 __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __restrict__ table, int64_t n_rows,
-                                                               int64_t ld, const float* __restrict__ q_fixed,
-                                                               const float* __restrict__ q_rel,
+                                                               int64_t ld, const QRows q_fixed,
+                                                               const QRows q_rel,
                                                                const float* __restrict__ key_true, int64_t q_head,
                                                                int64_t Q, int words_per_query,
                                                                const unsigned* __restrict__ flags,
@@ -501,7 +501,7 @@ size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
 }
 
 template <int D>
-static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
+static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
                                 const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
                                 const FilterSpec& filter, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -561,8 +561,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     return err != hipSuccess ? err : hipGetLastError();
 }
 
-hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                               const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                               const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
                                int64_t q_tail, const FilterSpec& filter, int32_t* counts,
                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                hipEvent_t ev_stop) {

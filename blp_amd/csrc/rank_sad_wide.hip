@@ -71,8 +71,8 @@ __device__ __forceinline__ float transe_key_rt(const float* __restrict__ e, cons
 }
 
 __global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restrict__ table, int64_t ld, int D,
-                                                            const float* __restrict__ q_fixed,
-                                                            const float* __restrict__ q_rel,
+                                                            const QRows q_fixed,
+                                                            const QRows q_rel,
                                                             const int64_t* __restrict__ true_row,
                                                             const float* __restrict__ q_true, int64_t q_head, int64_t Q,
                                                             float* __restrict__ key_true,
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void wide_range_kernel(const float* __restrict__ table, int64_t N, int64_t ld, int D,
-                                                         const float* __restrict__ q_fixed,
-                                                         const float* __restrict__ q_rel, int64_t q_head, int64_t Q,
+                                                         const QRows q_fixed,
+                                                         const QRows q_rel, int64_t q_head, int64_t Q,
                                                          SadParams* __restrict__ partial) {
     SadRange range;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void wide_quantize_table_kernel(const float* _
 
 // One wave per query: its 2-byte image (Dp / 2 dwords) and the two thresholds; the first candidate slab's
 // flag bitmap is zeroed on the way.
-__global__ __launch_bounds__(256) void wide_quantize_queries_kernel(const float* __restrict__ q_fixed,
-                                                                    const float* __restrict__ q_rel, int64_t q_head,
+__global__ __launch_bounds__(256) void wide_quantize_queries_kernel(const QRows q_fixed,
+                                                                    const QRows q_rel, int64_t q_head,
                                                                     int64_t Q, int D, int Dp,
                                                                     const float* __restrict__ key_true,
                                                                     const SadParams* __restrict__ p,
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
 // whole cache lines and transposed through LDS (exact_coop.h: transe_key_64_rt) instead of every lane reading its
 // own three rows 16 bytes at a time.
 __global__ __launch_bounds__(64) void wide_refine_pairs_kernel(const float* __restrict__ table, int64_t ld, int D,
-                                                               const float* __restrict__ q_fixed,
-                                                               const float* __restrict__ q_rel,
+                                                               const QRows q_fixed,
+                                                               const QRows q_rel,
                                                                const float* __restrict__ key_true, int64_t q_head,
                                                                const uint2* __restrict__ pairs,
                                                                const SadParams* __restrict__ params,
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(64) void wide_refine_pairs_kernel(const float* __re
 
 // Pass 2b: one wave per query over its flagged 64-candidate tiles (all tiles when the pre-pass did not run).
 __global__ __launch_bounds__(256) void wide_refine_tiles_kernel(const float* __restrict__ table, int64_t n_rows,
-                                                                int64_t ld, int D, const float* __restrict__ q_fixed,
-                                                                const float* __restrict__ q_rel,
+                                                                int64_t ld, int D, const QRows q_fixed,
+                                                                const QRows q_rel,
                                                                 const float* __restrict__ key_true, int64_t q_head,
                                                                 int64_t Q, int words_per_query,
                                                                 const unsigned* __restrict__ flags,
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void wide_refine_tiles_kernel(const float* __r
 // Last kernel of a call (as rank_all.hip's filter_finalize_kernel, run-time width): a workgroup owns 64 queries, its
 // waves take the ones that have filter entries in turn, thread q writes query q's four counts.
 __global__ __launch_bounds__(256) void wide_filter_finalize_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
-                                                                   int D, const float* __restrict__ q_fixed,
-                                                                   const float* __restrict__ q_rel,
+                                                                   int D, const QRows q_fixed,
+                                                                   const QRows q_rel,
                                                                    const float* __restrict__ key_true, int64_t q_head,
                                                                    int64_t Q, const FilterSpec filter,
                                                                    const unsigned long long* __restrict__ acc,
@@ -492,8 +492,8 @@ size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head
     return carve_wide(nullptr, D, N, q_head + q_tail).bytes;
 }
 
-hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                                    const float* q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                                    const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
                                     int64_t q_tail, const FilterSpec& filter,
                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
                                     hipEvent_t ev_start, hipEvent_t ev_stop) {

@@ -193,8 +193,8 @@ __device__ unsigned long long g_small_timing[8];
 // the one-tile kernel (loop-invariant code motion out of that loop costs registers the common case needs).
 template <int MODEL, int D, bool MULTI>
 __global__ __launch_bounds__(kWaves * 64, 2) void rank_small_kernel(
-    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ q_fixed,
-    const float* __restrict__ q_rel, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles, int n_slots,
+    const float* __restrict__ table, int64_t N, int64_t ld, const QRows q_fixed,
+    const QRows q_rel, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles, int n_slots,
     int q_chunk, unsigned long long* __restrict__ partial) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
@@ -332,7 +332,7 @@ int rank_small_slots(int64_t N) {
 }
 
 template <int MODEL, int D>
-static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, const float* q_fixed, const float* q_rel,
+static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
                                   const float* key_true, int64_t q_head, int64_t q_tail, unsigned long long* partial, int n_cu,
                                   hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
@@ -359,8 +359,8 @@ static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, con
     return hipGetLastError();
 }
 
-hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, int64_t ld, const float* q_fixed,
-                             const float* q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
+hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+                             const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                              unsigned long long* partial, int n_cu, hipStream_t stream) {
 #define BLP_SMALL_CASE(M, DD) \
     case M * 1000 + DD: return rank_small_impl<M, DD>(table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, partial, n_cu, stream);

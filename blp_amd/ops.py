@@ -141,6 +141,51 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     return counts
 
 
+def rank_all_idx(rel_model, table, fixed_row, rel_emb, rel_ids, q_head, true_row, filter=None, out=None):
+    """rank_all with the queries left as INDICES (blp_rank_all_idx): query q's fixed-entity vector is row
+    ``fixed_row[q]`` of ``table``, its relation vector row ``rel_ids[q]`` of ``rel_emb`` (R, D) -- what the reference
+    gathers into ``ent_emb[tails]`` / ``rel_emb(rels)`` (train.py:141-145), un-gathered: no (Q, D) arrays are built or
+    streamed.  All indices must be in range (build_queries clamps and flags bad ids).  Same counts as rank_all."""
+    _require_device(table, fixed_row, rel_emb, rel_ids, true_row)
+    table = _f32_rows(table, "table")
+    rel_emb = _f32_rows(rel_emb, "rel_emb").contiguous()
+    N, D = table.shape
+    fixed_row = fixed_row.reshape(-1).to(torch.int64).contiguous()
+    rel_ids = rel_ids.reshape(-1).to(torch.int64).contiguous()
+    true_row = true_row.reshape(-1).to(torch.int64).contiguous()
+    Q = fixed_row.shape[0]
+    if rel_ids.shape[0] != Q or true_row.shape[0] != Q or rel_emb.shape[1] != D:
+        raise ValueError("fixed_row, rel_ids and true_row need one entry per query; rel_emb must be (R, D)")
+    if not 0 <= q_head <= Q:
+        raise ValueError(f"q_head = {q_head} outside [0, {Q}]")
+    dev = table.device
+    counts = out if out is not None else torch.empty((Q, 4), dtype=torch.int32, device=dev)
+    if counts.shape != (Q, 4) or counts.dtype != torch.int32 or not counts.is_contiguous():
+        raise ValueError("out must be a contiguous (Q, 4) int32 tensor")
+    if Q == 0:
+        return counts
+    L = _lib.lib()
+    model = _lib.MODEL_IDS[rel_model]
+    ws_bytes = L.blp_rank_all_workspace_bytes(model, N, D, q_head, Q - q_head)
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    spec = None
+    if filter is not None:
+        seg = [None if x is None else x.to(device=dev, dtype=torch.int64).contiguous()
+               for x in (filter.seg_lo, filter.seg_hi, filter.values, filter.exclude, filter.ent2idx)]
+        if seg[0].shape[0] != Q or seg[1].shape[0] != Q or (seg[3] is not None and seg[3].shape[0] != Q):
+            raise ValueError("SegmentFilter: seg_lo, seg_hi and exclude need one entry per query")
+        spec = ctypes.byref(_lib.BlpFilter(seg[0].data_ptr(), seg[1].data_ptr(),
+                                           seg[2].data_ptr() if seg[2].numel() else seg[0].data_ptr(),
+                                           None if seg[3] is None else seg[3].data_ptr(),
+                                           None if seg[4] is None else seg[4].data_ptr(),
+                                           0 if seg[4] is None else seg[4].shape[0], int(filter.row_base)))
+    status = L.blp_rank_all_idx(model, _ptr(table), N, D, table.stride(0) if N > 1 else D, _ptr(fixed_row), _ptr(rel_emb),
+                                rel_emb.shape[0], _ptr(rel_ids), _ptr(true_row), q_head, Q - q_head, spec, _ptr(counts),
+                                _ptr(workspace), ws_bytes, dev.index, _stream(dev))
+    _lib.check(status, "blp_rank_all_idx")
+    return counts
+
+
 def rank_from_scores(scores, true_idx=None, true_score=None, filt_rowptr=None, filt_col=None):
     """Counts (Q, 4) int32 from a dense (Q, N) score matrix on the device (utils.py:103-105 +
     train.py:159-167): the true entity as column index ``true_idx`` (Q,) or as score ``true_score`` (Q,)."""
@@ -196,26 +241,29 @@ def rank_metric_sums(counts, k_values=(1, 3, 10)):
 
 
 # ------------------------------------------------------------------------------- evaluation prelude
-QueryBlock = collections.namedtuple("QueryBlock", "q_fixed q_rel true_row rel_ids ids_min filter")
+QueryBlock = collections.namedtuple("QueryBlock", "q_fixed q_rel fixed_row true_row rel_ids ids_min filter")
 
 
-def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_base=0):
+def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_base=0, gather=True):
     """train.py:132-145 (+ utils.py:46-83 with ``index``) for a whole set of triples in one kernel (blp_build_queries).
 
     triples (n, 3) int64 rows (head id, tail id, relation id) on the table's device; ent2idx: id -> table row (-1: not a
     candidate) or None (ids are rows); table (N, D) f32; rel_emb (R, D) f32 (model.rel_emb.weight); queries come out
     block after block of ``block_size`` triples, each block as [head-replacing | tail-replacing] queries.
     index: a utils.FilterIndex -> ``filter`` is the SegmentFilter of all 2n queries (slice it per block).
-    Returns QueryBlock(q_fixed (2n, D), q_rel (2n, D), true_row (2n,), rel_ids (2n,), ids_min (0-dim int32: -1 if any
-    id had no row -- the reference's assertion train.py:137-138, left on the device), filter or None)."""
+    gather=False: no vectors are built (q_fixed = q_rel = None); rank_all_idx takes fixed_row / rel_ids instead.
+    Returns QueryBlock(q_fixed (2n, D), q_rel (2n, D), fixed_row (2n,), true_row (2n,), rel_ids (2n,), ids_min (0-dim
+    int32: -1 if any id had no row -- the reference's assertion train.py:137-138, left on the device), filter or
+    None)."""
     _require_device(triples, ent2idx, table, rel_emb)
     dev = table.device
     table = _f32_rows(table, "table")
     rel_emb = _f32_rows(rel_emb, "rel_emb").contiguous()
     triples = triples.to(torch.int64).contiguous()
     n, D = triples.shape[0], table.shape[1]
-    q_fixed = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
-    q_rel = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
+    q_fixed = torch.empty((2 * n, D), dtype=torch.float32, device=dev) if gather else None
+    q_rel = torch.empty((2 * n, D), dtype=torch.float32, device=dev) if gather else None
+    fixed_row = torch.empty(2 * n, dtype=torch.int64, device=dev)
     true_row = torch.empty(2 * n, dtype=torch.int64, device=dev)
     rel_ids = torch.empty(2 * n, dtype=torch.int64, device=dev)
     ids_min = torch.empty((), dtype=torch.int32, device=dev)
@@ -226,8 +274,9 @@ def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_
         a.ent2idx, a.ent2idx_len = ent2idx.data_ptr(), ent2idx.shape[0]
     a.source, a.src_rows, a.ld, a.D = table.data_ptr(), table.shape[0], table.stride(0) if table.shape[0] > 1 else D, D
     a.rel_emb, a.R = rel_emb.data_ptr(), rel_emb.shape[0]
-    a.q_fixed, a.q_rel, a.true_row, a.rel_ids, a.ids_min = (q_fixed.data_ptr(), q_rel.data_ptr(), true_row.data_ptr(),
-                                                            rel_ids.data_ptr(), ids_min.data_ptr())
+    if gather:
+        a.q_fixed, a.q_rel = q_fixed.data_ptr(), q_rel.data_ptr()
+    a.fixed_row, a.true_row, a.rel_ids, a.ids_min = fixed_row.data_ptr(), true_row.data_ptr(), rel_ids.data_ptr(), ids_min.data_ptr()
     filt = None
     if index is not None:
         heads_key, tails_key, values, n_head_vals = index.device_arrays(dev)
@@ -241,7 +290,7 @@ def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_
         filt = SegmentFilter(seg_lo, seg_hi, values, exclude, ent2idx, row_base)
     status = _lib.lib().blp_build_queries(ctypes.byref(a), dev.index, _stream(dev))
     _lib.check(status, "blp_build_queries")
-    return QueryBlock(q_fixed, q_rel, true_row, rel_ids, ids_min, filt)
+    return QueryBlock(q_fixed, q_rel, fixed_row, true_row, rel_ids, ids_min, filt)
 
 
 # ------------------------------------------------------------------------------- table build epilogue

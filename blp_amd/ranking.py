@@ -308,8 +308,10 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     # at the reference's Wikidata5M batching (2 triples per table pass) cost more than a sixth of the pass.
     if fused and not by_candidate and model.rel_emb.weight.dtype == torch.float32:
         # one kernel (blp_build_queries) instead of ~35 small torch kernels: lookups, gathers, binary searches
-        qb = ops.build_queries(triples[mine], ent2idx, table, model.rel_emb.weight, block_size, index=index)
-        q_fixed, q_rel, true_src, rel_ids, seg, q_true = qb.q_fixed, qb.q_rel, qb.true_row, qb.rel_ids, qb.filter, None
+        # ... and the queries stay INDICES into the table and rel_emb (blp_rank_all_idx): no (2n, D) arrays at all
+        qb = ops.build_queries(triples[mine], ent2idx, table, model.rel_emb.weight, block_size, index=index, gather=False)
+        q_fixed = q_rel = q_true = None
+        fixed_src, true_src, rel_ids, seg = qb.fixed_row, qb.true_row, qb.rel_ids, qb.filter
         ids_ok = qb.ids_min >= 0
     else:
         heads = ent2idx[triples[:, 0]]
@@ -356,6 +358,9 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
             filt = dict(filt_rowptr=rowptr, filt_col=col)
         if by_candidate:
             ranker.rank_block(q_fixed[sl], q_rel[sl], q_true[sl], b, rel_ids=rel_ids[sl], **filt)
+        elif q_fixed is None:
+            ops.rank_all_idx(model.rel_model, table, fixed_src[sl], model.rel_emb.weight, rel_ids[sl], b, true_src[sl],
+                             filter=filt.get("filter"), out=counts[sl])
         else:
             rank_block(model, table, q_fixed[sl], q_rel[sl], b, true_row=true_src[sl], rel_ids=rel_ids[sl], out=counts[sl],
                        **filt)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 202 /* major*10000 + minor*100 + patch */
+#define BLP_HIP_VERSION 203 /* major*10000 + minor*100 + patch */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -144,6 +144,18 @@ int blp_rank_all_ex(int model, const float *table, int64_t N, int D, int64_t ld,
                     const float *q_true, int64_t q_head, int64_t q_tail, const blp_filter *filter,
                     int32_t *counts, void *workspace, size_t workspace_bytes, int device, void *stream);
 
+/* The same with the queries given as INDICES instead of vectors: query q's fixed-entity vector is row fixed_row[q] of
+ * `table` itself, its relation vector row rel_id[q] of rel_emb (R, D) f32 contiguous -- exactly what the reference
+ * gathers, `ent_emb[tails]` / `ent_emb[heads]` / `rel_emb(rels)` (train.py:141-145), left un-gathered.  No (Q, D) query
+ * arrays exist: the prep, true-key, refinement and filter kernels read the rows out of the cache-resident tables
+ * instead of streaming 2 x Q x D x 4 bytes each.  Same arithmetic, same counts.  The true entity is a row
+ * (true_row).  fixed_row / rel_id / true_row (Q,) int64 on the device, every entry in range -- the library cannot
+ * check device data (blp_build_queries clamps and flags bad ids). */
+int blp_rank_all_idx(int model, const float *table, int64_t N, int D, int64_t ld, const int64_t *fixed_row,
+                     const float *rel_emb, int64_t R, const int64_t *rel_id, const int64_t *true_row,
+                     int64_t q_head, int64_t q_tail, const blp_filter *filter, int32_t *counts,
+                     void *workspace, size_t workspace_bytes, int device, void *stream);
+
 /* Measurement aid (bench.py): the NEXT blp_rank_all issued by the calling thread records the two
  * hipEvent_t (created by the caller with timing enabled) on its stream immediately before and after
  * the rank pass (rank_tiles, or pre-pass + refinement), so its duration can be read without a profiler.  One-shot;
@@ -251,10 +263,12 @@ int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, co
  *   source       (src_rows, D) f32, row stride ld: the entity table;  rel_emb (R, D) f32 contiguous
  *   heads_key / tails_key  sorted keys entity * index_R + relation of the filtering graph's (tail, rel) -> heads and
  *                (head, rel) -> tails indices (blp_amd.utils.FilterIndex); both NULL: no filter outputs
- * Outputs (2n rows each): q_fixed, q_rel (2n, D) f32; true_row, rel_ids int64; seg_lo / seg_hi: the query's slice of
- * the caller's value array [heads' values | tails' values] (tail-side slices are offset by n_heads); exclude: the
- * triple's own entity id; *ids_min: 0, or -1 if any id has no row / any relation is outside [0, R) (such queries get
- * zero vectors and true_row -1: the caller must check before ranking, as train.py:137-138 asserts).
+ * Outputs (2n rows each): q_fixed, q_rel (2n, D) f32 (both NULL: no vectors are gathered -- blp_rank_all_idx takes
+ * fixed_row / rel_ids instead); fixed_row, true_row, rel_ids int64 (fixed_row may be NULL); seg_lo / seg_hi: the
+ * query's slice of the caller's value array [heads' values | tails' values] (tail-side slices are offset by n_heads);
+ * exclude: the triple's own entity id; *ids_min: 0, or -1 if any id has no row / any relation is outside [0, R) (such
+ * queries get zero vectors and rows / relation 0: the caller must check before trusting the counts, as
+ * train.py:137-138 asserts).
  * D % 4 == 0; 16-byte aligned source / rel_emb / q_fixed / q_rel; ld % 4 == 0.
  * -------------------------------------------------------------------------------------------- */
 typedef struct blp_queries {
@@ -267,6 +281,7 @@ typedef struct blp_queries {
     int64_t index_R;
     float *q_fixed; float *q_rel; int64_t *true_row; int64_t *rel_ids; int32_t *ids_min;
     int64_t *seg_lo; int64_t *seg_hi; int64_t *exclude;
+    int64_t *fixed_row;
 } blp_queries;
 int blp_build_queries(const blp_queries *q, int device, void *stream);
 

@@ -412,6 +412,7 @@ def test_build_queries_equals_the_torch_prelude(n, block, D):
         rel = rel_emb[triples[t, 2].cuda()]
         assert torch.equal(qb.q_rel[hs], rel) and torch.equal(qb.q_rel[ts], rel)
         assert torch.equal(qb.true_row[hs], heads[t]) and torch.equal(qb.true_row[ts], tails[t])
+        assert torch.equal(qb.fixed_row[hs], tails[t]) and torch.equal(qb.fixed_row[ts], heads[t])
         assert torch.equal(qb.rel_ids[hs].cpu(), triples[t, 2]) and torch.equal(qb.rel_ids[ts].cpu(), triples[t, 2])
         for name in ("seg_lo", "seg_hi", "exclude"):
             want = getattr(seg_all, name)
@@ -419,6 +420,11 @@ def test_build_queries_equals_the_torch_prelude(n, block, D):
             assert torch.equal(got[hs], want[first: first + nb]) and torch.equal(got[ts], want[n + first: n + first + nb]), name
         pos += 2 * nb
     assert torch.equal(qb.filter.values, seg_all.values)
+    qi = ops.build_queries(triples.cuda(), ent2idx, table, rel_emb, block, index=index, gather=False)   # index form
+    assert qi.q_fixed is None and qi.q_rel is None
+    for name in ("fixed_row", "true_row", "rel_ids"):
+        assert torch.equal(getattr(qi, name), getattr(qb, name)), name
+    assert torch.equal(qi.filter.seg_lo, qb.filter.seg_lo) and torch.equal(qi.filter.seg_hi, qb.filter.seg_hi)
     bad = triples.clone()
     bad[n // 2, 0] = int((ent2idx < 0).nonzero()[0])            # an entity id that is not a candidate
     assert int(ops.build_queries(bad.cuda(), ent2idx, table, rel_emb, block).ids_min) == -1
@@ -428,3 +434,41 @@ def test_build_queries_equals_the_torch_prelude(n, block, D):
     bad = triples.clone()
     bad[0, 2] = R
     assert int(ops.build_queries(bad.cuda(), ent2idx, table, rel_emb, block).ids_min) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rel_model,D,n,N", [("transe", 128, 40, 900), ("transe", 128, 700, 900), ("transe", 64, 300, 2000),
+                                              ("transe", 300, 400, 700), ("transe", 768, 200, 500), ("transe", 256, 90, 800),
+                                              ("distmult", 128, 40, 900), ("distmult", 128, 500, 1500), ("complex", 64, 333, 1000),
+                                              ("simple", 128, 257, 1200), ("complex", 256, 70, 600)])
+def test_rank_all_idx_equals_rank_all_on_gathered_vectors(rel_model, D, n, N, knobs):
+    """blp_rank_all_idx (queries as rows of the table / of rel_emb, nothing gathered) == blp_rank_all_ex on the gathered
+    vectors, through every kernel family (small-block kernel, exact tiles, fixed-point pre-pass at 64 / 128 / 256 and
+    any width, bf16 x 3 GEMM), with the segment filter; and == the CPU oracle on the gathered vectors."""
+    from blp_amd import ops, utils
+    from oracle import oracle as orc
+    g = torch.Generator().manual_seed(n + D)
+    table = torch.randn(N, D, generator=g)
+    table = torch.nn.functional.normalize(table, dim=-1) if rel_model == "transe" else table * 0.1
+    rel_emb = (torch.rand(13, D, generator=g) - 0.5) * 0.25
+    ent2idx = torch.arange(N)
+    triples = torch.stack((torch.randint(0, N, (n,), generator=g), torch.randint(0, N, (n,), generator=g),
+                           torch.randint(0, 13, (n,), generator=g)), dim=1)
+    edges = torch.cat((triples, torch.stack((torch.randint(0, N, (5000,), generator=g), torch.randint(0, N, (5000,), generator=g),
+                                             torch.randint(0, 13, (5000,), generator=g)), dim=1)))
+    index = utils.FilterIndex(edges, num_relations=13)
+    dt, dr = table.cuda(), rel_emb.cuda()
+    for routing in ({}, {"small_kernel": 2, "sad_min_queries": 64}):
+        for k, v in routing.items():
+            knobs(k, v)
+        qb = ops.build_queries(triples.cuda(), ent2idx.cuda(), dt, dr, 1 << 20, index=index)
+        dense = ops.rank_all(rel_model, dt, qb.q_fixed, qb.q_rel, n, true_row=qb.true_row, filter=qb.filter)
+        idx = ops.rank_all_idx(rel_model, dt, qb.fixed_row, dr, qb.rel_ids, n, qb.true_row, filter=qb.filter)
+        assert torch.equal(idx, dense), routing
+    rowptr, col = index.csr(triples, ent2idx)
+    want = np.concatenate([
+        orc.rank_counts(rel_model, side, table.numpy(), qb.q_fixed[sl].cpu().numpy(), qb.q_rel[sl].cpu().numpy(),
+                        true_row=qb.true_row[sl].cpu().numpy(), filt_rowptr=(rowptr[lo:hi + 1] - rowptr[lo]).numpy(),
+                        filt_col=col[rowptr[lo]:rowptr[hi]].numpy())
+        for side, sl, lo, hi in ((orc.SIDE_HEAD, slice(0, n), 0, n), (orc.SIDE_TAIL, slice(n, 2 * n), n, 2 * n))])
+    assert np.array_equal(idx.cpu().numpy(), want)
