@@ -401,8 +401,12 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
     __shared__ __attribute__((aligned(16))) float slabs[MODEL == TRANSE ? 4 * 64 * kRefStride : 4];
     const int64_t Q = q_head + q_tail, q_base = (int64_t)blockIdx.x * kSweepQueries;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ const float* frow[kSweepQueries];  // the queries' two vectors: looked up once (indexed queries: a
+    __shared__ const float* rrow[kSweepQueries];  // dependent load each), not once per filter entry
     if (threadIdx.x < 64) {
         const int64_t q = q_base + lane;
+        frow[lane] = q_fixed + (q < Q ? q : 0) * D;
+        rrow[lane] = q_rel + (q < Q ? q : 0) * D;
         int n = q < Q ? (int)(filter.hi[q] - filter.lo[q]) : 0;
         n = n > 0 ? n : 0;
         removed[lane][0] = removed[lane][1] = 0;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             int slot = 0;
             if (x < total) locate(x, q, row, slot);
             const bool live = row >= 0, head = q < q_head;
-            const float key = transe_key_64<D>(table + (live ? row : 0) * ld, q_fixed + q * D, q_rel + q * D, head, slab, lane);
+            const float key = transe_key_64<D>(table + (live ? row : 0) * ld, frow[slot], rrow[slot], head, slab, lane);
             const float kt = key_true[q];
             if (live && key > kt) atomicAdd(&removed[slot][0], 1u);
             if (live && key >= kt) atomicAdd(&removed[slot][1], 1u);
@@ -451,8 +455,8 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             const bool live = row >= 0, head = q < q_head;
             const float* e = table + (live ? row : 0) * ld;
             float key;
-            if (head) key = coop_score<MODEL, HEAD, D>(e, q_fixed + q * D, q_rel + q * D, sub);
-            else key = coop_score<MODEL, TAIL, D>(e, q_fixed + q * D, q_rel + q * D, sub);
+            if (head) key = coop_score<MODEL, HEAD, D>(e, frow[slot], rrow[slot], sub);
+            else key = coop_score<MODEL, TAIL, D>(e, frow[slot], rrow[slot], sub);
             const float kt = key_true[q];
             if (sub == 0 && live && key > kt) atomicAdd(&removed[slot][0], 1u);
             if (sub == 0 && live && key >= kt) atomicAdd(&removed[slot][1], 1u);

@@ -95,7 +95,13 @@ __global__ __launch_bounds__(256) void wide_range_kernel(const float* __restrict
         const float4 v = *reinterpret_cast<const float4*>(table + (i / quads) * ld + (i % quads) * 4);
         range.see(v.x); range.see(v.y); range.see(v.z); range.see(v.w);
     }
-    for (int64_t i = t0; i < Q * D; i += stride) range.see(sad_coef(q_fixed[i], q_rel[i], i / D < q_head));
+    for (int64_t u = t0; u < Q * quads; u += stride) {  // four coefficients per step: one row lookup each side
+        const bool head = u / quads < q_head;
+        const float4 f = *reinterpret_cast<const float4*>(q_fixed + 4 * u);
+        const float4 r = *reinterpret_cast<const float4*>(q_rel + 4 * u);
+        range.see(sad_coef(f.x, r.x, head)); range.see(sad_coef(f.y, r.y, head));
+        range.see(sad_coef(f.z, r.z, head)); range.see(sad_coef(f.w, r.w, head));
+    }
     sad_range_block_store(range, partial);
 }
 
