@@ -67,23 +67,42 @@ __global__ void prep_coef_kernel(const QRows q_fixed, const QRows q_rel,
     }
 }
 
-// One lane per query: the true entity's key by the same Scorer<> routine as every other exact key (identical
-// rounding by construction), the query's coefficients computed in place; the query's accumulator starts at zero.
+// The true entities' keys, by the cooperative exact routines of exact_coop.h (operation for operation the Scorer<>
+// arithmetic: the same routines re-score the undecided pairs, whose keys are compared with these for ties).  A wave of
+// 64 queries: TransE one lane per query with the three rows of every query fetched 8 rows x 128 B per instruction and
+// transposed through LDS; the bilinear models 32 lanes per query, four queries per (one-wave) workgroup.  (One lane per query loading
+// its own rows 16 bytes at a time: 96 load instructions x 64 cache lines each -- 28 us for the FB15k-237 test set.)
+// The queries' accumulators start at zero.
+__host__ __device__ constexpr int true_key_queries_per_block(int model) { return model == TRANSE ? 64 : 4; }
 template <int MODEL, int D>
 __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ table, int64_t ld,
                                 const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc) {
-    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (q >= q_head + q_tail) return;
-    acc[q] = 0;
-    float e[D];
-    load_row<D>(e, true_row ? table + true_row[q] * ld : q_true + q * D);
-    const float* f = q_fixed + q * D;
-    const float* r = q_rel + q * D;
-    key_true[q] = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r})
-                             : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
+    constexpr int QB = true_key_queries_per_block(MODEL);
+    const int64_t Q = q_head + q_tail, q0 = blockIdx.x * (int64_t)QB;
+    const int lane = threadIdx.x;
+    if (lane < QB && q0 + lane < Q) acc[q0 + lane] = 0;
+    auto true_vec = [&](int64_t q) { return true_row ? table + true_row[q] * ld : q_true + q * D; };
+    if constexpr (MODEL == TRANSE) {
+        __shared__ __attribute__((aligned(16))) float slab[64 * kRefStride];
+        const int64_t q = q0 + lane < Q ? q0 + lane : Q - 1;
+        // (the run-time-width routine: its chunk loop is not unrolled -- unrolled, the compiler hoists every chunk's
+        //  24 row loads to the top, 390 registers at D = 128 and spills at 256)
+        const float key = transe_key_64_rt(true_vec(q), q_fixed + q * D, q_rel + q * D, D, q < q_head, slab, lane);
+        if (q0 + lane < Q) key_true[q] = key;
+    } else {
+        const int half = lane >> 5, sub = lane & 31;
+        for (int i = 0; i < QB / 2; ++i) {  // wave-uniform
+            const int64_t qq = q0 + 2 * i + half, q = qq < Q ? qq : Q - 1;
+            const float* e = true_vec(q);
+            const float* f = q_fixed + q * D;
+            const float* r = q_rel + q * D;
+            const float key = q < q_head ? coop_score<MODEL, HEAD, D>(e, f, r, sub) : coop_score<MODEL, TAIL, D>(e, f, r, sub);
+            if (sub == 0 && qq < Q) key_true[qq] = key;
+        }
+    }
 }
 
 // Stage `count` floats (a multiple of 4, at most 2 * 4 * 256) from global memory into LDS with
@@ -593,7 +612,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
     if (rank_small_applicable(MODEL, D, N, q_head, q_tail)) {  // small block: 3 launches, no coefficient array
         const int slots = rank_small_slots(N);
         RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail, slots);
-        true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(
+        true_key_kernel<MODEL, D><<<(unsigned)((Q + true_key_queries_per_block(MODEL) - 1) / true_key_queries_per_block(MODEL)), 64, 0, stream>>>(
             table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc);
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, w.acc, n_cu, stream);
@@ -608,7 +627,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         const int64_t blocks = (total + 255) / 256;
         const int grid = (int)(blocks < 8192 ? blocks : 8192);
         prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail);
-        true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(
+        true_key_kernel<MODEL, D><<<(unsigned)((Q + true_key_queries_per_block(MODEL) - 1) / true_key_queries_per_block(MODEL)), 64, 0, stream>>>(
             table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc);
     }
 
@@ -714,7 +733,7 @@ static hipError_t true_keys_impl(const QRows q_fixed, const QRows q_rel, int64_t
                                  const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
                                  float* key_true, unsigned long long* acc, hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
-    true_key_kernel<MODEL, D><<<(int)((Q + 63) / 64), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail,
+    true_key_kernel<MODEL, D><<<(unsigned)((Q + true_key_queries_per_block(MODEL) - 1) / true_key_queries_per_block(MODEL)), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail,
                                                                         key_true, acc);
     return hipGetLastError();
 }
