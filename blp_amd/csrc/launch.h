@@ -16,25 +16,22 @@ namespace blp {
 // The query vectors of a block, q_fixed / q_rel, are (Q, D) row arrays -- either DENSE (row q = base + q * D) or INDEXED
 // (row q = base + idx[q] * ld: the fixed-entity vector is a row of the entity table, the relation vector a row of
 // rel_emb).  Indexed queries cost no gather and no 2 x Q x D x 4 bytes that every prep / true-key / refinement /
-// filter kernel would stream again; their rows come out of L2 instead.  Kernels address both forms as
-// `q_fixed + q * D` (and flat `q_fixed[q * D + c]`): operator+ takes the FLAT offset of the dense form.
+// filter kernel would stream again; their rows come out of L2 instead.  Kernels address both forms through row(q)
+// (and flat(offset, D) for the few element-wise sweeps, D the caller's -- usually compile-time -- width).
 struct QRows {
     const float* base = nullptr;
     const int64_t* idx = nullptr;  // NULL: dense
     int64_t ld = 0;                // row stride in floats (dense: D)
-    int D = 0, shift = -1;         // shift: log2(D) if D is a power of two (the division below is then a shift)
-    __host__ __device__ const float* operator+(int64_t off) const {
-        const int64_t q = shift >= 0 ? off >> shift : off / D;
-        return base + (idx ? idx[q] : q) * ld + (off - q * D);
+    __host__ __device__ const float* row(int64_t q) const { return base + (idx ? idx[q] : q) * ld; }
+    __host__ __device__ const float* flat(int64_t off, int D) const {
+        const int64_t q = off / D;
+        return row(q) + (off - q * D);
     }
-    __host__ __device__ float operator[](int64_t off) const { return *(*this + off); }
-    static QRows dense(const float* p, int D) { return make(p, nullptr, D, D); }
-    static QRows rows_of(const float* table, const int64_t* idx, int64_t ld, int D) { return make(table, idx, ld, D); }
-    static QRows make(const float* p, const int64_t* idx, int64_t ld, int D) {
+    static QRows dense(const float* p, int D) { return make(p, nullptr, D); }
+    static QRows rows_of(const float* table, const int64_t* idx, int64_t ld) { return make(table, idx, ld); }
+    static QRows make(const float* p, const int64_t* idx, int64_t ld) {
         QRows r;
-        r.base = p; r.idx = idx; r.ld = ld; r.D = D;
-        r.shift = -1;
-        for (int s = 0; s < 31; ++s) if ((1 << s) == D) r.shift = s;
+        r.base = p; r.idx = idx; r.ld = ld;
         return r;
     }
 };

@@ -59,10 +59,10 @@ __global__ void prep_coef_kernel(const QRows q_fixed, const QRows q_rel,
          i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n_head) {
             const int64_t q = i / SH::C;
-            coef_head[i] = SH::coef(q_fixed + q * D, q_rel + q * D, (int)(i % SH::C));
+            coef_head[i] = SH::coef(q_fixed.row(q), q_rel.row(q), (int)(i % SH::C));
         } else {
             const int64_t k = i - n_head, q = k / ST::C;
-            coef_tail[k] = ST::coef(q_fixed + (q_head + q) * D, q_rel + (q_head + q) * D, (int)(k % ST::C));
+            coef_tail[k] = ST::coef(q_fixed.row(q_head + q), q_rel.row(q_head + q), (int)(k % ST::C));
         }
     }
 }
@@ -90,18 +90,55 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
         const int64_t q = q0 + lane < Q ? q0 + lane : Q - 1;
         // (the run-time-width routine: its chunk loop is not unrolled -- unrolled, the compiler hoists every chunk's
         //  24 row loads to the top, 390 registers at D = 128 and spills at 256)
-        const float key = transe_key_64_rt(true_vec(q), q_fixed + q * D, q_rel + q * D, D, q < q_head, slab, lane);
+        const float key = transe_key_64_rt(true_vec(q), q_fixed.row(q), q_rel.row(q), D, q < q_head, slab, lane);
         if (q0 + lane < Q) key_true[q] = key;
     } else {
         const int half = lane >> 5, sub = lane & 31;
         for (int i = 0; i < QB / 2; ++i) {  // wave-uniform
             const int64_t qq = q0 + 2 * i + half, q = qq < Q ? qq : Q - 1;
             const float* e = true_vec(q);
-            const float* f = q_fixed + q * D;
-            const float* r = q_rel + q * D;
+            const float* f = q_fixed.row(q);
+            const float* r = q_rel.row(q);
             const float key = q < q_head ? coop_score<MODEL, HEAD, D>(e, f, r, sub) : coop_score<MODEL, TAIL, D>(e, f, r, sub);
             if (sub == 0 && qq < Q) key_true[qq] = key;
         }
+    }
+}
+
+// Few queries: latency, not throughput, is what a true-key launch costs, and one lane per query with all 96 of its
+// row loads in flight at once is a single memory round trip (the cooperative kernel above walks four chunks one after
+// the other: 128-query call 40 -> 49 us when it replaced this one outright).  Same Scorer<> arithmetic, bit for bit.
+template <int MODEL, int D>
+__global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restrict__ table, int64_t ld,
+                                const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
+                                const QRows q_fixed, const QRows q_rel,
+                                int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
+                                unsigned long long* __restrict__ acc) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= q_head + q_tail) return;
+    acc[q] = 0;
+    float e[D];
+    load_row<D>(e, true_row ? table + true_row[q] * ld : q_true + q * D);
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
+    key_true[q] = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r})
+                             : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
+}
+
+constexpr int64_t kTrueKeyLaneMaxQueries = 2048;
+
+template <int MODEL, int D>
+static void launch_true_key(const float* table, int64_t ld, const int64_t* true_row, const float* q_true, const QRows& q_fixed,
+                            const QRows& q_rel, int64_t q_head, int64_t q_tail, float* key_true, unsigned long long* acc,
+                            hipStream_t stream) {
+    const int64_t Q = q_head + q_tail;
+    if (Q <= kTrueKeyLaneMaxQueries) {
+        true_key_lane_kernel<MODEL, D><<<(unsigned)((Q + 63) / 64), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel,
+                                                                                      q_head, q_tail, key_true, acc);
+    } else {
+        constexpr int QB = true_key_queries_per_block(MODEL);
+        true_key_kernel<MODEL, D><<<(unsigned)((Q + QB - 1) / QB), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel,
+                                                                                     q_head, q_tail, key_true, acc);
     }
 }
 
@@ -424,8 +461,8 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
     __shared__ const float* rrow[kSweepQueries];  // dependent load each), not once per filter entry
     if (threadIdx.x < 64) {
         const int64_t q = q_base + lane;
-        frow[lane] = q_fixed + (q < Q ? q : 0) * D;
-        rrow[lane] = q_rel + (q < Q ? q : 0) * D;
+        frow[lane] = q_fixed.row(q < Q ? q : 0);
+        rrow[lane] = q_rel.row(q < Q ? q : 0);
         int n = q < Q ? (int)(filter.hi[q] - filter.lo[q]) : 0;
         n = n > 0 ? n : 0;
         removed[lane][0] = removed[lane][1] = 0;
@@ -612,8 +649,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
     if (rank_small_applicable(MODEL, D, N, q_head, q_tail)) {  // small block: 3 launches, no coefficient array
         const int slots = rank_small_slots(N);
         RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail, slots);
-        true_key_kernel<MODEL, D><<<(unsigned)((Q + true_key_queries_per_block(MODEL) - 1) / true_key_queries_per_block(MODEL)), 64, 0, stream>>>(
-            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc);
+        launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream);
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, w.acc, n_cu, stream);
         if (err != hipSuccess) return err;
@@ -627,8 +663,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         const int64_t blocks = (total + 255) / 256;
         const int grid = (int)(blocks < 8192 ? blocks : 8192);
         prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail);
-        true_key_kernel<MODEL, D><<<(unsigned)((Q + true_key_queries_per_block(MODEL) - 1) / true_key_queries_per_block(MODEL)), 64, 0, stream>>>(
-            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc);
+        launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream);
     }
 
     if (N > 0) {
@@ -733,8 +768,7 @@ static hipError_t true_keys_impl(const QRows q_fixed, const QRows q_rel, int64_t
                                  const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
                                  float* key_true, unsigned long long* acc, hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
-    true_key_kernel<MODEL, D><<<(unsigned)((Q + true_key_queries_per_block(MODEL) - 1) / true_key_queries_per_block(MODEL)), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail,
-                                                                        key_true, acc);
+    launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, stream);
     return hipGetLastError();
 }
 

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void prep_gemm_kernel(const QRows q_fixed,
     const int64_t q_local = tile * kGQT + ql;
     const bool q_ok = q_local < n_side;
     const int64_t q = (head ? 0 : q_head) + (q_ok ? q_local : n_side - 1);
-    const float* f = q_fixed + q * D;
-    const float* r = q_rel + q * D;
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
     float bsq = 0.f;
     for (int i = 0; i < D / 32; ++i) {
 #pragma unroll
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const QRows q_fixed
     const int64_t q_local = tile * kGQT + ql;
     const bool q_ok = q_local < n_side;
     const int64_t q = (head ? 0 : q_head) + (q_ok ? q_local : n_side - 1);
-    const float* f = q_fixed + q * D;
-    const float* r = q_rel + q * D;
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
     float bsq = 0.f, bmax = 0.f;
     bool bad = false;
     for (int i = 0; i < D / 32; ++i) {
@@ -863,8 +863,8 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
         const int64_t row0 = (int64_t)(p.y >> 16) * kGCT;
         unsigned und = live ? p.y & 0xffffu : 0u;
         const bool is_head = q < q_head;
-        const float* f = q_fixed + q * D;
-        const float* r = q_rel + q * D;
+        const float* f = q_fixed.row(q);
+        const float* r = q_rel.row(q);
         const float kt = key_true[q];
         unsigned gt = 0, ge = 0;
         while (__ballot(und != 0)) {  // the halves walk their own masks; an exhausted half idles
@@ -898,8 +898,8 @@ __global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __r
     float e[D];
     load_row<D>(e, table + (int64_t)p.y * ld);
     float key;
-    const float* f = q_fixed + q * D;
-    const float* r = q_rel + q * D;
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
     if (q < q_head) key = Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r});
     else key = Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
     const float kt = key_true[q];
@@ -924,8 +924,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
     const int64_t q = q_base + list[i];
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
-    const float* f = q_fixed + q * D;
-    const float* rl = q_rel + q * D;
+    const float* f = q_fixed.row(q);
+    const float* rl = q_rel.row(q);
     unsigned gt = 0, ge = 0;
     for (int w0 = 0; w0 < words_per_query; w0 += 64) {
         const unsigned mine = w0 + lane < words_per_query ? row[w0 + lane] : 0u;

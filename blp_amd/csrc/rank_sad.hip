@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict_
     }
     for (int64_t u = t0; u < Q * (D / 4); u += stride) {  // four coefficients per step: one row lookup each side
         const bool head = u / (D / 4) < q_head;
-        const float4 f = *reinterpret_cast<const float4*>(q_fixed + 4 * u);
-        const float4 r = *reinterpret_cast<const float4*>(q_rel + 4 * u);
+        const float4 f = *reinterpret_cast<const float4*>(q_fixed.flat(4 * u, D));
+        const float4 r = *reinterpret_cast<const float4*>(q_rel.flat(4 * u, D));
         range.see(sad_coef(f.x, r.x, head)); range.see(sad_coef(f.y, r.y, head));
         range.see(sad_coef(f.z, r.z, head)); range.see(sad_coef(f.w, r.w, head));
     }
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const QRows q
     float res = 0.f, qmax = 0.f;  // qmax: the query's largest |fixed|, |rel| (its share of the rounding term rho)
     bool outside = false;         // a coefficient the map does not cover: the query is left to the exact path
     if (live) {
-        const float2 f = *reinterpret_cast<const float2*>(q_fixed + 2 * i);
-        const float2 r = *reinterpret_cast<const float2*>(q_rel + 2 * i);
+        const float2 f = *reinterpret_cast<const float2*>(q_fixed.flat(2 * i, D));
+        const float2 r = *reinterpret_cast<const float2*>(q_rel.flat(2 * i, D));
         unsigned w = sad_quant(sad_coef(f.x, r.x, head), sc, res, outside);
         w |= sad_quant(sad_coef(f.y, r.y, head), sc, res, outside) << 16;
         qimg[i] = w;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __res
         const bool live = p.x != kSNoPair;
         const int64_t q = live ? p.x : 0;
         const bool head = q < q_head;
-        const float key = transe_key_64<D>(table + (live ? (int64_t)p.y : 0) * ld, q_fixed + q * D, q_rel + q * D, head, slab, lane);
+        const float key = transe_key_64<D>(table + (live ? (int64_t)p.y : 0) * ld, q_fixed.row(q), q_rel.row(q), head, slab, lane);
         const float kt = key_true[q];
         const unsigned long long gt = live && key > kt, ge_ = live && key >= kt;
         if (gt | ge_) atomicAdd(acc + q, gt | (ge_ << 32));
@@ -372,8 +372,8 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
     const int64_t q = q_base + list[i];
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
-    const float* f = q_fixed + q * D;
-    const float* rl = q_rel + q * D;
+    const float* f = q_fixed.row(q);
+    const float* rl = q_rel.row(q);
     unsigned gt = 0, ge = 0;
     for (int w0 = 0; w0 < words_per_query; w0 += 64) {
         const unsigned mine = w0 + lane < words_per_query ? (all ? 0xFFFFFFFFu : row[w0 + lane]) : 0u;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restr
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
     const float* e = true_row ? table + true_row[q] * ld : q_true + q * D;
-    key_true[q] = transe_key_rt(e, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+    key_true[q] = transe_key_rt(e, q_fixed.row(q), q_rel.row(q), D, q < q_head);
     acc[q] = 0;
 }
 
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256) void wide_range_kernel(const float* __restrict
     }
     for (int64_t u = t0; u < Q * quads; u += stride) {  // four coefficients per step: one row lookup each side
         const bool head = u / quads < q_head;
-        const float4 f = *reinterpret_cast<const float4*>(q_fixed + 4 * u);
-        const float4 r = *reinterpret_cast<const float4*>(q_rel + 4 * u);
+        const float4 f = *reinterpret_cast<const float4*>(q_fixed.flat(4 * u, D));
+        const float4 r = *reinterpret_cast<const float4*>(q_rel.flat(4 * u, D));
         range.see(sad_coef(f.x, r.x, head)); range.see(sad_coef(f.y, r.y, head));
         range.see(sad_coef(f.z, r.z, head)); range.see(sad_coef(f.w, r.w, head));
     }
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void wide_quantize_queries_kernel(const QRows 
     if (q >= Q) return;
     const int lane = threadIdx.x & 63;
     const bool head = q < q_head;
-    const float* f = q_fixed + q * D;
-    const float* r = q_rel + q * D;
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
     float res = 0.f, qmax = 0.f;
     bool outside = false;  // a coefficient the map does not cover: the query is left to the exact path
     for (int j = lane; j < Dp / 2; j += 64) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void wide_refine_pairs_kernel(const float* __re
         const uint2 p = i < n ? pairs[i] : make_uint2(kSNoPair, 0u);
         const bool live = p.x != kSNoPair;
         const int64_t q = live ? p.x : 0;
-        const float key = transe_key_64_rt(table + (live ? (int64_t)p.y : 0) * ld, q_fixed + q * D, q_rel + q * D, D,
+        const float key = transe_key_64_rt(table + (live ? (int64_t)p.y : 0) * ld, q_fixed.row(q), q_rel.row(q), D,
                                            q < q_head, slab, lane);
         const float kt = key_true[q];
         const unsigned long long gt = live && key > kt, ge = live && key >= kt;
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void wide_refine_tiles_kernel(const float* __r
     const int64_t q = q_base + list[i];
     const unsigned* row = flags + q * words_per_query;
     const float kt = key_true[q];
-    const float* f = q_fixed + q * D;
-    const float* r = q_rel + q * D;
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
     const bool head = q < q_head;
     unsigned gt = 0, ge = 0;
     for (int w0 = 0; w0 < words_per_query; w0 += 64) {
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void wide_filter_finalize_kernel(const float* 
         for (int64_t k = filter.lo[q] + lane; k < filter.hi[q]; k += 64) {
             const int64_t row = filter_row(filter, q, k, N);
             if (row < 0) continue;
-            const float key = transe_key_rt(table + row * ld, q_fixed + q * D, q_rel + q * D, D, q < q_head);
+            const float key = transe_key_rt(table + row * ld, q_fixed.row(q), q_rel.row(q), D, q < q_head);
             gt += key > kt;
             ge += key >= kt;
         }

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void rank_small_kernel(
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int j = j0 + k * QPP + jo, q = q0 + (j < nr ? j : nr - 1);
-                const float* f = q_fixed + (size_t)q * D;
-                const float* r = q_rel + (size_t)q * D;
+                const float* f = q_fixed.row(q);
+                const float* r = q_rel.row(q);
                 v[k] = 0.0f;
                 if (q < q_head) { if (i < SH::C) v[k] = SH::coef(f, r, i); }
                 else            { if (i < ST::C) v[k] = ST::coef(f, r, i); }
