@@ -252,9 +252,11 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
         sdrain(cur);
         unsigned cnt_reg = 0;  // lane j: certainly-above count of query q0 + j for this wave's tile
         unsigned long long bit = 1;
+        unsigned carried = first ? bias : psum[wave][0][lane];  // the next query's partial SAD, read one query ahead
         for (int j = 0; j < nq; ++j, row += row_dwords, bit <<= 1) {
             const float* next_row = row + row_dwords;
-            unsigned sad = first ? bias : psum[wave][j][lane];
+            unsigned sad = carried;
+            if (!first && j + 1 < nq) carried = psum[wave][j + 1][lane];  // its LDS latency hides behind this query's SADs
             static_for<4>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
                 sf16 nxt;
