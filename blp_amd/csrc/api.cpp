@@ -262,7 +262,8 @@ int blp_rank_all_idx(int model, const float* table, int64_t N, int D, int64_t ld
     if (q_head + q_tail > 0 && (!fixed_row || !rel_id || !rel_emb || !true_row || R <= 0))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all_idx: NULL fixed_row / rel_id / rel_emb / true_row or R <= 0");
     return rank_all_checked(model, table, N, D, ld, blp::QRows::rows_of(table, fixed_row, ld),
-                            blp::QRows::rows_of(rel_emb, rel_id, D), rel_id, true_row, nullptr, q_head, q_tail, filter,
+                            blp::QRows::rows_of(rel_emb, rel_id, D), /*q_rel_id (a hint for sorted blocks)*/ nullptr, true_row, nullptr, q_head,
+                            q_tail, filter,
                             counts, workspace, workspace_bytes, device, stream);
 }
 

@@ -7,10 +7,12 @@
 //
 // Kernel pipeline of one blp_rank_all call on the exact path (all on the caller's stream, no host sync):
 //   1. prep_coef    (q, i) elementwise: hoist the query-only part of the score into C coefficients
-//   2. true_key     one lane per query: score of the true entity, by the same Scorer<> routine
-//   3. rank_tiles   the hot kernel, below
-//   4. filter_finalize  one wave per query: scores of the filtered rows vs the true score, then
+//   2. true_key     score of the true entity, by the same arithmetic (one lane per query up to 2 048 queries,
+//                   the cooperative routines of exact_coop.h above)
+//   3. rank_tiles   the hot kernel, below  (small blocks: rank_small.hip instead of 1 and 3)
+//   4. filter_finalize  64 queries per workgroup: scores of the filtered rows vs the true score, then
 //                       counts[q] = {gt, ge, gt - fgt, ge - fge}  (no filter: a plain unpack of the accumulators)
+// Queries arrive as QRows (launch.h): dense (Q, D) vectors or rows of the table / of rel_emb by index.
 //
 // rank_tiles layout.  One wavefront owns a tile of 64 consecutive table rows, one row per lane, held
 // in D VGPRs (the sequential f32 sum of the reference forces one lane per (candidate, query) chain).

@@ -28,7 +28,6 @@ import torch.distributed as dist
 from . import models, ops, utils
 
 HIT_POSITIONS = (1, 3, 10)
-EXACT_TRANSE_MAX_PAIRS = 4_000_000  # blp_amd/csrc/sad_common.h: kSadMinPairs (a speed hint only: results never depend on it)
 
 
 # ----------------------------------------------------------------------------------- one block
@@ -269,23 +268,16 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     index     utils.FilterIndex of the filtering graph, or None (filtered counts = raw counts)
     table     world == 1 or axis == "query": the full (num_entities, D) table; axis == "candidate": this rank's
               rows shard_bounds(num_entities, world, rank) of it
-    Returns (triples in evaluation order -- grouped by relation where that helps the kernel, else as given --, counts
-    (2T, 4) int32 in that order with every head query first,
+    Returns (triples in evaluation order -- as given --, counts (2T, 4) int32 in that order with every head query first,
     ids_ok: 0-dim bool tensor or None -- the reference's assertion train.py:137-138, left on the device).
 
-    Everything runs on the table's device without a host round trip: the relation sort, the id lookups
-    (train.py:134-135), the query gathers and the filter segments are device work.  The metrics are sums over
-    triples, so the evaluation order is free: for small blocks triples are grouped by relation, which lets the exact
-    TransE kernel share e + r among the head-replacing queries of a relation.  Collectives: candidate axis -- one all-reduce of
+    Everything runs on the table's device without a host round trip: the id lookups (train.py:134-135), the layout of
+    the queries -- left as (table row, relation) index pairs where the fused kernels take the block -- and the filter
+    segments are one kernel (ops.build_queries).  Collectives: candidate axis -- one all-reduce of
     the vectors of the entities in the triples and ONE all-gather of the (2T, 4) counts; query axis -- ONE
     all-gather of the per-triple counts."""
     device = table.device
     num_entities = table.shape[0] if num_entities is None else num_entities
-    # Grouping by relation only pays where the exact TransE kernel serves the blocks (small blocks: the library hands
-    # TransE blocks of >= ~4 M (query, candidate) pairs to the fixed-point pre-pass, which ignores the hint, as do the
-    # bilinear models' kernels); elsewhere the sort would be 50 us of wasted device time per evaluation.
-    if model.rel_model == "transe" and 2 * min(block_size, triples.shape[0]) * num_entities < EXACT_TRANSE_MAX_PAIRS:
-        triples = triples[torch.argsort(triples[:, 2], stable=True)]
     num_triples = triples.shape[0]
     by_query = world > 1 and axis == "query"
     by_candidate = world > 1 and not by_query
