@@ -87,7 +87,7 @@ hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q
 
 // rank_small.hip: the exact f32 kernel for small blocks (coefficients computed in the kernel, LDS broadcasts, TransE
 // chains interleaved): the ranking pass only, between launch_true_keys and launch_filter_finalize.
-constexpr long long kSmallMaxPairsTransE = 2000000;    // above: rank_tiles, then (kSadMinPairs) the fixed-point pre-pass
+constexpr long long kSmallMaxPairsTransE = 4000000;    // above (== kSadMinPairs): the fixed-point pre-pass
 constexpr long long kSmallMaxPairsBilinear = 1500000;  // above: the bf16 x 3 MFMA pre-pass (tools/exact_small_probe.py)
 constexpr int kSmallMaxSlots = 256;                    // partial counts per query it leaves (one per tile slot)
 constexpr long long kSmallMaxQueries = 4096;           // whatever the knob says

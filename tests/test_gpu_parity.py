@@ -154,14 +154,15 @@ def test_small_block_kernel_vs_oracle(ops, oracle, knobs, model, D, q_head, q_ta
     """rank_small.hip (coefficients computed in the kernel, LDS broadcasts, four TransE chains interleaved) on every
     block it can take: both sides, one side only, query counts that are no multiple of its group of four, a table that
     is no multiple of a workgroup's 256 rows (the last quad has an empty tile), CSR filter.  == oracle."""
-    knobs("small_kernel", 1)
     N = 1000 + D // 64 if q_head != 37 else 300
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=D + q_head + len(model))
     rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + q_tail)
     want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
-    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
-                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
-    assert np.array_equal(got, want)
+    for variant in ((1, 3) if model == "transe" else (1,)):  # TransE: 1 = the tile in LDS, 3 = the tile in registers
+        knobs("small_kernel", variant)
+        got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                           filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+        assert np.array_equal(got, want), variant
 
 
 @pytest.mark.default_routing
@@ -170,13 +171,14 @@ def test_small_block_kernel_vs_oracle(ops, oracle, knobs, model, D, q_head, q_ta
 def test_small_block_kernel_query_chunks(ops, oracle, knobs, model, chunk):
     """Any number of queries per workgroup (the host picks a multiple of 32 by the size of the block): partial rounds,
     waves with no query, chunks that straddle the head / tail boundary."""
-    knobs("small_kernel", 1)
     knobs("exact_query_chunk", chunk)
     N, D, q_head, q_tail = 777, 128, 45, 38
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=chunk)
     want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
-    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda()).cpu().numpy()
-    assert np.array_equal(got, want)
+    for variant in ((1, 3) if model == "transe" else (1,)):
+        knobs("small_kernel", variant)
+        got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda()).cpu().numpy()
+        assert np.array_equal(got, want), variant
 
 
 @pytest.mark.default_routing
@@ -199,7 +201,7 @@ def test_small_block_kernel_table_of_more_tiles_than_slots(ops, oracle, knobs, m
 def test_small_block_kernel_ties_and_nonfinite(ops, oracle, knobs, model):
     """Duplicated rows (ties with the true entity: > vs >=), a NaN row, an infinite value, true entity given as a
     vector (candidate shards): the small-block kernel keeps the reference's counts."""
-    knobs("small_kernel", 1)
+    knobs("small_kernel", 1)   # (TransE: the LDS-tile kernel; the register-tile one shares score_side with the others)
     N, D, q_head, q_tail = 600, 128, 21, 22
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=len(model))
     table[100:140] = table[true_row[:40]]           # exact duplicates of true entities

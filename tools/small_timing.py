@@ -12,7 +12,7 @@ from blp_amd import ops
 import bench
 dev = torch.device("cuda", 0)
 L = _lib.lib()
-for wl in sys.argv[2:] or ("fb15k237-transe", "fb15k237-distmult"):
+for wl in sys.argv[2:] or ("fb15k237-transe",):
     cfg = bench.WORKLOADS[wl]
     table, rel_w, heads, tails, rels = bench.make_data(cfg, dev)
     q_fixed, q_rel, true_row = bench.build_queries(table, rel_w, heads, tails, rels)
