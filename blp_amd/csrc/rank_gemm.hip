@@ -565,6 +565,10 @@ __device__ __forceinline__ void kstep_main(f32x16_t& n0, f32x16_t& n1, u32x4_t h
 //   x = query * 2 + half ;  y = (candidate tile within the slab) << 16 | mask, bit 15 - r of the mask = accumulator
 //   register r = row acc_row(r, half) of the tile is undecided.
 constexpr int kBfMaxSlabTiles = 65536 - 16;  // the tile index must fit 16 bits
+#ifndef BLP_CHUNK_BLOCK
+#define BLP_CHUNK_BLOCK 3  // measured fabric reads per launch (FB15k-237 DistMult): 1: 493 MB, 2: 335, 3: 331, 4: 359, 5: 410, 8: 608
+#endif
+constexpr unsigned kBfChunkBlock = BLP_CHUNK_BLOCK;       // query chunks whose workgroups share a candidate group's L2-resident image
 
 // DUMP = true (tests only, blp_debug_gemm_dump): the same MFMA sequence and band arithmetic, but instead of deciding the
 // kernel stores S~ and the band half-width eps of every (query, candidate) pair into dense (Q, n_rows) matrices.
@@ -595,7 +599,16 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     // and find it in that L2, instead of every XCD fetching every chunk.
     const unsigned n_blocks = gridDim.x, xcd = blockIdx.x & 7u, per_xcd = n_blocks >> 3, rem = n_blocks & 7u;
     const unsigned logical = (xcd < rem ? xcd * (per_xcd + 1) : rem * (per_xcd + 1) + (xcd - rem) * per_xcd) + (blockIdx.x >> 3);
-    const int group = (int)(logical % (unsigned)n_groups), chunk = (int)(logical / (unsigned)n_groups);
+    // Inside an XCD's range the workgroups go (block of kBfChunkBlock query chunks) x (candidate group) x (chunk of the
+    // block): the ~64 workgroups resident on the XCD are then ~21 groups x 3 chunks, so a group's operand image (128 KB;
+    // all groups together 7.4 MB -- more than the 4 MB L2) is fetched from the fabric once per three chunks instead of
+    // once per chunk, while each chunk's query image is still streamed by workgroups that run together (larger blocks
+    // thrash the L2 with query images).  Fabric reads 493 -> 331 MB per launch = 2.8 x the algorithmic bytes; the
+    // kernel is MFMA / VALU-issue bound, its time does not change.
+    const unsigned n_chunks_all = (unsigned)((n_blocks + n_groups - 1) / n_groups);
+    const unsigned per_block = (unsigned)n_groups * kBfChunkBlock, cb = logical / per_block, in_block = logical % per_block;
+    const unsigned chunks_here = n_chunks_all - cb * kBfChunkBlock < kBfChunkBlock ? n_chunks_all - cb * kBfChunkBlock : kBfChunkBlock;
+    const int group = (int)(in_block / chunks_here), chunk = (int)(cb * kBfChunkBlock + in_block % chunks_here);
     const bool head = chunk < chunks_head;
     const int side_chunk = head ? chunk : chunk - chunks_head;
     const int n_side = head ? q_head : q_tail, q_base = head ? 0 : q_head;
