@@ -175,6 +175,11 @@ struct SadTiles {
     unsigned long long exact_rows[TPW];  // lanes whose row is marked exact-only (kSRowExact): undecided for every query
 };
 
+#ifndef BLP_SAD_CHUNK_BLOCK
+#define BLP_SAD_CHUNK_BLOCK 4  // FB15k-237 block, ranking pass ms | fabric MB per launch: 2: 3.07 | -, 4: 3.06 | 319, 8: 3.08 | 261, 16: 3.09 | 170, 32: 3.09 | 136 (was 3.24 | 1390)
+#endif
+constexpr unsigned kSadChunkBlock = BLP_SAD_CHUNK_BLOCK;  // query chunks whose workgroups run together on an XCD
+
 template <int D, int TPW>
 __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 128 ? 3 : 2)) void rank_sad_kernel(
     const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups, int q_per_group,
@@ -189,8 +194,19 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int group = blockIdx.x % n_groups;
-    const int64_t q0 = (int64_t)(blockIdx.x / n_groups) * q_per_group;  // q_per_group <= kSChunk
+    // Workgroup order.  Blocks are dispatched to the 8 XCDs round-robin (block b -> XCD b % 8), each with its own 4 MB L2.
+    // With b = chunk * n_groups + group every XCD saw every query chunk and, with ~160 workgroups resident, ~22 chunks'
+    // images at a time next to the whole candidate image: 1.39 GB of fabric reads per launch for 118 MB of data.  Each
+    // XCD now walks a contiguous range of a logical index laid out as (block of kSadChunkBlock query chunks) x (candidate
+    // group) x (chunk of the block): a query chunk's image is read by one XCD only, the candidate image once per block
+    // of chunks.
+    const unsigned n_blocks = gridDim.x, xcd = blockIdx.x & 7u, per_xcd = n_blocks >> 3, rem_b = n_blocks & 7u;
+    const unsigned logical = (xcd < rem_b ? xcd * (per_xcd + 1) : rem_b * (per_xcd + 1) + (xcd - rem_b) * per_xcd) + (blockIdx.x >> 3);
+    const unsigned n_chunks_all = n_blocks / (unsigned)n_groups;  // the grid is n_groups x chunks
+    const unsigned per_cb = (unsigned)n_groups * kSadChunkBlock, cb = logical / per_cb, in_cb = logical % per_cb;
+    const unsigned chunks_here = n_chunks_all - cb * kSadChunkBlock < kSadChunkBlock ? n_chunks_all - cb * kSadChunkBlock : kSadChunkBlock;
+    const int group = (int)(in_cb / chunks_here);
+    const int64_t q0 = (int64_t)(cb * kSadChunkBlock + in_cb % chunks_here) * q_per_group;  // q_per_group <= kSChunk
     const int nq = (int)(Q - q0 < q_per_group ? Q - q0 : q_per_group);
 
     for (int i = tid; i < kSChunk; i += kSW * 64) cnt[i] = 0;

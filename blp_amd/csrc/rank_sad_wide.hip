@@ -26,6 +26,10 @@ namespace blp {
 
 constexpr int kWChunk = 32;    // queries per workgroup (their partial SADs live in LDS: 8 KB per wave)
 constexpr int kWQuota = 128;   // undecided pairs a workgroup can list (4 per query)
+#ifndef BLP_WIDE_CHUNK_BLOCK
+#define BLP_WIDE_CHUNK_BLOCK 4  // D = 768 block, ranking pass: 4: 21.33 ms, 8: 21.45, 16: 21.39, 32: 21.48, 64: 22.0 (group-major order: 24.07)
+#endif
+constexpr unsigned kWideChunkBlock = BLP_WIDE_CHUNK_BLOCK;  // query chunks whose workgroups run together on an XCD
 constexpr int kWMaxD = 1024;
 
 // models.py:222-223 for one (candidate, query) pair, any width: ((h + r) - t), |.|, sequential f32 sum
@@ -214,9 +218,16 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     // D = 768) are what a workgroup streams chunk by chunk, and with the query chunk as the fast index every one of the
     // 3 305 query chunks of the FB15k-237 block fetched them again from the fabric (77 GB per launch, 111 x the
     // algorithmic bytes); now they stay in the L2s while the group's chunks go by.
-    const int n_chunks = (int)(gridDim.x / (unsigned)n_groups);
-    const int group = blockIdx.x / n_chunks;
-    const int64_t q0 = (int64_t)(blockIdx.x % n_chunks) * kWChunk;
+    // (round 2, later: each XCD -- blocks go to them round-robin, b % 8 -- walks a contiguous range of a logical index
+    // laid out as (block of kWideChunkBlock query chunks) x (candidate group) x (chunk of the block), as in rank_sad.hip:
+    // a query chunk's image is read by one XCD only, a group's tile images once per block of chunks)
+    const unsigned n_blocks = gridDim.x, xcd = blockIdx.x & 7u, per_xcd = n_blocks >> 3, rem_b = n_blocks & 7u;
+    const unsigned logical = (xcd < rem_b ? xcd * (per_xcd + 1) : rem_b * (per_xcd + 1) + (xcd - rem_b) * per_xcd) + (blockIdx.x >> 3);
+    const unsigned n_chunks_all = n_blocks / (unsigned)n_groups;
+    const unsigned per_cb = (unsigned)n_groups * kWideChunkBlock, cb = logical / per_cb, in_cb = logical % per_cb;
+    const unsigned chunks_here = n_chunks_all - cb * kWideChunkBlock < kWideChunkBlock ? n_chunks_all - cb * kWideChunkBlock : kWideChunkBlock;
+    const int group = (int)(in_cb / chunks_here);
+    const int64_t q0 = (int64_t)(cb * kWideChunkBlock + in_cb % chunks_here) * kWChunk;
     const int nq = (int)(Q - q0 < kWChunk ? Q - q0 : kWChunk);
 
     if (tid < kWChunk) {
