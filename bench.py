@@ -74,7 +74,7 @@ SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe-block
 def make_data(cfg, device, seed=1, sort=True):
     """Synthetic FB15k-237 / Wikidata5M-shaped inputs: table rows L2-normalised for
     TransE (models.py:40-41), 0.1 * randn otherwise; rel_emb Xavier-uniform (models.py:28-29).  ``sort``:
-    triples grouped by relation (tools that call ops.rank_all directly); the bench step sorts by itself."""
+    triples grouped by relation (tools that call ops.rank_all directly); the bench step takes them as they come."""
     g = torch.Generator(device=device).manual_seed(seed)
     N, D, R, T = cfg["N"], cfg["D"], cfg["R"], cfg["triples"]
     table = torch.randn(N, D, device=device, generator=g)
@@ -500,7 +500,14 @@ def main():
             torch.cuda.empty_cache()
             for name in SUB_RESULTS:
                 sub = Job(name, device)
-                f, t, c = sub.measure(max(2, min(args.steps, 5)), 3, events)  # (allocator growth / lazy loads settle in 2 steps)
+                # best of two timed runs of K steps: a one-off stall (a code object loaded on first use, the allocator growing)
+                # inside a 5-step run once made a 1.2 ms evaluation read as 16 ms
+                k_sub = max(2, min(args.steps, 5))
+                f, t, c = sub.measure(k_sub, 3, events)
+                f2, t2, c2 = sub.measure(k_sub, 1, events)
+                if f2["ms_per_step"] < f["ms_per_step"]:
+                    f, t, c = f2, t2, c2
+                f["steps"], f["timed_runs"] = k_sub, 2
                 f["unit"] = "scored triples/s"
                 f["parity_check"] = parity_spot_check(sub, t, c)
                 f.pop("kernel_ms_per_rank")
