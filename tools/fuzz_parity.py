@@ -58,15 +58,17 @@ def make_case(rng):
     elif kind == "constant":
         table[:] = float(rng.choice([0.0, 0.25, -3.0]))
     Q = q_head + q_tail
-    q_fixed = table[torch.randint(0, N, (Q,), generator=g)].clone()
+    fixed_idx = torch.randint(0, N, (Q,), generator=g)
+    q_fixed = table[fixed_idx].clone()
     q_rel = torch.randn(Q, D, generator=g) * float(rng.choice([0.0, 0.1, 1.0]))
     true_row = torch.randint(0, N, (Q,), generator=g)
-    rel_ids = None
-    if model == "transe" and rng.random() < 0.3:
+    rel_ids, rel_table = None, None
+    if rng.random() < 0.3:  # queries that are (table row, relation row) pairs: also ranked through blp_rank_all_idx
         rel_ids = torch.randint(0, 7, (Q,), generator=g)
         if rng.random() < 0.5:
             rel_ids[:q_head] = torch.sort(rel_ids[:q_head]).values
-        q_rel = (torch.randn(7, D, generator=g) * 0.2)[rel_ids]
+        rel_table = torch.randn(7, D, generator=g) * 0.2
+        q_rel = rel_table[rel_ids]
     csr = random_csr(Q, N, true_row.numpy(), seed=int(rng.integers(0, 2 ** 31))) if rng.random() < 0.5 else None
     by_vector = rng.random() < 0.3
     if rng.random() < 0.2:  # a strided view (ld > D)
@@ -90,7 +92,7 @@ def make_case(rng):
         env["small_kernel"] = int(rng.choice([1, 3]))  # (3: TransE on the register-tile variant) wherever it can run (D = 64 / 128, up to 4 096 queries), whatever the block size
         if rng.random() < 0.5:
             env["exact_query_chunk"] = int(rng.integers(1, 200))
-    return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids
+    return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids, (fixed_idx, rel_table)
 
 
 def main():
@@ -100,7 +102,7 @@ def main():
     while time.time() - t0 < budget:
         seed = seed0 + n
         rng = np.random.default_rng(seed)
-        model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids = make_case(rng)
+        model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids, (fixed_idx, rel_table) = make_case(rng)
         if os.environ.get("BLP_FUZZ_TRACE"):  # the last line names the case a crash happened in
             print(f"seed={seed} model={model} D={D} N={N} q=({q_head},{q_tail}) data={kind} csr={csr is not None} "
                   f"by_vector={by_vector} env={env}", file=sys.stderr, flush=True)
@@ -115,7 +117,18 @@ def main():
             if rel_ids is not None:
                 gkw["rel_ids"] = rel_ids.cuda()
             dev_table = table.cuda() if table.is_contiguous() else table._base.cuda()[:, :D]
+            if rel_ids is not None and model != "transe":
+                gkw.pop("rel_ids")  # the hint is TransE's
             got = ops.rank_all(model, dev_table, q_fixed.cuda(), q_rel.cuda(), q_head, **gkw).cpu().numpy()
+            if rel_table is not None and not by_vector and ops.rank_all_supported(model, D, q_head, q_tail):
+                filt = None
+                if csr is not None:  # the CSR as a segment filter
+                    rp = torch.from_numpy(csr[0]).cuda()
+                    filt = ops.SegmentFilter(rp[:-1].contiguous(), rp[1:].contiguous(), torch.from_numpy(csr[1]).cuda(), None, None, 0)
+                got_idx = ops.rank_all_idx(model, dev_table, fixed_idx.cuda(), rel_table.cuda(), rel_ids.cuda(), q_head,
+                                           true_row.cuda(), filter=filt).cpu().numpy()
+                if not np.array_equal(got_idx, want):
+                    got = got_idx  # reported below as a mismatch
         finally:
             _lib.reset_knobs()
         if not np.array_equal(got, want):
