@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libblp_hip.so")
-SOURCES = ["rank_all.hip", "rank_small.hip", "rank_gemm.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_dense.hip", "score.hip", "inbatch_loss.hip", "project.hip", "queries.hip", "api.cpp"]
+SOURCES = ["rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_gemm.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_dense.hip", "score.hip", "inbatch_loss.hip", "project.hip", "queries.hip", "api.cpp"]
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "blp_hip.h")
 # -ffp-contract=off: the kernels restate the reference's per-operation rounding; an FMA would change
 # the last bit of a score and with it a rank.  No fast-math for the same reason.

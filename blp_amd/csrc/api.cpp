@@ -86,7 +86,8 @@ int check_score_dim(int model, int D) {
 std::atomic<long long> g_knobs[blp::KNOB_COUNT];  // zero-initialised: every knob automatic
 const char* const kKnobNames[blp::KNOB_COUNT] = {"rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups",
                                                  "sad_min_queries", "gemm_pass_words", "gemm_tiles_per_chunk",
-                                                 "exact_query_chunk", "small_kernel"};
+                                                 "exact_query_chunk", "small_kernel",
+                                                 "stream_kernel"};
 
 }  // namespace
 

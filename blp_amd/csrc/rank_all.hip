@@ -7,8 +7,8 @@
 //
 // Kernel pipeline of one blp_rank_all call on the exact path (all on the caller's stream, no host sync):
 //   1. prep_coef    (q, i) elementwise: hoist the query-only part of the score into C coefficients
-//   2. true_key     score of the true entity, by the same arithmetic (one lane per query up to 2 048 queries,
-//                   the cooperative routines of exact_coop.h above)
+//   2. true_key     score of the true entity, by the same arithmetic (one lane per query up to 2 048 queries -- 1 and 2
+//                   are then one launch --, the cooperative routines of exact_coop.h above)
 //   3. rank_tiles   the hot kernel, below  (small blocks: rank_small.hip instead of 1 and 3)
 //   4. filter_finalize  64 queries per workgroup: scores of the filtered rows vs the true score, then
 //                       counts[q] = {gt, ge, gt - fgt, ge - fge}  (no filter: a plain unpack of the accumulators)
@@ -110,12 +110,31 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
 // Few queries: latency, not throughput, is what a true-key launch costs, and one lane per query with all 96 of its
 // row loads in flight at once is a single memory round trip (the cooperative kernel above walks four chunks one after
 // the other: 128-query call 40 -> 49 us when it replaced this one outright).  Same Scorer<> arithmetic, bit for bit.
+// Workgroups [key_blocks, gridDim.x), if any: the coefficient rows of prep_coef_kernel -- the exact path's two
+// query-side launches in one (a 4-query pass over a 1/8 shard of the Wikidata5M table is ~50 us of table read; every
+// launch of the chain is 4-5 us on top).
 template <int MODEL, int D>
 __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restrict__ table, int64_t ld,
                                 const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
-                                unsigned long long* __restrict__ acc) {
+                                unsigned long long* __restrict__ acc, unsigned key_blocks,
+                                float* __restrict__ coef_head, float* __restrict__ coef_tail) {
+    if (blockIdx.x >= key_blocks) {
+        using SH = Scorer<MODEL, HEAD, D>;
+        using ST = Scorer<MODEL, TAIL, D>;
+        const int64_t n_head = q_head * SH::C, total = n_head + q_tail * ST::C;
+        for (int64_t i = (blockIdx.x - key_blocks) * 64ll + threadIdx.x; i < total; i += (gridDim.x - key_blocks) * 64ll) {
+            if (i < n_head) {
+                const int64_t q = i / SH::C;
+                coef_head[i] = SH::coef(q_fixed.row(q), q_rel.row(q), (int)(i % SH::C));
+            } else {
+                const int64_t k = i - n_head, q = k / ST::C;
+                coef_tail[k] = ST::coef(q_fixed.row(q_head + q), q_rel.row(q_head + q), (int)(k % ST::C));
+            }
+        }
+        return;
+    }
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (q >= q_head + q_tail) return;
     acc[q] = 0;
@@ -129,15 +148,23 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restri
 
 constexpr int64_t kTrueKeyLaneMaxQueries = 2048;
 
+// True keys (and zeroed accumulators); with coef_head / coef_tail also the coefficient rows of the exact path.
 template <int MODEL, int D>
 static void launch_true_key(const float* table, int64_t ld, const int64_t* true_row, const float* q_true, const QRows& q_fixed,
                             const QRows& q_rel, int64_t q_head, int64_t q_tail, float* key_true, unsigned long long* acc,
-                            hipStream_t stream) {
+                            hipStream_t stream, float* coef_head = nullptr, float* coef_tail = nullptr) {
     const int64_t Q = q_head + q_tail;
+    const int64_t n_coef = coef_head ? q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C : 0;
     if (Q <= kTrueKeyLaneMaxQueries) {
-        true_key_lane_kernel<MODEL, D><<<(unsigned)((Q + 63) / 64), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel,
-                                                                                      q_head, q_tail, key_true, acc);
+        const int64_t key_blocks = (Q + 63) / 64, want = (n_coef + 63) / 64, coef_blocks = want < 4096 ? want : 4096;
+        true_key_lane_kernel<MODEL, D><<<(unsigned)(key_blocks + coef_blocks), 64, 0, stream>>>(
+            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail);
     } else {
+        if (n_coef) {
+            const int64_t blocks = (n_coef + 255) / 256;
+            prep_coef_kernel<MODEL, D><<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail,
+                                                                                                 coef_head, coef_tail);
+        }
         constexpr int QB = true_key_queries_per_block(MODEL);
         true_key_kernel<MODEL, D><<<(unsigned)((Q + QB - 1) / QB), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel,
                                                                                      q_head, q_tail, key_true, acc);
@@ -660,13 +687,8 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                                       stream, slots);
     }
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
-    {
-        const int64_t total = q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C;
-        const int64_t blocks = (total + 255) / 256;
-        const int grid = (int)(blocks < 8192 ? blocks : 8192);
-        prep_coef_kernel<MODEL, D><<<grid, 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, w.coef_head, w.coef_tail);
-        launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream);
-    }
+    launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
+                              w.coef_tail);
 
     if (N > 0) {
         const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
@@ -702,7 +724,11 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                      (size_t)kWaves * 2 * kQueryChunk * 4;
 
         if (ev_start) (void)hipEventRecord(ev_start, stream);
-        if (static_mode)
+        if (static_mode && knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(MODEL, D, N, ld, q_head, q_tail)) {
+            const hipError_t err = launch_rank_stream(D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
+                                                      w.acc, n_cu, stream);
+            if (err != hipSuccess) return err;
+        } else if (static_mode)
             rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
                 (int)groups, q_chunk, q_rel_id, w.acc);
@@ -769,7 +795,6 @@ template <int MODEL, int D>
 static hipError_t true_keys_impl(const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
                                  const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
                                  float* key_true, unsigned long long* acc, hipStream_t stream) {
-    const int64_t Q = q_head + q_tail;
     launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, stream);
     return hipGetLastError();
 }

@@ -1,0 +1,204 @@
+// rank_stream.hip -- TransE, a handful of queries against a LONG table (the reference's Wikidata5M evaluation batch:
+// eval_batch_size 2 = 4 queries per pass over 4.6 M rows, scripts/blp-transe-wikidata5m.sh:18; train.py:128-171): the
+// pass is one read of the table, HBM-bound, and what matters is that the read never stops.
+//
+// rank_tiles<STATIC> (rank_all.hip) fetches a whole tile (64 rows x D floats, all D/4 loads of a lane at once), then
+// scores it: a wave alternates between a load phase and an arithmetic phase and only the drift between the waves of a
+// SIMD overlaps the two.  On the full table the waves have 23 tiles to drift apart (6.0 TB/s); on a 1/8 shard of it --
+// what a rank of an 8-GPU evaluation holds -- they have three, and the chip runs load phase / arithmetic phase in lock-step
+// (3.8 TB/s: [measured] 77 us for 294 MB).
+//
+// Here a wave consumes its tile 32 columns at a time -- TransE's sum runs strictly left to right over the row, so the
+// partial sums of the <= 4 + 4 queries are all that crosses a step -- from a ring of two 32-column pieces (2 x 8 loads of
+// 16 B per lane) that is refilled two steps ahead, ACROSS tile boundaries: every wave has 8-16 KB in flight at all
+// times and the arithmetic of a step runs under the loads of the next two.  64 + 32 + 8 live data registers instead of D
+// + 40: four waves per SIMD.  Keys: the operations of Scorer<TRANSE, SIDE, D>::score<false> in its order (score_core.h),
+// coefficients as SGPR operands from the scalar cache as in rank_tiles<STATIC>: counts are bit-identical.
+// Counts: scalar registers per (wave, query), summed over the workgroup's waves in LDS, one 64-bit atomic per
+// (workgroup, query) at the end.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch.h"
+#include "rank_common.h"
+#include "score_core.h"
+#include "tile.h"
+
+#pragma clang fp contract(off)
+
+namespace blp {
+
+constexpr int kStreamQ = 4;  // queries per side (== rank_all.hip's kQB: what its static mode takes)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The 8 loads of one 32-column piece: piece s of the tile whose first row is `base` (byte offsets boff[i] of this lane's
+// part of rows 8i .. 8i + 7, clamped to the table by the caller).  Streamed once: non-temporal.
+template <class Off>
+__device__ __forceinline__ void piece_fetch(f32x4 (&b)[8], const float* __restrict__ base, const Off (&boff)[8], int s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff[i] + s * (kSubCols * 4)));
+}
+
+// One query's partial sum over the 32 columns x[] = columns 32 s .. 32 s + 31 of the lane's row; c: the query's
+// coefficient row (wave-uniform -> scalar loads, SGPR operands).  FIRST: column 0 starts the sum (score<false>).
+template <int SIDE, int D, bool FIRST>
+__device__ __forceinline__ float piece_sum(float acc, const float (&x)[kSubCols], const float* __restrict__ c) {
+#pragma unroll
+    for (int k = 0; k < kSubCols; ++k) {
+        float d;
+        if constexpr (SIDE == TAIL) {
+            d = c[k] - x[k];              // (h + r) - e, h + r hoisted
+        } else {
+            const float y = x[k] + c[k];  // (e + r) - t
+            d = y - c[D + k];
+        }
+        acc = (FIRST && k == 0) ? fabsf(d) : acc + fabsf(d);
+    }
+    return acc;
+}
+
+template <int D>
+__global__ __launch_bounds__(kWaves * 64, 4) void rank_stream_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
+    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
+    unsigned long long* __restrict__ acc) {
+    constexpr int NP = D / kSubCols;  // pieces per tile
+    static_assert(NP % 2 == 0, "the ring of two pieces assumes an even number of pieces per tile");
+    __shared__ __attribute__((aligned(16))) float slabs[kWaves * kSlabFloats];
+    __shared__ unsigned long long wg_cnt[2 * kStreamQ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* slab = slabs + wave * kSlabFloats;
+    const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
+    float* wr = slab + sub_row * kLdsStride + sub_col;
+    const float* rd = slab + lane * kLdsStride;
+    if (tid < 2 * kStreamQ) wg_cnt[tid] = 0;
+
+    // the wave's tiles: four consecutive tiles per workgroup and round, workgroups grid-stride over the rounds
+    const int stride = gridDim.x * kWaves;
+    int tile = blockIdx.x * kWaves + wave;
+
+    // byte offsets of this lane's parts of a tile's rows (rows past the end of the table: the last row, masked later)
+    unsigned boff[8];
+    auto offsets = [&](int t) {
+        const int64_t left = N - (int64_t)t * kTileRows;
+        const int last = left < kTileRows ? (int)left - 1 : kTileRows - 1;  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * i + sub_row;
+            boff[i] = (unsigned)(((r < last ? r : last) * (int)ld + sub_col) * 4);
+        }
+    };
+    auto tile_base = [&](int t) { return table + (int64_t)t * kTileRows * ld; };
+
+    unsigned n_gt[2 * kStreamQ] = {}, n_ge[2 * kStreamQ] = {};  // wave-uniform: scalar registers
+    f32x4 ring[2][8];
+    if (tile < n_tiles) {
+        offsets(tile);
+        piece_fetch(ring[0], tile_base(tile), boff, 0);
+        piece_fetch(ring[1], tile_base(tile), boff, 1);
+    }
+    for (; tile < n_tiles; tile += stride) {
+        const int next = tile + stride;
+        const bool more = next < n_tiles;  // wave-uniform
+        const float* base = tile_base(tile);
+        float sum[2 * kStreamQ] = {};
+        static_for<NP>([&](auto ss) {
+            constexpr int s = decltype(ss)::value, p = s & 1;
+            // piece s: registers -> slab (transposing) ...
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(wr + 8 * i * kLdsStride) = ring[p][i];
+            // ... and its ring slot is refilled with the piece two steps ahead: this tile's, or the next tile's
+            if constexpr (s + 2 < NP) {
+                piece_fetch(ring[p], base, boff, s + 2);
+            } else {
+                if constexpr (s + 2 == NP) {
+                    if (more) offsets(next);
+                }
+                if (more) piece_fetch(ring[p], tile_base(next), boff, s + 2 - NP);
+            }
+            wave_lds_sync();
+            float x[kSubCols];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rd + 4 * j);
+                x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+            }
+            wave_lds_sync();  // the reads are out before the next piece overwrites the slab
+            static_for<kStreamQ>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if (j < q_tail) sum[kStreamQ + j] = piece_sum<TAIL, D, s == 0>(sum[kStreamQ + j], x, coef_tail + j * D + s * kSubCols);
+            });
+            static_for<kStreamQ>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if (j < q_head) sum[j] = piece_sum<HEAD, D, s == 0>(sum[j], x, coef_head + j * 2 * D + s * kSubCols);
+            });
+        });
+        const bool valid = (int64_t)tile * kTileRows + lane < N;
+        static_for<kStreamQ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if (j < q_head) {
+                const float key = -sum[j], kt = key_true[j];
+                n_gt[j] += __popcll(__ballot(valid && key > kt));
+                n_ge[j] += __popcll(__ballot(valid && key >= kt));
+            }
+            if (j < q_tail) {
+                const float key = -sum[kStreamQ + j], kt = key_true[q_head + j];
+                n_gt[kStreamQ + j] += __popcll(__ballot(valid && key > kt));
+                n_ge[kStreamQ + j] += __popcll(__ballot(valid && key >= kt));
+            }
+        });
+    }
+
+    __syncthreads();  // wg_cnt is zero
+    if (lane < 2 * kStreamQ) {
+        unsigned gt = 0, ge = 0;
+        static_for<2 * kStreamQ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if (lane == j) { gt = n_gt[j]; ge = n_ge[j]; }
+        });
+        const unsigned long long v = (unsigned long long)gt | ((unsigned long long)ge << 32);
+        if (v) atomicAdd(&wg_cnt[lane], v);
+    }
+    __syncthreads();
+    if (tid < 2 * kStreamQ) {  // slot j < 4: head query j; slot 4 + j: tail query j
+        const int side_q = tid < kStreamQ ? tid : tid - kStreamQ;
+        const bool live = tid < kStreamQ ? side_q < q_head : side_q < q_tail;
+        const unsigned long long v = wg_cnt[tid];
+        if (live && v) atomicAdd(acc + (tid < kStreamQ ? side_q : q_head + side_q), v);
+    }
+}
+
+bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
+    // (byte offsets inside a tile are 32-bit: 64 rows x ld floats)
+    return model == TRANSE && (D == 64 || D == 128 || D == 256) && q_head <= kStreamQ && q_tail <= kStreamQ && N > 0 &&
+           ld < (1 << 22);
+}
+
+hipError_t launch_rank_stream(int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
+                              const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
+                              unsigned long long* acc, int n_cu, hipStream_t stream) {
+    const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
+    if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
+    const int64_t n_rounds = (n_tiles + kWaves - 1) / kWaves;
+    const int64_t resident = (int64_t)n_cu * 4;  // four workgroups of four waves per CU: 4 waves per SIMD
+    const unsigned blocks = (unsigned)(n_rounds < resident ? n_rounds : resident);
+#define BLP_STREAM_CASE(DD)                                                                                          \
+    case DD:                                                                                                         \
+        rank_stream_kernel<DD><<<blocks, kWaves * 64, 0, stream>>>(table, N, ld, coef_head, coef_tail, key_true,      \
+                                                                   (int)q_head, (int)q_tail, (int)n_tiles, acc);     \
+        break;
+    switch (D) {
+        BLP_STREAM_CASE(64)
+        BLP_STREAM_CASE(128)
+        BLP_STREAM_CASE(256)
+    default: return hipErrorInvalidValue;
+    }
+#undef BLP_STREAM_CASE
+    return hipGetLastError();
+}
+
+}  // namespace blp

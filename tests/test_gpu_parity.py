@@ -234,6 +234,31 @@ def test_small_blocks_default_routing_equals_the_other_kernels(ops, model, knobs
 
 
 @pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("q_head,q_tail", [(2, 2), (4, 4), (0, 3), (1, 0), (3, 1)])
+def test_transe_stream_kernel_vs_oracle(ops, oracle, knobs, D, q_head, q_tail):
+    """A handful of TransE queries (the reference's Wikidata5M eval batch: 2 triples = 4 queries per table pass,
+    scripts/blp-transe-wikidata5m.sh:18) go to rank_stream.hip: the table consumed 32 columns at a time from a load ring
+    that runs across tile boundaries.  Tables of 1 row .. many tiles per wave with a ragged last tile, a tie with the
+    true entity, a non-finite row, a filter; counts against the oracle and against rank_tiles<STATIC> (knob)."""
+    for N in (1, 63, 130, 70001):
+        table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=N + D + q_head)
+        if N > 100:
+            table[17] = table[int(true_row[0])]  # an exact tie with query 0's true entity
+            table[N - 1, 3] = float("inf")
+            table[N // 2, 0] = float("nan")
+        rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=N)
+        want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+        args = ("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+        kw = dict(true_row=true_row.cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col))
+        knobs("stream_kernel", 0)
+        got = ops.rank_all(*args, **kw).cpu().numpy()
+        knobs("stream_kernel", 2)
+        tiles = ops.rank_all(*args, **kw).cpu().numpy()
+        assert np.array_equal(got, want), (N, got, want)
+        assert np.array_equal(tiles, want)
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
 def test_transe_exact_kernels_many_queries(ops, oracle, D, knobs):
     """Q >= 256 TransE normally takes the fixed-point pre-pass; the rank_kernel knob selects the exact f32
     kernel (hand-pipelined VALU) for the same block.  Same counts."""

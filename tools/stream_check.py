@@ -1,0 +1,38 @@
+import sys, time, torch
+sys.path.insert(0, "/root/repo")
+from blp_amd import ops, _lib
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(5)
+bad = 0
+for D in (64, 128, 256):
+    for N in (1, 63, 64, 65, 257, 5000, 70001, 575000):
+        table = torch.nn.functional.normalize(torch.randn((N, D), device=dev, generator=g), dim=-1)
+        if N > 300: table[17] = table[5]  # ties
+        rel = torch.randn((9, D), device=dev, generator=g) * 0.1
+        for qh, qt in ((2, 2), (4, 4), (0, 3), (1, 0), (3, 1)):
+            Q = qh + qt
+            fixed = torch.randint(0, N, (Q,), device=dev, generator=g)
+            true = torch.randint(0, N, (Q,), device=dev, generator=g)
+            if N > 300: true[0] = 5
+            r = torch.randint(0, 9, (Q,), device=dev, generator=g)
+            qf, qr = table[fixed].contiguous(), rel[r].contiguous()
+            _lib.reset_knobs(); _lib.set_knob("small_kernel", 2)
+            a = ops.rank_all("transe", table, qf, qr, qh, true_row=true)
+            _lib.set_knob("stream_kernel", 2)
+            b = ops.rank_all("transe", table, qf, qr, qh, true_row=true)
+            if not torch.equal(a, b):
+                bad += 1; print("MISMATCH", D, N, qh, qt, a.tolist(), b.tolist())
+print("mismatches", bad)
+_lib.reset_knobs()
+for N in (575000, 4600000):
+    table = torch.nn.functional.normalize(torch.randn((N, 128), device=dev, generator=g), dim=-1)
+    rel = torch.randn((9, 128), device=dev, generator=g) * 0.1
+    fixed = torch.randint(0, N, (4,), device=dev, generator=g); true = torch.randint(0, N, (4,), device=dev, generator=g)
+    qf, qr, qt = table[fixed].contiguous(), rel[:4].contiguous(), table[true].contiguous()
+    out = torch.empty((4, 4), dtype=torch.int32, device=dev)
+    for knob in (0, 2):
+        _lib.set_knob("stream_kernel", knob)
+        def step():
+            for _ in range(64): ops.rank_all("transe", table, qf, qr, 2, q_true=qt, out=out)
+        step(); torch.cuda.synchronize(); t0 = time.perf_counter(); step(); step(); torch.cuda.synchronize()
+        print(f"N={N} stream_kernel={knob}: {(time.perf_counter() - t0) / 128 * 1e6:.1f} us per pass")
