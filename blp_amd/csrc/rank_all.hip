@@ -725,7 +725,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
 
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         if (static_mode && knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(MODEL, D, N, ld, q_head, q_tail)) {
-            const hipError_t err = launch_rank_stream(D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
+            const hipError_t err = launch_rank_stream(MODEL, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
                                                       w.acc, n_cu, stream);
             if (err != hipSuccess) return err;
         } else if (static_mode)

@@ -97,10 +97,11 @@ hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, in
                              const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                              unsigned long long* partial, int n_cu, hipStream_t stream);
 
-// rank_stream.hip: TransE, <= 4 + 4 queries, long table: the table streamed 32 columns at a time from a load ring that
-// never drains (the ranking pass only: coefficients and true keys as for rank_tiles<STATIC>; adds to acc[q]).
+// rank_stream.hip: <= 4 + 4 queries, long table: the table streamed through a load pipeline that never drains (TransE: a
+// wave's ring of 32-column pieces; bilinear models: a workgroup's double-buffered LDS tile).  The ranking pass only:
+// coefficients and true keys as for rank_tiles<STATIC>; adds to acc[q].
 bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail);
-hipError_t launch_rank_stream(int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
+hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
                               unsigned long long* acc, int n_cu, hipStream_t stream);
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ float piece_sum(float acc, const float (&x)[kSubCols]
 }
 
 template <int D>
-__global__ __launch_bounds__(kWaves * 64, 4) void rank_stream_kernel(
+__global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
     unsigned long long* __restrict__ acc) {
@@ -172,19 +172,213 @@ __global__ __launch_bounds__(kWaves * 64, 4) void rank_stream_kernel(
     }
 }
 
-bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
-    // (byte offsets inside a tile are 32-bit: 64 rows x ld floats)
-    return model == TRANSE && (D == 64 || D == 128 || D == 256) && q_head <= kStreamQ && q_tail <= kStreamQ && N > 0 &&
-           ld < (1 << 22);
+// ---- the bilinear models ---------------------------------------------------------------------------------------------
+// torch.sum's order (score_core.h: 32 running sums per key, every one fed by every 32-column piece of the row) leaves
+// nothing small to carry across pieces, so a key needs its whole row at once -- in registers, next to the 32 sums: no
+// room for a load ring as well at more than one wave per SIMD.  Here the WORKGROUP owns the tile instead of the wave
+// (as in rank_small.hip): its four waves fetch the next tile together (16 B per thread x 8, in flight in 32 registers
+// while the current tile is scored), hand it over through a double-buffered LDS tile (row stride D + 4 floats: lane l
+// reads its row with conflict-free ds_read_b128), and split the QUERIES -- wave w scores queries w and w + 4 against
+// the whole tile with Scorer<>::score, coefficients as SGPR operands (SgprStreamCoef, above).  One barrier per tile; two
+// workgroups per CU.
+// Coefficients as SGPR operands WITHOUT the scalar-cache latency on the critical path.  Plain scalar loads (PtrCoef) are
+// issued by the compiler right where a chunk is first needed and waited for on the spot: 8-16 exposed round trips per
+// key, which two waves per SIMD do not hide ([measured] ComplEx, 4 queries, 4.6 M rows: 491 us = 4.8 TB/s with PtrCoef,
+// no better than rank_tiles<STATIC>).  Every bilinear Scorer<> walks NS parallel coefficient streams (index I: stream
+// I / L, position I % L) front to back, term by term, touching stream 0 first -- so the accessor itself keeps a ring of
+// two CH-float chunks per stream in SGPRs: the first touch of chunk k waits for it and requests chunk k + 1.
+typedef float sf8 __attribute__((ext_vector_type(8)));
+template <int CH> struct SVec;
+template <> struct SVec<8> { typedef sf8 type; };
+template <> struct SVec<16> { typedef sf16 type; };
+
+template <int OFF>
+__device__ __forceinline__ void sload(sf8& v, const float* base) {
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(base), "i"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void sload(sf16& v, const float* base) {
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "i"(OFF) : "memory");
+}
+template <class V> __device__ __forceinline__ void sdrain_n(V (&b)[1]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0]) : : "memory"); }
+template <class V> __device__ __forceinline__ void sdrain_n(V (&b)[2]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0]), "+s"(b[1]) : : "memory"); }
+template <class V> __device__ __forceinline__ void sdrain_n(V (&b)[3]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0]), "+s"(b[1]), "+s"(b[2]) : : "memory"); }
+template <class V> __device__ __forceinline__ void sdrain_n(V (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0]), "+s"(b[1]), "+s"(b[2]), "+s"(b[3]) : : "memory");
 }
 
-hipError_t launch_rank_stream(int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
+template <int L, int NS, int CH>
+struct SgprStreamCoef {
+    typedef typename SVec<CH>::type V;
+    const float* base;   // the query's coefficient row (wave-uniform)
+    V (&ring)[2][NS];
+    template <int K>
+    __device__ __forceinline__ void request() const {  // chunk K of every stream -> ring[K & 1]
+        static_for<NS>([&](auto ss) {
+            constexpr int st = decltype(ss)::value;
+            sload<(st * L + K * CH) * 4>(ring[K & 1][st], base);
+        });
+    }
+    template <int I>
+    __device__ __forceinline__ float operator()(ic<I>) const {
+        constexpr int st = I / L, j = I % L, k = j / CH, i = j % CH;
+        static_assert(st < NS, "coefficient index outside the streams");
+        if constexpr (st == 0 && i == 0) {  // first touch of chunk k (the Scorer reads stream 0 first in every term)
+            sdrain_n(ring[k & 1]);
+            if constexpr ((k + 1) * CH < L) request<k + 1>();
+        }
+        return ring[k & 1][st][i];
+    }
+};
+
+// streams of Scorer<MODEL, SIDE, D>: count, length, and the chunk that keeps 2 x NS x CH floats within the SGPR file
+template <int MODEL, int SIDE, int D> struct StreamPlan;
+template <int D> struct StreamPlan<DISTMULT, TAIL, D> { static constexpr int NS = 1, L = D, CH = 16; };
+template <int D> struct StreamPlan<DISTMULT, HEAD, D> { static constexpr int NS = 2, L = D, CH = 16; };
+template <int SIDE, int D> struct StreamPlan<COMPLEX, SIDE, D> { static constexpr int NS = 4, L = D / 2, CH = 8; };
+template <int SIDE, int D> struct StreamPlan<SIMPLE, SIDE, D> { static constexpr int NS = 3, L = D / 2, CH = 8; };
+
+template <int MODEL, int SIDE, int D>
+__device__ __forceinline__ float score_sgpr_stream(const float (&e)[D], const float* row) {
+    using P = StreamPlan<MODEL, SIDE, D>;
+    static_assert(Scorer<MODEL, SIDE, D>::C == P::NS * P::L, "stream plan does not cover the coefficient row");
+    typename SVec<P::CH>::type ring[2][P::NS];
+    const SgprStreamCoef<P::L, P::NS, P::CH> c{row, ring};
+    c.template request<0>();
+    return Scorer<MODEL, SIDE, D>::template score<false>(e, c);
+}
+
+template <int MODEL, int D>
+__global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
+    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
+    unsigned long long* __restrict__ acc) {
+    using SH = Scorer<MODEL, HEAD, D>;
+    using ST = Scorer<MODEL, TAIL, D>;
+    constexpr int TS = D + 4;  // row stride of an LDS tile, floats
+    constexpr int kPieces = kTileRows * (D / 4) / (kWaves * 64);
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x kTileRows x TS
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Q = q_head + q_tail;
+
+    // thread t moves 16-byte pieces t, t + 256, ... of the 64 x D block (whole rows per D / 4 threads); rows past the end
+    // of the table: the last row, masked when counting.  TWO tiles in flight per workgroup (a register ring): with one,
+    // the memory pipeline drains while the workgroup hands a tile over, and the pass runs at load latency + arithmetic
+    // per tile instead of the larger of the two.
+    f32x4 ring[2][kPieces];
+    auto fetch = [&](f32x4 (&piece)[kPieces], int t) {
+        const int64_t row0 = (int64_t)t * kTileRows;
+        static_for<kPieces>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const int idx = tid + k * kWaves * 64, r = idx / (D / 4), c = idx % (D / 4);
+            int64_t row = row0 + r;
+            row = row < N ? row : N - 1;
+            piece[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(table + row * ld + 4 * c));
+        });
+    };
+    auto put = [&](float* tile, const f32x4 (&piece)[kPieces]) {
+        static_for<kPieces>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const int idx = tid + k * kWaves * 64, r = idx / (D / 4), c = idx % (D / 4);
+            *reinterpret_cast<f32x4*>(tile + r * TS + 4 * c) = piece[k];
+        });
+    };
+    unsigned n_gt[2] = {0, 0}, n_ge[2] = {0, 0};  // wave-uniform
+    const int qw = wave;  // wave w scores queries w and w + 4
+    // score the tile in LDS buffer `cur` (tile index t) with this wave's queries
+    auto score_tile = [&](int t, int cur) {
+        const float* tile = smem + cur * (kTileRows * TS);
+        float e[D];
+        static_for<D / 4>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            const float4 w = *reinterpret_cast<const float4*>(tile + lane * TS + 4 * j);
+            e[4 * j] = w.x; e[4 * j + 1] = w.y; e[4 * j + 2] = w.z; e[4 * j + 3] = w.w;
+        });
+        const bool valid = (int64_t)t * kTileRows + lane < N;
+        static_for<2>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            const int q = qw + kWaves * s;
+            if (q < Q) {
+                const float key = q < q_head ? score_sgpr_stream<MODEL, HEAD, D>(e, coef_head + (size_t)q * SH::C)
+                                             : score_sgpr_stream<MODEL, TAIL, D>(e, coef_tail + (size_t)(q - q_head) * ST::C);
+                const float kt = key_true[q];
+                n_gt[s] += __popcll(__ballot(valid && key > kt));
+                n_ge[s] += __popcll(__ballot(valid && key >= kt));
+            }
+        });
+    };
+
+    // tiles t0, t0 + G, t0 + 2G, ...: in LDS tile i (buffer i & 1), in ring[(i + 1) & 1] tile i + 1, in ring[i & 1] tile i + 2
+    const int G = gridDim.x;
+    int t = blockIdx.x;  // (the grid has at most n_tiles workgroups)
+    fetch(ring[0], t);
+    if (t + G < n_tiles) fetch(ring[1], t + G);
+    put(smem, ring[0]);
+    if (t + 2 * G < n_tiles) fetch(ring[0], t + 2 * G);
+    __syncthreads();
+    for (;;) {  // two tiles per trip, so that the ring slots and LDS buffers are compile-time
+        score_tile(t, 0);
+        if (t + G >= n_tiles) break;
+        put(smem + kTileRows * TS, ring[1]);
+        if (t + 3 * G < n_tiles) fetch(ring[1], t + 3 * G);
+        __syncthreads();  // tile t + G is in LDS buffer 1; every wave is done with buffer 0
+        score_tile(t + G, 1);
+        if (t + 2 * G >= n_tiles) break;
+        put(smem, ring[0]);
+        if (t + 4 * G < n_tiles) fetch(ring[0], t + 4 * G);
+        __syncthreads();
+        t += 2 * G;
+    }
+    if (lane == 0) {
+        static_for<2>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            const int q = qw + kWaves * s;
+            const unsigned long long v = (unsigned long long)n_gt[s] | ((unsigned long long)n_ge[s] << 32);
+            if (q < Q && v) atomicAdd(acc + q, v);
+        });
+    }
+}
+
+bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
+    if (q_head > kStreamQ || q_tail > kStreamQ || N <= 0) return false;
+    if (model == TRANSE) return (D == 64 || D == 128 || D == 256) && ld < (1 << 22);  // (32-bit byte offsets inside a tile)
+    return D == 64 || D == 128;  // a whole row + 32 sums in registers
+}
+
+template <int MODEL, int D>
+static hipError_t launch_stream_wg(const float* table, int64_t N, int64_t ld, const float* coef_head, const float* coef_tail,
+                                   const float* key_true, int q_head, int q_tail, int n_tiles, unsigned long long* acc,
+                                   int n_cu, hipStream_t stream) {
+    const size_t lds = (size_t)2 * kTileRows * (D + 4) * 4;
+    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_stream_wg_kernel<MODEL, D>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int resident = 2 * n_cu;
+    rank_stream_wg_kernel<MODEL, D><<<(unsigned)(n_tiles < resident ? n_tiles : resident), kWaves * 64, lds, stream>>>(
+        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, n_tiles, acc);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
                               unsigned long long* acc, int n_cu, hipStream_t stream) {
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
+    if (model != TRANSE) {
+#define BLP_STREAM_WG(MM, DD)                                                                                        \
+    if (model == MM && D == DD)                                                                                      \
+        return launch_stream_wg<MM, DD>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,       \
+                                        (int)n_tiles, acc, n_cu, stream);
+        BLP_STREAM_WG(DISTMULT, 64) BLP_STREAM_WG(DISTMULT, 128) BLP_STREAM_WG(COMPLEX, 64) BLP_STREAM_WG(COMPLEX, 128)
+        BLP_STREAM_WG(SIMPLE, 64) BLP_STREAM_WG(SIMPLE, 128)
+#undef BLP_STREAM_WG
+        return hipErrorInvalidValue;
+    }
     const int64_t n_rounds = (n_tiles + kWaves - 1) / kWaves;
-    const int64_t resident = (int64_t)n_cu * 4;  // four workgroups of four waves per CU: 4 waves per SIMD
+    const int64_t resident = (int64_t)n_cu * (D == 256 ? 3 : 4);  // workgroups of four waves per CU: 4 (3) waves per SIMD
     const unsigned blocks = (unsigned)(n_rounds < resident ? n_rounds : resident);
 #define BLP_STREAM_CASE(DD)                                                                                          \
     case DD:                                                                                                         \

@@ -233,22 +233,24 @@ def test_small_blocks_default_routing_equals_the_other_kernels(ops, model, knobs
     assert np.array_equal(auto, tiles) and np.array_equal(auto, prepass)
 
 
-@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("model,D", [("transe", 64), ("transe", 128), ("transe", 256), ("distmult", 64), ("distmult", 128),
+                                     ("complex", 64), ("complex", 128), ("simple", 64), ("simple", 128)])
 @pytest.mark.parametrize("q_head,q_tail", [(2, 2), (4, 4), (0, 3), (1, 0), (3, 1)])
-def test_transe_stream_kernel_vs_oracle(ops, oracle, knobs, D, q_head, q_tail):
-    """A handful of TransE queries (the reference's Wikidata5M eval batch: 2 triples = 4 queries per table pass,
-    scripts/blp-transe-wikidata5m.sh:18) go to rank_stream.hip: the table consumed 32 columns at a time from a load ring
-    that runs across tile boundaries.  Tables of 1 row .. many tiles per wave with a ragged last tile, a tie with the
-    true entity, a non-finite row, a filter; counts against the oracle and against rank_tiles<STATIC> (knob)."""
+def test_stream_kernels_vs_oracle(ops, oracle, knobs, model, D, q_head, q_tail):
+    """A handful of queries (the reference's Wikidata5M eval batch: 2 triples = 4 queries per table pass,
+    scripts/blp-*-wikidata5m.sh:18) go to rank_stream.hip: TransE consumes the table 32 columns at a time from a load
+    ring that runs across tile boundaries, the bilinear models through a workgroup's double-buffered LDS tile.  Tables of
+    1 row .. many tiles per wave with a ragged last tile, a tie with the true entity, non-finite rows, a filter; counts
+    against the oracle and against rank_tiles<STATIC> (knob)."""
     for N in (1, 63, 130, 70001):
-        table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=N + D + q_head)
+        table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=N + D + q_head)
         if N > 100:
             table[17] = table[int(true_row[0])]  # an exact tie with query 0's true entity
             table[N - 1, 3] = float("inf")
             table[N // 2, 0] = float("nan")
         rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=N)
-        want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
-        args = ("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+        want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+        args = (model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
         kw = dict(true_row=true_row.cuda(), filt_rowptr=dev(rowptr), filt_col=dev(col))
         knobs("stream_kernel", 0)
         got = ops.rank_all(*args, **kw).cpu().numpy()

@@ -25,7 +25,7 @@ def make_case(rng):
     N = int(rng.integers(1, 2500)) if rng.random() < 0.9 else int(rng.integers(2500, 12000))
     q_head, q_tail = int(rng.integers(0, 500)), int(rng.integers(0, 500))
     if rng.random() < 0.1:
-        q_head, q_tail = int(rng.integers(0, 3)), int(rng.integers(0, 3))  # the few-queries (HBM-streaming) mode
+        q_head, q_tail = int(rng.integers(0, 5)), int(rng.integers(0, 5))  # the few-queries (HBM-streaming) mode
     elif rng.random() < 0.1:  # many query tiles per side (chunking of the pair lists), few candidates
         q_head, q_tail = int(rng.integers(0, 4000)), int(rng.integers(0, 4000))
         N = int(rng.integers(1, 600))
@@ -92,6 +92,8 @@ def make_case(rng):
         env["small_kernel"] = int(rng.choice([1, 3]))  # (3: TransE on the register-tile variant) wherever it can run (D = 64 / 128, up to 4 096 queries), whatever the block size
         if rng.random() < 0.5:
             env["exact_query_chunk"] = int(rng.integers(1, 200))
+    if rng.random() < 0.3:
+        env["stream_kernel"] = 2     # TransE with <= 4 + 4 queries on rank_tiles<STATIC> instead of rank_stream.hip
     return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids, (fixed_idx, rel_table)
 
 

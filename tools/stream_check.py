@@ -4,7 +4,7 @@ from blp_amd import ops, _lib
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(5)
 bad = 0
-for D in (64, 128, 256):
+for model, D in (("transe", 64), ("transe", 128), ("transe", 256), ("distmult", 128), ("complex", 64), ("complex", 128), ("simple", 128)):
     for N in (1, 63, 64, 65, 257, 5000, 70001, 575000):
         table = torch.nn.functional.normalize(torch.randn((N, D), device=dev, generator=g), dim=-1)
         if N > 300: table[17] = table[5]  # ties
@@ -17,11 +17,11 @@ for D in (64, 128, 256):
             r = torch.randint(0, 9, (Q,), device=dev, generator=g)
             qf, qr = table[fixed].contiguous(), rel[r].contiguous()
             _lib.reset_knobs(); _lib.set_knob("small_kernel", 2)
-            a = ops.rank_all("transe", table, qf, qr, qh, true_row=true)
+            a = ops.rank_all(model, table, qf, qr, qh, true_row=true)
             _lib.set_knob("stream_kernel", 2)
-            b = ops.rank_all("transe", table, qf, qr, qh, true_row=true)
+            b = ops.rank_all(model, table, qf, qr, qh, true_row=true)
             if not torch.equal(a, b):
-                bad += 1; print("MISMATCH", D, N, qh, qt, a.tolist(), b.tolist())
+                bad += 1; print("MISMATCH", model, D, N, qh, qt, a.tolist(), b.tolist())
 print("mismatches", bad)
 _lib.reset_knobs()
 for N in (575000, 4600000):
@@ -30,9 +30,10 @@ for N in (575000, 4600000):
     fixed = torch.randint(0, N, (4,), device=dev, generator=g); true = torch.randint(0, N, (4,), device=dev, generator=g)
     qf, qr, qt = table[fixed].contiguous(), rel[:4].contiguous(), table[true].contiguous()
     out = torch.empty((4, 4), dtype=torch.int32, device=dev)
-    for knob in (0, 2):
-        _lib.set_knob("stream_kernel", knob)
-        def step():
-            for _ in range(64): ops.rank_all("transe", table, qf, qr, 2, q_true=qt, out=out)
-        step(); torch.cuda.synchronize(); t0 = time.perf_counter(); step(); step(); torch.cuda.synchronize()
-        print(f"N={N} stream_kernel={knob}: {(time.perf_counter() - t0) / 128 * 1e6:.1f} us per pass")
+    for model in ("transe", "distmult", "complex", "simple"):
+        for knob in (0, 2):
+            _lib.set_knob("stream_kernel", knob)
+            def step():
+                for _ in range(64): ops.rank_all(model, table, qf, qr, 2, q_true=qt, out=out)
+            step(); torch.cuda.synchronize(); t0 = time.perf_counter(); step(); step(); torch.cuda.synchronize()
+            print(f"{model} N={N} stream_kernel={knob}: {(time.perf_counter() - t0) / 128 * 1e6:.1f} us per pass")
