@@ -16,7 +16,7 @@ fixed = torch.randint(0, $ROWS, ($Q,), device=dev, generator=g)
 true = torch.randint(0, $ROWS, ($Q,), device=dev, generator=g)
 r = torch.randint(0, 822, ($Q,), device=dev, generator=g)
 qf, qr, qt = table[fixed].contiguous(), rel[r].contiguous(), table[true].contiguous()
-for _ in range(8):
+for _ in range(200):
     c = ops.rank_all("$M", table, qf, qr, $Q // 2, q_true=qt)
 torch.cuda.synchronize()
 PY
@@ -28,7 +28,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if "blp::" in r["Kernel_Name"]]
 names = [r["Kernel_Name"] for r in rows]
 first = names[-1]  # walk back to the start of the last call: the last occurrence of the call's first kernel
-n_call = len(rows) // 8
+n_call = len(rows) // 200
 seg = rows[-n_call:]
 prev_end = None; busy = 0; gaps = 0
 for r in seg:
