@@ -137,16 +137,9 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restri
     }
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (q >= q_head + q_tail) return;
-    acc[q] = 0;
-    float e[D];
-    load_row<D>(e, true_row ? table + true_row[q] * ld : q_true + q * D);
-    const float* f = q_fixed.row(q);
-    const float* r = q_rel.row(q);
-    key_true[q] = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r})
-                             : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
+    true_key_lane<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q, q_head, key_true, acc);
 }
 
-constexpr int64_t kTrueKeyLaneMaxQueries = 2048;
 
 // True keys (and zeroed accumulators); with coef_head / coef_tail also the coefficient rows of the exact path.
 template <int MODEL, int D>

@@ -80,6 +80,8 @@ hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t 
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
                                   hipStream_t stream, int n_partials = 1);
 
+constexpr int64_t kTrueKeyLaneMaxQueries = 2048;  // up to here true keys are one lane per query (exact_coop.h: true_key_lane)
+
 // rank_all.hip: true-entity keys by the exact routine (and the Q rank-count accumulators `acc` zeroed on the way)
 hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
                             const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
@@ -88,7 +90,7 @@ hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q
 // rank_small.hip: the exact f32 kernel for small blocks (coefficients computed in the kernel, LDS broadcasts, TransE
 // chains interleaved): the ranking pass only, between launch_true_keys and launch_filter_finalize.
 constexpr long long kSmallMaxPairsTransE = 4000000;    // above (== kSadMinPairs): the fixed-point pre-pass
-constexpr long long kSmallMaxPairsBilinear = 1500000;  // above: the bf16 x 3 MFMA pre-pass (tools/exact_small_probe.py)
+constexpr long long kSmallMaxPairsBilinear = 800000;   // above (and from 64 queries on): the bf16 x 3 MFMA pre-pass (tools/exact_small_probe.py)
 constexpr int kSmallMaxSlots = 256;                    // partial counts per query it leaves (one per tile slot)
 constexpr long long kSmallMaxQueries = 4096;           // whatever the knob says
 bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);

@@ -340,17 +340,17 @@ __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, uns
 }
 
 // Query tile image for the bf16 kernel: uint4 index (s * 64 + l) of the hi part, then of the lo part,
-// holds W_{q = l & 31}[16 s + 8 (l >> 5) + j], j = 0..7, as four packed bf16 pairs.
+// holds W_{q = l & 31}[16 s + 8 (l >> 5) + j], j = 0..7, as four packed bf16 pairs.  A workgroup of 256 threads, query
+// tile `vblock` of the th head-side + tt tail-side tiles.
 template <int MODEL, int D>
-__global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const QRows q_fixed,
-                                                             const QRows q_rel, int64_t q_head,
-                                                             int64_t q_tail, uint4* __restrict__ img_head,
-                                                             uint4* __restrict__ img_tail, float* __restrict__ eps_q) {
+__device__ __forceinline__ void prep_query_tile_bf16(int64_t vblock, const QRows& q_fixed, const QRows& q_rel, int64_t q_head,
+                                                     int64_t q_tail, uint4* __restrict__ img_head,
+                                                     uint4* __restrict__ img_tail, float* __restrict__ eps_q,
+                                                     float (&w_s)[kGQT][D + 1]) {
     constexpr int STEPS = D / 16, U4 = STEPS * 64;  // uint4 per part
-    __shared__ float w_s[kGQT][D + 1];
     const int64_t th = (q_head + kGQT - 1) / kGQT;
-    const bool head = blockIdx.x < th;
-    const int64_t tile = head ? blockIdx.x : blockIdx.x - th;
+    const bool head = vblock < th;
+    const int64_t tile = head ? vblock : vblock - th;
     const int64_t n_side = head ? q_head : q_tail;
     const int ql = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const int64_t q_local = tile * kGQT + ql;
@@ -404,12 +404,11 @@ __global__ __launch_bounds__(256) void prep_gemm_bf16_kernel(const QRows q_fixed
 // factor (||e|| rounded up, inf for rows the relative bounds do not cover) among the 16 rows the accumulator
 // registers of a lane in that half hold.  Tiles are padded to whole workgroup loads (kBfW * kBfTPW tiles).
 template <int D>
-__global__ __launch_bounds__(64) void prep_cand_bf16_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
-                                                            uint4* __restrict__ cimg, float* __restrict__ cnmax) {
+__device__ __forceinline__ void prep_cand_tile_bf16(int64_t tile, int lane, const float* __restrict__ table, int64_t N,
+                                                    int64_t ld, uint4* __restrict__ cimg, float* __restrict__ cnmax,
+                                                    float (&nrm)[32]) {  // one wave per tile; nrm: the wave's own
     constexpr int STEPS = D / 16;
-    __shared__ float nrm[32];
-    const int lane = threadIdx.x, half = lane >> 5;
-    const int64_t tile = blockIdx.x;
+    const int half = lane >> 5;
     const int64_t row = tile * kGCT + (lane & 31);
     const bool exists = row < N;
     const float* src = table + (exists ? row : 0) * ld + 8 * half;
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(64) void prep_cand_bf16_kernel(const float* __restr
     mx = m2 > mx ? m2 : mx;
     bad |= (bool)__shfl_xor((int)bad, 32);
     if (lane < 32) nrm[lane] = exists ? band_norm(ss, bad ? __builtin_inff() : mx) : 0.f;
-    __syncthreads();
+    wave_lds_sync();
     if (lane < 2) {  // lane = half
         float m = 0.f;
 #pragma unroll
@@ -453,6 +452,38 @@ __global__ __launch_bounds__(64) void prep_cand_bf16_kernel(const float* __restr
         }
         cnmax[tile * 2 + lane] = m;
     }
+}
+
+// Everything the bf16 pre-pass needs before its first MFMA, in ONE launch (they were four: a call with the reference's
+// 128-query batch is a chain of ~5 us launches around an 11 us GEMM):
+//   workgroups [0, q_blocks): a query tile each -- its operand image and band factors; its queries' rows of the flag
+//     bitmap zeroed (slab 0; `words` per query); and, for calls of up to kTrueKeyLaneMaxQueries queries (true_keys), the
+//     true-entity keys of the tile's queries, one lane each (above that the cooperative kernel does them, launched before);
+//   workgroups after them: four candidate tiles each, one per wave -- the table's operand images.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void gemm_prelude_bf16_kernel(
+    const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail, uint4* __restrict__ img_head,
+    uint4* __restrict__ img_tail, float* __restrict__ eps_q, unsigned q_blocks, const float* __restrict__ table, int64_t N,
+    int64_t ld, int64_t cand_tiles, uint4* __restrict__ cimg, float* __restrict__ cnmax, unsigned* __restrict__ n_pairs,
+    unsigned* __restrict__ flags, int words, int true_keys, const int64_t* __restrict__ true_row,
+    const float* __restrict__ q_true, float* __restrict__ key_true, unsigned long long* __restrict__ acc) {
+    __shared__ float w_s[kGQT][D + 1];
+    __shared__ float nrm[4][32];
+    if (blockIdx.x >= q_blocks) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int64_t tile = (int64_t)(blockIdx.x - q_blocks) * 4 + wave;
+        if (tile < cand_tiles) prep_cand_tile_bf16<D>(tile, lane, table, N, ld, cimg, cnmax, nrm[wave]);
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) n_pairs[threadIdx.x] = 0;  // the entry counter (and its padding)
+    const int64_t th = (q_head + kGQT - 1) / kGQT;
+    const bool head = blockIdx.x < th;
+    const int64_t q0 = head ? (int64_t)blockIdx.x * kGQT : q_head + ((int64_t)blockIdx.x - th) * kGQT;
+    const int64_t q1 = head ? (q0 + kGQT < q_head ? q0 + kGQT : q_head) : (q0 + kGQT < q_head + q_tail ? q0 + kGQT : q_head + q_tail);
+    for (int64_t i = q0 * words + threadIdx.x; i < q1 * words; i += 256) flags[i] = 0;
+    if (true_keys && threadIdx.x >= 192 && q0 + (threadIdx.x - 192) < q1)  // (the last wave: kGQT = 32 of its lanes)
+        true_key_lane<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q0 + (threadIdx.x - 192), q_head, key_true, acc);
+    prep_query_tile_bf16<MODEL, D>(blockIdx.x, q_fixed, q_rel, q_head, q_tail, img_head, img_tail, eps_q, w_s);
 }
 
 template <int D>
@@ -1072,18 +1103,14 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     const int64_t Q = q_head + q_tail;
     GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
     const int64_t pass_tiles = w.pass_ctiles;
-    hipError_t err = launch_true_keys(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.key_true, w.acc,
-                                      stream);
-    if (err != hipSuccess) return err;
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
     const bool f32_kernel = gemm_use_f32();
-    if (f32_kernel)
-        prep_gemm_kernel<MODEL, D><<<dim3((unsigned)(th + tt)), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail,
-                                                                                 w.img_head, w.img_tail, w.eps_q);
-    else
-        prep_gemm_bf16_kernel<MODEL, D><<<dim3((unsigned)(th + tt)), 256, 0, stream>>>(
-            q_fixed, q_rel, q_head, q_tail, reinterpret_cast<uint4*>(w.img_head), reinterpret_cast<uint4*>(w.img_tail),
-            w.eps_q);
+    // the bf16 path folds the true keys of a small call into its prelude launch (below)
+    const bool keys_in_prelude = !f32_kernel && Q <= kTrueKeyLaneMaxQueries;
+    hipError_t err = hipSuccess;
+    if (!keys_in_prelude)
+        err = launch_true_keys(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.key_true, w.acc, stream);
+    if (err != hipSuccess) return err;
     const size_t lds_f32 = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
                            (size_t)kPairQuota * 8 + 16;
     float* dump_s = g_dump_s;
@@ -1091,17 +1118,31 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     g_dump_s = g_dump_eps = nullptr;
     if (dump_s && (f32_kernel || D != 128 || N > pass_tiles * kGCT)) return hipErrorInvalidValue;  // one slab of the bf16 kernel
     if (ev_start) (void)hipEventRecord(ev_start, stream);
-    if (!f32_kernel) {  // the table as bf16 hi / lo MFMA operands + band factors, once per call
+    auto slab_words = [&](int64_t slab0) {  // flag words per query of the slab that starts at row slab0
+        const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
+        return (int)(((n_rows + kGCT - 1) / kGCT + 15) / 16);
+    };
+    if (f32_kernel) {
+        prep_gemm_kernel<MODEL, D><<<dim3((unsigned)(th + tt)), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail,
+                                                                                 w.img_head, w.img_tail, w.eps_q);
+    } else {
+        // query operand images + the table as bf16 hi / lo MFMA operands with band factors (once per call) + slab 0's
+        // zeroed flag bitmap and entry counter (+ the true keys of a small call): one launch
         const int64_t per_group = kBfW * kBfTPW;
         const int64_t tiles = ((N + kGCT - 1) / kGCT + per_group - 1) / per_group * per_group;
-        if (tiles > 0) prep_cand_bf16_kernel<D><<<dim3((unsigned)tiles), 64, 0, stream>>>(table, N, ld, w.cimg, w.cnmax);
+        const int64_t blocks = th + tt + (tiles + 3) / 4;
+        if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+        gemm_prelude_bf16_kernel<MODEL, D><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+            q_fixed, q_rel, q_head, q_tail, reinterpret_cast<uint4*>(w.img_head), reinterpret_cast<uint4*>(w.img_tail), w.eps_q,
+            (unsigned)(th + tt), table, N, ld, tiles, w.cimg, w.cnmax, w.n_pairs, w.flags, slab_words(0), keys_in_prelude ? 1 : 0,
+            true_row, q_true, w.key_true, w.acc);
     }
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_tiles * kGCT) {  // one iteration unless the bitmap is capped
         const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
         const int64_t n_ctiles = (n_rows + kGCT - 1) / kGCT;
         const int tiles_per_group = f32_kernel ? kGW : kBfW * kBfTPW;
         const int64_t n_groups = (n_ctiles + tiles_per_group - 1) / tiles_per_group;
-        const int words = (int)((n_ctiles + 15) / 16);
+        const int words = slab_words(slab0);
         int tiles_per_chunk = kGTilesPerChunk;
         if (!f32_kernel) {
             // smallest estimated time: rounds of the resident workgroups (2 per CU) x (set-up + query tiles).  A
@@ -1122,8 +1163,10 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                                 (size_t)kBfQuotaPerTile * tiles_per_chunk * 8 + (size_t)tiles_per_chunk * kGQT * 8 +
                                 (size_t)kBfW * kBfTPW * 2 * 8 + 16;
         const int64_t n_blocks = n_groups * (chunks_head + chunks_tail);
-        err = hipMemsetAsync(w.n_pairs, 0, 256 + (size_t)Q * words * 4, stream);  // the entry counter and the flag bitmap
-        if (err != hipSuccess) return err;
+        if (f32_kernel || slab0 > 0) {  // the entry counter and the flag bitmap (slab 0 of the bf16 path: zeroed by its prelude)
+            err = hipMemsetAsync(w.n_pairs, 0, 256 + (size_t)Q * words * 4, stream);
+            if (err != hipSuccess) return err;
+        }
         const float* slab = table + slab0 * ld;
         if (f32_kernel) {
             const int64_t n_entries = n_blocks * kPairQuota;
