@@ -520,7 +520,10 @@ bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t 
     const int64_t Q = q_head + q_tail;
     if (Q == 0 || Q > kSmallMaxQueries || N <= 0) return false;
     if (forced == 1 || forced == 3) return true;
-    if (q_head <= 4 && q_tail <= 4) return false;  // a reference batch against a huge table: the HBM-streaming kernel
+    // <= 4 + 4 queries (the reference's Wikidata5M batch) against more than one tile per slot: the streaming kernels
+    // (rank_stream.hip); against a small table -- the reference's own Wikidata5M protocol ranks against the ~7.4 k entities of
+    // the evaluated triples (train.py:312-314) -- this kernel (tools/few_queries_probe.py: 8 queries x 7 400 rows 31 -> 21 us)
+    if (q_head <= 4 && q_tail <= 4 && N > (int64_t)kSmallMaxSlots * kTileRows) return false;
     if (model == TRANSE && knob(KNOB_SAD_MIN_QUERIES) > 0 && Q >= knob(KNOB_SAD_MIN_QUERIES)) return false;  // A/B knob
     return Q * N < (model == TRANSE ? kSmallMaxPairsTransE : kSmallMaxPairsBilinear);
 }

@@ -143,7 +143,7 @@ def test_transe_small_blocks_take_the_exact_kernels(ops, oracle, q_head, q_tail)
     assert np.array_equal(got, want)
 
 
-SMALL_SHAPES = [(5, 7), (64, 64), (0, 33), (37, 0), (130, 129)]
+SMALL_SHAPES = [(5, 7), (64, 64), (0, 33), (37, 0), (130, 129), (2, 2), (4, 3), (1, 0)]
 
 
 @pytest.mark.default_routing
