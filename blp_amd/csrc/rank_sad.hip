@@ -69,13 +69,11 @@ __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict_
 // 4 j4 .. 4 j4 + 3 of row (tile * 64 + lane); dword j packs elements 2j (low half) and 2j + 1.
 // resid[row] = the row's rounding residual E_c, rounded up to an integer.
 template <int D>
-__global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __restrict__ table, int64_t N,
-                                                                 int64_t ld, const SadParams* __restrict__ p,
-                                                                 uint4* __restrict__ cimg,
-                                                                 unsigned* __restrict__ resid) {
+__device__ __forceinline__ void sad_quantize_table_tile(int64_t tile, const float* __restrict__ table, int64_t N,
+                                                        int64_t ld, const SadParams* __restrict__ p,
+                                                        uint4* __restrict__ cimg, unsigned* __restrict__ resid) {
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
-    const int64_t tile = blockIdx.x;
     const int row_in = threadIdx.x >> 2, part = threadIdx.x & 3;
     const int64_t row = tile * 64 + row_in;
     constexpr int F = D / 4;  // floats per thread
@@ -109,16 +107,17 @@ __global__ __launch_bounds__(256) void sad_quantize_table_kernel(const float* __
 
 // Query image (D/2 dwords per query, same packing) and the two signed thresholds {T_lo, T_hi}.
 // D/2 consecutive threads per query (32, 64 or 128: whole waves or half-waves).
+// (workgroup vblock of vgrid)
 template <int D>
-__global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const QRows q_fixed,
-                                                                   const QRows q_rel, int64_t q_head,
-                                                                   int64_t Q, const float* __restrict__ key_true,
-                                                                   const SadParams* __restrict__ p,
-                                                                   unsigned* __restrict__ qimg,
-                                                                   int2* __restrict__ thr, unsigned* __restrict__ flags,
-                                                                   int64_t n_flag_words) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t j = i; j < n_flag_words; j += (int64_t)gridDim.x * blockDim.x) flags[j] = 0;  // first slab's bitmap
+__device__ __forceinline__ void sad_quantize_queries_block(int64_t vblock, int64_t vgrid, const QRows& q_fixed,
+                                                           const QRows& q_rel, int64_t q_head,
+                                                           int64_t Q, const float* __restrict__ key_true,
+                                                           const SadParams* __restrict__ p,
+                                                           unsigned* __restrict__ qimg,
+                                                           int2* __restrict__ thr, unsigned* __restrict__ flags,
+                                                           int64_t n_flag_words) {
+    const int64_t i = vblock * 256 + threadIdx.x;
+    for (int64_t j = i; j < n_flag_words; j += vgrid * 256) flags[j] = 0;  // first slab's bitmap
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
     __shared__ float part_res[4], part_max[4];
@@ -165,6 +164,22 @@ __global__ __launch_bounds__(256) void sad_quantize_queries_kernel(const QRows q
         }
         thr[q] = make_int2(t_lo, t_hi);
     }
+}
+
+// Both images in one launch: workgroups [0, table_blocks) a candidate tile each, the rest the queries.
+template <int D>
+__global__ __launch_bounds__(256) void sad_quantize_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
+                                                           const SadParams* __restrict__ p, uint4* __restrict__ cimg,
+                                                           unsigned* __restrict__ resid, unsigned table_blocks,
+                                                           const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t Q,
+                                                           const float* __restrict__ key_true, unsigned* __restrict__ qimg,
+                                                           int2* __restrict__ thr, unsigned* __restrict__ flags,
+                                                           int64_t n_flag_words) {
+    if (blockIdx.x < table_blocks)
+        sad_quantize_table_tile<D>(blockIdx.x, table, N, ld, p, cimg, resid);
+    else
+        sad_quantize_queries_block<D>(blockIdx.x - table_blocks, gridDim.x - table_blocks, q_fixed, q_rel, q_head, Q, key_true, p,
+                                      qimg, thr, flags, n_flag_words);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -530,6 +545,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     constexpr int TPW = sad_tiles_per_wave(D);
     const int64_t Q = q_head + q_tail;
     SadWorkspace w = carve_sad(workspace, D, N, q_head, q_tail);
+    // (the true keys of a small call folded into the range launch, one lane per query: tried -- 2 us slower from 256
+    //  queries on, where this path starts)
     hipError_t err = launch_true_keys(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.key_true, w.acc,
                                       stream);
     if (err != hipSuccess) return err;
@@ -546,10 +563,13 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     const int64_t first_rows = N < w.pass_groups * kSW * TPW * 64 ? N : w.pass_groups * kSW * TPW * 64;
     const int64_t first_groups = ((first_rows + 63) / 64 + kSW * TPW - 1) / (kSW * TPW);
     const int64_t first_words = (first_groups * kSW * TPW + 31) / 32;
-    if (n_tiles > 0)
-        sad_quantize_table_kernel<D><<<dim3((unsigned)n_tiles), 256, 0, stream>>>(table, N, ld, w.params, w.cimg, w.resid);
-    sad_quantize_queries_kernel<D><<<dim3((unsigned)((Q * (D / 2) + 255) / 256)), 256, 0, stream>>>(
-        q_fixed, q_rel, q_head, Q, w.key_true, w.params, w.qimg, w.thr, w.flags, first_words * Q);
+    {
+        const int64_t query_blocks = (Q * (D / 2) + 255) / 256;
+        if (n_tiles + query_blocks > 0x7fffffff) return hipErrorInvalidValue;
+        sad_quantize_kernel<D><<<dim3((unsigned)(n_tiles + query_blocks)), 256, 0, stream>>>(
+            table, N, ld, w.params, w.cimg, w.resid, (unsigned)n_tiles, q_fixed, q_rel, q_head, Q, w.key_true, w.qimg, w.thr,
+            w.flags, first_words * Q);
+    }
 
     const int64_t tiles_per_group = kSW * TPW;
     const int per_group = sad_queries_per_group(D, N, Q);
