@@ -518,7 +518,7 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     return w;
 }
 
-// Worth it once its longer launch chain (range, quantisation, pre-pass, two refinement kernels: 9 launches against
+// Worth it once its longer launch chain (range, quantisation, pre-pass, two refinement kernels: 8 launches against
 // the exact path's 4) is paid for by the 2.3x cheaper pair-element: measured on the FB15k-237 table (14 541 rows) the
 // exact f32 kernels win up to ~256 queries (128 queries: 42 vs 59 us), on the 4.6 M-row table the pre-pass wins from 64
 // queries on -- i.e. from about 4 million (query, candidate) pairs (tools/bench_small_blocks.py).
