@@ -15,6 +15,10 @@ CASES = [  # model, D, N, q_head, q_tail
     ("transe", 128, 64, 128, 128), ("transe", 128, 65, 129, 127), ("transe", 256, 4096, 64, 64),
     ("distmult", 128, 32, 32, 32), ("distmult", 128, 33, 2049, 2047), ("complex", 128, 16384, 16, 48),
     ("transe", 300, 5, 300, 0), ("transe", 768, 129, 0, 257), ("transe", 36, 1000, 256, 1),
+    # a handful of queries against long tables (rank_stream.hip): many tiles per wave, a ragged last tile, one side only
+    ("transe", 128, 1_500_001, 2, 2), ("transe", 256, 300_007, 4, 4), ("transe", 64, 2_000_003, 0, 3),
+    ("distmult", 128, 1_200_005, 2, 2), ("complex", 128, 700_001, 4, 4), ("simple", 64, 1_000_001, 1, 0),
+    ("complex", 256, 200_003, 2, 2),
 ]
 bad = 0
 for model, D, N, qh, qt in CASES:
