@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256) void sad_range_kernel(const float* __restrict_
 // Candidate tile image: 64 rows per tile, uint4 index ((tile * D/8 + j4) * 64 + lane) holds dwords
 // 4 j4 .. 4 j4 + 3 of row (tile * 64 + lane); dword j packs elements 2j (low half) and 2j + 1.
 // resid[row] = the row's rounding residual E_c, rounded up to an integer.
+constexpr int64_t kSFoldFinishBlocks = 1024;  // quantising workgroups up to which they finish the range themselves ...
+constexpr int64_t kSFoldRangeBlocks = 256;    // ... from at most this many partial results
+
 template <int D>
 __device__ __forceinline__ void sad_quantize_table_tile(int64_t tile, const float* __restrict__ table, int64_t N,
                                                         int64_t ld, const SadParams* __restrict__ p,
@@ -166,19 +169,36 @@ __device__ __forceinline__ void sad_quantize_queries_block(int64_t vblock, int64
     }
 }
 
-// Both images in one launch: workgroups [0, table_blocks) a candidate tile each, the rest the queries.
+// Both images in one launch: workgroups [0, table_blocks) a candidate tile each, the rest the queries.  n_partial > 0
+// (small calls: a few hundred workgroups): every workgroup first reduces the range pass's partial results itself -- in
+// the fixed order of sad_range_finish_wave, so all of them quantise with the same map -- instead of waiting for a launch of
+// its own to do it once; workgroup 0 leaves the result in *p for the kernels that follow.
 template <int D>
 __global__ __launch_bounds__(256) void sad_quantize_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
-                                                           const SadParams* __restrict__ p, uint4* __restrict__ cimg,
+                                                           SadParams* __restrict__ p, const SadParams* __restrict__ partial,
+                                                           int n_partial, uint4* __restrict__ cimg,
                                                            unsigned* __restrict__ resid, unsigned table_blocks,
                                                            const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t Q,
                                                            const float* __restrict__ key_true, unsigned* __restrict__ qimg,
                                                            int2* __restrict__ thr, unsigned* __restrict__ flags,
                                                            int64_t n_flag_words) {
+    __shared__ SadParams p_block;
+    const SadParams* pp = p;
+    if (n_partial > 0) {
+        if (threadIdx.x < 64) {
+            const SadParams r = sad_range_finish_wave(partial, n_partial, threadIdx.x);
+            if (threadIdx.x == 0) {
+                p_block = r;
+                if (blockIdx.x == 0) *p = r;
+            }
+        }
+        __syncthreads();
+        pp = &p_block;
+    }
     if (blockIdx.x < table_blocks)
-        sad_quantize_table_tile<D>(blockIdx.x, table, N, ld, p, cimg, resid);
+        sad_quantize_table_tile<D>(blockIdx.x, table, N, ld, pp, cimg, resid);
     else
-        sad_quantize_queries_block<D>(blockIdx.x - table_blocks, gridDim.x - table_blocks, q_fixed, q_rel, q_head, Q, key_true, p,
+        sad_quantize_queries_block<D>(blockIdx.x - table_blocks, gridDim.x - table_blocks, q_fixed, q_rel, q_head, Q, key_true, pp,
                                       qimg, thr, flags, n_flag_words);
 }
 
@@ -552,24 +572,25 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     if (err != hipSuccess) return err;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     const int64_t n_tiles = (N + 63) / 64;
+    const int64_t query_blocks = (Q * (D / 2) + 255) / 256;
+    if (n_tiles + query_blocks > 0x7fffffff) return hipErrorInvalidValue;
+    // small calls: no launch for the range's last step -- the quantising workgroups do it themselves (from fewer partials)
+    const bool fold_finish = n_tiles + query_blocks <= kSFoldFinishBlocks;
+    int64_t range_blocks;
     {
-        const int64_t items = N * (D / 4) > Q * D ? N * (D / 4) : Q * D;
-        int64_t blocks = (items + 255) / 256;
-        blocks = blocks < kSRangeBlocks ? (blocks > 0 ? blocks : 1) : kSRangeBlocks;
-        sad_range_kernel<D><<<dim3((unsigned)blocks), 256, 0, stream>>>(table, N, ld, q_fixed, q_rel, q_head, Q, w.partial);
-        sad_range_finish_kernel<<<1, 64, 0, stream>>>(w.partial, (int)blocks, w.params);
+        const int64_t items = N * (D / 4) > Q * D ? N * (D / 4) : Q * D, cap = fold_finish ? kSFoldRangeBlocks : kSRangeBlocks;
+        range_blocks = (items + 255) / 256;
+        range_blocks = range_blocks < cap ? (range_blocks > 0 ? range_blocks : 1) : cap;
+        sad_range_kernel<D><<<dim3((unsigned)range_blocks), 256, 0, stream>>>(table, N, ld, q_fixed, q_rel, q_head, Q, w.partial);
+        if (!fold_finish) sad_range_finish_kernel<<<1, 64, 0, stream>>>(w.partial, (int)range_blocks, w.params);
     }
     // the first slab's flag bitmap and pair counter are zeroed by the prep kernels (later slabs: memsets)
     const int64_t first_rows = N < w.pass_groups * kSW * TPW * 64 ? N : w.pass_groups * kSW * TPW * 64;
     const int64_t first_groups = ((first_rows + 63) / 64 + kSW * TPW - 1) / (kSW * TPW);
     const int64_t first_words = (first_groups * kSW * TPW + 31) / 32;
-    {
-        const int64_t query_blocks = (Q * (D / 2) + 255) / 256;
-        if (n_tiles + query_blocks > 0x7fffffff) return hipErrorInvalidValue;
-        sad_quantize_kernel<D><<<dim3((unsigned)(n_tiles + query_blocks)), 256, 0, stream>>>(
-            table, N, ld, w.params, w.cimg, w.resid, (unsigned)n_tiles, q_fixed, q_rel, q_head, Q, w.key_true, w.qimg, w.thr,
-            w.flags, first_words * Q);
-    }
+    sad_quantize_kernel<D><<<dim3((unsigned)(n_tiles + query_blocks)), 256, 0, stream>>>(
+        table, N, ld, w.params, w.partial, fold_finish ? (int)range_blocks : 0, w.cimg, w.resid, (unsigned)n_tiles, q_fixed, q_rel,
+        q_head, Q, w.key_true, w.qimg, w.thr, w.flags, first_words * Q);
 
     const int64_t tiles_per_group = kSW * TPW;
     const int per_group = sad_queries_per_group(D, N, Q);

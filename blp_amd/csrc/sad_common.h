@@ -115,27 +115,32 @@ __device__ __forceinline__ void sad_range_block_store(SadRange r, SadParams* __r
     }
 }
 
-static __global__ __launch_bounds__(64) void sad_range_finish_kernel(const SadParams* __restrict__ partial, int n,
-                                                              SadParams* __restrict__ out) {
+// The range of the whole input from the n partial results, by one wave (fixed order: every caller gets the same bits);
+// the result is valid on lane 0.
+__device__ __forceinline__ SadParams sad_range_finish_wave(const SadParams* __restrict__ partial, int n, int lane) {
     SadRange r;
-    for (int i = threadIdx.x; i < n; i += 64) {
+    for (int i = lane; i < n; i += 64) {
         const SadParams p = partial[i];
         r.merge(p.lo_ord, p.hi_ord, p.nonfinite, p.sum, p.sumsq, p.count);
     }
     r.wave_reduce();
-    if (threadIdx.x == 0) {
-        SadParams p = r.record();
-        p.n_pairs = 0;
-        if (r.count > 0 && r.lo <= r.hi) {  // clamp the range to mean +- kSClampSigmas standard deviations
-            const double mean = r.sum / (double)r.count;
-            const double var = r.sumsq / (double)r.count - mean * mean;
-            const double sd = var > 0.0 ? sqrt(var) : 0.0;
-            const float lo_c = (float)(mean - kSClampSigmas * sd), hi_c = (float)(mean + kSClampSigmas * sd);
-            if (lo_c > ord2f(r.lo)) p.lo_ord = f2ord(lo_c);
-            if (hi_c < ord2f(r.hi)) p.hi_ord = f2ord(hi_c);
-        }
-        *out = p;
+    SadParams p = r.record();
+    p.n_pairs = 0;
+    if (r.count > 0 && r.lo <= r.hi) {  // clamp the range to mean +- kSClampSigmas standard deviations
+        const double mean = r.sum / (double)r.count;
+        const double var = r.sumsq / (double)r.count - mean * mean;
+        const double sd = var > 0.0 ? sqrt(var) : 0.0;
+        const float lo_c = (float)(mean - kSClampSigmas * sd), hi_c = (float)(mean + kSClampSigmas * sd);
+        if (lo_c > ord2f(r.lo)) p.lo_ord = f2ord(lo_c);
+        if (hi_c < ord2f(r.hi)) p.hi_ord = f2ord(hi_c);
     }
+    return p;
+}
+
+static __global__ __launch_bounds__(64) void sad_range_finish_kernel(const SadParams* __restrict__ partial, int n,
+                                                              SadParams* __restrict__ out) {
+    const SadParams p = sad_range_finish_wave(partial, n, threadIdx.x);
+    if (threadIdx.x == 0) *out = p;
 }
 
 }  // namespace blp
