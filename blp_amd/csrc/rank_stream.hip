@@ -1,6 +1,7 @@
-// rank_stream.hip -- TransE, a handful of queries against a LONG table (the reference's Wikidata5M evaluation batch:
-// eval_batch_size 2 = 4 queries per pass over 4.6 M rows, scripts/blp-transe-wikidata5m.sh:18; train.py:128-171): the
-// pass is one read of the table, HBM-bound, and what matters is that the read never stops.
+// rank_stream.hip -- a handful of queries against a LONG table (the reference's Wikidata5M evaluation batch:
+// eval_batch_size 2 = 4 queries per pass over 4.6 M rows, scripts/blp-*-wikidata5m.sh:18; train.py:128-171): the
+// pass is one read of the table, HBM-bound, and what matters is that the read never stops.  TransE first; the
+// bilinear models' kernel is further down.
 //
 // rank_tiles<STATIC> (rank_all.hip) fetches a whole tile (64 rows x D floats, all D/4 loads of a lane at once), then
 // scores it: a wave alternates between a load phase and an arithmetic phase and only the drift between the waves of a
@@ -8,7 +9,7 @@
 // what a rank of an 8-GPU evaluation holds -- they have three, and the chip runs load phase / arithmetic phase in lock-step
 // (3.8 TB/s: [measured] 77 us for 294 MB).
 //
-// Here a wave consumes its tile 32 columns at a time -- TransE's sum runs strictly left to right over the row, so the
+// TransE: a wave consumes its tile 32 columns at a time -- TransE's sum runs strictly left to right over the row, so the
 // partial sums of the <= 4 + 4 queries are all that crosses a step -- from a ring of two 32-column pieces (2 x 8 loads of
 // 16 B per lane) that is refilled two steps ahead, ACROSS tile boundaries: every wave has 8-16 KB in flight at all
 // times and the arithmetic of a step runs under the loads of the next two.  64 + 32 + 8 live data registers instead of D
