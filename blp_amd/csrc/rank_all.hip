@@ -671,9 +671,12 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
     if (rank_small_applicable(MODEL, D, N, q_head, q_tail)) {  // small block: 3 launches, no coefficient array
         const int slots = rank_small_slots(N);
         RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail, slots);
-        launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream);
+        const bool coef = rank_small_wants_coef(MODEL, D, N);
+        launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream,
+                                  coef ? w.coef_head : nullptr, coef ? w.coef_tail : nullptr);
         if (ev_start) (void)hipEventRecord(ev_start, stream);
-        const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, w.acc, n_cu, stream);
+        const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.coef_head, w.coef_tail, w.key_true, q_head,
+                                                 q_tail, w.acc, n_cu, stream);
         if (err != hipSuccess) return err;
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
         return launch_filter_finalize(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter, w.acc, counts,

@@ -95,9 +95,10 @@ constexpr int kSmallMaxSlots = 256;                    // partial counts per que
 constexpr long long kSmallMaxQueries = 4096;           // whatever the knob says
 bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 int rank_small_slots(int64_t N);  // partial[slot * Q + q], slot < rank_small_slots(N): what the kernel writes (every entry)
+bool rank_small_wants_coef(int model, int D, int64_t N);  // its kernel reads materialised coefficient rows (coef_head / coef_tail)
 hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                             const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
-                             unsigned long long* partial, int n_cu, hipStream_t stream);
+                             const QRows q_rel, const float* coef_head, const float* coef_tail, const float* key_true,
+                             int64_t q_head, int64_t q_tail, unsigned long long* partial, int n_cu, hipStream_t stream);
 
 // rank_stream.hip: <= 4 + 4 queries, long table: the table streamed through a load pipeline that never drains (TransE: a
 // wave's ring of 32-column pieces; bilinear models: a workgroup's double-buffered LDS tile).  The ranking pass only:

@@ -511,21 +511,107 @@ __global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_lds_kernel(
 #endif
 }
 
+// ---- TransE, the tile in LDS, the coefficients in scalar registers ---------------------------------------------------------
+// The kernel above is bound by LDS traffic: per 4-element step a wave reads its row quad AND four or eight coefficient
+// quads (broadcasts).  Here the coefficients do not go through LDS at all: the true-key launch materialises the
+// coefficient rows (true_key_lane_kernel's extra workgroups -- still three launches), a wave reads them through the scalar
+// cache as SGPR operands (the way rank_stream.hip does), and the tile row is read 32 columns at a time -- eight
+// ds_read_b128 per piece and group of FOUR queries, whose partial sums are all that crosses a piece (TransE sums left to
+// right).  LDS traffic per (wave, query) drops from 2-3 KB to 128 B per lane; what is left is the VALU and the workgroup's
+// start (tile -> LDS).  Eight waves per workgroup, four per SIMD; groups of four queries go round the waves; counts
+// straight to the slot's partial counts.  Same operations in the same order as Scorer<TRANSE, SIDE, D>::score<false>.
+template <int D>
+__global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_sgpr_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
+    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles, int q_chunk,
+    unsigned long long* __restrict__ partial) {
+    constexpr int TS = D + 4, NT = kSmallLdsWaves * 64, NP = D / kSubCols;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // the tile: 64 x TS
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int chunk = blockIdx.x / n_tiles, slot = blockIdx.x % n_tiles;
+    const int Q = q_head + q_tail;
+    const int qa = chunk * q_chunk;
+    const int qb = qa + q_chunk < Q ? qa + q_chunk : Q;
+    const int64_t row0 = (int64_t)slot * kTileRows;
+    {   // the tile, 16-byte pieces tid, tid + 512, ...: whole 512-byte rows per 32 threads; rows past the end: the last row
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        constexpr int kPieces = kTileRows * (D / 4) / NT;
+        floatx4 piece[kPieces];
+        static_for<kPieces>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const int idx = tid + k * NT, r = idx / (D / 4), c = idx % (D / 4);
+            int64_t row = row0 + r;
+            row = row < N ? row : N - 1;
+            piece[k] = *reinterpret_cast<const floatx4*>(table + row * ld + 4 * c);
+        });
+        static_for<kPieces>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const int idx = tid + k * NT, r = idx / (D / 4), c = idx % (D / 4);
+            *reinterpret_cast<floatx4*>(smem + r * TS + 4 * c) = piece[k];
+        });
+    }
+    __syncthreads();
+    const bool valid = row0 + lane < N;
+    const float* rd = smem + lane * TS;
+    // groups of four consecutive queries of the chunk, group g to wave g % 8
+    for (int q0 = qa + 4 * wave; q0 < qb; q0 += 4 * kSmallLdsWaves) {
+        const int n = qb - q0 < 4 ? qb - q0 : 4;
+        // (the sums start at 0 instead of at the first |difference|: 0 + |d| == |d| bit for bit, |d| being +0, positive or NaN;
+        //  the piece loop is not unrolled -- unrolled, the compiler hoists every piece's LDS reads: 128 registers and spills)
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s = 0; s < NP; ++s) {
+            float x[kSubCols];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(rd + kSubCols * s + 4 * j);
+                x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+            }
+            static_for<4>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if (j < n) {
+                    const int q = q0 + j;  // wave-uniform
+                    if (q < q_head) sum[j] = transe_piece_sum<HEAD, D, false>(sum[j], x, coef_head + (size_t)q * 2 * D + s * kSubCols);
+                    else sum[j] = transe_piece_sum<TAIL, D, false>(sum[j], x, coef_tail + (size_t)(q - q_head) * D + s * kSubCols);
+                }
+            });
+        }
+        static_for<4>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if (j < n) {
+                const float key = -sum[j], kt = key_true[q0 + j];
+                const unsigned long long gt = __popcll(__ballot(valid && key > kt)), ge = __popcll(__ballot(valid && key >= kt));
+                if (lane == 0) partial[(size_t)slot * Q + q0 + j] = gt | (ge << 32);
+            }
+        });
+    }
+}
+
 // Blocks this kernel takes by itself (knob small_kernel: 1 = every block it can, 2 = none).  Above a few hundred
 // queries the pre-pass paths (TransE: >= kSadMinPairs pairs, bilinear: the MFMA GEMM) are faster.
 bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
     const long long forced = knob(KNOB_SMALL_KERNEL);
     if (forced == 2 || (D != 64 && D != 128) || knob(KNOB_RANK_KERNEL) == 1) return false;
-    // (forced == 3: as 1, with TransE on the register-tile kernel instead of the LDS-tile one)
+    // (forced == 3 / 4: as 1, with TransE on the register-tile / LDS-broadcast kernel instead of the SGPR-coefficient one)
     const int64_t Q = q_head + q_tail;
     if (Q == 0 || Q > kSmallMaxQueries || N <= 0) return false;
-    if (forced == 1 || forced == 3) return true;
+    if (forced == 1 || forced == 3 || forced == 4) return true;
     // <= 4 + 4 queries (the reference's Wikidata5M batch) against more than one tile per slot: the streaming kernels
     // (rank_stream.hip); against a small table -- the reference's own Wikidata5M protocol ranks against the ~7.4 k entities of
     // the evaluated triples (train.py:312-314) -- this kernel (tools/few_queries_probe.py: 8 queries x 7 400 rows 31 -> 21 us)
     if (q_head <= 4 && q_tail <= 4 && N > (int64_t)kSmallMaxSlots * kTileRows) return false;
     if (model == TRANSE && knob(KNOB_SAD_MIN_QUERIES) > 0 && Q >= knob(KNOB_SAD_MIN_QUERIES)) return false;  // A/B knob
     return Q * N < (model == TRANSE ? kSmallMaxPairsTransE : kSmallMaxPairsBilinear);
+}
+
+// TransE against a table of at most kSmallMaxSlots tiles: rank_small_sgpr_kernel, which reads materialised coefficient
+// rows (the caller has the true-key launch write them).  Knob small_kernel = 3 / 4: the register-tile / LDS-broadcast
+// kernels instead (A/B runs, tests).
+bool rank_small_wants_coef(int model, int D, int64_t N) {
+    const long long forced = knob(KNOB_SMALL_KERNEL);
+    return model == TRANSE && (N + kTileRows - 1) / kTileRows <= kSmallMaxSlots && forced != 3 && forced != 4;
 }
 
 int rank_small_slots(int64_t N) {
@@ -535,8 +621,8 @@ int rank_small_slots(int64_t N) {
 
 template <int MODEL, int D>
 static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
-                                  const float* key_true, int64_t q_head, int64_t q_tail, unsigned long long* partial, int n_cu,
-                                  hipStream_t stream) {
+                                  const float* coef_head, const float* coef_tail, const float* key_true, int64_t q_head,
+                                  int64_t q_tail, unsigned long long* partial, int n_cu, hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
     const int64_t n_slots = rank_small_slots(N);
@@ -553,6 +639,16 @@ static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, con
     const size_t lds = ((size_t)kTileRows * (D + 4) + (size_t)kSmallRound * small_coef_stride(D) + kSmallRound) * 4 +
                        (size_t)kSmallMaxChunk * 8;
     if constexpr (MODEL == TRANSE) {
+        if (rank_small_wants_coef(MODEL, D, N)) {  // the tile in LDS, coefficients through the scalar cache
+            // 45 registers: four workgroups per CU (LDS), eight waves per SIMD -- what hides the scalar-cache latency.  One
+            // round per workgroup: chunks of 32 queries ([measured] 128 queries: 33.5 us per call at 64, 30.0 at 32)
+            int64_t qc = kSmallRound;
+            if (const long long forced = knob(KNOB_EXACT_QUERY_CHUNK); forced >= 1) qc = forced > kSmallMaxChunk ? kSmallMaxChunk : forced;
+            const int64_t grid = n_tiles * ((Q + qc - 1) / qc);
+            rank_small_sgpr_kernel<D><<<dim3((unsigned)grid), kSmallLdsWaves * 64, (size_t)kTileRows * (D + 4) * 4, stream>>>(
+                table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)qc, partial);
+            return hipGetLastError();
+        }
         if (n_tiles <= n_slots && knob(KNOB_SMALL_KERNEL) != 3) {  // (knob 3: the register-tile kernel, for A/B runs and tests)
             const size_t lds2 = ((size_t)kTileRows * (D + 4) + (size_t)kSmallRound * small_coef_stride(D) + kSmallRound) * 4;
             rank_small_lds_kernel<D><<<dim3((unsigned)blocks), kSmallLdsWaves * 64, lds2, stream>>>(
@@ -570,10 +666,10 @@ static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, con
 }
 
 hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                             const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
-                             unsigned long long* partial, int n_cu, hipStream_t stream) {
+                             const QRows q_rel, const float* coef_head, const float* coef_tail, const float* key_true,
+                             int64_t q_head, int64_t q_tail, unsigned long long* partial, int n_cu, hipStream_t stream) {
 #define BLP_SMALL_CASE(M, DD) \
-    case M * 1000 + DD: return rank_small_impl<M, DD>(table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, partial, n_cu, stream);
+    case M * 1000 + DD: return rank_small_impl<M, DD>(table, N, ld, q_fixed, q_rel, coef_head, coef_tail, key_true, q_head, q_tail, partial, n_cu, stream);
     switch (model * 1000 + D) {
         BLP_SMALL_CASE(TRANSE, 64) BLP_SMALL_CASE(TRANSE, 128)
         BLP_SMALL_CASE(DISTMULT, 64) BLP_SMALL_CASE(DISTMULT, 128)

@@ -42,24 +42,6 @@ __device__ __forceinline__ void piece_fetch(f32x4 (&b)[8], const float* __restri
         b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff[i] + s * (kSubCols * 4)));
 }
 
-// One query's partial sum over the 32 columns x[] = columns 32 s .. 32 s + 31 of the lane's row; c: the query's
-// coefficient row (wave-uniform -> scalar loads, SGPR operands).  FIRST: column 0 starts the sum (score<false>).
-template <int SIDE, int D, bool FIRST>
-__device__ __forceinline__ float piece_sum(float acc, const float (&x)[kSubCols], const float* __restrict__ c) {
-#pragma unroll
-    for (int k = 0; k < kSubCols; ++k) {
-        float d;
-        if constexpr (SIDE == TAIL) {
-            d = c[k] - x[k];              // (h + r) - e, h + r hoisted
-        } else {
-            const float y = x[k] + c[k];  // (e + r) - t
-            d = y - c[D + k];
-        }
-        acc = (FIRST && k == 0) ? fabsf(d) : acc + fabsf(d);
-    }
-    return acc;
-}
-
 template <int D>
 __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
@@ -131,11 +113,11 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
             wave_lds_sync();  // the reads are out before the next piece overwrites the slab
             static_for<kStreamQ>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
-                if (j < q_tail) sum[kStreamQ + j] = piece_sum<TAIL, D, s == 0>(sum[kStreamQ + j], x, coef_tail + j * D + s * kSubCols);
+                if (j < q_tail) sum[kStreamQ + j] = transe_piece_sum<TAIL, D, s == 0>(sum[kStreamQ + j], x, coef_tail + j * D + s * kSubCols);
             });
             static_for<kStreamQ>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
-                if (j < q_head) sum[j] = piece_sum<HEAD, D, s == 0>(sum[j], x, coef_head + j * 2 * D + s * kSubCols);
+                if (j < q_head) sum[j] = transe_piece_sum<HEAD, D, s == 0>(sum[j], x, coef_head + j * 2 * D + s * kSubCols);
             });
         });
         const bool valid = (int64_t)tile * kTileRows + lane < N;

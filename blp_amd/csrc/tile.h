@@ -72,4 +72,22 @@ __device__ __forceinline__ void load_tile(float (&e)[D], const float* __restrict
     tile_transpose<D>(e, slab, lane);
 }
 
+// TransE, one query's partial sum over the 32 columns x[] = columns 32 s .. 32 s + 31 of the lane's row; c: the query's
+// coefficient row (wave-uniform -> scalar loads, SGPR operands).  FIRST: column 0 starts the sum (score<false>).
+template <int SIDE, int D, bool FIRST>
+__device__ __forceinline__ float transe_piece_sum(float acc, const float (&x)[kSubCols], const float* __restrict__ c) {
+#pragma unroll
+    for (int k = 0; k < kSubCols; ++k) {
+        float d;
+        if constexpr (SIDE == TAIL) {
+            d = c[k] - x[k];              // (h + r) - e, h + r hoisted
+        } else {
+            const float y = x[k] + c[k];  // (e + r) - t
+            d = y - c[D + k];
+        }
+        acc = (FIRST && k == 0) ? fabsf(d) : acc + fabsf(d);
+    }
+    return acc;
+}
+
 }  // namespace blp
