@@ -511,6 +511,85 @@ __global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_lds_kernel(
 #endif
 }
 
+// Partial sums of n <= 4 queries of one side over the lane's row (rd: its LDS address), 32 columns at a time, coefficient
+// rows crow, crow + C, ... as SGPR operands.  The scalar loads are issued by hand one UNIT -- 16 columns of one query --
+// ahead of their use, into a ring of two units, and drained after the arithmetic of the unit before: the compiler's own
+// scalar loads are waited for right where they are issued, one exposed scalar-cache round trip per 32-48 instructions.
+// (The sums start at 0 instead of at the first |difference|: 0 + |d| == |d| bit for bit, |d| being +0, positive or NaN.  The
+// piece loop is not unrolled: unrolled, the compiler hoists every piece's LDS reads -- 128 registers and spills.)
+template <int SIDE, int D>
+__device__ __forceinline__ void sgpr_group_sums(const float* rd, const float* __restrict__ crow, int n, float (&sum)[4]) {
+    constexpr int C = SIDE == TAIL ? D : 2 * D, NP = D / kSubCols;
+    // Always four queries: a short group repeats its last query (results ignored by the caller) -- straight-line code, every
+    // ring slot assigned exactly once per unit (conditional loads cost hundreds of spilled scalar registers).
+    const float* row[4];
+    static_for<4>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        row[j] = crow + (size_t)(j < n ? j : n - 1) * C;
+        sum[j] = 0.f;
+    });
+    sf16 ra[2], rb[2];  // ring slot = half of the piece; ra: h + r (tail) or r (head); rb: t (head only)
+    ra[0] = sload16<0>(row[0]);
+    if constexpr (SIDE == HEAD) rb[0] = sload16<D * 4>(row[0]);
+#pragma unroll 1
+    for (int s = 0; s < NP; ++s) {
+        float x[kSubCols];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(rd + kSubCols * s + 4 * j);
+            x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+        }
+        // (the compiler's waits for these LDS reads belong HERE: placed at the first use, after the hand-issued scalar load
+        //  of the first unit, they would drain that request as well -- LDS and scalar loads share a counter)
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                     "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+        asm volatile("" : "+v"(x[16]), "+v"(x[17]), "+v"(x[18]), "+v"(x[19]), "+v"(x[20]), "+v"(x[21]), "+v"(x[22]), "+v"(x[23]),
+                     "+v"(x[24]), "+v"(x[25]), "+v"(x[26]), "+v"(x[27]), "+v"(x[28]), "+v"(x[29]), "+v"(x[30]), "+v"(x[31]));
+        // after the last piece: the group's first unit again (a load nobody waits for)
+        const float* next_first = s + 1 < NP ? row[0] + kSubCols * (s + 1) : row[0];
+        static_for<4>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            const float* cs = row[j] + kSubCols * s;
+            static_for<2>([&](auto hh) {
+                constexpr int h = decltype(hh)::value;
+                // this unit's coefficients have landed (requested one unit ago; the wait takes the previous unit's sum as an
+                // operand so that its arithmetic cannot sink below it) ...
+                float& prev = sum[h == 1 ? j : (j + 3) % 4];
+                if constexpr (SIDE == HEAD) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra[h]), "+s"(rb[h]), "+v"(prev) : : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra[h]), "+v"(prev) : : "memory");
+                // ... and the next unit's are requested before its arithmetic: the other half of this query's piece, the next
+                // query's first half, the next piece
+                if constexpr (h == 0) {
+                    ra[1] = sload16<16 * 4>(cs);
+                    if constexpr (SIDE == HEAD) rb[1] = sload16<(D + 16) * 4>(cs);
+                } else {
+                    const float* nx;
+                    if constexpr (j + 1 < 4) nx = row[j + 1] + kSubCols * s; else nx = next_first;
+                    ra[0] = sload16<0>(nx);
+                    if constexpr (SIDE == HEAD) rb[0] = sload16<D * 4>(nx);
+                }
+                // (nothing of this unit's arithmetic before the requests above: left alone, the compiler schedules it ahead
+                //  of them and the request is drained a few instructions after it was made)
+                asm volatile("" : "+v"(sum[j]), "+v"(x[16 * h]), "+v"(x[16 * h + 1]), "+v"(x[16 * h + 2]), "+v"(x[16 * h + 3]),
+                             "+v"(x[16 * h + 4]), "+v"(x[16 * h + 5]), "+v"(x[16 * h + 6]), "+v"(x[16 * h + 7]), "+v"(x[16 * h + 8]),
+                             "+v"(x[16 * h + 9]), "+v"(x[16 * h + 10]), "+v"(x[16 * h + 11]), "+v"(x[16 * h + 12]),
+                             "+v"(x[16 * h + 13]), "+v"(x[16 * h + 14]), "+v"(x[16 * h + 15]));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float d;
+                    if constexpr (SIDE == TAIL) {
+                        d = ra[h][k] - x[16 * h + k];              // (h + r) - e, h + r hoisted
+                    } else {
+                        const float y = x[16 * h + k] + ra[h][k];  // (e + r) - t
+                        d = y - rb[h][k];
+                    }
+                    sum[j] = sum[j] + fabsf(d);
+                }
+            });
+        });
+    }
+}
+
 // ---- TransE, the tile in LDS, the coefficients in scalar registers ---------------------------------------------------------
 // The kernel above is bound by LDS traffic: per 4-element step a wave reads its row quad AND four or eight coefficient
 // quads (broadcasts).  Here the coefficients do not go through LDS at all: the true-key launch materialises the
@@ -555,35 +634,24 @@ __global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_sgpr_kernel
     __syncthreads();
     const bool valid = row0 + lane < N;
     const float* rd = smem + lane * TS;
-    // groups of four consecutive queries of the chunk, group g to wave g % 8
-    for (int q0 = qa + 4 * wave; q0 < qb; q0 += 4 * kSmallLdsWaves) {
-        const int n = qb - q0 < 4 ? qb - q0 : 4;
-        // (the sums start at 0 instead of at the first |difference|: 0 + |d| == |d| bit for bit, |d| being +0, positive or NaN;
-        //  the piece loop is not unrolled -- unrolled, the compiler hoists every piece's LDS reads: 128 registers and spills)
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int s = 0; s < NP; ++s) {
-            float x[kSubCols];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(rd + kSubCols * s + 4 * j);
-                x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
-            }
-            static_for<4>([&](auto jj) {
-                constexpr int j = decltype(jj)::value;
-                if (j < n) {
-                    const int q = q0 + j;  // wave-uniform
-                    if (q < q_head) sum[j] = transe_piece_sum<HEAD, D, false>(sum[j], x, coef_head + (size_t)q * 2 * D + s * kSubCols);
-                    else sum[j] = transe_piece_sum<TAIL, D, false>(sum[j], x, coef_tail + (size_t)(q - q_head) * D + s * kSubCols);
-                }
-            });
-        }
+    // groups of up to four queries of ONE side (the chunk's head-replacing queries, then its tail-replacing ones), group g
+    // to wave g % 8
+    const int nh = q_head > qa ? (q_head < qb ? q_head - qa : qb - qa) : 0;  // head-replacing queries of the chunk
+    const int gh = (nh + 3) >> 2, gt = (qb - qa - nh + 3) >> 2;
+    for (int g = wave; g < gh + gt; g += kSmallLdsWaves) {
+        const bool head = g < gh;
+        const int q0 = head ? qa + 4 * g : qa + nh + 4 * (g - gh);
+        const int end = head ? qa + nh : qb;
+        const int n = end - q0 < 4 ? end - q0 : 4;
+        float sum[4];
+        if (head) sgpr_group_sums<HEAD, D>(rd, coef_head + (size_t)q0 * 2 * D, n, sum);
+        else sgpr_group_sums<TAIL, D>(rd, coef_tail + (size_t)(q0 - q_head) * D, n, sum);
         static_for<4>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
             if (j < n) {
                 const float key = -sum[j], kt = key_true[q0 + j];
-                const unsigned long long gt = __popcll(__ballot(valid && key > kt)), ge = __popcll(__ballot(valid && key >= kt));
-                if (lane == 0) partial[(size_t)slot * Q + q0 + j] = gt | (ge << 32);
+                const unsigned long long gt_ = __popcll(__ballot(valid && key > kt)), ge_ = __popcll(__ballot(valid && key >= kt));
+                if (lane == 0) partial[(size_t)slot * Q + q0 + j] = gt_ | (ge_ << 32);
             }
         });
     }
@@ -603,7 +671,9 @@ bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t 
     // the evaluated triples (train.py:312-314) -- this kernel (tools/few_queries_probe.py: 8 queries x 7 400 rows 31 -> 21 us)
     if (q_head <= 4 && q_tail <= 4 && N > (int64_t)kSmallMaxSlots * kTileRows) return false;
     if (model == TRANSE && knob(KNOB_SAD_MIN_QUERIES) > 0 && Q >= knob(KNOB_SAD_MIN_QUERIES)) return false;  // A/B knob
-    return Q * N < (model == TRANSE ? kSmallMaxPairsTransE : kSmallMaxPairsBilinear);
+    if (model == TRANSE)  // (the scalar-register kernel -- tables of up to kSmallMaxSlots tiles -- holds out longer)
+        return Q * N < (rank_small_wants_coef(model, D, N) ? kSmallMaxPairsTransESgpr : kSmallMaxPairsTransE);
+    return Q * N < kSmallMaxPairsBilinear;
 }
 
 // TransE against a table of at most kSmallMaxSlots tiles: rank_small_sgpr_kernel, which reads materialised coefficient
