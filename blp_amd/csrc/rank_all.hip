@@ -119,11 +119,16 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restri
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc, unsigned key_blocks,
-                                float* __restrict__ coef_head, float* __restrict__ coef_tail) {
+                                float* __restrict__ coef_head, float* __restrict__ coef_tail, int64_t zero_slots) {
     if (blockIdx.x >= key_blocks) {
         using SH = Scorer<MODEL, HEAD, D>;
         using ST = Scorer<MODEL, TAIL, D>;
         const int64_t n_head = q_head * SH::C, total = n_head + q_tail * ST::C;
+        // (partial counts of slots 1 .. zero_slots - 1, for a kernel that ADDS to them; slot 0 = acc[q]: the key lanes)
+        for (int64_t i = (q_head + q_tail) + (blockIdx.x - key_blocks) * 64ll + threadIdx.x; i < zero_slots * (q_head + q_tail);
+             i += (gridDim.x - key_blocks) * 64ll)
+            acc[i] = 0;
+        if (!coef_head) return;
         for (int64_t i = (blockIdx.x - key_blocks) * 64ll + threadIdx.x; i < total; i += (gridDim.x - key_blocks) * 64ll) {
             if (i < n_head) {
                 const int64_t q = i / SH::C;
@@ -145,14 +150,17 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restri
 template <int MODEL, int D>
 static void launch_true_key(const float* table, int64_t ld, const int64_t* true_row, const float* q_true, const QRows& q_fixed,
                             const QRows& q_rel, int64_t q_head, int64_t q_tail, float* key_true, unsigned long long* acc,
-                            hipStream_t stream, float* coef_head = nullptr, float* coef_tail = nullptr) {
+                            hipStream_t stream, float* coef_head = nullptr, float* coef_tail = nullptr, int64_t zero_slots = 0) {
     const int64_t Q = q_head + q_tail;
     const int64_t n_coef = coef_head ? q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C : 0;
     if (Q <= kTrueKeyLaneMaxQueries) {
-        const int64_t key_blocks = (Q + 63) / 64, want = (n_coef + 63) / 64, coef_blocks = want < 4096 ? want : 4096;
+        const int64_t key_blocks = (Q + 63) / 64, work = n_coef > zero_slots * Q ? n_coef : zero_slots * Q, want = (work + 63) / 64,
+                      coef_blocks = want < 4096 ? want : 4096;
         true_key_lane_kernel<MODEL, D><<<(unsigned)(key_blocks + coef_blocks), 64, 0, stream>>>(
-            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail);
+            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail,
+            zero_slots);
     } else {
+        if (zero_slots > 1) (void)hipMemsetAsync(acc + Q, 0, (size_t)(zero_slots - 1) * Q * 8, stream);
         if (n_coef) {
             const int64_t blocks = (n_coef + 255) / 256;
             prep_coef_kernel<MODEL, D><<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail,
@@ -672,8 +680,10 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         const int slots = rank_small_slots(N);
         RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail, slots);
         const bool coef = rank_small_wants_coef(MODEL, D, N);
+        // (tiles sharing slots -- more tiles than slots, the scalar-register kernel only -- add to zeroed counts)
+        const bool shared_slots = coef && (N + kTileRows - 1) / kTileRows > slots;
         launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream,
-                                  coef ? w.coef_head : nullptr, coef ? w.coef_tail : nullptr);
+                                  coef ? w.coef_head : nullptr, coef ? w.coef_tail : nullptr, shared_slots ? slots : 0);
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.coef_head, w.coef_tail, w.key_true, q_head,
                                                  q_tail, w.acc, n_cu, stream);

@@ -602,18 +602,21 @@ __device__ __forceinline__ void sgpr_group_sums(const float* rd, const float* __
 template <int D>
 __global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_sgpr_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
-    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles, int q_chunk,
-    unsigned long long* __restrict__ partial) {
+    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles, int n_slots,
+    int q_chunk, unsigned long long* __restrict__ partial) {
     constexpr int TS = D + 4, NT = kSmallLdsWaves * 64, NP = D / kSubCols;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // the tile: 64 x TS
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int chunk = blockIdx.x / n_tiles, slot = blockIdx.x % n_tiles;
+    // workgroup -> (query chunk, tile).  Tables of more tiles than slots (WN18RR: 640): tiles t, t + n_slots, ... ADD to one
+    // slot's counts (zeroed by the true-key launch; two or three workgroups per address: no contention to speak of)
+    const int chunk = blockIdx.x / n_tiles, tile_i = blockIdx.x % n_tiles, slot = tile_i % n_slots;
+    const bool shared_slot = n_tiles > n_slots;
     const int Q = q_head + q_tail;
     const int qa = chunk * q_chunk;
     const int qb = qa + q_chunk < Q ? qa + q_chunk : Q;
-    const int64_t row0 = (int64_t)slot * kTileRows;
+    const int64_t row0 = (int64_t)tile_i * kTileRows;
     {   // the tile, 16-byte pieces tid, tid + 512, ...: whole 512-byte rows per 32 threads; rows past the end: the last row
         typedef float floatx4 __attribute__((ext_vector_type(4)));
         constexpr int kPieces = kTileRows * (D / 4) / NT;
@@ -651,7 +654,10 @@ __global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_sgpr_kernel
             if (j < n) {
                 const float key = -sum[j], kt = key_true[q0 + j];
                 const unsigned long long gt_ = __popcll(__ballot(valid && key > kt)), ge_ = __popcll(__ballot(valid && key >= kt));
-                if (lane == 0) partial[(size_t)slot * Q + q0 + j] = gt_ | (ge_ << 32);
+                if (lane == 0) {
+                    if (shared_slot) atomicAdd(partial + (size_t)slot * Q + q0 + j, gt_ | (ge_ << 32));
+                    else partial[(size_t)slot * Q + q0 + j] = gt_ | (ge_ << 32);
+                }
             }
         });
     }
@@ -676,12 +682,12 @@ bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t 
     return Q * N < kSmallMaxPairsBilinear;
 }
 
-// TransE against a table of at most kSmallMaxSlots tiles: rank_small_sgpr_kernel, which reads materialised coefficient
-// rows (the caller has the true-key launch write them).  Knob small_kernel = 3 / 4: the register-tile / LDS-broadcast
+// TransE against a table of at most kSmallSgprMaxTiles tiles: rank_small_sgpr_kernel, which reads materialised coefficient
+// rows (the caller has the true-key launch write them -- and zero the slots' counts when tiles share slots).  Knob small_kernel = 3 / 4: the register-tile / LDS-broadcast
 // kernels instead (A/B runs, tests).
 bool rank_small_wants_coef(int model, int D, int64_t N) {
     const long long forced = knob(KNOB_SMALL_KERNEL);
-    return model == TRANSE && (N + kTileRows - 1) / kTileRows <= kSmallMaxSlots && forced != 3 && forced != 4;
+    return model == TRANSE && (N + kTileRows - 1) / kTileRows <= kSmallSgprMaxTiles && forced != 3 && forced != 4;
 }
 
 int rank_small_slots(int64_t N) {
@@ -716,7 +722,7 @@ static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, con
             if (const long long forced = knob(KNOB_EXACT_QUERY_CHUNK); forced >= 1) qc = forced > kSmallMaxChunk ? kSmallMaxChunk : forced;
             const int64_t grid = n_tiles * ((Q + qc - 1) / qc);
             rank_small_sgpr_kernel<D><<<dim3((unsigned)grid), kSmallLdsWaves * 64, (size_t)kTileRows * (D + 4) * 4, stream>>>(
-                table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)qc, partial);
+                table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)n_slots, (int)qc, partial);
             return hipGetLastError();
         }
         if (n_tiles <= n_slots && knob(KNOB_SMALL_KERNEL) != 3) {  // (knob 3: the register-tile kernel, for A/B runs and tests)

@@ -185,16 +185,23 @@ def test_small_block_kernel_query_chunks(ops, oracle, knobs, model, chunk):
 @pytest.mark.default_routing
 @pytest.mark.parametrize("model,q_head,q_tail", [("transe", 40, 50), ("distmult", 3, 9), ("simple", 70, 0)])
 def test_small_block_kernel_table_of_more_tiles_than_slots(ops, oracle, knobs, model, q_head, q_tail):
-    """A table of more than 256 tiles: a workgroup then walks several tiles (coefficients staged once for up to two
-    rounds, again per tile otherwise) and its slot's partial counts add them up."""
-    knobs("small_kernel", 1)
-    N, D = 256 * 64 * 2 + 777, 64
-    table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=q_head)
-    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=q_tail)
-    want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
-    got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
-                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
-    assert np.array_equal(got, want)
+    """Tables of more than 256 tiles.  The register-tile kernel: a workgroup walks several tiles (coefficients staged once
+    for up to two rounds, again per tile otherwise) and its slot's partial counts add them up.  TransE's scalar-register
+    kernel (tables of up to 1 024 tiles): one workgroup per (tile, chunk), the tiles of a slot ADD to counts the true-key
+    launch has zeroed; beyond 1 024 tiles TransE is back on the register-tile kernel."""
+    for N in (256 * 64 * 2 + 777, 1024 * 64 + 5):
+        D = 64
+        table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=q_head)
+        rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=q_tail)
+        want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+        for variant in ((1, 3, 4) if model == "transe" else (1,)):
+            knobs("small_kernel", variant)
+            got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                               filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+            assert np.array_equal(got, want), (N, variant)
+            got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                               filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()  # (a second call: the slots' counts start at zero again)
+            assert np.array_equal(got, want), (N, variant, "second call")
 
 
 @pytest.mark.default_routing
