@@ -499,11 +499,11 @@ static WideWorkspace carve_wide(void* base, int D, int64_t N, int64_t Q) {
     return w;
 }
 
-// TransE at a width the register-resident kernels are not compiled for, with enough queries to pay for
-// the quantisation passes.
+// TransE at a width the register-resident kernels are not compiled for.  Any number of queries: the alternative for a
+// small block is the dense route (blp_score_fwd + blp_rank_from_scores), 0.7 ms for 32 queries x 14 541 rows at D = 300
+// against 0.1 ms here (tools/wide_small_probe.py) -- round 1 drew the line at 256 queries without measuring it.
 bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
-    return model == TRANSE && D != 64 && D != 128 && D != 256 && D >= 4 && D % 4 == 0 && D <= kWMaxD &&
-           q_head + q_tail >= 256;
+    return model == TRANSE && D != 64 && D != 128 && D != 256 && D >= 4 && D % 4 == 0 && D <= kWMaxD && q_head + q_tail >= 1;
 }
 
 size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {

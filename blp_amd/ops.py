@@ -57,7 +57,7 @@ def dim_supported(rel_model, dim):
 
 def rank_all_supported(rel_model, dim, q_head, q_tail):
     """True if rank_all takes a block of this shape (fused kernels at 64 / 128 / 256, or the any-width
-    TransE pre-pass for blocks of >= 256 queries); otherwise use score + rank_from_scores."""
+    TransE pre-pass at any D % 4 == 0 up to 1024); otherwise use score + rank_from_scores."""
     return bool(_lib.lib().blp_rank_all_supported(_lib.MODEL_IDS[rel_model], int(dim), int(q_head), int(q_tail)))
 
 

@@ -108,8 +108,8 @@ int blp_dim_supported(int model, int D);
 size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head, int64_t q_tail);
 
 /* 1 if blp_rank_all takes a block of this shape: D in {64, 128, 256} (what blp_dim_supported reports), or
- * TransE with q_head + q_tail >= 256 at any D % 4 == 0, D <= 1024 (the 300 / 768-wide bag-of-words and
- * DKRL encoders, models.py:118-135, 165-172).  Otherwise callers use blp_score_fwd + blp_rank_from_scores. */
+ * TransE at any D % 4 == 0, D <= 1024 (the 300 / 768-wide bag-of-words and DKRL encoders, models.py:118-135,
+ * 165-172).  Otherwise callers use blp_score_fwd + blp_rank_from_scores. */
 int blp_rank_all_supported(int model, int D, int64_t q_head, int64_t q_tail);
 int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
                  const float *q_fixed, const float *q_rel, const int64_t *q_rel_id, const int64_t *true_row,

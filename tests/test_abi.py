@@ -34,10 +34,10 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 8)  # coefficients, key, accumulator
-    # blocks blp_rank_all takes: the compiled widths always; TransE with >= 256 queries at any D % 4 == 0
+    # blocks blp_rank_all takes: the compiled widths always; TransE at any D % 4 == 0 up to 1024
     assert L.blp_rank_all_supported(0, 128, 1, 1) == 1 and L.blp_rank_all_supported(2, 128, 1, 1) == 1
     assert L.blp_rank_all_supported(0, 300, 150, 170) == 1 and L.blp_rank_all_supported(0, 768, 256, 0) == 1
-    assert L.blp_rank_all_supported(0, 300, 10, 10) == 0 and L.blp_rank_all_supported(1, 300, 150, 170) == 0
+    assert L.blp_rank_all_supported(0, 300, 10, 10) == 1 and L.blp_rank_all_supported(1, 300, 150, 170) == 0
     assert L.blp_rank_all_supported(0, 302, 150, 170) == 0 and L.blp_rank_all_supported(0, 2048, 150, 170) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 768, 300, 300) > 14541 * 768 * 2  # holds the 2-byte table image
 
@@ -48,7 +48,9 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     # argument validation happens before any device call, so this runs without a GPU
     rc = L.blp_rank_all(7, None, 0, 128, 128, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
     assert rc == -1 and b"unknown model" in L.blp_last_error()
-    rc = L.blp_rank_all(0, None, 0, 100, 100, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    rc = L.blp_rank_all(1, None, 0, 100, 100, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    assert rc == -2  # (DistMult at D = 100; TransE is taken at any D % 4 == 0)
+    rc = L.blp_rank_all(0, None, 0, 102, 104, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
     assert rc == -2
     rc = L.blp_score_fwd(1, 100, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
     assert rc == -1 and b"NULL" in L.blp_last_error()  # any width is scored; the pointers are what is wrong here

@@ -245,7 +245,7 @@ def test_generic_width_route_matches_oracle(rel_model, D, oracle):
     got = ranking._rank_block_generic_width(model, t, f, r, q_head, None, t[true_row.cuda()], rp.cuda(), cl.cuda(),
                                             max_matrix_bytes=4 * N * 7)  # 7-query slabs
     assert np.array_equal(got.cpu().numpy(), want)
-    # a block of >= 256 queries: rank_block routes TransE to the any-width pre-pass, the rest stays dense
+    # a larger block: rank_block routes TransE to the any-width pre-pass (as it does the small one), the rest stays dense
     q_head, q_tail = 140, 131
     table, q_fixed, q_rel, true_row = random_problem(rel_model, N, D, q_head, q_tail, seed=D + 1)
     rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + 1)

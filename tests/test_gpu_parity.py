@@ -351,11 +351,22 @@ def test_sad_candidate_slabs_and_shard_vectors(ops, oracle, knobs):
 @pytest.mark.parametrize("D", [300, 768, 100, 4, 1024])
 def test_transe_any_width_prepass(ops, oracle, D, knobs):
     """TransE at the widths of the reference's BOW / DKRL encoders (300 GloVe, 768 BERT) and other widths
-    the register-resident kernels are not compiled for: blocks of >= 256 queries take the any-width
-    fixed-point pre-pass (rank_sad_wide.hip).  Counts identical to the oracle with a CSR filter, with the
-    true entity given as a row or as a vector, with exact ties, and over candidate slabs."""
+    the register-resident kernels are not compiled for: the any-width fixed-point pre-pass (rank_sad_wide.hip),
+    whatever the number of queries (the BOW scripts evaluate 16 or 32 triples at a time).  Counts identical to the
+    oracle with a CSR filter, with the true entity given as a row or as a vector, with exact ties, and over
+    candidate slabs."""
     assert not ops.dim_supported("transe", D) and ops.rank_all_supported("transe", D, 150, 170)
-    assert not ops.rank_all_supported("transe", D, 100, 100) and not ops.rank_all_supported("distmult", D, 150, 170)
+    assert ops.rank_all_supported("transe", D, 1, 0) and not ops.rank_all_supported("distmult", D, 150, 170)
+    for q_head, q_tail in ((3, 4), (0, 33), (16, 16), (1, 0)):  # the reference's small eval batches
+        N = 702 + 9 * q_head
+        table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=D + q_tail)
+        table[::9] = table[1::9]  # exact ties
+        q_fixed = table[torch.arange(q_head + q_tail) * 3 % N].clone()
+        rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + 2)
+        want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+        got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                           filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+        assert np.array_equal(got, want), (q_head, q_tail)
     N, q_head, q_tail = 1000 + 37, 150, 170
     table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=D)
     table[::9] = table[1::9][: table[::9].shape[0]]  # exact ties
@@ -881,10 +892,10 @@ def test_transe_wide_rows_score_fn(ops):
 
 
 def test_errors_are_loud(ops):
-    table = torch.randn(8, 96).cuda()  # D = 96 is not a compiled ranking width
+    table = torch.randn(8, 96).cuda()  # D = 96 is not a compiled ranking width (TransE alone is taken at any D % 4 == 0)
     q = torch.randn(2, 96).cuda()
     with pytest.raises(RuntimeError, match="UNSUPPORTED_DIM"):
-        ops.rank_all("transe", table, q, q, 1, true_row=torch.zeros(2, dtype=torch.int64).cuda())
+        ops.rank_all("distmult", table, q, q, 1, true_row=torch.zeros(2, dtype=torch.int64).cuda())
     with pytest.raises(RuntimeError, match="CPU tensor"):
         ops.rank_all("transe", torch.randn(8, 128), torch.randn(2, 128), torch.randn(2, 128), 1,
                      true_row=torch.zeros(2, dtype=torch.int64))

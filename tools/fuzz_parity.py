@@ -31,8 +31,6 @@ def make_case(rng):
         N = int(rng.integers(1, 600))
     if q_head + q_tail == 0:
         q_tail = 1
-    if D not in (64, 128, 256) and q_head + q_tail < 256:
-        q_head += 256
     g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
     kind = rng.choice(["normal", "normalized", "dyadic", "ties", "outlier", "tiny", "mixed_scale", "nan", "inf", "zero_rows",
                        "constant"])
