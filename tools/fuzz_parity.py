@@ -29,6 +29,11 @@ def make_case(rng):
     elif rng.random() < 0.1:  # many query tiles per side (chunking of the pair lists), few candidates
         q_head, q_tail = int(rng.integers(0, 4000)), int(rng.integers(0, 4000))
         N = int(rng.integers(1, 600))
+    if rng.random() < 0.06:  # a table of more than 256 tiles (tiles sharing slots in the small-block kernels; the streaming kernels)
+        N = int(rng.integers(16385, 80000))
+        q_head, q_tail = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        if rng.random() < 0.4:
+            q_head, q_tail = int(rng.integers(0, 5)), int(rng.integers(0, 5))
     if q_head + q_tail == 0:
         q_tail = 1
     g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
