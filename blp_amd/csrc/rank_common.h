@@ -91,7 +91,7 @@ hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q
 // chains interleaved): the ranking pass only, between launch_true_keys and launch_filter_finalize.
 constexpr long long kSmallMaxPairsTransE = 4000000;    // above (== kSadMinPairs): the fixed-point pre-pass
 constexpr long long kSmallMaxPairsTransESgpr = 6000000;  // the same for tables of up to kSmallMaxSlots tiles (tools/exact_small_probe.py: 440 queries x 14 541 rows; the scalar-register kernel: up to kSmallSgprMaxTiles tiles)
-constexpr long long kSmallMaxPairsBilinear = 800000;   // above (and from 64 queries on): the bf16 x 3 MFMA pre-pass (tools/exact_small_probe.py)
+constexpr long long kSmallMaxPairsBilinear = 400000;   // above (and from 32 queries on): the bf16 x 3 MFMA pre-pass (tools/exact_small_probe.py)
 constexpr int kSmallMaxSlots = 256;                    // partial counts per query it leaves (one per tile slot)
 constexpr int kSmallSgprMaxTiles = 1024;               // tables the scalar-register TransE kernel takes (tiles beyond the slots share them)
 constexpr long long kSmallMaxQueries = 4096;           // whatever the knob says

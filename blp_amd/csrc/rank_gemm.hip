@@ -1080,9 +1080,10 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     return w;
 }
 
+constexpr int64_t kGemmMinQueries = 32;  // (one query tile: the chain's five launches are what a call this small costs)
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
     if (knob(KNOB_RANK_KERNEL) == 1) return false;  // test knob: the exact f32 kernels
-    return (model == DISTMULT || model == COMPLEX || model == SIMPLE) && (D == 64 || D == 128) && q_head + q_tail >= 64;
+    return (model == DISTMULT || model == COMPLEX || model == SIMPLE) && (D == 64 || D == 128) && q_head + q_tail >= kGemmMinQueries;
 }
 
 size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {

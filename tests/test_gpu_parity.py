@@ -26,7 +26,7 @@ def prepass_from_64_queries(request):
     from blp_amd import _lib
     if "default_routing" not in request.keywords:
         _lib.set_knob("sad_min_queries", 64)
-        _lib.set_knob("small_kernel", 2)  # same reason: the MFMA pre-pass, not the small-block kernel, from 64 queries on
+        _lib.set_knob("small_kernel", 2)  # same reason: the MFMA pre-pass, not the small-block kernel, from 32 queries on
     yield
     _lib.reset_knobs()
 
@@ -664,11 +664,11 @@ def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, knobs):
             knobs("rank_kernel", 1)
             exact = ops.rank_all(model, table, q_fixed, q_rel, q_half, true_row=true_row)
             knobs("rank_kernel", 0)
-        else:  # blocks of < 64 queries take the exact VALU kernel
-            parts_h = [ops.rank_all(model, table, q_fixed[a:a + 32], q_rel[a:a + 32], 32, true_row=true_row[a:a + 32])
-                       for a in range(0, q_half, 32)]
-            parts_t = [ops.rank_all(model, table, q_fixed[a:a + 32], q_rel[a:a + 32], 0, true_row=true_row[a:a + 32])
-                       for a in range(q_half, Q, 32)]
+        else:  # blocks of < 32 queries take the exact VALU kernel
+            parts_h = [ops.rank_all(model, table, q_fixed[a:a + 16], q_rel[a:a + 16], 16, true_row=true_row[a:a + 16])
+                       for a in range(0, q_half, 16)]
+            parts_t = [ops.rank_all(model, table, q_fixed[a:a + 16], q_rel[a:a + 16], 0, true_row=true_row[a:a + 16])
+                       for a in range(q_half, Q, 16)]
             exact = torch.cat(parts_h + parts_t)
         assert torch.equal(fast, exact), model
         assert int(fast[:, 1].min()) >= 1
