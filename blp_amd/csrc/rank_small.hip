@@ -22,6 +22,9 @@
 //     are not served by the XCD-local L2): +30 us.  Every (wave, query) pair is unique in a workgroup, so a workgroup
 //     keeps plain counters in LDS and stores them as its slot's partial counts; the finalize kernel adds the slots.
 // Launch chain of a small block: true_key -> rank_small -> filter + finalize.
+// Two kernels: rank_small_kernel (all of the above; the bilinear models, and TransE against tables of more than 1 024
+// tiles) and rank_small_sgpr_kernel (TransE: the tile stays in LDS, the coefficients come as scalar registers from rows the
+// true-key launch materialises; further down).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -313,203 +316,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void rank_small_kernel(
 #endif
 }
 
-// ---- TransE, the tile left in LDS -------------------------------------------------------------------------------
-// A lane that keeps its 128-float row in registers leaves room for two waves per SIMD, and a wave issues one VALU
-// instruction per ~4.5 cycles whatever it does: the kernel above runs the 2 x 8.3 us of a 128-query block's scoring at
-// that per-wave rate.  TransE consumes the row strictly left to right, four elements per step -- so here the row stays
-// in LDS and every step reads its four elements (ds_read_b128, lane l its own row: conflict-free at the row stride
-// D + 4) next to the coefficient broadcasts: ~70 registers, EIGHT waves per workgroup and two workgroups per CU = four
-// waves per SIMD, each wave one group of four queries per round.  LDS traffic is the price (tail side 5, head side 9
-// reads per step of 32 / 48 VALU instructions: about as busy as the VALU pipe).  One tile per workgroup (tables of up
-// to kSmallMaxSlots tiles); counts go straight to the slot's partial counts (every (wave, query) pair is unique).
-constexpr int kSmallLdsWaves = 8;
-
-__device__ __forceinline__ void lds_landed5(f4& t, f4& a, f4& b, f4& c, f4& d, float& s0, float& s1, float& s2, float& s3) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
-}
-__device__ __forceinline__ void pin5(f4& t, f4& a, f4& b, f4& c, f4& d, float& s0, float& s1, float& s2, float& s3) {
-    asm volatile("" : "+v"(t), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
-}
-__device__ __forceinline__ void lds_landed9(f4& t, f4& a, f4& b, f4& c, f4& d, f4& e, f4& f, f4& g, f4& h, float& s0, float& s1,
-                                            float& s2, float& s3) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(t), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(s0), "+v"(s1), "+v"(s2),
-                   "+v"(s3));
-}
-__device__ __forceinline__ void pin9(f4& t, f4& a, f4& b, f4& c, f4& d, f4& e, f4& f, f4& g, f4& h, float& s0, float& s1, float& s2,
-                                     float& s3) {
-    asm volatile("" : "+v"(t), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(s0), "+v"(s1),
-                 "+v"(s2), "+v"(s3));
-}
-
-// keys of FOUR queries of one side against the wave's 64 rows: erow = LDS byte address of the lane's row, row[g] = of
-// query g's coefficients.  Same operations in the same order as Scorer<TRANSE, SIDE, D>::score<false>.
-template <int SIDE, int D>
-__device__ __forceinline__ void transe_keys_lds(unsigned erow, const unsigned (&row)[4], float (&key)[4]) {
-    constexpr int NS = D / 4, NR = SIDE == TAIL ? 4 : 8;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    f4 tile[2], buf[2][NR];  // buf slot: tail = query g; head = 2g + w (w: 0 = r, 1 = t)
-    auto issue = [&](auto ss) {
-        constexpr int s = decltype(ss)::value;
-        tile[s & 1] = lds_bcast16<16 * s>(erow);
-        static_for<NR>([&](auto tt) {
-            constexpr int t = decltype(tt)::value;
-            if constexpr (SIDE == TAIL) buf[s & 1][t] = lds_bcast16<16 * s>(row[t]);
-            else buf[s & 1][t] = lds_bcast16<((t & 1) * D + 4 * s) * 4>(row[t >> 1]);
-        });
-    };
-    auto landed = [&](int n) {
-        if constexpr (SIDE == TAIL)
-            lds_landed5(tile[n], buf[n][0], buf[n][1], buf[n][2], buf[n][3], acc[0], acc[1], acc[2], acc[3]);
-        else
-            lds_landed9(tile[n], buf[n][0], buf[n][1], buf[n][2], buf[n][3], buf[n][4], buf[n][5], buf[n][6], buf[n][7], acc[0],
-                        acc[1], acc[2], acc[3]);
-    };
-    issue(ic<0>{});
-    landed(0);
-    static_for<NS>([&](auto ss) {
-        constexpr int s = decltype(ss)::value, p = s & 1;
-        if constexpr (s + 1 < NS) {  // next step's reads first; the pin keeps this step's arithmetic behind them
-            issue(ic<s + 1>{});
-            if constexpr (SIDE == TAIL) pin5(tile[p], buf[p][0], buf[p][1], buf[p][2], buf[p][3], acc[0], acc[1], acc[2], acc[3]);
-            else pin9(tile[p], buf[p][0], buf[p][1], buf[p][2], buf[p][3], buf[p][4], buf[p][5], buf[p][6], buf[p][7], acc[0],
-                      acc[1], acc[2], acc[3]);
-        }
-        static_for<4>([&](auto kk) {
-            constexpr int k = decltype(kk)::value, d = 4 * s + k;
-            static_for<4>([&](auto gg) {
-                constexpr int g = decltype(gg)::value;
-                float x;
-                if constexpr (SIDE == TAIL) {
-                    x = buf[p][g][k] - tile[p][k];
-                } else {
-                    const float y = tile[p][k] + buf[p][2 * g][k];
-                    x = y - buf[p][2 * g + 1][k];
-                }
-                const float cur = fabsf(x);
-                acc[g] = d == 0 ? cur : acc[g] + cur;
-            });
-        });
-        if constexpr (s + 1 < NS) landed((s + 1) & 1);
-    });
-    static_for<4>([&](auto gg) { key[decltype(gg)::value] = -acc[decltype(gg)::value]; });
-}
-
-template <int D>
-__global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_lds_kernel(  // 4 waves per SIMD: <= 128 VGPRs
-    const float* __restrict__ table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
-    const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles, int q_chunk,
-    unsigned long long* __restrict__ partial) {
-    using SH = Scorer<TRANSE, HEAD, D>;
-    using ST = Scorer<TRANSE, TAIL, D>;
-    constexpr int CS = small_coef_stride(D), CMAX = 2 * D, TS = D + 4, NT = kSmallLdsWaves * 64;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    float* tile = smem;                        // 64 x TS
-    float* coef = tile + kTileRows * TS;       // kSmallRound x CS
-    float* kt = coef + kSmallRound * CS;       // kSmallRound
-    const int chunk = blockIdx.x / n_tiles, slot = blockIdx.x % n_tiles;
-    const int Q = q_head + q_tail;
-    const int qa = chunk * q_chunk;
-    const int qb = qa + q_chunk < Q ? qa + q_chunk : Q;
-    const int64_t row0 = (int64_t)slot * kTileRows;
-#ifdef BLP_TIMING
-    unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = wall_clock64();
-#endif
-
-    // the tile: 16-byte pieces, whole 512-byte rows per 32 threads; rows past the end clamped (masked when counting)
-    typedef float floatx4 __attribute__((ext_vector_type(4)));
-    constexpr int kPieces = kTileRows * (D / 4) / NT;
-    floatx4 piece[kPieces];
-    static_for<kPieces>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        const int idx = tid + k * NT, r = idx / (D / 4), c = idx % (D / 4);
-        int64_t row = row0 + r;
-        row = row < N ? row : N - 1;
-        piece[k] = *reinterpret_cast<const floatx4*>(table + row * ld + 4 * c);
-    });
-    // coefficients + true keys of a round: thread <-> coefficient index, NV values per thread, every load in flight at once
-    constexpr int QPP = NT / CMAX, NV = kSmallRound / QPP;
-    const int ci = tid % CMAX, cjo = tid / CMAX;
-    auto stage_load = [&](int q0, int nr, float (&v)[NV], float& ktv) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int j = k * QPP + cjo, q = q0 + (j < nr ? j : nr - 1);
-            const float* f = q_fixed.row(q);
-            const float* r = q_rel.row(q);
-            v[k] = 0.0f;
-            if (q < q_head) { if (ci < SH::C) v[k] = SH::coef(f, r, ci); }
-            else            { if (ci < ST::C) v[k] = ST::coef(f, r, ci); }
-        }
-        ktv = key_true[q0 + (tid < nr ? tid : nr - 1)];
-    };
-    auto stage_store = [&](int nr, const float (&v)[NV], float ktv) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int j = k * QPP + cjo;
-            if (j < nr) coef[j * CS + ci] = v[k];
-        }
-        if (tid < nr) kt[tid] = ktv;
-    };
-    float v[NV], ktv;
-    stage_load(qa, qb - qa < kSmallRound ? qb - qa : kSmallRound, v, ktv);
-    static_for<kPieces>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        const int idx = tid + k * NT, r = idx / (D / 4), c = idx % (D / 4);
-        *reinterpret_cast<floatx4*>(tile + r * TS + 4 * c) = piece[k];
-    });
-    stage_store(qb - qa < kSmallRound ? qb - qa : kSmallRound, v, ktv);
-    BLP_ST(0);
-    __syncthreads();
-    BLP_ST(1);
-
-    const bool valid = row0 + lane < N;
-    const unsigned erow = lds_address(tile + lane * TS);
-    for (int q0 = qa; q0 < qb; q0 += kSmallRound) {
-        const int nr = qb - q0 < kSmallRound ? qb - q0 : kSmallRound;
-        const int q_next = q0 + kSmallRound, nr_next = qb - q_next < kSmallRound ? qb - q_next : kSmallRound;
-        // wave w: queries [4 w, 4 w + 4) of the round, the head-replacing ones (if any) first
-        const int ja = 4 * wave < nr ? 4 * wave : nr, jb = ja + 4 < nr ? ja + 4 : nr;
-        const int n_h = (q0 + jb < q_head ? jb : (q_head - q0 > ja ? q_head - q0 : ja)) - ja;
-        for (int side = 0; side < 2; ++side) {  // wave-uniform
-            const int j0 = side == 0 ? ja : ja + n_h, n = side == 0 ? n_h : jb - ja - n_h;
-            if (n <= 0) continue;
-            unsigned row[4];
-            static_for<4>([&](auto gg) {
-                constexpr int g = decltype(gg)::value;
-                row[g] = lds_address(coef + (j0 + (g < n ? g : n - 1)) * CS);  // a short group repeats its last query
-            });
-            float key[4];
-            if (side == 0) transe_keys_lds<HEAD, D>(erow, row, key);
-            else transe_keys_lds<TAIL, D>(erow, row, key);
-            static_for<4>([&](auto gg) {
-                constexpr int g = decltype(gg)::value;
-                if (g < n) {
-                    const float k_true = kt[j0 + g];
-                    const unsigned long long gt = __popcll(__ballot(valid && key[g] > k_true));
-                    const unsigned long long ge = __popcll(__ballot(valid && key[g] >= k_true));
-                    if (lane == 0) partial[(size_t)slot * Q + q0 + j0 + g] = gt | (ge << 32);
-                }
-            });
-        }
-        BLP_ST(2);
-        if (q_next < qb) {  // (loading the next round's values before this round's scoring bought nothing: 28.4 vs 28.1 us)
-            __syncthreads();  // every wave is done with this round's coefficients
-            stage_load(q_next, nr_next, v, ktv);
-            stage_store(nr_next, v, ktv);
-            __syncthreads();
-        }
-        BLP_ST(3);
-    }
-#ifdef BLP_TIMING
-    if (lane == 0) {
-        for (int i = 0; i < 4; ++i) atomicAdd(&g_small_timing[i], tacc[i]);
-        atomicAdd(&g_small_timing[7], 1ull);
-    }
-#endif
-}
+constexpr int kSmallLdsWaves = 8;  // waves per workgroup of the TransE kernel below
 
 // Partial sums of n <= 4 queries of one side over the lane's row (rd: its LDS address), 32 columns at a time, coefficient
 // rows crow, crow + C, ... as SGPR operands.  The scalar loads are issued by hand one UNIT -- 16 columns of one query --
@@ -591,8 +398,10 @@ __device__ __forceinline__ void sgpr_group_sums(const float* rd, const float* __
 }
 
 // ---- TransE, the tile in LDS, the coefficients in scalar registers ---------------------------------------------------------
-// The kernel above is bound by LDS traffic: per 4-element step a wave reads its row quad AND four or eight coefficient
-// quads (broadcasts).  Here the coefficients do not go through LDS at all: the true-key launch materialises the
+// A lane that keeps its 128-float row in registers leaves room for two waves per SIMD, and a wave issues one VALU
+// instruction per ~4.5 cycles whatever it does.  TransE consumes the row strictly left to right, so the row can stay in LDS.
+// (An earlier kernel read the coefficients from LDS as well, as broadcasts next to the row quads: bound by LDS traffic,
+// 28.6 us for 128 queries.)  Here the coefficients do not go through LDS at all: the true-key launch materialises the
 // coefficient rows (true_key_lane_kernel's extra workgroups -- still three launches), a wave reads them through the scalar
 // cache as SGPR operands (the way rank_stream.hip does), and the tile row is read 32 columns at a time -- eight
 // ds_read_b128 per piece and group of FOUR queries, whose partial sums are all that crosses a piece (TransE sums left to
@@ -604,7 +413,7 @@ __global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_sgpr_kernel
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles, int n_slots,
     int q_chunk, unsigned long long* __restrict__ partial) {
-    constexpr int TS = D + 4, NT = kSmallLdsWaves * 64, NP = D / kSubCols;
+    constexpr int TS = D + 4, NT = kSmallLdsWaves * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // the tile: 64 x TS
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -668,10 +477,10 @@ __global__ __launch_bounds__(kSmallLdsWaves * 64, 4) void rank_small_sgpr_kernel
 bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
     const long long forced = knob(KNOB_SMALL_KERNEL);
     if (forced == 2 || (D != 64 && D != 128) || knob(KNOB_RANK_KERNEL) == 1) return false;
-    // (forced == 3 / 4: as 1, with TransE on the register-tile / LDS-broadcast kernel instead of the SGPR-coefficient one)
+    // (forced == 3: as 1, with TransE on the register-tile kernel instead of the scalar-register one)
     const int64_t Q = q_head + q_tail;
     if (Q == 0 || Q > kSmallMaxQueries || N <= 0) return false;
-    if (forced == 1 || forced == 3 || forced == 4) return true;
+    if (forced == 1 || forced == 3) return true;
     // <= 4 + 4 queries (the reference's Wikidata5M batch) against more than one tile per slot: the streaming kernels
     // (rank_stream.hip); against a small table -- the reference's own Wikidata5M protocol ranks against the ~7.4 k entities of
     // the evaluated triples (train.py:312-314) -- this kernel (tools/few_queries_probe.py: 8 queries x 7 400 rows 31 -> 21 us)
@@ -683,11 +492,11 @@ bool rank_small_applicable(int model, int D, int64_t N, int64_t q_head, int64_t 
 }
 
 // TransE against a table of at most kSmallSgprMaxTiles tiles: rank_small_sgpr_kernel, which reads materialised coefficient
-// rows (the caller has the true-key launch write them -- and zero the slots' counts when tiles share slots).  Knob small_kernel = 3 / 4: the register-tile / LDS-broadcast
-// kernels instead (A/B runs, tests).
+// rows (the caller has the true-key launch write them -- and zero the slots' counts when tiles share slots).  Knob small_kernel = 3: the register-tile kernel
+// instead (A/B runs, tests).
 bool rank_small_wants_coef(int model, int D, int64_t N) {
     const long long forced = knob(KNOB_SMALL_KERNEL);
-    return model == TRANSE && (N + kTileRows - 1) / kTileRows <= kSmallSgprMaxTiles && forced != 3 && forced != 4;
+    return model == TRANSE && (N + kTileRows - 1) / kTileRows <= kSmallSgprMaxTiles && forced != 3;
 }
 
 int rank_small_slots(int64_t N) {
@@ -723,12 +532,6 @@ static hipError_t rank_small_impl(const float* table, int64_t N, int64_t ld, con
             const int64_t grid = n_tiles * ((Q + qc - 1) / qc);
             rank_small_sgpr_kernel<D><<<dim3((unsigned)grid), kSmallLdsWaves * 64, (size_t)kTileRows * (D + 4) * 4, stream>>>(
                 table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)n_slots, (int)qc, partial);
-            return hipGetLastError();
-        }
-        if (n_tiles <= n_slots && knob(KNOB_SMALL_KERNEL) != 3) {  // (knob 3: the register-tile kernel, for A/B runs and tests)
-            const size_t lds2 = ((size_t)kTileRows * (D + 4) + (size_t)kSmallRound * small_coef_stride(D) + kSmallRound) * 4;
-            rank_small_lds_kernel<D><<<dim3((unsigned)blocks), kSmallLdsWaves * 64, lds2, stream>>>(
-                table, N, ld, q_fixed, q_rel, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)q_chunk, partial);
             return hipGetLastError();
         }
     }

@@ -158,8 +158,8 @@ def test_small_block_kernel_vs_oracle(ops, oracle, knobs, model, D, q_head, q_ta
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=D + q_head + len(model))
     rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + q_tail)
     want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
-    # TransE: 1 = the tile in LDS + coefficients in scalar registers, 3 = the tile in registers, 4 = tile and coefficients in LDS
-    for variant in ((1, 3, 4) if model == "transe" else (1,)):
+    # TransE: 1 = the tile in LDS + coefficients in scalar registers, 3 = the tile in registers
+    for variant in ((1, 3) if model == "transe" else (1,)):
         knobs("small_kernel", variant)
         got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
                            filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
@@ -176,7 +176,7 @@ def test_small_block_kernel_query_chunks(ops, oracle, knobs, model, chunk):
     N, D, q_head, q_tail = 777, 128, 45, 38
     table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=chunk)
     want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
-    for variant in ((1, 3, 4) if model == "transe" else (1,)):
+    for variant in ((1, 3) if model == "transe" else (1,)):
         knobs("small_kernel", variant)
         got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda()).cpu().numpy()
         assert np.array_equal(got, want), variant
@@ -194,7 +194,7 @@ def test_small_block_kernel_table_of_more_tiles_than_slots(ops, oracle, knobs, m
         table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=q_head)
         rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=q_tail)
         want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
-        for variant in ((1, 3, 4) if model == "transe" else (1,)):
+        for variant in ((1, 3) if model == "transe" else (1,)):
             knobs("small_kernel", variant)
             got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
                                filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
@@ -217,9 +217,8 @@ def test_small_block_kernel_ties_and_nonfinite(ops, oracle, knobs, model):
     table[11] = 0.0
     q_true = table[true_row].clone()
     want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, q_true=q_true)
-    # TransE: the LDS-tile kernels, coefficients in scalar registers (1) or in LDS (4); the register-tile one (3) shares
-    # score_side with the other models' kernel
-    for variant in ((1, 4) if model == "transe" else (1,)):
+    # TransE: the LDS-tile kernel with the coefficients in scalar registers (1) and the register-tile one (3)
+    for variant in ((1, 3) if model == "transe" else (1,)):
         knobs("small_kernel", variant)
         got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, q_true=q_true.cuda()).cpu().numpy()
         assert np.array_equal(got, want), variant

@@ -92,7 +92,7 @@ def make_case(rng):
     if u < 0.35:
         env["small_kernel"] = 2      # ... and every small block the small-block kernel
     elif u < 0.6:
-        env["small_kernel"] = int(rng.choice([1, 3, 4]))  # (3 / 4: TransE on the register-tile / LDS-broadcast variant) wherever it can run (D = 64 / 128, up to 4 096 queries), whatever the block size
+        env["small_kernel"] = int(rng.choice([1, 3]))  # (3: TransE on the register-tile variant) wherever it can run (D = 64 / 128, up to 4 096 queries), whatever the block size
         if rng.random() < 0.5:
             env["exact_query_chunk"] = int(rng.integers(1, 200))
     if rng.random() < 0.3:
