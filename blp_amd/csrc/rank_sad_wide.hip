@@ -88,6 +88,51 @@ __global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restr
     acc[q] = 0;
 }
 
+// The same keys for a SMALL call, one WAVE per query: a lane that walks three rows on its own is one memory round trip
+// per 16 elements (13 / 31 us at D = 300 / 768 whatever the number of queries).  Here the wave's lanes fetch the rows
+// coalesced and compute the |differences| -- elementwise, any lane gets the reference's bits -- into LDS, and lane 0 adds
+// them up in the reference's order, left to right.
+constexpr int64_t kWTrueKeyWaveMaxQueries = 2048;
+__global__ __launch_bounds__(256) void wide_true_key_wave_kernel(const float* __restrict__ table, int64_t ld, int D,
+                                                                 const QRows q_fixed, const QRows q_rel,
+                                                                 const int64_t* __restrict__ true_row,
+                                                                 const float* __restrict__ q_true, int64_t q_head, int64_t Q,
+                                                                 float* __restrict__ key_true,
+                                                                 unsigned long long* __restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) float terms[4][kWMaxD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= Q) return;  // (wave-uniform; nothing below synchronises the workgroup)
+    const float* e = true_row ? table + true_row[q] * ld : q_true + q * D;
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
+    const bool head = q < q_head;
+    for (int c = 4 * lane; c < D; c += 256) {
+        const float4 ev = *reinterpret_cast<const float4*>(e + c);
+        const float4 fv = *reinterpret_cast<const float4*>(f + c);
+        const float4 rv = *reinterpret_cast<const float4*>(r + c);
+        const float es[4] = {ev.x, ev.y, ev.z, ev.w}, fs[4] = {fv.x, fv.y, fv.z, fv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = (head ? es[i] : fs[i]) + rs[i];
+            x = x - (head ? fs[i] : es[i]);
+            t[i] = fabsf(x);
+        }
+        *reinterpret_cast<float4*>(&terms[wave][c]) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    wave_lds_sync();
+    if (lane == 0) {
+        float sum = 0.0f;
+        for (int d = 0; d < D; d += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(&terms[wave][d]);
+            sum = sum + t.x; sum = sum + t.y; sum = sum + t.z; sum = sum + t.w;
+        }
+        key_true[q] = -sum;
+        acc[q] = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void wide_range_kernel(const float* __restrict__ table, int64_t N, int64_t ld, int D,
                                                          const QRows q_fixed,
                                                          const QRows q_rel, int64_t q_head, int64_t Q,
@@ -110,13 +155,11 @@ __global__ __launch_bounds__(256) void wide_range_kernel(const float* __restrict
 }
 
 // Candidate tile image as in rank_sad.hip, Dp / 8 uint4 per lane (Dp = D rounded up to 128, zero padded).
-__global__ __launch_bounds__(256) void wide_quantize_table_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
-                                                                  int D, int Dp, const SadParams* __restrict__ p,
-                                                                  uint4* __restrict__ cimg,
-                                                                  unsigned* __restrict__ resid) {
+__device__ __forceinline__ void wide_quantize_table_tile(int64_t tile, const float* __restrict__ table, int64_t N, int64_t ld,
+                                                         int D, int Dp, const SadParams* __restrict__ p,
+                                                         uint4* __restrict__ cimg, unsigned* __restrict__ resid) {
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
-    const int64_t tile = blockIdx.x;
     const int row_in = threadIdx.x >> 2, part = threadIdx.x & 3;
     const int64_t row = tile * 64 + row_in;
     const float* src = table + (row < N ? row : 0) * ld;
@@ -146,18 +189,17 @@ __global__ __launch_bounds__(256) void wide_quantize_table_kernel(const float* _
 
 // One wave per query: its 2-byte image (Dp / 2 dwords) and the two thresholds; the first candidate slab's
 // flag bitmap is zeroed on the way.
-__global__ __launch_bounds__(256) void wide_quantize_queries_kernel(const QRows q_fixed,
-                                                                    const QRows q_rel, int64_t q_head,
-                                                                    int64_t Q, int D, int Dp,
-                                                                    const float* __restrict__ key_true,
-                                                                    const SadParams* __restrict__ p,
-                                                                    unsigned* __restrict__ qimg, int2* __restrict__ thr,
-                                                                    unsigned* __restrict__ flags, int64_t n_flag_words) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_flag_words; j += (int64_t)gridDim.x * blockDim.x)
-        flags[j] = 0;
+__device__ __forceinline__ void wide_quantize_queries_block(int64_t vblock, int64_t vgrid, const QRows& q_fixed,
+                                                            const QRows& q_rel, int64_t q_head,
+                                                            int64_t Q, int D, int Dp,
+                                                            const float* __restrict__ key_true,
+                                                            const SadParams* __restrict__ p,
+                                                            unsigned* __restrict__ qimg, int2* __restrict__ thr,
+                                                            unsigned* __restrict__ flags, int64_t n_flag_words) {
+    for (int64_t j = vblock * 256 + threadIdx.x; j < n_flag_words; j += vgrid * 256) flags[j] = 0;
     const SadScale sc = sad_scale(p);
     if (!sc.ok) return;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t q = vblock * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
     const int lane = threadIdx.x & 63;
     const bool head = q < q_head;
@@ -197,6 +239,36 @@ __global__ __launch_bounds__(256) void wide_quantize_queries_kernel(const QRows 
     }
 }
 
+// Both images in one launch (as rank_sad.hip's sad_quantize_kernel): workgroups [0, table_blocks) a candidate tile each,
+// the rest four queries each; with n_partial > 0 (small calls) every workgroup first finishes the range pass itself.
+__global__ __launch_bounds__(256) void wide_quantize_kernel(const float* __restrict__ table, int64_t N, int64_t ld, int D, int Dp,
+                                                            SadParams* __restrict__ p, const SadParams* __restrict__ partial,
+                                                            int n_partial, uint4* __restrict__ cimg,
+                                                            unsigned* __restrict__ resid, unsigned table_blocks,
+                                                            const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t Q,
+                                                            const float* __restrict__ key_true, unsigned* __restrict__ qimg,
+                                                            int2* __restrict__ thr, unsigned* __restrict__ flags,
+                                                            int64_t n_flag_words) {
+    __shared__ SadParams p_block;
+    const SadParams* pp = p;
+    if (n_partial > 0) {
+        if (threadIdx.x < 64) {
+            const SadParams r = sad_range_finish_wave(partial, n_partial, threadIdx.x);
+            if (threadIdx.x == 0) {
+                p_block = r;
+                if (blockIdx.x == 0) *p = r;
+            }
+        }
+        __syncthreads();
+        pp = &p_block;
+    }
+    if (blockIdx.x < table_blocks)
+        wide_quantize_table_tile(blockIdx.x, table, N, ld, D, Dp, pp, cimg, resid);
+    else
+        wide_quantize_queries_block(blockIdx.x - table_blocks, gridDim.x - table_blocks, q_fixed, q_rel, q_head, Q, D, Dp, key_true,
+                                    pp, qimg, thr, flags, n_flag_words);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pass 1.  One candidate tile per wave; the row is walked in chunks of 128 elements (64 VGPRs), the
 // workgroup's queries run inside each chunk and their partial SADs wait in LDS between chunks.
@@ -204,7 +276,7 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups,
     const unsigned* __restrict__ qimg, const int2* __restrict__ thr, int64_t Q, int Dp, int words_per_query,
     unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs,
-    SadParams* __restrict__ params) {
+    SadParams* __restrict__ params, int q_per_wg) {  // q_per_wg <= kWChunk: wide_chunk_queries()
     if (!sad_scale(params).ok) return;
     __shared__ unsigned psum[kSW][kWChunk][64];
     __shared__ int2 thr_s[kWChunk];
@@ -227,8 +299,8 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     const unsigned per_cb = (unsigned)n_groups * kWideChunkBlock, cb = logical / per_cb, in_cb = logical % per_cb;
     const unsigned chunks_here = n_chunks_all - cb * kWideChunkBlock < kWideChunkBlock ? n_chunks_all - cb * kWideChunkBlock : kWideChunkBlock;
     const int group = (int)(in_cb / chunks_here);
-    const int64_t q0 = (int64_t)(cb * kWideChunkBlock + in_cb % chunks_here) * kWChunk;
-    const int nq = (int)(Q - q0 < kWChunk ? Q - q0 : kWChunk);
+    const int64_t q0 = (int64_t)(cb * kWideChunkBlock + in_cb % chunks_here) * q_per_wg;
+    const int nq = (int)(Q - q0 < q_per_wg ? Q - q0 : q_per_wg);
 
     if (tid < kWChunk) {
         thr_s[tid] = tid < nq ? thr[q0 + tid] : make_int2(0, 0);
@@ -462,9 +534,20 @@ struct WideWorkspace {
 
 static int padded_width(int D) { return (D + 127) / 128 * 128; }
 
+// Queries per workgroup of the pre-pass: kWChunk, fewer when (candidate groups) x (query chunks) would not fill the chip
+// -- the BOW / DKRL scripts' eval batches: 64 queries against 14 541 rows were 114 workgroups ([measured] D = 300:
+// 38.6 us for the pre-pass kernel of a 110 us call).
+static int wide_chunk_queries(int64_t N, int64_t Q) {
+    const int64_t n_groups = ((N + 63) / 64 + kSW - 1) / kSW;
+    int cs = kWChunk;
+    while (cs > 8 && n_groups * ((Q + cs - 1) / cs) < 2 * 256) cs >>= 1;
+    return cs;
+}
+
 static int64_t wide_groups_per_pass(int64_t N, int64_t Q) {
     const int64_t n_groups = ((N + 63) / 64 + kSW - 1) / kSW;
-    const int64_t n_chunks = (Q + kWChunk - 1) / kWChunk;
+    const int cs = wide_chunk_queries(N, Q);
+    const int64_t n_chunks = (Q + cs - 1) / cs;
     const int64_t cap = (int64_t)256 << 20;
     const int64_t by_pairs = cap / (kWQuota * 8) / (n_chunks > 0 ? n_chunks : 1);
     const int64_t by_flags = cap / 4 / (Q > 0 ? Q : 1) * 32 / kSW;
@@ -494,7 +577,8 @@ static WideWorkspace carve_wide(void* base, int D, int64_t N, int64_t Q) {
     const int64_t words = (w.pass_groups * kSW + 31) / 32;
     w.flags = reinterpret_cast<unsigned*>(p + off); off = align_up(off + (size_t)Q * words * 4, 256);
     w.pairs = reinterpret_cast<uint2*>(p + off);
-    off = align_up(off + (size_t)w.pass_groups * ((Q + kWChunk - 1) / kWChunk) * kWQuota * 8, 256);
+    const int cs = wide_chunk_queries(N, Q);
+    off = align_up(off + (size_t)w.pass_groups * ((Q + cs - 1) / cs) * kWQuota * 8, 256);
     w.bytes = off;
     return w;
 }
@@ -519,26 +603,34 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
     const int64_t Q = q_head + q_tail;
     const int Dp = padded_width(D);
     WideWorkspace w = carve_wide(workspace, D, N, Q);
-    wide_true_key_kernel<<<dim3((unsigned)((Q + 255) / 256)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, true_row, q_true,
-                                                                               q_head, Q, w.key_true, w.acc);
+    if (Q <= kWTrueKeyWaveMaxQueries)
+        wide_true_key_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, true_row, q_true,
+                                                                                  q_head, Q, w.key_true, w.acc);
+    else
+        wide_true_key_kernel<<<dim3((unsigned)((Q + 255) / 256)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, true_row, q_true,
+                                                                                   q_head, Q, w.key_true, w.acc);
     if (ev_start) (void)hipEventRecord(ev_start, stream);
-    const int64_t n_tiles = (N + 63) / 64;
+    const int64_t n_tiles = (N + 63) / 64, query_blocks = (Q + 3) / 4;
+    if (n_tiles + query_blocks > 0x7fffffff) return hipErrorInvalidValue;
+    // small calls: no launch for the range's last step -- the quantising workgroups do it themselves (from fewer partials)
+    const bool fold_finish = n_tiles + query_blocks <= 1024;
+    int64_t range_blocks;
     {
-        const int64_t items = N * (D / 4) > Q * D ? N * (D / 4) : Q * D;
-        int64_t blocks = (items + 255) / 256;
-        blocks = blocks < kSRangeBlocks ? (blocks > 0 ? blocks : 1) : kSRangeBlocks;
-        wide_range_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(table, N, ld, D, q_fixed, q_rel, q_head, Q, w.partial);
-        sad_range_finish_kernel<<<1, 64, 0, stream>>>(w.partial, (int)blocks, w.params);
+        const int64_t items = N * (D / 4) > Q * D ? N * (D / 4) : Q * D, cap = fold_finish ? 512 : kSRangeBlocks;
+        range_blocks = (items + 255) / 256;
+        range_blocks = range_blocks < cap ? (range_blocks > 0 ? range_blocks : 1) : cap;
+        wide_range_kernel<<<dim3((unsigned)range_blocks), 256, 0, stream>>>(table, N, ld, D, q_fixed, q_rel, q_head, Q, w.partial);
+        if (!fold_finish) sad_range_finish_kernel<<<1, 64, 0, stream>>>(w.partial, (int)range_blocks, w.params);
     }
     const int64_t pass_rows = w.pass_groups * kSW * 64;
     const int64_t first_rows = N < pass_rows ? N : pass_rows;
     const int64_t first_words = ((((first_rows + 63) / 64 + kSW - 1) / kSW) * kSW + 31) / 32;
-    if (n_tiles > 0)
-        wide_quantize_table_kernel<<<dim3((unsigned)n_tiles), 256, 0, stream>>>(table, N, ld, D, Dp, w.params, w.cimg, w.resid);
-    wide_quantize_queries_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(
-        q_fixed, q_rel, q_head, Q, D, Dp, w.key_true, w.params, w.qimg, w.thr, w.flags, first_words * Q);
+    wide_quantize_kernel<<<dim3((unsigned)(n_tiles + query_blocks)), 256, 0, stream>>>(
+        table, N, ld, D, Dp, w.params, w.partial, fold_finish ? (int)range_blocks : 0, w.cimg, w.resid, (unsigned)n_tiles, q_fixed,
+        q_rel, q_head, Q, w.key_true, w.qimg, w.thr, w.flags, first_words * Q);
 
-    const int64_t n_chunks = (Q + kWChunk - 1) / kWChunk;
+    const int q_per_wg = wide_chunk_queries(N, Q);
+    const int64_t n_chunks = (Q + q_per_wg - 1) / q_per_wg;
     hipError_t err = hipSuccess;
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_rows) {  // one iteration unless the caps bind
         const int64_t n_rows = N - slab0 < pass_rows ? N - slab0 : pass_rows;
@@ -554,7 +646,7 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
         const float* slab = table + slab0 * ld;
         wide_rank_sad_kernel<<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
             w.cimg + (slab0 / 64) * (Dp / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, Dp, words, w.acc,
-            w.flags, w.pairs, w.params);
+            w.flags, w.pairs, w.params, q_per_wg);
         const int64_t pair_blocks = (n_blocks * kWQuota + 63) / 64;
         wide_refine_pairs_kernel<<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 40 ? pair_blocks : (int64_t)n_cu * 40)), 64, 0,
                                    stream>>>(slab, ld, D, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc);
