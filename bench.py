@@ -392,14 +392,14 @@ def load_pmc(workload, key="hbm_bytes_per_launch"):
         return None
 
 
-def hbm_probe(device, events, reps=10):
+def hbm_probe(device, events, reps=30):
     """The exact ranking kernel at its HBM-bound operating point (BASELINE config 4 at 1 GPU): 4.6 M x 128 f32
     table = 2.355 GB, reference batching 2 triples = 4 queries per table pass, the bare C-ABI call."""
     from blp_amd import _lib, ops
     cfg = WORKLOADS["wikidata5m-transe"]
     table, rel_w, heads, tails, rels = make_data(cfg, device, seed=5)
     q_fixed, q_rel, true_row = build_queries(table, rel_w, heads[:2], tails[:2], rels[:2])
-    for _ in range(2):
+    for _ in range(20):  # (the first passes over a freshly written 2.4 GB table run ~5 % slower)
         ops.rank_all("transe", table, q_fixed, q_rel, 2, true_row=true_row)
     pairs = []
     for _ in range(reps):
@@ -409,11 +409,13 @@ def hbm_probe(device, events, reps=10):
         pairs.append((a, b))
     torch.cuda.synchronize()
     ms = sum(events.elapsed_ms(a, b) for a, b in pairs) / len(pairs)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ops.rank_metrics(ops.rank_all("transe", table, q_fixed, q_rel, 2, true_row=true_row))
-    torch.cuda.synchronize()
-    call_ms = (time.perf_counter() - t0) / reps * 1e3
+    call_ms = float("inf")
+    for _ in range(3):  # (the better of three loops: a one-off host stall inside one of them read as 2 ms per call)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ops.rank_metrics(ops.rank_all("transe", table, q_fixed, q_rel, 2, true_row=true_row))
+        torch.cuda.synchronize()
+        call_ms = min(call_ms, (time.perf_counter() - t0) / 10 * 1e3)
     alg_bytes = cfg["N"] * cfg["D"] * 4 + 4 * (2 * cfg["D"] * 4 + 24)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"workload": "wikidata5m-transe, 4 queries per table pass (bare blp_rank_all call)", "bound": "hbm",
