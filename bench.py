@@ -228,7 +228,7 @@ class Job:
         peak_tf = F32_PEAK_TFLOPS if transe else BF16X3_PEAK_TFLOPS
         if alg_bytes / (HBM_PEAK_GBPS * 1e9) >= alg_flops / (peak_tf * 1e12):
             roof = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "kernel": "rank_stream_kernel (exact f32 keys; the table streamed once, 32 columns at a time from a load ring that never drains)"}
+                    "kernel": "rank_stream_wg_kernel (exact f32 keys; the table streamed once through workgroup tiles, two tiles in flight per workgroup)"}
         elif transe:
             wide = D not in (64, 128, 256)
             roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",

@@ -1,7 +1,7 @@
 // rank_stream.hip -- a handful of queries against a LONG table (the reference's Wikidata5M evaluation batch:
 // eval_batch_size 2 = 4 queries per pass over 4.6 M rows, scripts/blp-*-wikidata5m.sh:18; train.py:128-171): the
-// pass is one read of the table, HBM-bound, and what matters is that the read never stops.  TransE first; the
-// bilinear models' kernel is further down.
+// pass is one read of the table, HBM-bound, and what matters is that the read never stops.  TransE's per-wave ring first
+// (tables of up to 1.7 M rows); the workgroup-tile kernel (the bilinear models; TransE on longer tables) is further down.
 //
 // rank_tiles<STATIC> (rank_all.hip) fetches a whole tile (64 rows x D floats, all D/4 loads of a lane at once), then
 // scores it: a wave alternates between a load phase and an arithmetic phase and only the drift between the waves of a
@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
 #include "score_core.h"
@@ -30,6 +31,7 @@
 namespace blp {
 
 constexpr int kStreamQ = 4;  // queries per side (== rank_all.hip's kQB: what its static mode takes)
+constexpr int64_t kStreamWgMinRows = 1700000;  // TransE: from here on the workgroup-tile kernel (launch_rank_stream)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -216,6 +218,8 @@ struct SgprStreamCoef {
 
 // streams of Scorer<MODEL, SIDE, D>: count, length, and the chunk that keeps 2 x NS x CH floats within the SGPR file
 template <int MODEL, int SIDE, int D> struct StreamPlan;
+template <int D> struct StreamPlan<TRANSE, TAIL, D> { static constexpr int NS = 1, L = D, CH = 16; };
+template <int D> struct StreamPlan<TRANSE, HEAD, D> { static constexpr int NS = 2, L = D, CH = 16; };
 template <int D> struct StreamPlan<DISTMULT, TAIL, D> { static constexpr int NS = 1, L = D, CH = 16; };
 template <int D> struct StreamPlan<DISTMULT, HEAD, D> { static constexpr int NS = 2, L = D, CH = 16; };
 template <int SIDE, int D> struct StreamPlan<COMPLEX, SIDE, D> { static constexpr int NS = 4, L = D / 2, CH = 8; };
@@ -350,12 +354,17 @@ hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, i
                               unsigned long long* acc, int n_cu, hipStream_t stream) {
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
-    if (model != TRANSE) {
+    // TransE: the per-wave ring ramps up and down faster (1/8 Wikidata5M shard: 58 us against 72), the workgroup-tile kernel
+    // streams a long table better ([measured] 4-query pass: 1.15 M rows 103 / 109, 2.3 M rows 198 / 188, 4.6 M rows 384 / 353 us
+    // = 6.7 TB/s); knob stream_kernel = 3 / 4 forces the workgroup-tile / the ring kernel
+    const long long forced = knob(KNOB_STREAM_KERNEL);
+    const bool wg_tile = model != TRANSE || (D != 256 && forced != 4 && (forced == 3 || N >= kStreamWgMinRows));
+    if (wg_tile) {
 #define BLP_STREAM_WG(MM, DD)                                                                                        \
     if (model == MM && D == DD)                                                                                      \
         return launch_stream_wg<MM, DD>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,       \
                                         (int)n_tiles, acc, n_cu, stream);
-        BLP_STREAM_WG(DISTMULT, 64) BLP_STREAM_WG(DISTMULT, 128) BLP_STREAM_WG(COMPLEX, 64) BLP_STREAM_WG(COMPLEX, 128)
+        BLP_STREAM_WG(TRANSE, 64) BLP_STREAM_WG(TRANSE, 128) BLP_STREAM_WG(DISTMULT, 64) BLP_STREAM_WG(DISTMULT, 128) BLP_STREAM_WG(COMPLEX, 64) BLP_STREAM_WG(COMPLEX, 128)
         BLP_STREAM_WG(SIMPLE, 64) BLP_STREAM_WG(SIMPLE, 128)
 #undef BLP_STREAM_WG
         return hipErrorInvalidValue;

@@ -268,6 +268,10 @@ def test_stream_kernels_vs_oracle(ops, oracle, knobs, model, D, q_head, q_tail):
         tiles = ops.rank_all(*args, **kw).cpu().numpy()
         assert np.array_equal(got, want), (N, got, want)
         assert np.array_equal(tiles, want)
+        if model == "transe":  # both of its streaming kernels (the library picks by table length)
+            for variant in (3, 4):
+                knobs("stream_kernel", variant)
+                assert np.array_equal(ops.rank_all(*args, **kw).cpu().numpy(), want), (N, variant)
 
 
 @pytest.mark.parametrize("D", [64, 128, 256])

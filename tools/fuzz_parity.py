@@ -95,8 +95,8 @@ def make_case(rng):
         env["small_kernel"] = int(rng.choice([1, 3]))  # (3: TransE on the register-tile variant) wherever it can run (D = 64 / 128, up to 4 096 queries), whatever the block size
         if rng.random() < 0.5:
             env["exact_query_chunk"] = int(rng.integers(1, 200))
-    if rng.random() < 0.3:
-        env["stream_kernel"] = 2     # TransE with <= 4 + 4 queries on rank_tiles<STATIC> instead of rank_stream.hip
+    if rng.random() < 0.45:
+        env["stream_kernel"] = int(rng.choice([2, 2, 3, 4]))  # <= 4 + 4 queries on rank_tiles<STATIC> (2) / TransE's workgroup-tile (3) or ring (4) kernel
     return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids, (fixed_idx, rel_table)
 
 
