@@ -20,7 +20,8 @@ Workloads (synthetic data of the published shapes, seeded; BASELINE.json configs
   wikidata5m-transe (configs[3]) 4.6 M x 128 table (2.36 GB), reference batching: 2 triples = 4 queries per
                     table pass (scripts/blp-transe-wikidata5m.sh:18); a step = 64 passes
   wikidata5m-transe-block / -complex-block   the same table, the 6 894 test triples as ONE query block
-The default single-GPU run also reports fb15k237-distmult, fb15k237-complex and wikidata5m-transe-block as
+The default single-GPU run also reports fb15k237-distmult, fb15k237-complex and wikidata5m-transe-block (the default
+N > 1 run: wikidata5m-transe-block on the candidate axis) as
 `sub_results` (each with its own roofline), and the HBM-bound operating point as `hbm_probe`.
 
 With N > 1 the evaluation is sharded along one axis (blp_amd.ranking.choose_shard_axis, --shard-axis):
@@ -495,6 +496,21 @@ def main():
             result["cpu_baseline"] = cpu_baseline(job)
             result["torch_gpu_baseline"] = torch_gpu_baseline(job)
     del triples, counts
+    if world > 1 and not args.no_sub_results and args.workload == "fb15k237-transe":
+        # the north-star axis next to the default workload's query axis: the Wikidata5M-scale table sharded along the
+        # CANDIDATE axis, the test set as one block (every rank takes part: the step has one all-gather of rank counts)
+        del job
+        torch.cuda.empty_cache()
+        name = "wikidata5m-transe-block"
+        sub = Job(name, device, world, rank, "auto", backend)
+        k_sub = max(2, min(args.steps, 5))
+        f, t, c = sub.measure(k_sub, 1, events)
+        if rank == 0:
+            f["steps"], f["unit"], f["shard_axis"] = k_sub, "scored triples/s", sub.axis
+            f["parity_check"] = parity_spot_check(sub, t, c)
+            result["sub_results"] = {name: f}
+        del sub, t, c
+        torch.cuda.empty_cache()
     if world == 1:
         subs = {}
         if not args.no_sub_results and args.workload == "fb15k237-transe":

@@ -176,6 +176,36 @@ def test_bench_two_ranks_share_one_gpu_functional(axis):
     assert b["parity_check"].endswith("identical counts")
 
 
+def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
+    """The line the driver gets from `bench.py --gpus N` with its defaults (here N = 2 over gloo on this one GPU): the
+    FB15k-237 evaluation on the query axis and, as a sub-result, the Wikidata5M-scale block on the candidate axis (the
+    north_star's sharding: shards of the table, one all-gather of rank counts) -- both with the MRR of the one-rank runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BLP_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["shard_axis"] == "query" and b["parity_check"].endswith("identical counts")
+    sub = b["sub_results"]["wikidata5m-transe-block"]
+    assert sub["shard_axis"] == "candidate" and len(sub["kernel_ms_per_rank"]) == 2 and sub["roofline"]["frac"] > 0
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload",
+                          "wikidata5m-transe-block", "--no-cpu-baseline", "--no-hbm-probe", "--no-sub-results"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    assert abs(a["mrr"] - sub["mrr"]) < 1e-15 and abs(a["mrr_filtered"] - sub["mrr_filtered"]) < 1e-15
+    assert a["hits@1,3,10"] == pytest.approx(sub["hits@1,3,10"], abs=1e-15)
+
+
 def test_bench_line_keeps_the_contract():
     """`python bench.py` with its defaults: ONE JSON line on stdout with the driver's keys; the step is the whole
     evaluation (raw + filtered), with the raw-only time beside it; the roofline of the dominant kernel; the CPU
