@@ -19,15 +19,21 @@ Workloads (synthetic data of the published shapes, seeded; BASELINE.json configs
   fb15k237-distmult / -complex / -simple   (configs[2]) same shapes, un-normalised table
   wikidata5m-transe (configs[3]) 4.6 M x 128 table (2.36 GB), reference batching: 2 triples = 4 queries per
                     table pass (scripts/blp-transe-wikidata5m.sh:18); a step = 64 passes
+  wikidata5m-complex   the same batching with ComplEx (BASELINE config 5's model; scripts/blp-complex-wikidata5m.sh:16-18)
   wikidata5m-transe-block / -complex-block   the same table, the 6 894 test triples as ONE query block
-The default single-GPU run also reports fb15k237-distmult, fb15k237-complex and wikidata5m-transe-block (the default
-N > 1 run: wikidata5m-transe-block on the candidate axis) as
-`sub_results` (each with its own roofline), and the HBM-bound operating point as `hbm_probe`.
+The default single-GPU run also reports fb15k237-distmult, fb15k237-complex, wikidata5m-transe (reference batching, with
+its filter), wikidata5m-complex and wikidata5m-transe-block as `sub_results` (each with its own roofline), and the
+HBM-bound operating point as `hbm_probe`.  The default N > 1 run reports, next to the FB15k-237 headline on the axis
+ranking.choose_shard_axis picks (query), the north_star's CANDIDATE axis three times: fb15k237-transe, wikidata5m-transe
+(reference batching) and wikidata5m-transe-block -- each with `exchange_ms` (device events around the collectives, per
+rank), `kernel_ms_per_rank` and the ranks the process group reports.
 
 With N > 1 the evaluation is sharded along one axis (blp_amd.ranking.choose_shard_axis, --shard-axis):
   "candidate" (north_star; the default for the Wikidata5M-scale table): rank r ranks every query against table
-              rows [lo, hi); one all-reduce replicates the vectors of the entities in the test triples, ONE RCCL
-              all-gather of the int32 counts + a sum per evaluation (SURVEY.md 8e);
+              rows [lo, hi) through the same fused device path as one GPU (blp_rank_all_shard); the vectors the
+              queries are made of are replicated once (all-gather of the table when it is small, else one all-reduce
+              of the vectors of the entities in the test triples), ONE RCCL all-gather of the int32 counts + a sum per
+              evaluation (SURVEY.md 8e);
   "query"     (small table, many triples -- FB15k-237): the table is replicated, rank r ranks its slice of the
               triples, ONE all-gather of the per-triple counts.
 Total work is fixed as N grows -> "scaling": "strong".
@@ -65,11 +71,14 @@ WORKLOADS = {
     # reference batching: eval_batch_size = 2 triples per table pass, 64 passes per step; the reference's
     # Wikidata5M filtering graph is the evaluated split's own triples (train.py:381-393)
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0),
+    "wikidata5m-complex": dict(model="complex", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0),
     # the same table with the whole Wikidata5M test set (6 894 triples) as ONE query block
     "wikidata5m-transe-block": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
     "wikidata5m-complex-block": dict(model="complex", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
 }
-SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe-block")
+SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-block")
+# N > 1: (workload, shard axis) next to the headline -- the north_star's candidate axis on all three shapes
+SUB_RESULTS_SHARDED = (("fb15k237-transe", "candidate"), ("wikidata5m-transe", "candidate"), ("wikidata5m-transe-block", "candidate"))
 
 
 def make_data(cfg, device, seed=1, sort=True):
@@ -171,12 +180,12 @@ class Job:
             self.step(filtered)
         self.fence()
 
-    def step(self, filtered=True):
+    def step(self, filtered=True, timing=None):
         from blp_amd import ops
         triples, counts, ids_ok = self.ranking.rank_triples(
             self.model, self.table, self.triples, self.ent2idx, self.index if filtered else None,
             num_entities=self.N, world=self.world, rank=self.rank, axis=self.axis if self.world > 1 else "candidate",
-            block_size=self.cfg["block"])
+            block_size=self.cfg["block"], timing=timing)
         sums = ops.rank_metric_sums(counts)
         return triples, counts, sums
 
@@ -215,6 +224,19 @@ class Job:
         torch.cuda.synchronize()
         return sum(events.elapsed_ms(a, b) for a, b in pairs) / len(pairs)
 
+    def exchange_ms(self, reps):
+        """Milliseconds per step inside the collectives of this rank (device events around each exchange on the stream
+        the kernels run on; includes waiting for the slowest rank).  0 on one GPU."""
+        if self.world == 1:
+            return 0.0
+        total = 0.0
+        for _ in range(reps):
+            timing = {}
+            self.step(True, timing=timing)
+            torch.cuda.synchronize()
+            total += self.ranking.exchange_ms(timing)
+        return total / reps
+
     def roofline(self, kernel_ms):
         """Roof of the dominant kernel: algorithmic work of ONE ranking launch on this rank / its time."""
         model, D, Q = self.cfg["model"], self.D, 2 * min(self.T, self.cfg["block"])
@@ -239,7 +261,14 @@ class Job:
                     "note": "VALU roof (an L1 norm has no matrix-core form): 157.3 Tops/s is the f32 vector-FMA peak and "
                             "also what v_sad_u16 delivers at 4 cycles/instruction (2 elements x (subtract + |.|-accumulate) "
                             "x 64 lanes); the exact f32 add/sub kernel tops out at half of it.  achieved = 2 ops x D x Q x N "
-                            "/ time of the whole rank pass."}
+                            "/ time of the whole rank pass.  SURVEY 8(d)'s own accounting for the reference's f32 arithmetic "
+                            "-- N x Q x D x c lane-ops, c = 3 on the head side (add r, subtract t, |.|-accumulate) and 2 on the "
+                            "tail side, against the 78.6 T/s non-FMA f32 lane-op rate -- is in `survey_8d_lane_ops`: a frac "
+                            "above 1 there says the kernel does NOT execute those f32 lane-ops (it decides >= 99.8 % of the "
+                            "pairs in 16-bit fixed point, two elements per v_sad_u16, and re-scores the rest exactly).",
+                    "survey_8d_lane_ops": {"lane_ops_per_launch": 2.5 * n_local * D * Q,
+                                           "achieved_Tops": 2.5 * n_local * D * Q / t_k / 1e12, "peak_Tops": F32_PEAK_TFLOPS / 2,
+                                           "frac": 2.5 * n_local * D * Q / t_k / 1e12 / (F32_PEAK_TFLOPS / 2)}}
         else:
             roof = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                     "kernel": f"rank_gemm_bf16_kernel<{model.upper()},128> + refine_* (bf16 x 3 split MFMA GEMM + band + exact "
@@ -247,10 +276,19 @@ class Job:
                     "note": "achieved = 2 flops x D x Q x N (the f32 GEMM the reference's scores amount to) / time of GEMM "
                             "pre-pass + exact refinement.  Every f32 product is three bf16 MFMA products (hi*hi + hi*lo + "
                             "lo*hi), so the roof is the dense bf16 MFMA peak / 3 = 833 TF (5.3x the f32 MFMA peak).",
-                    "mfma_busy": load_pmc(self.name, "mfma_busy_frac_at_2.4GHz")}
+                    "mfma_busy": None}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = load_pmc(self.name)
         roof["kernel_ms"] = kernel_ms
+        # HBM bytes / matrix-pipe busy fraction of the dominant kernel come from the committed rocprofv3 PMC passes (a
+        # profiler cannot run inside this process): stamped with the round / commit they were taken at, and dropped
+        # (null) on more than one GPU or when the profiled kernel no longer looks like the live one.
+        roof["traffic"], roof["pmc_source"] = None, None
+        pmc, why = load_pmc(self.name, live_pass_ms=kernel_ms if self.world == 1 else None)
+        if pmc is not None:
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            if "mfma_busy" in roof:
+                roof["mfma_busy"] = pmc.get("mfma_busy_frac_at_2.4GHz")
+        roof["pmc_source"] = why
         roof["algorithmic_bytes_per_launch"] = alg_bytes
         roof["algorithmic_flops_per_launch"] = alg_flops
         return roof
@@ -260,12 +298,13 @@ class Job:
         elapsed, (triples, counts, sums) = self.timed(steps, warmup, filtered=True)
         raw_elapsed, _ = self.timed(max(1, min(steps, 5)), 1, filtered=False)
         kernel_ms = self.kernel_ms(events, max(1, min(steps, 10)))
+        exchange = self.exchange_ms(max(1, min(steps, 5)))
         scored = 2.0 * self.T * self.N
-        per_rank = [kernel_ms]
+        per_rank, exchange_per_rank = [kernel_ms], [exchange]
         if self.world > 1:
             box = [None] * self.world
-            dist.all_gather_object(box, kernel_ms)
-            per_rank = box
+            dist.all_gather_object(box, (kernel_ms, exchange))
+            per_rank, exchange_per_rank = [b[0] for b in box], [b[1] for b in box]
         sums = sums.cpu()
         out = {
             "value": scored * steps / elapsed,
@@ -276,6 +315,8 @@ class Job:
             "hits@1,3,10_filtered": [x.item() / (2 * self.T) for x in sums[5:8]],
             "roofline": self.roofline(kernel_ms),
             "kernel_ms_per_rank": per_rank,
+            "exchange_ms": max(exchange_per_rank), "exchange_ms_per_rank": exchange_per_rank,
+            "shard_axis": self.axis, "ranks": self.world,
         }
         return out, triples, counts
 
@@ -290,7 +331,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(job, budget_s=10.0, budget_1t_s=8.0):
+def cpu_baseline(job, budget_s=10.0):
     """The reference's CPU path restated (oracle/ref_port.py: same torch CPU kernels, incl. the dense filter mask
     overwrite of train.py:159-171), timed on this box's host cores on a bounded sample of reference batches
     (eval_batch_size = 64 triples for FB15k-237, 2 for Wikidata5M: scripts/blp-transe-{fb15k237,wikidata5m}.sh:18),
@@ -319,16 +360,25 @@ def cpu_baseline(job, budget_s=10.0, budget_1t_s=8.0):
             if el >= budget or done >= max_batches:
                 return done, el
 
-    threads = torch.get_num_threads()
-    done, el = run(budget_s, 64)
-    torch.set_num_threads(1)
-    done1, el1 = run(budget_1t_s, 4)
-    torch.set_num_threads(threads)
-    return {"value": 2.0 * B * cfg["N"] * done / el, "unit": "scored triples/s", "cores": threads, "kind": "port",
-            "value_1_thread": 2.0 * B * cfg["N"] * done1 / el1, "cpu_model": cpu_model_name(),
-            "logical_cpus": os.cpu_count(),
+    # best of a few thread counts: 128 threads on a 128-way box were SLOWER than one (oversubscribed reductions over a
+    # (128, 14 541) matrix); each leg is bounded, ~20 s of CPU work in all
+    all_threads = torch.get_num_threads()
+    legs = {}
+    for threads in sorted({1, 8, 32, all_threads}):
+        if threads > all_threads:
+            continue
+        torch.set_num_threads(threads)
+        done, el = run(budget_s / 2, 64 if threads > 1 else 6)
+        legs[threads] = (2.0 * B * cfg["N"] * done / el, done, el)
+    torch.set_num_threads(all_threads)
+    best = max(legs, key=lambda k: legs[k][0])
+    value, done, el = legs[best]
+    return {"value": value, "unit": "scored triples/s", "cores": best,
+            "kind": "port, vectorised filter (the reference's own networkx walk adds ~190 ms per batch: SURVEY.md 8a)",
+            "value_by_threads": {str(k): v[0] for k, v in legs.items()}, "value_1_thread": legs[1][0],
+            "cpu_model": cpu_model_name(), "logical_cpus": os.cpu_count(),
             "sample": f"{done} reference batches of {B} triples ({2 * B} queries) x {cfg['N']} candidates, raw + filtered, "
-                      f"{el:.1f} s of torch-CPU work on {threads} threads; {done1} batches in {el1:.1f} s on 1 thread"}
+                      f"{el:.1f} s of torch-CPU work on {best} threads (the best of {sorted(legs)} threads, each leg bounded)"}
 
 
 def torch_gpu_baseline(job, budget_s=3.0):
@@ -383,14 +433,29 @@ def parity_spot_check(job, triples, counts, n=32):
     return f"{2 * b} queries vs CPU oracle (raw + filtered): " + ("identical counts" if ok else "MISMATCH")
 
 
-def load_pmc(workload, key="hbm_bytes_per_launch"):
-    """A figure of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json):
-    HBM bytes per launch (FETCH_SIZE) or the matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES); else None."""
+def load_pmc(workload, live_pass_ms=None):
+    """The dominant kernel's figures from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py): HBM bytes per launch (FETCH_SIZE) and the matrix-pipe busy fraction
+    (SQ_VALU_MFMA_BUSY_CYCLES).  Returns (entry or None, provenance): the entry is dropped when there is no live
+    single-GPU pass time to hold it against or when the ranking pass of the profiled run (`bench_pass_ms`) differs
+    from the live one by more than 10 % -- the counters then describe another kernel than the one just timed."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(path)).get(workload, {}).get(key)
+        doc = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/pmc_traffic.json"
+    entry, stamp = doc.get(workload), doc.get("_profile", {})
+    where = f"profiles/{stamp.get('round', '?')}/{workload} (rocprofv3 --pmc, commit {stamp.get('commit', '?')})"
+    if not entry:
+        return None, f"no PMC pass recorded for {workload}"
+    if live_pass_ms is None:
+        return None, f"{where}: not applicable to this run (more than one GPU)"
+    recorded = entry.get("bench_pass_ms")
+    if recorded is None:
+        return None, f"{where}: no pass time recorded with the counters"
+    if abs(recorded - live_pass_ms) > 0.10 * live_pass_ms:
+        return None, f"{where}: stale -- profiled pass {recorded:.4g} ms, live pass {live_pass_ms:.4g} ms"
+    return entry, f"{where}; profiled pass {recorded:.4g} ms vs live {live_pass_ms:.4g} ms"
 
 
 def hbm_probe(device, events, reps=30):
@@ -419,10 +484,11 @@ def hbm_probe(device, events, reps=30):
         call_ms = min(call_ms, (time.perf_counter() - t0) / 10 * 1e3)
     alg_bytes = cfg["N"] * cfg["D"] * 4 + 4 * (2 * cfg["D"] * 4 + 24)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    pmc, why = load_pmc("wikidata5m-transe", live_pass_ms=ms)
     return {"workload": "wikidata5m-transe, 4 queries per table pass (bare blp_rank_all call)", "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "kernel_ms": ms,
             "whole_call_ms": call_ms, "scored_triples_per_s": 4.0 * cfg["N"] / (call_ms * 1e-3),
-            "traffic": load_pmc("wikidata5m-transe")}
+            "traffic": (pmc or {}).get("hbm_bytes_per_launch"), "pmc_source": why}
 
 
 def main():
@@ -497,20 +563,24 @@ def main():
             result["torch_gpu_baseline"] = torch_gpu_baseline(job)
     del triples, counts
     if world > 1 and not args.no_sub_results and args.workload == "fb15k237-transe":
-        # the north-star axis next to the default workload's query axis: the Wikidata5M-scale table sharded along the
-        # CANDIDATE axis, the test set as one block (every rank takes part: the step has one all-gather of rank counts)
+        # The north_star's axis next to the headline's: the CANDIDATE axis on the FB15k-237 table, on the Wikidata5M-scale
+        # table as the reference batches it (2 triples per table pass) and on the same table with the test set as one
+        # block.  Every rank takes part: each step has its exchanges (replicated query vectors, one all-gather of counts).
         del job
         torch.cuda.empty_cache()
-        name = "wikidata5m-transe-block"
-        sub = Job(name, device, world, rank, "auto", backend)
-        k_sub = max(2, min(args.steps, 5))
-        f, t, c = sub.measure(k_sub, 1, events)
+        subs = {}
+        for name, axis in SUB_RESULTS_SHARDED:
+            sub = Job(name, device, world, rank, axis, backend)
+            k_sub = max(2, min(args.steps, 5))
+            f, t, c = sub.measure(k_sub, 1, events)
+            if rank == 0:
+                f["steps"], f["unit"] = k_sub, "scored triples/s"
+                f["parity_check"] = parity_spot_check(sub, t, c)
+                subs[f"{name}@{axis}" if name == args.workload else name] = f
+            del sub, t, c
+            torch.cuda.empty_cache()
         if rank == 0:
-            f["steps"], f["unit"], f["shard_axis"] = k_sub, "scored triples/s", sub.axis
-            f["parity_check"] = parity_spot_check(sub, t, c)
-            result["sub_results"] = {name: f}
-        del sub, t, c
-        torch.cuda.empty_cache()
+            result["sub_results"] = subs
     if world == 1:
         subs = {}
         if not args.no_sub_results and args.workload == "fb15k237-transe":
@@ -528,7 +598,11 @@ def main():
                 f["steps"], f["timed_runs"] = k_sub, 2
                 f["unit"] = "scored triples/s"
                 f["parity_check"] = parity_spot_check(sub, t, c)
-                f.pop("kernel_ms_per_rank")
+                for key in ("kernel_ms_per_rank", "exchange_ms", "exchange_ms_per_rank", "shard_axis", "ranks"):
+                    f.pop(key)
+                if sub.cfg["block"] < sub.T:  # reference batching: a step is several table passes
+                    passes = -(-sub.T // sub.cfg["block"])
+                    f["table_passes_per_step"], f["ms_per_table_pass"] = passes, f["ms_per_step"] / passes
                 subs[name] = f
                 del sub, t, c
                 torch.cuda.empty_cache()

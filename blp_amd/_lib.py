@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblp_hip.so")
+HOOKS_LIB_PATH = os.path.join(_HERE, "libblp_hip.hooks.so")  # the -DBLP_TEST_HOOKS build (tests / tools only)
 
 MODEL_IDS = {"transe": 0, "distmult": 1, "complex": 2, "simple": 3}
 LOSS_IDS = {"margin": 0, "nll": 1}
@@ -21,10 +22,11 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 # every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
            "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex", "blp_rank_all_idx",
+           "blp_rank_all_shard", "blp_gather_triple_vectors",
            "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
-           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_build_queries", "blp_debug_set_knob",
-           "blp_debug_gemm_dump")
+           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_build_queries")
+HOOK_SYMBOLS = ("blp_debug_set_knob", "blp_debug_gemm_dump")  # libblp_hip.hooks.so only
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
          "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
          "small_kernel", "stream_kernel")  # blp_amd/csrc/knobs.h
@@ -60,31 +62,49 @@ class BlpQueries(ctypes.Structure):  # blp_queries of include/blp_hip.h
                 ("q_fixed", ctypes.c_void_p), ("q_rel", ctypes.c_void_p), ("true_row", ctypes.c_void_p),
                 ("rel_ids", ctypes.c_void_p), ("ids_min", ctypes.c_void_p),
                 ("seg_lo", ctypes.c_void_p), ("seg_hi", ctypes.c_void_p), ("exclude", ctypes.c_void_p),
-                ("fixed_row", ctypes.c_void_p)]
+                ("fixed_row", ctypes.c_void_p), ("by_position", ctypes.c_int64)]
 
 
-_lib = None
+_lib = None       # the library calls go to: the product, or the hooks build while a test holds a knob
+_product = None
+_hooks = None
 _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
 
 def lib():
-    """Load libblp_hip.so once.  Raises HipLibraryError (never falls back) if it is not built."""
-    global _lib
+    """The library every call goes to: libblp_hip.so, loaded once.  Raises HipLibraryError (never falls back) if it is
+    not built.  (While a test holds a knob -- set_knob -- calls go to the hooks build instead.)"""
+    global _lib, _product
     if _lib is not None:
         return _lib
+    if _product is None:
+        _product = _load(LIB_PATH, hooks=False)
+    _lib = _product
+    return _lib
+
+
+def hooks_lib():
+    """libblp_hip.hooks.so (tests / tools): the same kernels with blp_debug_set_knob / blp_debug_gemm_dump."""
+    global _hooks
+    if _hooks is None:
+        _hooks = _load(HOOKS_LIB_PATH, hooks=True)
+    return _hooks
+
+
+def _load(path, hooks):
     # torch first: its bundled libamdhip64 (SONAME libamdhip64.so.7) must already be mapped so that the
     # dynamic loader binds libblp_hip.so to the SAME HIP runtime instance torch's streams and
     # allocations belong to (two runtimes in one process cannot share hipStream_t handles).
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise HipLibraryError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m blp_amd.build` "
+            f"{path} not found: the HIP extension is not built. Run `python -m blp_amd.build` "
             "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback for "
             "CUDA/HIP tensors.")
     try:
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
     except OSError as exc:
-        raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+        raise HipLibraryError(f"cannot load {path}: {exc}") from exc
     L.blp_version.restype = _i
     L.blp_version.argtypes = []
     L.blp_last_error.restype = ctypes.c_char_p
@@ -106,6 +126,11 @@ def lib():
     L.blp_rank_all_idx.restype = _i
     L.blp_rank_all_idx.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, ctypes.POINTER(BlpFilter),
                                    _vp, _vp, _sz, _i, _vp]
+    L.blp_rank_all_shard.restype = _i
+    L.blp_rank_all_shard.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
+                                     ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
+    L.blp_gather_triple_vectors.restype = _i
+    L.blp_gather_triple_vectors.argtypes = [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _i, _vp]
     L.blp_profile_next_rank_kernel.restype = _i
     L.blp_profile_next_rank_kernel.argtypes = [_vp, _vp]
     L.blp_rank_from_scores.restype = _i
@@ -136,28 +161,58 @@ def lib():
     L.blp_project_rows_supported.argtypes = [_i, _i]
     L.blp_project_rows.restype = _i
     L.blp_project_rows.argtypes = [_vp, _i64, _i64, _vp, _i, _i, _i, _vp, _i64, _i, _vp]
-    L.blp_debug_gemm_dump.restype = _i
-    L.blp_debug_gemm_dump.argtypes = [_vp, _vp]
-    L.blp_debug_set_knob.restype = _i
-    L.blp_debug_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
-    _lib = L
+    if hooks:
+        L.blp_debug_gemm_dump.restype = _i
+        L.blp_debug_gemm_dump.argtypes = [_vp, _vp]
+        L.blp_debug_set_knob.restype = _i
+        L.blp_debug_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     return L
 
 
+_knobs_set = {}
+
+
 def set_knob(name, value):
-    """Test / A-B hook (include/blp_hip.h: blp_debug_set_knob); 0 restores the automatic choice."""
-    check(lib().blp_debug_set_knob(name.encode(), int(value)), "blp_debug_set_knob")
+    """Test / A-B hook (include/blp_hip.h: blp_debug_set_knob, hooks build only); 0 restores the automatic choice.
+    While any knob is non-zero every call of this process goes to libblp_hip.hooks.so; with all knobs back at 0 the
+    product library serves again -- so a test without knobs always exercises the shipped dispatch."""
+    global _lib
+    H = hooks_lib()
+    check(H.blp_debug_set_knob(name.encode(), int(value)), "blp_debug_set_knob", H)
+    if int(value):
+        _knobs_set[name] = int(value)
+    else:
+        _knobs_set.pop(name, None)
+    _lib = H if _knobs_set else None
 
 
 def reset_knobs():
-    for name in KNOBS:
-        set_knob(name, 0)
+    global _lib
+    if _hooks is not None:
+        for name in KNOBS:
+            check(_hooks.blp_debug_set_knob(name.encode(), 0), "blp_debug_set_knob", _hooks)
+    _knobs_set.clear()
+    _lib = None
 
 
-def check(status, what):
+class use_hooks_library:
+    """Context manager: route the calls inside it to the hooks build (for blp_debug_gemm_dump, which needs no knob)."""
+    def __enter__(self):
+        global _lib
+        self._prev = _lib
+        _lib = hooks_lib()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev if _knobs_set else None
+        return False
+
+
+def check(status, what, library=None):
     """Map a non-zero C status to RuntimeError(blp_last_error()) (SURVEY 8b error convention)."""
     if status != BLP_OK:
-        msg = lib().blp_last_error().decode(errors="replace")
+        msg = (library or lib()).blp_last_error().decode(errors="replace")
         raise RuntimeError(f"{what} failed with {STATUS_NAMES.get(status, status)}: {msg}")
 
 

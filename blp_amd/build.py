@@ -1,6 +1,10 @@
 """Build libblp_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build(); also runnable
 as ``python -m blp_amd.build``.  hipcc cross-compiles without a GPU.  The .so stays next to this
-file (git-ignored, but it travels with the tree to the GPU box)."""
+file (git-ignored, but it travels with the tree to the GPU box).
+
+Two libraries come out of the same sources: libblp_hip.so, the product (no test hooks, no mutable process-wide state),
+and libblp_hip.hooks.so (-DBLP_TEST_HOOKS: the same kernels + blp_debug_set_knob / blp_debug_gemm_dump), which only
+tests/ and tools/ load (blp_amd._lib.set_knob)."""
 import os
 import shutil
 import subprocess
@@ -11,6 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libblp_hip.so")
+HOOKS_VARIANT, HOOKS_FLAGS = "hooks", ("-DBLP_TEST_HOOKS",)
+HOOKS_LIB = os.path.join(HERE, f"libblp_hip.{HOOKS_VARIANT}.so")
 SOURCES = ["rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_gemm.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_dense.hip", "score.hip", "inbatch_loss.hip", "project.hip", "queries.hip", "api.cpp"]
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "blp_hip.h")
 # -ffp-contract=off: the kernels restate the reference's per-operation rounding; an FMA would change
@@ -42,6 +48,11 @@ def build(force=False, verbose=False, variant=None, variant_flags=()):
     return _build(force, verbose, global_obj, global_lib, list(variant_flags))
 
 
+def build_hooks(force=False, verbose=False):
+    """The test build: libblp_hip.hooks.so with the knobs and the dump hook compiled in."""
+    return build(force, verbose, variant=HOOKS_VARIANT, variant_flags=HOOKS_FLAGS)
+
+
 def _build(force, verbose, OBJ, LIB, variant_flags):
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
@@ -61,7 +72,7 @@ def _build(force, verbose, OBJ, LIB, variant_flags):
         subprocess.check_call(cmd)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=4) as pool:
+        with ThreadPoolExecutor(max_workers=max(4, min(8, os.cpu_count() or 4))) as pool:
             list(pool.map(run, jobs))
     objs = [os.path.join(OBJ, s + ".o") for s in SOURCES]
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
@@ -72,3 +83,4 @@ def _build(force, verbose, OBJ, LIB, variant_flags):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_hooks(force="--force" in sys.argv, verbose=True))

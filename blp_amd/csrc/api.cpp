@@ -83,20 +83,25 @@ int check_score_dim(int model, int D) {
     return BLP_OK;
 }
 
+#ifdef BLP_TEST_HOOKS
 std::atomic<long long> g_knobs[blp::KNOB_COUNT];  // zero-initialised: every knob automatic
 const char* const kKnobNames[blp::KNOB_COUNT] = {"rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups",
                                                  "sad_min_queries", "gemm_pass_words", "gemm_tiles_per_chunk",
                                                  "exact_query_chunk", "small_kernel",
                                                  "stream_kernel"};
+#endif
 
 }  // namespace
 
+#ifdef BLP_TEST_HOOKS
 namespace blp {
 long long knob(int which) { return g_knobs[which].load(std::memory_order_relaxed); }
 }  // namespace blp
+#endif
 
 extern "C" {
 
+#ifdef BLP_TEST_HOOKS
 int blp_debug_set_knob(const char* name, long long value) {
     if (!name) return fail(BLP_ERR_BAD_ARG, "blp_debug_set_knob: NULL name");
     for (int i = 0; i < blp::KNOB_COUNT; ++i)
@@ -112,6 +117,7 @@ int blp_debug_gemm_dump(float* scores, float* eps) {
     blp::gemm_set_dump(scores, eps);
     return BLP_OK;
 }
+#endif
 
 int blp_build_queries(const blp_queries* q, int device, void* stream) {
     if (!q) return fail(BLP_ERR_BAD_ARG, "blp_build_queries: NULL argument block");
@@ -132,9 +138,26 @@ int blp_build_queries(const blp_queries* q, int device, void* stream) {
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
     blp::QueryBuild a{q->triples, q->n, q->block, q->ent2idx, q->ent2idx_len, q->source, q->src_rows, q->ld, q->D,
                       q->rel_emb, q->R, q->heads_key, q->n_heads, q->tails_key, q->n_tails, q->index_R, q->q_fixed, q->q_rel,
-                      q->true_row, q->rel_ids, q->ids_min, with_index ? q->seg_lo : nullptr, q->seg_hi, q->exclude, q->fixed_row};
+                      q->true_row, q->rel_ids, q->ids_min, with_index ? q->seg_lo : nullptr, q->seg_hi, q->exclude, q->fixed_row,
+                      q->by_position};
     hipError_t err = blp::launch_build_queries(a, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_build_queries launch");
+    return BLP_OK;
+}
+
+int blp_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len, const float* table,
+                              int64_t N, int D, int64_t ld, int64_t row_base, float* out, int device, void* stream) {
+    if (n < 0 || N < 0 || D <= 0 || (D & 3) || (ld & 3) || ld < D || n > (1ll << 40) || (ent2idx && ent2idx_len < 0))
+        return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: bad sizes (n=%lld N=%lld D=%d ld=%lld)", (long long)n, (long long)N, D, (long long)ld);
+    if (n == 0) return BLP_OK;
+    if (!triples || !out || (N > 0 && !table)) return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: NULL pointer");
+    if (!aligned16(table) || !aligned16(out))
+        return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: table / out must be 16-byte aligned");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_gather_triple_vectors(triples, n, ent2idx, ent2idx_len, table, N, D, ld, row_base, out,
+                                                       static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_gather_triple_vectors launch");
     return BLP_OK;
 }
 
@@ -195,7 +218,7 @@ size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head,
 
 // Shared by blp_rank_all / _ex (dense query vectors) and blp_rank_all_idx (queries as rows of the table / of rel_emb)
 static int rank_all_checked(int model, const float* table, int64_t N, int D, int64_t ld, const blp::QRows& q_fixed,
-                            const blp::QRows& q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+                            const blp::QRows& q_rel, const int64_t* q_rel_id, const blp::QRows& q_true,
                             int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
                             size_t workspace_bytes, int device, void* stream) {
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
@@ -214,8 +237,7 @@ static int rank_all_checked(int model, const float* table, int64_t N, int D, int
                                      "shard the candidate axis");
     if (!q_fixed.base || !q_rel.base || !counts) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL q_fixed / q_rel / counts");
     if (N > 0 && !table) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: NULL table");
-    if ((true_row == nullptr) == (q_true == nullptr))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: exactly one of true_row / q_true must be given");
+    if (!q_true.base) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: exactly one of true_row / q_true must be given");
     blp::FilterSpec spec;
     if (filter) {
         if (!filter->seg_lo || !filter->seg_hi || !filter->values)
@@ -226,8 +248,8 @@ static int rank_all_checked(int model, const float* table, int64_t N, int D, int
         spec.ent2idx = filter->ent2idx; spec.ent2idx_len = filter->ent2idx ? filter->ent2idx_len : 0;
         spec.row_base = filter->row_base;
     }
-    if (!aligned16(table) || (ld & 3) || !aligned16(q_true) || !aligned16(counts) || !aligned16(q_fixed.base) ||
-        !aligned16(q_rel.base) || (q_fixed.ld & 3) || (q_rel.ld & 3) || (D & 3))
+    if (!aligned16(table) || (ld & 3) || !aligned16(q_true.base) || (q_true.ld & 3) || !aligned16(counts) ||
+        !aligned16(q_fixed.base) || !aligned16(q_rel.base) || (q_fixed.ld & 3) || (q_rel.ld & 3) || (D & 3))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: table / q_fixed / q_rel / q_true / counts must be 16-byte aligned, "
                                      "ld %% 4 == 0 and D %% 4 == 0");
     const size_t need = blp::rank_all_workspace_bytes(model, D, N, q_head, q_tail);
@@ -240,7 +262,7 @@ static int rank_all_checked(int model, const float* table, int64_t N, int D, int
     if (int rc = compute_units(device, &cu)) return rc;
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
-    hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail,
+    hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail,
                                           spec, counts, workspace, cu, static_cast<hipStream_t>(stream), ev0, ev1);
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all launch");
     return BLP_OK;
@@ -252,20 +274,34 @@ int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld,
                     const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
                     int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
                     size_t workspace_bytes, int device, void* stream) {
-    return rank_all_checked(model, table, N, D, ld, blp::QRows::dense(q_fixed, D), blp::QRows::dense(q_rel, D), q_rel_id,
-                            true_row, q_true, q_head, q_tail, filter, counts, workspace, workspace_bytes, device, stream);
+    blp::QRows truth;  // stays empty (-> BAD_ARG below, after the model / size checks) unless exactly one form is given
+    if ((true_row == nullptr) != (q_true == nullptr))
+        truth = true_row ? blp::QRows::rows_of(table, true_row, ld) : blp::QRows::dense(q_true, D);
+    return rank_all_checked(model, table, N, D, ld, blp::QRows::dense(q_fixed, D), blp::QRows::dense(q_rel, D), q_rel_id, truth,
+                            q_head, q_tail, filter, counts, workspace, workspace_bytes, device, stream);
+}
+
+int blp_rank_all_shard(int model, const float* table, int64_t N, int D, int64_t ld, const float* source, int64_t S,
+                       int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, int64_t R, const int64_t* rel_id,
+                       const int64_t* true_row, int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts,
+                       void* workspace, size_t workspace_bytes, int device, void* stream) {
+    if (q_head + q_tail > 0 && (!source || !fixed_row || !rel_id || !rel_emb || !true_row || R <= 0 || S <= 0))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_shard: NULL source / fixed_row / rel_id / rel_emb / true_row, or R <= 0 / S <= 0");
+    if (ld_src < D || (ld_src & 3) || !aligned16(source))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_shard: source must be 16-byte aligned with ld_src %% 4 == 0, ld_src >= D");
+    return rank_all_checked(model, table, N, D, ld, blp::QRows::rows_of(source, fixed_row, ld_src),
+                            blp::QRows::rows_of(rel_emb, rel_id, D), /*q_rel_id: equal ids are equal rows by construction*/ rel_id,
+                            blp::QRows::rows_of(source, true_row, ld_src), q_head, q_tail, filter, counts, workspace,
+                            workspace_bytes, device, stream);
 }
 
 int blp_rank_all_idx(int model, const float* table, int64_t N, int D, int64_t ld, const int64_t* fixed_row,
                      const float* rel_emb, int64_t R, const int64_t* rel_id, const int64_t* true_row, int64_t q_head,
                      int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace, size_t workspace_bytes,
                      int device, void* stream) {
-    if (q_head + q_tail > 0 && (!fixed_row || !rel_id || !rel_emb || !true_row || R <= 0))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_idx: NULL fixed_row / rel_id / rel_emb / true_row or R <= 0");
-    return rank_all_checked(model, table, N, D, ld, blp::QRows::rows_of(table, fixed_row, ld),
-                            blp::QRows::rows_of(rel_emb, rel_id, D), /*q_rel_id (a hint for sorted blocks)*/ nullptr, true_row, nullptr, q_head,
-                            q_tail, filter,
-                            counts, workspace, workspace_bytes, device, stream);
+    // the unsharded case: the queries' vectors are rows of the candidate table itself
+    return blp_rank_all_shard(model, table, N, D, ld, table, N, ld, fixed_row, rel_emb, R, rel_id, true_row, q_head, q_tail, filter,
+                              counts, workspace, workspace_bytes, device, stream);
 }
 
 int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,

@@ -1,7 +1,8 @@
-// knobs.h -- test / A-B hooks of libblp_hip.so (blp_debug_set_knob in include/blp_hip.h).  Process-wide
-// relaxed atomics, 0 = automatic.  Nothing in the product path sets them; there is no getenv() anywhere
-// in the library, so blp_rank_all_workspace_bytes and blp_rank_all always see the same values unless a
-// test changes a knob between the two calls.
+// knobs.h -- test / A-B hooks (blp_debug_set_knob in include/blp_hip.h).  They exist ONLY in the test build of the library
+// (-DBLP_TEST_HOOKS -> libblp_hip.hooks.so, loaded by tests/ and tools/): process-wide relaxed atomics, 0 = automatic.  In
+// the production library knob() is the constant 0 -- every `if (knob(...))` folds away, nothing is exported, the library
+// has no mutable process-wide state and there is no getenv() anywhere, so blp_rank_all_workspace_bytes and blp_rank_all
+// cannot disagree.
 #pragma once
 
 namespace blp {
@@ -20,6 +21,10 @@ enum Knob : int {
     KNOB_COUNT
 };
 
+#ifdef BLP_TEST_HOOKS
 long long knob(int which);  // api.cpp
+#else
+constexpr long long knob(int) { return 0; }
+#endif
 
 }  // namespace blp

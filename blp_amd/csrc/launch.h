@@ -52,7 +52,7 @@ size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
                            const QRows q_fixed, const QRows q_rel, const int64_t* q_rel_id,
-                           const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
+                           const QRows q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
                            hipEvent_t ev_stop = nullptr);
@@ -76,8 +76,12 @@ struct QueryBuild {
     float* q_fixed; float* q_rel; int64_t* true_row; int64_t* rel_ids; int* ids_min;
     int64_t* seg_lo; int64_t* seg_hi; int64_t* exclude;
     int64_t* fixed_row;
+    int64_t by_position;  // source = [head vectors of the n triples | tail vectors] (launch_gather_triple_vectors)
 };
 hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream);
+hipError_t launch_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len,
+                                        const float* table, int64_t N, int D, int64_t ld, int64_t row_base, float* out,
+                                        hipStream_t stream);
 
 bool project_rows_supported(int E, int D);
 hipError_t launch_project_rows(const float* x, int64_t n, int64_t ldx, const float* w, int E, int D, int normalize,

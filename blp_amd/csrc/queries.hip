@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a, unsign
         return (uint64_t)r < (uint64_t)a.src_rows ? r : -1;
     };
     const int64_t h_row = row_of(h_id), t_row = row_of(t_id);
-    const int64_t fixed_row = head_side ? t_row : h_row, true_row = head_side ? h_row : t_row;
+    int64_t fixed_row = head_side ? t_row : h_row, true_row = head_side ? h_row : t_row;
+    if (a.by_position) {  // `source` = [head vectors of the n triples | tail vectors]: positions instead of table rows
+        fixed_row = fixed_row < 0 ? -1 : (head_side ? a.n + t : t);
+        true_row = true_row < 0 ? -1 : (head_side ? t : a.n + t);
+    }
     const bool rel_ok = (uint64_t)r_id < (uint64_t)a.R;
     if (sub == 0) {  // (a bad id: row / relation 0, so that nothing downstream reads out of bounds; ids_min tells)
         a.true_row[p] = true_row >= 0 ? true_row : 0;
@@ -99,6 +103,41 @@ __global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a, unsign
         *reinterpret_cast<float4*>(fdst + c) = f;
         *reinterpret_cast<float4*>(rdst + c) = r;
     }
+}
+
+// blp_gather_triple_vectors: out[t] = the head's vector of triple t, out[n + t] = its tail's, for the rows this shard owns
+// (global row - row_base in [0, N)); zeros otherwise, so that one all-reduce over the ranks replicates every vector.
+// 32 lanes per vector, 16 bytes per lane and sweep.
+__global__ __launch_bounds__(256) void gather_triple_vectors_kernel(const int64_t* __restrict__ triples, int64_t n,
+                                                                    const int64_t* __restrict__ ent2idx, int64_t ent2idx_len,
+                                                                    const float* __restrict__ table, int64_t N, int D, int64_t ld,
+                                                                    int64_t row_base, float* __restrict__ out) {
+    const int sub = threadIdx.x & 31;
+    const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (p >= 2 * n) return;
+    const int64_t id = p < n ? triples[3 * p] : triples[3 * (p - n) + 1];
+    int64_t row = id;
+    if (ent2idx) row = (uint64_t)id < (uint64_t)ent2idx_len ? ent2idx[id] : -1;
+    row = row < 0 ? -1 : row - row_base;
+    const bool mine = (uint64_t)row < (uint64_t)N;
+    const float* src = table + (mine ? row : 0) * ld;
+    float* dst = out + p * D;
+    for (int c = 4 * sub; c < D; c += 128) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mine) v = *reinterpret_cast<const float4*>(src + c);
+        *reinterpret_cast<float4*>(dst + c) = v;
+    }
+}
+
+hipError_t launch_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len,
+                                        const float* table, int64_t N, int D, int64_t ld, int64_t row_base, float* out,
+                                        hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int64_t blocks = (2 * n + 7) / 8;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    gather_triple_vectors_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(triples, n, ent2idx, ent2idx_len, table, N, D, ld,
+                                                                             row_base, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream) {

@@ -78,7 +78,7 @@ __global__ void prep_coef_kernel(const QRows q_fixed, const QRows q_rel,
 __host__ __device__ constexpr int true_key_queries_per_block(int model) { return model == TRANSE ? 64 : 4; }
 template <int MODEL, int D>
 __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ table, int64_t ld,
-                                const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
+                                const QRows q_true,
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
     const int64_t Q = q_head + q_tail, q0 = blockIdx.x * (int64_t)QB;
     const int lane = threadIdx.x;
     if (lane < QB && q0 + lane < Q) acc[q0 + lane] = 0;
-    auto true_vec = [&](int64_t q) { return true_row ? table + true_row[q] * ld : q_true + q * D; };
+    auto true_vec = [&](int64_t q) { return q_true.row(q); };
     if constexpr (MODEL == TRANSE) {
         __shared__ __attribute__((aligned(16))) float slab[64 * kRefStride];
         const int64_t q = q0 + lane < Q ? q0 + lane : Q - 1;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
 // launch of the chain is 4-5 us on top).
 template <int MODEL, int D>
 __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restrict__ table, int64_t ld,
-                                const int64_t* __restrict__ true_row, const float* __restrict__ q_true,
+                                const QRows q_true,
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc, unsigned key_blocks,
@@ -142,13 +142,13 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restri
     }
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (q >= q_head + q_tail) return;
-    true_key_lane<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q, q_head, key_true, acc);
+    true_key_lane<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q, q_head, key_true, acc);
 }
 
 
 // True keys (and zeroed accumulators); with coef_head / coef_tail also the coefficient rows of the exact path.
 template <int MODEL, int D>
-static void launch_true_key(const float* table, int64_t ld, const int64_t* true_row, const float* q_true, const QRows& q_fixed,
+static void launch_true_key(const float* table, int64_t ld, const QRows q_true, const QRows& q_fixed,
                             const QRows& q_rel, int64_t q_head, int64_t q_tail, float* key_true, unsigned long long* acc,
                             hipStream_t stream, float* coef_head = nullptr, float* coef_tail = nullptr, int64_t zero_slots = 0) {
     const int64_t Q = q_head + q_tail;
@@ -157,7 +157,7 @@ static void launch_true_key(const float* table, int64_t ld, const int64_t* true_
         const int64_t key_blocks = (Q + 63) / 64, work = n_coef > zero_slots * Q ? n_coef : zero_slots * Q, want = (work + 63) / 64,
                       coef_blocks = want < 4096 ? want : 4096;
         true_key_lane_kernel<MODEL, D><<<(unsigned)(key_blocks + coef_blocks), 64, 0, stream>>>(
-            table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail,
+            table, ld, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail,
             zero_slots);
     } else {
         if (zero_slots > 1) (void)hipMemsetAsync(acc + Q, 0, (size_t)(zero_slots - 1) * Q * 8, stream);
@@ -167,7 +167,7 @@ static void launch_true_key(const float* table, int64_t ld, const int64_t* true_
                                                                                                  coef_head, coef_tail);
         }
         constexpr int QB = true_key_queries_per_block(MODEL);
-        true_key_kernel<MODEL, D><<<(unsigned)((Q + QB - 1) / QB), 64, 0, stream>>>(table, ld, true_row, q_true, q_fixed, q_rel,
+        true_key_kernel<MODEL, D><<<(unsigned)((Q + QB - 1) / QB), 64, 0, stream>>>(table, ld, q_true, q_fixed, q_rel,
                                                                                      q_head, q_tail, key_true, acc);
     }
 }
@@ -671,7 +671,7 @@ size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
 
 template <int MODEL, int D>
 static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                                const QRows q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+                                const QRows q_rel, const int64_t* q_rel_id, const QRows q_true,
                                 int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
@@ -682,7 +682,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         const bool coef = rank_small_wants_coef(MODEL, D, N);
         // (tiles sharing slots -- more tiles than slots, the scalar-register kernel only -- add to zeroed counts)
         const bool shared_slots = coef && (N + kTileRows - 1) / kTileRows > slots;
-        launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream,
+        launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream,
                                   coef ? w.coef_head : nullptr, coef ? w.coef_tail : nullptr, shared_slots ? slots : 0);
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.coef_head, w.coef_tail, w.key_true, q_head,
@@ -693,7 +693,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                                       stream, slots);
     }
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
-    launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
+    launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
                               w.coef_tail);
 
     if (N > 0) {
@@ -751,12 +751,12 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
 
 template <int MODEL>
 static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                               const QRows q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
+                               const QRows q_rel, const int64_t* q_rel_id, const QRows q_true,
                                int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace, int n_cu,
                                hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define BLP_RANK_CASE(DD)                                                                              \
     case DD:                                                                                           \
-        return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, \
+        return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, \
                                         filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (D) {
         BLP_RANK_CASE(64)
@@ -770,26 +770,26 @@ static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld,
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
                            const QRows q_fixed, const QRows q_rel, const int64_t* q_rel_id,
-                           const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
+                           const QRows q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                            hipEvent_t ev_stop) {
     const bool small = rank_small_applicable(model, D, N, q_head, q_tail);  // a small block: rank_small.hip, below
     if (!small && rank_gemm_applicable(model, D, q_head, q_tail))
-        return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail,
+        return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail,
                                     filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     if (!small && rank_sad_wide_applicable(model, D, q_head, q_tail))
-        return launch_rank_all_sad_wide(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
+        return launch_rank_all_sad_wide(D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter,
                                         counts, workspace, n_cu, stream, ev_start, ev_stop);
     if (!small && rank_sad_applicable(model, D, N, q_head, q_tail))
-        return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,
+        return launch_rank_all_sad(D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter,
                                    counts, workspace, n_cu, stream, ev_start, ev_stop);
     // everything else: the exact f32 kernels (few queries, D = 256 bilinear, or the rank_kernel knob)
     switch (model) {
-    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     default:       return hipErrorInvalidValue;
     }
 }
@@ -799,9 +799,9 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 // accumulators) and the filter / finalize step.  They read the query vectors directly: no coefficient array.
 template <int MODEL, int D>
 static hipError_t true_keys_impl(const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
-                                 const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
+                                 const float* table, int64_t ld, const QRows q_true,
                                  float* key_true, unsigned long long* acc, hipStream_t stream) {
-    launch_true_key<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, stream);
+    launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, stream);
     return hipGetLastError();
 }
 
@@ -833,9 +833,9 @@ static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld
     }
 
 hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
-                            const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
+                            const float* table, int64_t ld, const QRows q_true,
                             float* key_true, unsigned long long* acc, hipStream_t stream) {
-    BLP_DISPATCH_MODEL_DIM(true_keys_impl, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, key_true, acc, stream)
+    BLP_DISPATCH_MODEL_DIM(true_keys_impl, q_fixed, q_rel, q_head, q_tail, table, ld, q_true, key_true, acc, stream)
 }
 
 hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,

@@ -84,7 +84,7 @@ constexpr int64_t kTrueKeyLaneMaxQueries = 2048;  // up to here true keys are on
 
 // rank_all.hip: true-entity keys by the exact routine (and the Q rank-count accumulators `acc` zeroed on the way)
 hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
-                            const float* table, int64_t ld, const int64_t* true_row, const float* q_true,
+                            const float* table, int64_t ld, const QRows q_true,
                             float* key_true, unsigned long long* acc, hipStream_t stream);
 
 // rank_small.hip: the exact f32 kernel for small blocks (coefficients computed in the kernel, LDS broadcasts, TransE
@@ -115,8 +115,7 @@ void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,
-                                const QRows q_fixed, const QRows q_rel, const int64_t* true_row,
-                                const float* q_true, int64_t q_head, int64_t q_tail,
+                                const QRows q_fixed, const QRows q_rel, const QRows q_true, int64_t q_head, int64_t q_tail,
                                 const FilterSpec& filter, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop);
@@ -126,7 +125,7 @@ hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N,
 bool rank_sad_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                               const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                               const QRows q_rel, const QRows q_true, int64_t q_head,
                                int64_t q_tail, const FilterSpec& filter, int32_t* counts,
                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                hipEvent_t ev_stop);
@@ -136,7 +135,7 @@ hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld,
 bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                                    const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                                    const QRows q_rel, const QRows q_true, int64_t q_head,
                                     int64_t q_tail, const FilterSpec& filter,
                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
                                     hipEvent_t ev_start, hipEvent_t ev_stop);

@@ -465,8 +465,7 @@ __global__ __launch_bounds__(256) void gemm_prelude_bf16_kernel(
     const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail, uint4* __restrict__ img_head,
     uint4* __restrict__ img_tail, float* __restrict__ eps_q, unsigned q_blocks, const float* __restrict__ table, int64_t N,
     int64_t ld, int64_t cand_tiles, uint4* __restrict__ cimg, float* __restrict__ cnmax, unsigned* __restrict__ n_pairs,
-    unsigned* __restrict__ flags, int words, int true_keys, const int64_t* __restrict__ true_row,
-    const float* __restrict__ q_true, float* __restrict__ key_true, unsigned long long* __restrict__ acc) {
+    unsigned* __restrict__ flags, int words, int true_keys, const QRows q_true, float* __restrict__ key_true, unsigned long long* __restrict__ acc) {
     __shared__ float w_s[kGQT][D + 1];
     __shared__ float nrm[4][32];
     if (blockIdx.x >= q_blocks) {
@@ -482,7 +481,7 @@ __global__ __launch_bounds__(256) void gemm_prelude_bf16_kernel(
     const int64_t q1 = head ? (q0 + kGQT < q_head ? q0 + kGQT : q_head) : (q0 + kGQT < q_head + q_tail ? q0 + kGQT : q_head + q_tail);
     for (int64_t i = q0 * words + threadIdx.x; i < q1 * words; i += 256) flags[i] = 0;
     if (true_keys && threadIdx.x >= 192 && q0 + (threadIdx.x - 192) < q1)  // (the last wave: kGQT = 32 of its lanes)
-        true_key_lane<MODEL, D>(table, ld, true_row, q_true, q_fixed, q_rel, q0 + (threadIdx.x - 192), q_head, key_true, acc);
+        true_key_lane<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q0 + (threadIdx.x - 192), q_head, key_true, acc);
     prep_query_tile_bf16<MODEL, D>(blockIdx.x, q_fixed, q_rel, q_head, q_tail, img_head, img_tail, eps_q, w_s);
 }
 
@@ -1092,13 +1091,15 @@ size_t rank_gemm_workspace_bytes(int model, int D, int64_t N, int64_t q_head, in
 }
 
 // blp_debug_gemm_dump: the next bilinear pre-pass of this thread stores S~ and eps instead of deciding (tests)
+#ifdef BLP_TEST_HOOKS
 static thread_local float* g_dump_s = nullptr;
 static thread_local float* g_dump_eps = nullptr;
 void gemm_set_dump(float* s, float* eps) { g_dump_s = s; g_dump_eps = eps; }
+#endif
 
 template <int MODEL, int D>
 static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
-                                 const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
+                                 const QRows q_true, int64_t q_head, int64_t q_tail,
                                  const FilterSpec& filter, int32_t* counts, void* workspace,
                                  hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
@@ -1110,13 +1111,18 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     const bool keys_in_prelude = !f32_kernel && Q <= kTrueKeyLaneMaxQueries;
     hipError_t err = hipSuccess;
     if (!keys_in_prelude)
-        err = launch_true_keys(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.key_true, w.acc, stream);
+        err = launch_true_keys(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, q_true, w.key_true, w.acc, stream);
     if (err != hipSuccess) return err;
     const size_t lds_f32 = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
                            (size_t)kPairQuota * 8 + 16;
+#ifdef BLP_TEST_HOOKS
     float* dump_s = g_dump_s;
     float* dump_eps = g_dump_eps;
-    g_dump_s = g_dump_eps = nullptr;
+    g_dump_s = g_dump_eps = nullptr;  // one-shot: the pointers are not kept beyond this call
+#else
+    constexpr float* dump_s = nullptr;
+    constexpr float* dump_eps = nullptr;
+#endif
     if (dump_s && (f32_kernel || D != 128 || N > pass_tiles * kGCT)) return hipErrorInvalidValue;  // one slab of the bf16 kernel
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     auto slab_words = [&](int64_t slab0) {  // flag words per query of the slab that starts at row slab0
@@ -1136,7 +1142,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
         gemm_prelude_bf16_kernel<MODEL, D><<<dim3((unsigned)blocks), 256, 0, stream>>>(
             q_fixed, q_rel, q_head, q_tail, reinterpret_cast<uint4*>(w.img_head), reinterpret_cast<uint4*>(w.img_tail), w.eps_q,
             (unsigned)(th + tt), table, N, ld, tiles, w.cimg, w.cnmax, w.n_pairs, w.flags, slab_words(0), keys_in_prelude ? 1 : 0,
-            true_row, q_true, w.key_true, w.acc);
+            q_true, w.key_true, w.acc);
     }
     for (int64_t slab0 = 0; slab0 < N; slab0 += pass_tiles * kGCT) {  // one iteration unless the bitmap is capped
         const int64_t n_rows = N - slab0 < pass_tiles * kGCT ? N - slab0 : pass_tiles * kGCT;
@@ -1205,15 +1211,14 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
 }
 
 hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N, int64_t ld,
-                                const QRows q_fixed, const QRows q_rel, const int64_t* true_row,
-                                const float* q_true, int64_t q_head, int64_t q_tail,
+                                const QRows q_fixed, const QRows q_rel, const QRows q_true, int64_t q_head, int64_t q_tail,
                                 const FilterSpec& filter, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop) {
     (void)n_cu;
 #define BLP_GEMM_CASE(M, DD)                                                                                    \
     if (model == M && D == DD)                                                                                  \
-        return rank_gemm_impl<M, DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter, \
+        return rank_gemm_impl<M, DD>(table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter, \
                                      counts, workspace, stream, ev_start, ev_stop);
     BLP_GEMM_CASE(DISTMULT, 128) BLP_GEMM_CASE(DISTMULT, 64)
     BLP_GEMM_CASE(COMPLEX, 128) BLP_GEMM_CASE(COMPLEX, 64)

@@ -559,7 +559,7 @@ size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
 
 template <int D>
 static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
-                                const int64_t* true_row, const float* q_true, int64_t q_head, int64_t q_tail,
+                                const QRows q_true, int64_t q_head, int64_t q_tail,
                                 const FilterSpec& filter, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     constexpr int TPW = sad_tiles_per_wave(D);
@@ -567,7 +567,7 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     SadWorkspace w = carve_sad(workspace, D, N, q_head, q_tail);
     // (the true keys of a small call folded into the range launch, one lane per query: tried -- 2 us slower from 256
     //  queries on, where this path starts)
-    hipError_t err = launch_true_keys(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, true_row, q_true, w.key_true, w.acc,
+    hipError_t err = launch_true_keys(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, q_true, w.key_true, w.acc,
                                       stream);
     if (err != hipSuccess) return err;
     if (ev_start) (void)hipEventRecord(ev_start, stream);
@@ -625,13 +625,13 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
 }
 
 hipError_t launch_rank_all_sad(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                               const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                               const QRows q_rel, const QRows q_true, int64_t q_head,
                                int64_t q_tail, const FilterSpec& filter, int32_t* counts,
                                void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                hipEvent_t ev_stop) {
 #define BLP_SAD_CASE(DD)                                                                                          \
     if (D == DD)                                                                                                  \
-        return rank_sad_impl<DD>(table, N, ld, q_fixed, q_rel, true_row, q_true, q_head, q_tail, filter,          \
+        return rank_sad_impl<DD>(table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter,          \
                                  counts, workspace, n_cu, stream, ev_start, ev_stop);
     BLP_SAD_CASE(64) BLP_SAD_CASE(128) BLP_SAD_CASE(256)
 #undef BLP_SAD_CASE

@@ -77,13 +77,12 @@ __device__ __forceinline__ float transe_key_rt(const float* __restrict__ e, cons
 __global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restrict__ table, int64_t ld, int D,
                                                             const QRows q_fixed,
                                                             const QRows q_rel,
-                                                            const int64_t* __restrict__ true_row,
-                                                            const float* __restrict__ q_true, int64_t q_head, int64_t Q,
+                                                            const QRows q_true, int64_t q_head, int64_t Q,
                                                             float* __restrict__ key_true,
                                                             unsigned long long* __restrict__ acc) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
-    const float* e = true_row ? table + true_row[q] * ld : q_true + q * D;
+    const float* e = q_true.row(q);
     key_true[q] = transe_key_rt(e, q_fixed.row(q), q_rel.row(q), D, q < q_head);
     acc[q] = 0;
 }
@@ -95,15 +94,14 @@ __global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restr
 constexpr int64_t kWTrueKeyWaveMaxQueries = 2048;
 __global__ __launch_bounds__(256) void wide_true_key_wave_kernel(const float* __restrict__ table, int64_t ld, int D,
                                                                  const QRows q_fixed, const QRows q_rel,
-                                                                 const int64_t* __restrict__ true_row,
-                                                                 const float* __restrict__ q_true, int64_t q_head, int64_t Q,
+                                                                 const QRows q_true, int64_t q_head, int64_t Q,
                                                                  float* __restrict__ key_true,
                                                                  unsigned long long* __restrict__ acc) {
     __shared__ __attribute__((aligned(16))) float terms[4][kWMaxD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     if (q >= Q) return;  // (wave-uniform; nothing below synchronises the workgroup)
-    const float* e = true_row ? table + true_row[q] * ld : q_true + q * D;
+    const float* e = q_true.row(q);
     const float* f = q_fixed.row(q);
     const float* r = q_rel.row(q);
     const bool head = q < q_head;
@@ -596,7 +594,7 @@ size_t rank_sad_wide_workspace_bytes(int model, int D, int64_t N, int64_t q_head
 }
 
 hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                                    const QRows q_rel, const int64_t* true_row, const float* q_true, int64_t q_head,
+                                    const QRows q_rel, const QRows q_true, int64_t q_head,
                                     int64_t q_tail, const FilterSpec& filter,
                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream,
                                     hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -604,10 +602,10 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
     const int Dp = padded_width(D);
     WideWorkspace w = carve_wide(workspace, D, N, Q);
     if (Q <= kWTrueKeyWaveMaxQueries)
-        wide_true_key_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, true_row, q_true,
+        wide_true_key_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, q_true,
                                                                                   q_head, Q, w.key_true, w.acc);
     else
-        wide_true_key_kernel<<<dim3((unsigned)((Q + 255) / 256)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, true_row, q_true,
+        wide_true_key_kernel<<<dim3((unsigned)((Q + 255) / 256)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, q_true,
                                                                                    q_head, Q, w.key_true, w.acc);
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     const int64_t n_tiles = (N + 63) / 64, query_blocks = (Q + 3) / 4;

@@ -146,10 +146,23 @@ def rank_all_idx(rel_model, table, fixed_row, rel_emb, rel_ids, q_head, true_row
     ``fixed_row[q]`` of ``table``, its relation vector row ``rel_ids[q]`` of ``rel_emb`` (R, D) -- what the reference
     gathers into ``ent_emb[tails]`` / ``rel_emb(rels)`` (train.py:141-145), un-gathered: no (Q, D) arrays are built or
     streamed.  All indices must be in range (build_queries clamps and flags bad ids).  Same counts as rank_all."""
-    _require_device(table, fixed_row, rel_emb, rel_ids, true_row)
+    return rank_all_shard(rel_model, table, table, fixed_row, rel_emb, rel_ids, q_head, true_row, filter=filter, out=out)
+
+
+def rank_all_shard(rel_model, table, source, fixed_row, rel_emb, rel_ids, q_head, true_row, filter=None, out=None):
+    """One shard of the candidate axis (blp_rank_all_shard): ``table`` (N, D) holds this rank's rows of the entity table --
+    the candidates --, ``source`` (S, D) the vectors the queries themselves are made of (the whole table, or the vectors
+    of the entities in the triples: gather_triple_vectors), replicated on every rank; fixed_row / true_row (Q,) index
+    ``source``, rel_ids (Q,) index ``rel_emb`` (R, D).  A SegmentFilter's row_base = this shard's first global row.
+    Counts (Q, 4) int32 of this shard; the shards' counts add up to the unsharded ones.  ``source is table``: the
+    unsharded index form (rank_all_idx)."""
+    _require_device(table, source, fixed_row, rel_emb, rel_ids, true_row)
     table = _f32_rows(table, "table")
+    source = table if source is table else _f32_rows(source, "source")
     rel_emb = _f32_rows(rel_emb, "rel_emb").contiguous()
     N, D = table.shape
+    if source.dim() != 2 or source.shape[1] != D:
+        raise ValueError(f"source must be (S, {D}), got {tuple(source.shape)}")
     fixed_row = fixed_row.reshape(-1).to(torch.int64).contiguous()
     rel_ids = rel_ids.reshape(-1).to(torch.int64).contiguous()
     true_row = true_row.reshape(-1).to(torch.int64).contiguous()
@@ -179,11 +192,30 @@ def rank_all_idx(rel_model, table, fixed_row, rel_emb, rel_ids, q_head, true_row
                                            None if seg[3] is None else seg[3].data_ptr(),
                                            None if seg[4] is None else seg[4].data_ptr(),
                                            0 if seg[4] is None else seg[4].shape[0], int(filter.row_base)))
-    status = L.blp_rank_all_idx(model, _ptr(table), N, D, table.stride(0) if N > 1 else D, _ptr(fixed_row), _ptr(rel_emb),
-                                rel_emb.shape[0], _ptr(rel_ids), _ptr(true_row), q_head, Q - q_head, spec, _ptr(counts),
-                                _ptr(workspace), ws_bytes, dev.index, _stream(dev))
-    _lib.check(status, "blp_rank_all_idx")
+    status = L.blp_rank_all_shard(model, _ptr(table), N, D, table.stride(0) if N > 1 else D, _ptr(source), source.shape[0],
+                                  source.stride(0) if source.shape[0] > 1 else D, _ptr(fixed_row), _ptr(rel_emb),
+                                  rel_emb.shape[0], _ptr(rel_ids), _ptr(true_row), q_head, Q - q_head, spec, _ptr(counts),
+                                  _ptr(workspace), ws_bytes, dev.index, _stream(dev))
+    _lib.check(status, "blp_rank_all_shard")
     return counts
+
+
+def gather_triple_vectors(triples, ent2idx, table, row_base=0):
+    """(2n, D) f32: row t = the vector of triple t's head, row n + t = of its tail (train.py:141-142 for the whole set),
+    for the entities whose global row ent2idx[id] lies in [row_base, row_base + len(table)); zeros for the others, so
+    that ONE all-reduce over the ranks of a candidate-axis shard replicates every vector (blp_gather_triple_vectors)."""
+    _require_device(triples, ent2idx, table)
+    table = _f32_rows(table, "table")
+    triples = triples.to(torch.int64).contiguous()
+    n, (N, D) = triples.shape[0], table.shape
+    out = torch.empty((2 * n, D), dtype=torch.float32, device=table.device)
+    if ent2idx is not None:
+        ent2idx = ent2idx.to(torch.int64).contiguous()
+    status = _lib.lib().blp_gather_triple_vectors(_ptr(triples), n, _ptr(ent2idx), 0 if ent2idx is None else ent2idx.shape[0],
+                                                  _ptr(table), N, D, table.stride(0) if N > 1 else D, int(row_base), _ptr(out),
+                                                  table.device.index, _stream(table.device))
+    _lib.check(status, "blp_gather_triple_vectors")
+    return out
 
 
 def rank_from_scores(scores, true_idx=None, true_score=None, filt_rowptr=None, filt_col=None):
@@ -244,7 +276,8 @@ def rank_metric_sums(counts, k_values=(1, 3, 10)):
 QueryBlock = collections.namedtuple("QueryBlock", "q_fixed q_rel fixed_row true_row rel_ids ids_min filter")
 
 
-def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_base=0, gather=True):
+def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_base=0, gather=True, by_position=False,
+                  num_rows=None):
     """train.py:132-145 (+ utils.py:46-83 with ``index``) for a whole set of triples in one kernel (blp_build_queries).
 
     triples (n, 3) int64 rows (head id, tail id, relation id) on the table's device; ent2idx: id -> table row (-1: not a
@@ -252,6 +285,8 @@ def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_
     block after block of ``block_size`` triples, each block as [head-replacing | tail-replacing] queries.
     index: a utils.FilterIndex -> ``filter`` is the SegmentFilter of all 2n queries (slice it per block).
     gather=False: no vectors are built (q_fixed = q_rel = None); rank_all_idx takes fixed_row / rel_ids instead.
+    by_position: ``table`` is the (2n, D) array of gather_triple_vectors and fixed_row / true_row come out as positions in
+    it (head of triple t = t, tail = n + t); ``num_rows`` = rows of the whole entity table (the id check's bound).
     Returns QueryBlock(q_fixed (2n, D), q_rel (2n, D), fixed_row (2n,), true_row (2n,), rel_ids (2n,), ids_min (0-dim
     int32: -1 if any id had no row -- the reference's assertion train.py:137-138, left on the device), filter or
     None)."""
@@ -273,6 +308,10 @@ def build_queries(triples, ent2idx, table, rel_emb, block_size, index=None, row_
         ent2idx = ent2idx.to(torch.int64).contiguous()
         a.ent2idx, a.ent2idx_len = ent2idx.data_ptr(), ent2idx.shape[0]
     a.source, a.src_rows, a.ld, a.D = table.data_ptr(), table.shape[0], table.stride(0) if table.shape[0] > 1 else D, D
+    if by_position:
+        if table.shape[0] != 2 * n or num_rows is None:
+            raise ValueError("by_position: the source is the (2n, D) array of gather_triple_vectors; give num_rows")
+        a.by_position, a.src_rows = 1, int(num_rows)
     a.rel_emb, a.R = rel_emb.data_ptr(), rel_emb.shape[0]
     if gather:
         a.q_fixed, a.q_rel = q_fixed.data_ptr(), q_rel.data_ptr()

@@ -258,8 +258,34 @@ class ShardedRanker:
 
 
 # ----------------------------------------------------------------------------------- a set of triples
+class _Stopwatch:
+    """Device-side timing of the collectives of one evaluation (bench.py's ``exchange_ms``): events around each exchange
+    on the current stream, read after the caller's synchronisation.  ``timing`` = None: nothing is recorded."""
+
+    def __init__(self, timing, device):
+        self.timing = timing if (timing is not None and device.type == "cuda") else None
+
+    def __enter__(self):
+        if self.timing is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.stop = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timing is not None:
+            self.stop.record()
+            self.timing.setdefault("exchange_events", []).append((self.start, self.stop))
+        return False
+
+
+def exchange_ms(timing):
+    """Milliseconds the recorded exchanges of ``timing`` took (call after a device synchronisation)."""
+    return sum(a.elapsed_time(b) for a, b in timing.get("exchange_events", []))
+
+
 def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=None, group=None, world=1, rank=0,
-                 axis="candidate", block_size=65536):
+                 axis="candidate", block_size=65536, timing=None):
     """The reference's evaluation loop body (train.py:128-171) for a whole set of triples at once: rank counts of
     every triple's head and tail query against all ``num_entities`` candidates, raw and filtered.
 
@@ -268,14 +294,17 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     index     utils.FilterIndex of the filtering graph, or None (filtered counts = raw counts)
     table     world == 1 or axis == "query": the full (num_entities, D) table; axis == "candidate": this rank's
               rows shard_bounds(num_entities, world, rank) of it
+    timing    optional dict: the collectives are bracketed by device events (exchange_ms(timing) after a synchronise)
     Returns (triples in evaluation order -- as given --, counts (2T, 4) int32 in that order with every head query first,
     ids_ok: 0-dim bool tensor or None -- the reference's assertion train.py:137-138, left on the device).
 
     Everything runs on the table's device without a host round trip: the id lookups (train.py:134-135), the layout of
-    the queries -- left as (table row, relation) index pairs where the fused kernels take the block -- and the filter
-    segments are one kernel (ops.build_queries).  Collectives: candidate axis -- one all-reduce of
-    the vectors of the entities in the triples and ONE all-gather of the (2T, 4) counts; query axis -- ONE
-    all-gather of the per-triple counts."""
+    the queries -- left as (vector row, relation) index pairs -- and the filter segments are one kernel
+    (ops.build_queries); a block is then ONE library call (blp_rank_all_shard: <= 8 launches, none of them torch's).
+    Collectives: candidate axis -- the vectors the queries are made of are replicated ONCE (the whole table by one
+    all-gather when it is smaller than the 2T vectors of the triples, else those vectors by one all-reduce of an
+    owner-filled array) and the (2T, 4) counts of every shard are combined by ONE all-gather + sum; query axis -- ONE
+    all-gather of the per-triple counts.  No size is decided on the device (no torch.unique, no .item())."""
     device = table.device
     num_entities = table.shape[0] if num_entities is None else num_entities
     num_triples = triples.shape[0]
@@ -284,8 +313,10 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     t_lo, t_hi = shard_bounds(num_triples, world, rank) if by_query else (0, num_triples)
     n = t_hi - t_lo
     mine = slice(t_lo, t_hi)
-    fused = n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n))
-    ranker = ShardedRanker(model, table, num_entities, group) if by_candidate else None
+    tail_block = n % block_size or min(block_size, n)  # the last block may be short: it must take the same route
+    fused = (n > 0 and model.rel_emb.weight.dtype == torch.float32
+             and fused_ranking_takes(model, table, 2 * min(block_size, n)) and fused_ranking_takes(model, table, 2 * tail_block))
+    row_lo = shard_bounds(num_entities, world, rank)[0] if by_candidate else 0
     head_pos = tail_pos = None
 
     def block_positions():
@@ -294,31 +325,51 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         hp = first + idx                                                                # = 2 * first + (idx - first)
         return idx, hp, hp + torch.clamp(n - first, max=block_size)
 
-    # Everything a block needs is laid out ONCE for the whole set, block after block, each block as [its head
-    # queries | its tail queries] (train.py:149 order): the fixed-entity vectors, the relation vectors, the true rows
-    # and the filter segments.  A block is then a set of contiguous views -- no per-block gather / cat kernels, which
-    # at the reference's Wikidata5M batching (2 triples per table pass) cost more than a sixth of the pass.
-    if fused and not by_candidate and model.rel_emb.weight.dtype == torch.float32:
-        # one kernel (blp_build_queries) instead of ~35 small torch kernels: lookups, gathers, binary searches
-        # ... and the queries stay INDICES into the table and rel_emb (blp_rank_all_idx): no (2n, D) arrays at all
-        qb = ops.build_queries(triples[mine], ent2idx, table, model.rel_emb.weight, block_size, index=index, gather=False)
-        q_fixed = q_rel = q_true = None
-        fixed_src, true_src, rel_ids, seg = qb.fixed_row, qb.true_row, qb.rel_ids, qb.filter
+    if fused:
+        # The queries stay INDICES: (row of `source`, row of rel_emb) -- no (2n, D) arrays at all.  `source` holds the
+        # vectors the queries are made of: the table itself, or on a candidate shard a replicated copy of what the
+        # triples need from the other shards.
+        rel_w = model.rel_emb.weight
+        source, by_position = table, False
+        if by_candidate and num_entities <= 2 * num_triples:      # small table: all of it, one all-gather
+            with _Stopwatch(timing, device):
+                source = all_gather_rows(table, num_entities, world, group)
+        elif by_candidate:                                        # big table: the 2T vectors of the triples, one all-reduce
+            source = ops.gather_triple_vectors(triples, ent2idx, table, row_base=row_lo)
+            with _Stopwatch(timing, device):
+                _all_reduce(source, group)
+            by_position = True
+        # one kernel (blp_build_queries) instead of ~35 small torch kernels: lookups, layout, binary searches
+        qb = ops.build_queries(triples[mine], ent2idx, source, rel_w, block_size, index=index, gather=False, row_base=row_lo,
+                               by_position=by_position, num_rows=num_entities)
         ids_ok = qb.ids_min >= 0
+        counts = torch.empty((2 * n, 4), dtype=torch.int32, device=device)
+        for start in range(0, n, block_size):
+            b = min(start + block_size, n) - start
+            sl = slice(2 * start, 2 * (start + b))
+            seg = qb.filter
+            if seg is not None:
+                seg = seg._replace(seg_lo=seg.seg_lo[sl], seg_hi=seg.seg_hi[sl], exclude=seg.exclude[sl])
+            ops.rank_all_shard(model.rel_model, table, source, qb.fixed_row[sl], rel_w, qb.rel_ids[sl], b, qb.true_row[sl],
+                               filter=seg, out=counts[sl])
+        if by_candidate:  # ONE all-gather for the whole set; the shards' counts add up exactly
+            with _Stopwatch(timing, device):
+                gathered = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=device)
+                _all_gather_into(gathered.view(-1), counts.view(-1), group)
+                counts = gathered.sum(dim=0, dtype=torch.int32)
     else:
+        # CPU tensors, half-precision relation tables, widths the fused kernels do not take: the torch prelude and
+        # gathered query vectors (dense routes; a CSR filter per block).
+        ranker = ShardedRanker(model, table, num_entities, group) if by_candidate else None
         heads = ent2idx[triples[:, 0]]
         tails = ent2idx[triples[:, 1]]
         ids_ok = torch.minimum(heads.min(), tails.min()) >= 0 if num_triples else None
-        if by_candidate:  # replicate the vectors of every entity that occurs in a triple: one exchange
-            if num_triples > 512:
-                uniq, inverse = torch.unique(torch.cat((heads, tails)), return_inverse=True)
-                vectors = ranker.gather_rows(uniq)
-                head_pos_v, tail_pos_v = inverse[:num_triples], inverse[num_triples:]
-            else:  # a reference-sized batch: no host decision at all (torch.unique sizes its output on the host)
-                vectors = ranker.gather_rows(torch.cat((heads, tails)))
-                head_pos_v = torch.arange(num_triples, device=device)
-                tail_pos_v = head_pos_v + num_triples
-            source, head_ref, tail_ref = vectors, head_pos_v[mine], tail_pos_v[mine]
+        heads, tails = heads.clamp_min(0), tails.clamp_min(0)  # a bad id reads row 0 instead of out of bounds; ids_ok tells
+        if by_candidate:  # replicate the vectors of the entities in the triples: one exchange
+            with _Stopwatch(timing, device):
+                source = ranker.gather_rows(torch.cat((heads, tails)))
+            head_ref = torch.arange(num_triples, device=device)
+            tail_ref = head_ref + num_triples
         else:
             source, head_ref, tail_ref = table, heads[mine], tails[mine]
         idx, head_pos, tail_pos = block_positions()
@@ -334,36 +385,35 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         q_rel = model.rel_emb(rel_ids)
         q_true = source[true_src] if by_candidate else None
         seg = None
-        if index is not None and fused:  # slices of the sorted index: nothing is listed per batch
+        if index is not None and n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n)) \
+                and fused_ranking_takes(model, table, 2 * tail_block):  # slices of the sorted index: nothing is listed per batch
             seg = index.segments(triples[mine], ent2idx, device)
             seg = seg._replace(seg_lo=seg.seg_lo[order_src], seg_hi=seg.seg_hi[order_src], exclude=seg.exclude[order_src])
-    counts = torch.empty((2 * n, 4), dtype=torch.int32, device=device)
-
-    for start in range(0, n, block_size):
-        b = min(start + block_size, n) - start
-        sl = slice(2 * start, 2 * (start + b))
-        filt = {}
-        if seg is not None:
-            filt = dict(filter=seg._replace(seg_lo=seg.seg_lo[sl], seg_hi=seg.seg_hi[sl], exclude=seg.exclude[sl]))
-        elif index is not None:  # dense any-width routes take a CSR
-            rowptr, col = index.csr(triples[t_lo + start: t_lo + start + b], ent2idx, device)
-            filt = dict(filt_rowptr=rowptr, filt_col=col)
+        counts = torch.empty((2 * n, 4), dtype=torch.int32, device=device)
+        for start in range(0, n, block_size):
+            b = min(start + block_size, n) - start
+            sl = slice(2 * start, 2 * (start + b))
+            filt = {}
+            if seg is not None:
+                filt = dict(filter=seg._replace(seg_lo=seg.seg_lo[sl], seg_hi=seg.seg_hi[sl], exclude=seg.exclude[sl]))
+            elif index is not None:  # dense any-width routes take a CSR
+                rowptr, col = index.csr(triples[t_lo + start: t_lo + start + b], ent2idx, device)
+                filt = dict(filt_rowptr=rowptr, filt_col=col)
+            if by_candidate:
+                ranker.rank_block(q_fixed[sl], q_rel[sl], q_true[sl], b, rel_ids=rel_ids[sl], **filt)
+            else:
+                rank_block(model, table, q_fixed[sl], q_rel[sl], b, true_row=true_src[sl], rel_ids=rel_ids[sl], out=counts[sl],
+                           **filt)
         if by_candidate:
-            ranker.rank_block(q_fixed[sl], q_rel[sl], q_true[sl], b, rel_ids=rel_ids[sl], **filt)
-        elif q_fixed is None:
-            ops.rank_all_idx(model.rel_model, table, fixed_src[sl], model.rel_emb.weight, rel_ids[sl], b, true_src[sl],
-                             filter=filt.get("filter"), out=counts[sl])
-        else:
-            rank_block(model, table, q_fixed[sl], q_rel[sl], b, true_row=true_src[sl], rel_ids=rel_ids[sl], out=counts[sl],
-                       **filt)
-    if by_candidate:
-        counts = ranker.finish()  # ONE all-gather for the whole set; blocks in the order they were queued
+            with _Stopwatch(timing, device):
+                counts = ranker.finish()  # ONE all-gather for the whole set; blocks in the order they were queued
     if n > block_size:  # every head query first, like one big batch
         if head_pos is None:
             _, head_pos, tail_pos = block_positions()
         counts = counts[torch.cat((head_pos, tail_pos))]
     if by_query:  # per-triple counts of every rank's slice: ONE all-gather for the whole set
-        both = all_gather_rows(torch.cat((counts[:n], counts[n:]), dim=1), num_triples, world, group)
+        with _Stopwatch(timing, device):
+            both = all_gather_rows(torch.cat((counts[:n], counts[n:]), dim=1), num_triples, world, group)
         counts = torch.cat((both[:, :4], both[:, 4:])).contiguous()
     return triples, counts, ids_ok
 

@@ -12,9 +12,9 @@
  *   - `device` is the HIP device ordinal the pointers live on, `stream` a hipStream_t (torch:
  *     torch.cuda.current_stream().cuda_stream; NULL = the legacy default stream).  Calls only
  *     enqueue work on `stream`: no host synchronisation, safe to capture in a hipGraph;
- *   - re-entrant: the only process-wide state is the set of test knobs behind blp_debug_set_knob
- *     (atomic integers, all 0 = automatic in production); one thread per device (nn.DataParallel
- *     replicas) may call concurrently.  ctypes releases the GIL for the duration of the call;
+ *   - re-entrant: no process-wide mutable state (the test knobs exist only in the -DBLP_TEST_HOOKS build, see the
+ *     end of this file); one thread per device (nn.DataParallel replicas) may call concurrently.  ctypes releases
+ *     the GIL for the duration of the call;
  *   - return 0 (BLP_OK) or a negative blp_status; blp_last_error() gives the thread-local message;
  *   - f32 tensors, int64 indices exactly as the reference produces them (neg_idx, true_idx);
  *   - arithmetic follows the torch-CPU evaluation order of the reference expressions (see
@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 203 /* major*10000 + minor*100 + patch */
+#define BLP_HIP_VERSION 300 /* major*10000 + minor*100 + patch */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -155,6 +155,31 @@ int blp_rank_all_idx(int model, const float *table, int64_t N, int D, int64_t ld
                      const float *rel_emb, int64_t R, const int64_t *rel_id, const int64_t *true_row,
                      int64_t q_head, int64_t q_tail, const blp_filter *filter, int32_t *counts,
                      void *workspace, size_t workspace_bytes, int device, void *stream);
+
+/* The same for ONE SHARD OF THE CANDIDATE AXIS (the north_star's multi-GPU layout: the entity table partitioned by rows over
+ * the ranks, every rank ranking every query against its own rows).  `table` is this rank's shard -- global rows
+ * [row_base, row_base + N), the CANDIDATES -- while the queries' own vectors, the fixed entity and the true entity of every
+ * triple, are rows of a second array `source` (S, D), row stride ld_src, that every rank holds in full: either the whole
+ * table (small tables: one all-gather per evaluation) or the vectors of the entities that occur in the triples
+ * (blp_gather_triple_vectors + one all-reduce).  fixed_row / true_row (Q,) index `source`; nothing else changes: the
+ * reference's `ent_emb[tails]`, `ent_emb[heads]`, `rel_emb(rels)` (train.py:141-145) stay un-gathered, `true_ents`
+ * (train.py:150) becomes the true entity's score from its vector, and the filter's row_base keeps the rows of other shards
+ * out (blp_filter).  Per-shard counts add up exactly to the unsharded counts: one all-gather of (Q, 4) int32 + a sum is
+ * the only exchange after the ranking.  blp_rank_all_idx is the case source == table, S == N, ld_src == ld.
+ * Workspace: blp_rank_all_workspace_bytes(model, N, D, q_head, q_tail). */
+int blp_rank_all_shard(int model, const float *table, int64_t N, int D, int64_t ld, const float *source, int64_t S,
+                       int64_t ld_src, const int64_t *fixed_row, const float *rel_emb, int64_t R, const int64_t *rel_id,
+                       const int64_t *true_row, int64_t q_head, int64_t q_tail, const blp_filter *filter, int32_t *counts,
+                       void *workspace, size_t workspace_bytes, int device, void *stream);
+
+/* Producer of `source` for big tables: out (2n, D) f32 contiguous, out[t] = the vector of triple t's head, out[n + t] = of
+ * its tail (train.py:141-142's `ent_emb[heads]` / `ent_emb[tails]` for the whole set of triples), filled only for the
+ * entities whose global row ent2idx[id] (NULL: the id itself) lies in this shard's [row_base, row_base + N) and ZERO
+ * otherwise -- so that one all-reduce (sum) over the ranks replicates all 2n vectors exactly (x + 0 = x).  With
+ * blp_queries.by_position the queries then index this array. */
+int blp_gather_triple_vectors(const int64_t *triples, int64_t n, const int64_t *ent2idx, int64_t ent2idx_len,
+                              const float *table, int64_t N, int D, int64_t ld, int64_t row_base, float *out, int device,
+                              void *stream);
 
 /* Measurement aid (bench.py): the NEXT blp_rank_all issued by the calling thread records the two
  * hipEvent_t (created by the caller with timing enabled) on its stream immediately before and after
@@ -282,6 +307,9 @@ typedef struct blp_queries {
     float *q_fixed; float *q_rel; int64_t *true_row; int64_t *rel_ids; int32_t *ids_min;
     int64_t *seg_lo; int64_t *seg_hi; int64_t *exclude;
     int64_t *fixed_row;
+    int64_t by_position;     /* 0: fixed_row / true_row are rows of `source` (= ent2idx[id]).  1: `source` is the (2n, D) array
+                              * of blp_gather_triple_vectors and fixed_row / true_row are POSITIONS in it (head of triple t = t,
+                              * tail = n + t); ent2idx and src_rows (= rows of the whole table) then only serve the id check. */
 } blp_queries;
 int blp_build_queries(const blp_queries *q, int device, void *stream);
 
@@ -305,20 +333,22 @@ int blp_project_rows(const float *x, int64_t n, int64_t ldx, const float *w, int
                      float *out, int64_t ldo, int device, void *stream);
 
 /* --------------------------------------------------------------------------------------------
- * Test / A-B hook.  The library never reads the environment; the kernel-selection and slab-size
- * overrides the parity tests need (force the exact f32 kernels, the f32-chain GEMM, tiny candidate
- * slabs, ...) are process-wide integer knobs, 0 = automatic (names: blp_amd/csrc/knobs.h).  Not for
- * production callers: a knob changed between blp_rank_all_workspace_bytes and blp_rank_all can make
- * the two disagree.  Results never depend on a knob.
+ * Test / A-B hooks -- NOT part of the production library.  They are compiled only with -DBLP_TEST_HOOKS, into a second
+ * library (blp_amd/libblp_hip.hooks.so) that tests/ and tools/ load; libblp_hip.so exports neither symbol and has no
+ * mutable process-wide state.  The library never reads the environment; the kernel-selection and slab-size overrides the
+ * parity tests need (force the exact f32 kernels, the f32-chain GEMM, tiny candidate slabs, ...) are process-wide integer
+ * knobs of the hooks build, 0 = automatic (names: blp_amd/csrc/knobs.h).  Results never depend on a knob.
  * -------------------------------------------------------------------------------------------- */
+#ifdef BLP_TEST_HOOKS
 int blp_debug_set_knob(const char *name, long long value);
 
 /* Test hook for the error band of the bilinear pre-pass: the NEXT blp_rank_all of the calling thread on a DistMult /
  * ComplEx / SimplE block (D = 128, >= 64 queries, one candidate slab) runs the SAME bf16 x 3 MFMA sequence and band
  * arithmetic as always but, instead of deciding, stores the approximate score S~ and the band half-width eps of every
- * (query, candidate) pair into two dense (Q, N) f32 matrices; `counts` of that call are meaningless.  One-shot; NULL,
- * NULL cancels.  tests/test_gpu_fullsize.py compares |S~ - S_ref| with eps on whole blocks. */
+ * (query, candidate) pair into two dense (Q, N) f32 matrices; `counts` of that call are meaningless.  One-shot (the
+ * pointers are dropped when that call returns); NULL, NULL cancels. */
 int blp_debug_gemm_dump(float *scores, float *eps);
+#endif
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,20 @@ REL_MODELS = ("transe", "distmult", "complex", "simple")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "default_routing: keep the library's own choice of TransE kernel (no sad_min_queries knob)")
+    config.addinivalue_line("markers", "default_routing: only at the shipped dispatch (no routing knobs), the product library")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU parity tests run twice (fixture `routing` of test_gpu_parity.py / test_gpu_eval.py): at the SHIPPED dispatch on
+    the product library, and with the knobs that keep the pre-pass kernels in play on small tables (hooks library).  Tests
+    marked default_routing make sense at the shipped dispatch only: their "prepass" instance is dropped here."""
+    keep = []
+    for item in items:
+        spec = getattr(item, "callspec", None)
+        if item.get_closest_marker("default_routing") and spec is not None and spec.params.get("routing") == "prepass":
+            continue
+        keep.append(item)
+    items[:] = keep
 
 
 def golden(name):
@@ -36,7 +49,8 @@ def oracle():
 
 @pytest.fixture
 def knobs():
-    """Set test knobs of libblp_hip.so (blp_debug_set_knob) for one test; every knob is automatic again afterwards."""
+    """Set test knobs (blp_debug_set_knob of the hooks build, libblp_hip.hooks.so -- which then serves every call until
+    the knobs are reset) for one test; every knob is automatic again afterwards and the product library serves."""
     from blp_amd import _lib
     yield _lib.set_knob
     _lib.reset_knobs()

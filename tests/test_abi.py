@@ -11,18 +11,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def built_lib():
     from blp_amd import build
+    build.build_hooks()
     return build.build()
 
 
-def _declared_symbols():
+def _declared_symbols(hooks=False):
+    """Functions include/blp_hip.h declares: outside (product) or inside (test build) its #ifdef BLP_TEST_HOOKS block."""
     text = open(os.path.join(ROOT, "include", "blp_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(blp_[a-z_0-9]+)\s*\(", text)))
+    inside = "".join(re.findall(r"#ifdef BLP_TEST_HOOKS(.*?)#endif", text, flags=re.S))
+    outside = re.sub(r"#ifdef BLP_TEST_HOOKS.*?#endif", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(blp_[a-z_0-9]+)\s*\(", inside if hooks else outside)))
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("blp_"))
 
 
 def test_header_symbols_match_binding(built_lib):
     from blp_amd import _lib
     assert _declared_symbols() == sorted(_lib.SYMBOLS)
+    assert _declared_symbols(hooks=True) == sorted(_lib.HOOK_SYMBOLS)
+
+
+def test_product_library_exports_no_test_hooks(built_lib):
+    """libblp_hip.so exports exactly the production ABI -- no knob, no dump hook, hence no mutable process-wide state;
+    libblp_hip.hooks.so (tests / tools) adds the two hooks."""
+    from blp_amd import _lib
+    assert _exported(_lib.LIB_PATH) == sorted(_lib.SYMBOLS)
+    assert _exported(_lib.HOOKS_LIB_PATH) == sorted(_lib.SYMBOLS + _lib.HOOK_SYMBOLS)
 
 
 def test_library_loads_and_exports_every_symbol(built_lib):
@@ -30,7 +49,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     L = _lib.lib()
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.blp_version() == 203
+    assert L.blp_version() == 300
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 8)  # coefficients, key, accumulator
@@ -85,12 +104,16 @@ def test_project_rows_argument_checks(built_lib):
 
 def test_knobs_are_named_and_reset(built_lib):
     from blp_amd import _lib
-    L = _lib.lib()
-    before = L.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300)
-    _lib.set_knob("rank_kernel", 1)  # exact f32 kernels: no images, no pair lists
-    assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300) < before
+    product = _lib.lib()
+    before = product.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300)
+    _lib.set_knob("rank_kernel", 1)  # exact f32 kernels: no images, no pair lists -- and calls now go to the hooks build
+    H = _lib.lib()
+    assert H is _lib.hooks_lib() and H is not product
+    assert H.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300) < before
+    assert product.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300) == before  # the product library has no knobs
     _lib.reset_knobs()
-    assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300) == before
+    assert _lib.lib() is product
+    assert H.blp_rank_all_workspace_bytes(0, 14541, 128, 300, 300) == before
     with pytest.raises(RuntimeError, match="unknown knob"):
         _lib.set_knob("no_such_knob", 1)
     with pytest.raises(RuntimeError, match="BLP_ERR_BAD_ARG"):

@@ -31,3 +31,41 @@ def test_link_prediction_cli_end_to_end(tmp_path):
     assert sorted(state) == ["embeddings.weight", "rel_emb.weight"]
     # TransE rows are L2-normalised (models.py:40-41)
     assert torch.allclose(ent_emb[0].norm(dim=-1), torch.ones(135), atol=1e-5)
+
+
+def test_node_classification_cli_on_saved_embeddings(tmp_path):
+    """train.py node_classification (train.py:408-481 of the reference): embeddings + ids in the files link_prediction
+    writes, class files in the dataset directory; classes that are linearly separable in the embeddings are learnt, the
+    classifier is saved in the reference's format."""
+    import joblib
+    import numpy as np
+    n, dim = 120, 16
+    g = torch.Generator().manual_seed(0)
+    labels = torch.arange(n) % 3
+    emb = torch.randn(n, dim, generator=g) * 0.1
+    emb[torch.arange(n), labels] += 1.0                      # class k stands out along axis k
+    ids = torch.randperm(n, generator=g) + 5                 # entity ids are not rows
+    (tmp_path / "output").mkdir()
+    torch.save(emb.unsqueeze(0), tmp_path / "output" / "ent_emb-7.pt")   # (1, N, D), as eval_link_prediction returns it
+    torch.save(ids, tmp_path / "output" / "ents-7.pt")
+    data = tmp_path / "data" / "toy"
+    data.mkdir(parents=True)
+    names = {f"ent{int(i)}": int(i) for i in ids}
+    torch.save({"ent_ids": names, "rel_ids": {}}, data / "maps.pt")
+    for split, rows in (("train", range(0, 60)), ("dev", range(60, 90)), ("test", range(90, 120))):
+        with open(data / f"{split}-ents-class.txt", "w") as f:
+            for r in rows:
+                f.write(f"ent{int(ids[r])} class{int(labels[r])}\n")
+    env = dict(os.environ, PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "node_classification", "with", "dataset=toy", "checkpoint=7",
+           f"data_root={tmp_path / 'data'}"]
+    proc = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    log = proc.stderr + proc.stdout
+    for needle in ("Loaded 120 embeddings with dim=16", "Best regularization coefficient:", "Test accuracy_score: 1.000",
+                   "Test balanced_accuracy_score: 1.000"):
+        assert needle in log, (needle, log[-1500:])
+    saved = joblib.load(tmp_path / "output" / "classifier-7.joblib")
+    assert sorted(saved["id_to_class"].values()) == ["class0", "class1", "class2"]
+    pred = saved["model"].predict(emb[90:].numpy())
+    assert np.array_equal([saved["id_to_class"][p] for p in pred], [f"class{int(l)}" for l in labels[90:]])

@@ -11,13 +11,16 @@ from conftest import REL_MODELS, golden, golden_names
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def prepass_from_64_queries():
-    """Small tables on purpose: keep the TransE pre-pass in play from 64 queries on (see tests/test_gpu_parity.py)."""
+@pytest.fixture(autouse=True, params=["shipped", "prepass"])
+def routing(request):
+    """Twice: at the shipped dispatch on the product library, and with the pre-pass kernels kept in play on these small
+    tables (see tests/test_gpu_parity.py)."""
     from blp_amd import _lib
-    _lib.set_knob("sad_min_queries", 64)
-    _lib.set_knob("small_kernel", 2)
-    yield
+    _lib.reset_knobs()
+    if request.param == "prepass":
+        _lib.set_knob("sad_min_queries", 64)
+        _lib.set_knob("small_kernel", 2)
+    yield request.param
     _lib.reset_knobs()
 
 
@@ -75,6 +78,7 @@ def test_eval_on_reference_table_is_exact(rel_model, oracle):
     assert np.array_equal(ranker.finish().cpu().numpy(), want)
 
 
+@pytest.mark.default_routing
 @pytest.mark.parametrize("name", golden_names("loss_")[:8])
 def test_link_prediction_module_on_gpu_uses_fused_loss(name):
     from blp_amd import models
@@ -93,6 +97,7 @@ def test_link_prediction_module_on_gpu_uses_fused_loss(name):
     np.testing.assert_allclose(model.rel_emb.weight.grad.cpu().numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.default_routing
 @pytest.mark.parametrize("n", [10_007, 5, 8192, 8193, 700_001])
 def test_rank_metric_sums_equals_reduced_rank_metrics(n):
     """blp_rank_metric_sums = get_metrics + the accumulation of train.py:152-157 on the device (one block up
@@ -143,6 +148,7 @@ def test_rank_all_replays_from_a_captured_graph(rel_model, q, oracle):
     assert torch.equal(sums.cpu(), ops.rank_metric_sums(torch.from_numpy(want).cuda()).cpu())
 
 
+@pytest.mark.default_routing
 @pytest.mark.parametrize("axis", ["candidate", "query"])
 def test_bench_two_ranks_share_one_gpu_functional(axis):
     """bench.py's N > 1 paths run as 2 ranks on this one GPU with the gloo backend.  Candidate shards:
@@ -176,6 +182,7 @@ def test_bench_two_ranks_share_one_gpu_functional(axis):
     assert b["parity_check"].endswith("identical counts")
 
 
+@pytest.mark.default_routing
 def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
     """The line the driver gets from `bench.py --gpus N` with its defaults (here N = 2 over gloo on this one GPU): the
     FB15k-237 evaluation on the query axis and, as a sub-result, the Wikidata5M-scale block on the candidate axis (the
@@ -195,8 +202,16 @@ def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
     assert len(lines) == 1
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["config"]["shard_axis"] == "query" and b["parity_check"].endswith("identical counts")
+    assert b["shard_axis"] == "query" and len(b["exchange_ms_per_rank"]) == 2 and b["exchange_ms"] > 0
+    assert set(b["sub_results"]) == {"fb15k237-transe@candidate", "wikidata5m-transe", "wikidata5m-transe-block"}
+    for name, sub in b["sub_results"].items():  # the north_star's axis, with what the exchange cost on every rank
+        assert sub["shard_axis"] == "candidate" and sub["ranks"] == 2, name
+        assert len(sub["kernel_ms_per_rank"]) == 2 and len(sub["exchange_ms_per_rank"]) == 2 and sub["exchange_ms"] > 0, name
+        assert sub["roofline"]["frac"] > 0 and sub["roofline"]["traffic"] is None, name  # no single-GPU PMC figure applies
+    same = b["sub_results"]["fb15k237-transe@candidate"]  # the same evaluation on the other axis: the same metrics
+    assert abs(same["mrr"] - b["mrr"]) < 1e-12 and abs(same["mrr_filtered"] - b["mrr_filtered"]) < 1e-12
+    assert same["parity_check"].endswith("identical counts")
     sub = b["sub_results"]["wikidata5m-transe-block"]
-    assert sub["shard_axis"] == "candidate" and len(sub["kernel_ms_per_rank"]) == 2 and sub["roofline"]["frac"] > 0
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload",
                           "wikidata5m-transe-block", "--no-cpu-baseline", "--no-hbm-probe", "--no-sub-results"],
                          capture_output=True, text=True, timeout=900, cwd=root)
@@ -206,6 +221,7 @@ def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
     assert a["hits@1,3,10"] == pytest.approx(sub["hits@1,3,10"], abs=1e-15)
 
 
+@pytest.mark.default_routing
 def test_bench_line_keeps_the_contract():
     """`python bench.py` with its defaults: ONE JSON line on stdout with the driver's keys; the step is the whole
     evaluation (raw + filtered), with the raw-only time beside it; the roofline of the dominant kernel; the CPU
@@ -237,16 +253,28 @@ def test_bench_line_keeps_the_contract():
     assert roof["bound"] == "valu" and roof["unit"] == "TFLOP/s"  # TransE: no matrix-core form of an L1 norm
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-6) and 0.0 < roof["frac"] < 1.0
     assert roof["kernel_ms"] <= r["ms_per_step"] * 1.25  # the ranking pass is part of a step (separate loops: noise)
+    # the VALU roof is the builder's (v_sad_u16 issue rate); SURVEY 8(d)'s f32 lane-op accounting sits next to it
+    lane = roof["survey_8d_lane_ops"]
+    assert lane["frac"] == pytest.approx(lane["achieved_Tops"] / lane["peak_Tops"], rel=1e-6) and "survey_8d_lane_ops" in roof["note"]
+    # PMC figures are read from the committed profile: stamped with where they come from, null when stale
+    assert "pmc_source" in roof and (roof["traffic"] is None or "commit" in roof["pmc_source"])
     cpu = r["cpu_baseline"]
-    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert cpu["kind"].startswith("port, vectorised filter") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     assert cpu["value_1_thread"] > 0 and cpu["cpu_model"] and cpu["logical_cpus"] >= cpu["cores"]
+    # the best of a few thread counts (an oversubscribed all-threads run was the slower one), thread count stated
+    assert "1" in cpu["value_by_threads"] and cpu["value"] == max(cpu["value_by_threads"].values())
+    assert cpu["value"] == cpu["value_by_threads"][str(cpu["cores"])]
     assert r["parity_check"].endswith("identical counts")
     subs = r["sub_results"]
-    assert set(subs) == {"fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe-block"}
+    assert set(subs) == {"fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex",
+                         "wikidata5m-transe-block"}
     for name, sub in subs.items():
         assert sub["value"] > 0 and sub["ms_per_step"] > 0 and sub["ms_per_step_raw_only"] > 0, name
         assert 0.0 < sub["roofline"]["frac"] < 1.0 and sub["roofline"]["kernel_ms"] <= sub["ms_per_step"] * 1.25, name
-        assert sub["roofline"]["bound"] == ("mfma" if "transe" not in name else "valu"), name
+        hbm = name in ("wikidata5m-transe", "wikidata5m-complex")  # reference batching: 4 queries per table pass
+        assert sub["roofline"]["bound"] == ("hbm" if hbm else "mfma" if "transe" not in name else "valu"), name
+        if hbm:
+            assert sub["table_passes_per_step"] == 64 and sub["ms_per_table_pass"] == pytest.approx(sub["ms_per_step"] / 64)
     assert subs["fb15k237-distmult"]["parity_check"].endswith("identical counts")
     assert r["hbm_probe"]["bound"] == "hbm" and 0.0 < r["hbm_probe"]["frac"] < 1.0
 
@@ -286,6 +314,7 @@ def test_generic_width_route_matches_oracle(rel_model, D, oracle):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.default_routing
 def test_device_sampler_law_on_the_gpu():
     """data.get_negative_sampling_indices_on_device drawn on the GPU (what train.py `device_sampler=True` puts into
     collate_fn): the law of the reference's sampler (data.py:35-81) -- one slot of the pair kept, the other replaced
@@ -314,6 +343,7 @@ def test_device_sampler_law_on_the_gpu():
     assert out.is_cuda and out.shape == (10, 8, 2) and int(out.max()) < 10 and int(out.min()) >= 0
 
 
+@pytest.mark.default_routing
 @pytest.mark.parametrize("amp", [None, "bf16"])
 def test_link_prediction_cli_on_gpu(tmp_path, amp):
     """python train.py link_prediction on the GPU: GloVe-BOW encoder at the GloVe width (300), TransE, the
@@ -344,6 +374,7 @@ def test_link_prediction_cli_on_gpu(tmp_path, amp):
     assert torch.allclose(ent_emb[0].float().norm(dim=-1).cpu(), torch.ones(135), atol=1e-3)
 
 
+@pytest.mark.default_routing
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,E,D", [(1, 32, 64), (63, 768, 128), (200, 768, 128), (130, 100, 256), (517, 1024, 64)])
 @pytest.mark.parametrize("normalize", [False, True])
@@ -371,6 +402,7 @@ def test_project_rows_vs_torch(n, E, D, normalize):
     assert (out == 0).all()
 
 
+@pytest.mark.default_routing
 @pytest.mark.gpu
 @pytest.mark.parametrize("rel_model", ["transe", "complex"])
 def test_bert_table_build_uses_the_fused_epilogue(rel_model, monkeypatch):
@@ -409,6 +441,7 @@ def test_bert_table_build_uses_the_fused_epilogue(rel_model, monkeypatch):
         assert len(calls) == n_before
 
 
+@pytest.mark.default_routing
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,block,D", [(1, 64, 128), (100, 64, 128), (128, 64, 64), (333, 50, 300), (70, 1000, 768)])
 def test_build_queries_equals_the_torch_prelude(n, block, D):

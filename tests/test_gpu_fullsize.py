@@ -130,9 +130,10 @@ def _dump_block(bench, model, data):
     b, Q, N = t.shape[0], 2 * t.shape[0], job.N
     S = torch.full((Q, N), float("nan"), device="cuda")
     E = torch.full((Q, N), float("nan"), device="cuda")
-    _lib.check(_lib.lib().blp_debug_gemm_dump(S.data_ptr(), E.data_ptr()), "blp_debug_gemm_dump")
-    ops.rank_all(model, table, fixed, rel2, b, true_row=torch.cat((t[:, 0], t[:, 1])))  # dump call: counts meaningless
-    torch.cuda.synchronize()
+    with _lib.use_hooks_library() as H:  # the dump hook exists in the hooks build only (same kernels, same band arithmetic)
+        _lib.check(H.blp_debug_gemm_dump(S.data_ptr(), E.data_ptr()), "blp_debug_gemm_dump", H)
+        ops.rank_all(model, table, fixed, rel2, b, true_row=torch.cat((t[:, 0], t[:, 1])))  # dump call: counts meaningless
+        torch.cuda.synchronize()
     assert not torch.isnan(S).any() and not torch.isnan(E).any()
     return table, fixed, rel2, b, S, E
 

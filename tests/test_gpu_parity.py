@@ -17,17 +17,18 @@ def ops():
     return _ops
 
 
-@pytest.fixture(autouse=True)
-def prepass_from_64_queries(request):
-    """The library sends blocks below ~4 million (query, candidate) pairs to the small-block exact f32 kernel (its short
-    launch chain wins there).  These tests use small tables on purpose, so the pre-pass paths are made to take
-    every block of >= 64 queries, as they do at evaluation sizes; tests marked `default_routing` keep the library's
-    own choice."""
+@pytest.fixture(autouse=True, params=["shipped", "prepass"])
+def routing(request):
+    """Every test here runs twice.  "shipped": no knob at all -- libblp_hip.so, the dispatch production callers get
+    (these tests use small tables, so most blocks then take the small-block / exact kernels).  "prepass": the hooks
+    library with the knobs that send every block of >= 64 (TransE) / 32 (bilinear) queries to the pre-pass kernels, as
+    at evaluation sizes.  Tests marked `default_routing` run at the shipped dispatch only (tests/conftest.py)."""
     from blp_amd import _lib
-    if "default_routing" not in request.keywords:
+    _lib.reset_knobs()
+    if request.param == "prepass":
         _lib.set_knob("sad_min_queries", 64)
-        _lib.set_knob("small_kernel", 2)  # same reason: the MFMA pre-pass, not the small-block kernel, from 32 queries on
-    yield
+        _lib.set_knob("small_kernel", 2)  # the MFMA pre-pass, not the small-block kernel, from 32 queries on
+    yield request.param
     _lib.reset_knobs()
 
 
@@ -621,6 +622,7 @@ def test_fb15k237_shape_vs_oracle(ops, oracle, model):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.default_routing
 def test_wikidata5m_scale_properties(ops, oracle):
     """BASELINE config 4 scale (4.6 M x 128, reference batch of 2 triples = 4 queries): too big for
     the oracle to rank in full, so check (a) a 200k-row slab against the oracle, (b) additivity of
@@ -649,6 +651,7 @@ def test_wikidata5m_scale_properties(ops, oracle):
     assert int(whole[:, 1].min()) >= 1  # the true entity itself is always >=
 
 
+@pytest.mark.default_routing
 def test_wikidata5m_scale_prepass_paths_equal_exact_kernels(ops, oracle, knobs):
     """4.6 M x 128 with enough queries for the pre-pass paths (TransE: fixed-point SAD, Q = 512;
     DistMult: bf16 x 3 GEMM, Q = 128).  Their counts must equal (a) the exact f32 kernels' on the whole
@@ -741,6 +744,7 @@ def test_gemm_f32_chain_variant(ops, oracle, model, knobs):
 
 
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.default_routing
 @pytest.mark.parametrize("name", golden_names("loss_"))
 def test_golden_inbatch_loss(ops, name):
     """Loss within 1e-6 relative, gradients within rtol 1e-5 / atol 1e-7 of the reference (f32
@@ -758,6 +762,7 @@ def test_golden_inbatch_loss(ops, name):
     np.testing.assert_allclose(rel_w.grad.cpu().numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.default_routing
 @pytest.mark.parametrize("model", REL_MODELS)
 @pytest.mark.parametrize("loss_fn", ["margin", "nll"])
 def test_inbatch_loss_training_shape_vs_port(ops, model, loss_fn):
@@ -789,6 +794,7 @@ def test_inbatch_loss_training_shape_vs_port(ops, model, loss_fn):
 
 @pytest.mark.parametrize("model,D", [("distmult", 100), ("complex", 200), ("simple", 300), ("transe", 1000),
                                      ("distmult", 1100)])
+@pytest.mark.default_routing
 def test_inbatch_loss_any_width(ops, model, D):
     """The reference takes any `dim` (glove-bow 300, bert-bow 768, a user's 100 / 200): the fused loss does too --
     reduction widths off the 32-grid or past torch.sum's first cascade (>= 512) and rows wider than one 768-element
@@ -818,6 +824,7 @@ def test_inbatch_loss_any_width(ops, model, D):
 @pytest.mark.parametrize("loss_fn", ["margin", "nll"])
 @pytest.mark.parametrize("dtype,rel_f32", [(torch.float16, False), (torch.float16, True), (torch.bfloat16, False),
                                             (torch.bfloat16, True)])
+@pytest.mark.default_routing
 def test_inbatch_loss_half_storage(ops, model, loss_fn, dtype, rel_f32):
     """BASELINE config 5 shape per GPU (B = 128, K = 64, D = 128) with half-precision embeddings (what
     the encoder emits under autocast; relation rows optionally still f32).  The reference has no half
@@ -849,6 +856,7 @@ def test_inbatch_loss_half_storage(ops, model, loss_fn, dtype, rel_f32):
     np.testing.assert_allclose(r.grad.float().cpu().numpy(), r_ref.grad.numpy(), rtol=tol(rel.dtype), atol=1e-7)
 
 
+@pytest.mark.default_routing
 def test_compute_loss_under_autocast(ops):
     """LinkPrediction.compute_loss with f16 embeddings and f32 relation rows (the autocast mix) takes the
     fused path and matches its own f32 evaluation of the widened inputs."""
@@ -866,6 +874,7 @@ def test_compute_loss_under_autocast(ops):
     assert half_loss.item() == pytest.approx(full_loss.item(), rel=1e-6)
 
 
+@pytest.mark.default_routing
 @pytest.mark.parametrize("model", REL_MODELS)
 def test_score_fn_training_broadcast_and_grad(ops, model):
     """score_fn on (B, K, D) x (B, 1, D) (models.py:67): golden-exact forward, analytic backward vs
@@ -886,6 +895,7 @@ def test_score_fn_training_broadcast_and_grad(ops, model):
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.default_routing
 def test_transe_wide_rows_score_fn(ops):
     """TransE on BOW widths (300 GloVe / 768 BERT embeddings): runtime-D path, golden-exact."""
     g = golden("score_pairs")
@@ -894,6 +904,7 @@ def test_transe_wide_rows_score_fn(ops):
         assert np.array_equal(out.cpu().numpy().view(np.uint32), g[f"transe_{d}"].view(np.uint32))
 
 
+@pytest.mark.default_routing
 def test_errors_are_loud(ops):
     table = torch.randn(8, 96).cuda()  # D = 96 is not a compiled ranking width (TransE alone is taken at any D % 4 == 0)
     q = torch.randn(2, 96).cuda()

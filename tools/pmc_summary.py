@@ -3,12 +3,17 @@
 HBM-side read bytes per launch of each workload's dominant kernel (pmc4.csv: FETCH_SIZE in KiB, x 1024 x 2 on
 gfx950 -- MI355X_MICROARCH.md, HBM section) and, for the MFMA kernels, the matrix-pipe busy fraction
 (pmc7.csv: SQ_VALU_MFMA_BUSY_CYCLES summed over the chip, normalised by 1024 SIMDs x kernel time x 2.4 GHz;
-kernel time from kernel_stats.csv)."""
+kernel time from kernel_stats.csv).  Every entry also records `bench_pass_ms`, the ranking-pass time of the bench line taken
+with the profile (bench.json: roofline.kernel_ms) -- bench.py drops the counters when its live pass time has moved away from
+it -- and the file is stamped with the round directory and the commit it describes (`_profile`)."""
 import csv, json, os, sys
+
+import subprocess
 
 DOMINANT = {"fb15k237-transe": "rank_sad_kernel", "fb15k237-distmult": "rank_gemm_bf16", "fb15k237-complex": "rank_gemm_bf16",
             "fb15k237-simple": "rank_gemm_bf16", "fb15k237-transe-d768": "wide_rank_sad_kernel",
-            "wikidata5m-transe": "rank_stream_wg_kernel", "wikidata5m-transe-block": "rank_sad_kernel"}
+            "wikidata5m-transe": "rank_stream_wg_kernel", "wikidata5m-complex": "rank_stream_wg_kernel",
+            "wikidata5m-transe-block": "rank_sad_kernel"}
 
 
 def rows(path):
@@ -18,7 +23,11 @@ def rows(path):
 def main(root):
     out_path = os.path.join(os.path.dirname(os.path.abspath(root)), "pmc_traffic.json")
     old = json.load(open(out_path)) if os.path.exists(out_path) else {}
-    out = {"_note": old.get("_note", "")}
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    except (OSError, subprocess.CalledProcessError):
+        commit = "unknown"
+    out = {"_note": old.get("_note", ""), "_profile": {"round": os.path.basename(os.path.normpath(root)), "commit": commit}}
     for workload, kernel in DOMINANT.items():
         d = os.path.join(root, workload)
         entry = {"kernel": kernel}
@@ -38,9 +47,15 @@ def main(root):
             if kernel in r["kernel"] and r["counter"] == "SQ_VALU_MFMA_BUSY_CYCLES" and float(r["mean_per_row"]) > 0 and ns:
                 entry["mfma_busy_cycles"] = float(r["mean_per_row"])
                 entry["mfma_busy_frac_at_2.4GHz"] = float(r["mean_per_row"]) / (1024 * ns * 2.4)
-        out[workload] = entry
+        try:
+            line = json.load(open(os.path.join(d, "bench.json")))
+            entry["bench_pass_ms"] = line["roofline"]["kernel_ms"]
+        except (OSError, ValueError, KeyError):
+            pass
+        if len(entry) > 1:
+            out[workload] = entry
     json.dump(out, open(out_path, "w"), indent=1)
-    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "comment"} for k, v in out.items() if k != "_note"}, indent=1))
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "comment"} for k, v in out.items() if not k.startswith("_")}, indent=1))
 
 
 if __name__ == "__main__":

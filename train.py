@@ -1,4 +1,4 @@
-"""python train.py link_prediction with key=value ...
+"""python train.py [link_prediction|node_classification] with key=value ...
 
 The reference's Sacred CLI (/root/reference/train.py) on the MI355X-native hot path: same commands,
 config keys and defaults (train.py:35-54), same outputs (output/model-{id}.pt, ent_emb-{id}.pt,
@@ -221,13 +221,11 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
 
 
 @ex.command
-def node_classification(dataset, checkpoint, _run, _log):
-    """The reference's downstream sklearn task on saved embeddings (train.py:408-481) is outside this package's
-    scope: it never touches the scoring / ranking path.  The command name is kept so that a
-    launch script fails with a clear message; run it from the reference checkout on the ent_emb-{id}.pt /
-    ents-{id}.pt files that link_prediction writes here in the reference's format."""
-    raise NotImplementedError("node_classification is not part of blp_amd: run the reference's train.py "
-                              f"node_classification on output/ent_emb-{checkpoint}.pt / output/ents-{checkpoint}.pt")
+def node_classification(dataset, checkpoint, data_root, _run, _log):
+    """The reference's downstream task on saved embeddings (train.py:408-481): logistic regression on
+    output/ent_emb-{checkpoint}.pt; CPU / scikit-learn, outside the HIP hot path (blp_amd.downstream)."""
+    from blp_amd.downstream import classify_nodes
+    return classify_nodes(dataset, checkpoint, _log, data_root=data_root, output_dir=OUT_PATH)
 
 
 if __name__ == '__main__':
