@@ -491,6 +491,83 @@ def hbm_probe(device, events, reps=30):
             "traffic": (pmc or {}).get("hbm_bytes_per_launch"), "pmc_source": why}
 
 
+INBATCH_SHAPES = {
+    # BASELINE config 1's training batch (scripts/blp-transe-fb15k237.sh: batch_size 64, num_negatives 64, dim 128)
+    "inbatch-fb15k237": dict(model="transe", loss="margin", B=64, K=64, D=128, dtype="float32", reg=0.0),
+    # BASELINE config 5: ComplEx, half-precision embeddings under autocast (f32 relation rows), per-GPU batch 128 -- and
+    # the reference's whole Wikidata5M batch of 1 024 on one GPU (scripts/blp-complex-wikidata5m.sh)
+    "inbatch-wikidata5m-complex-fp16": dict(model="complex", loss="margin", B=128, K=64, D=128, dtype="float16", reg=1e-3),
+    "inbatch-wikidata5m-complex-fp16-b1024": dict(model="complex", loss="margin", B=1024, K=64, D=128, dtype="float16", reg=1e-3),
+}
+
+
+def inbatch_bench(device, iters=200):
+    """The training-side kernel (compute_loss on in-batch negatives, models.py:51-70): one step
+    = fused forward + backward, three launches.  `us_per_step_kernels`: the raw C-ABI calls issued back to back (device
+    events; what the kernels and their launch gaps cost); `us_per_step_autograd`: ops.inbatch_loss(...).backward() from
+    Python, wall clock; `torch_us_per_step`: the reference's expressions (oracle/ref_port.py) through stock PyTorch-ROCm on
+    the same tensors.  Launch / latency-bound (~100 KB of data): microseconds, not a roofline fraction."""
+    from blp_amd import _lib, ops
+    from oracle import ref_port
+    out = {}
+    for name, c in INBATCH_SHAPES.items():
+        g = torch.Generator(device=device).manual_seed(7)
+        B, K, D = c["B"], c["K"], c["D"]
+        dtype = getattr(torch, c["dtype"])
+        ent = (torch.randn(B, 2, D, device=device, generator=g) * 0.4).to(dtype)
+        rel = torch.randn(B, 1, D, device=device, generator=g) * 0.3
+        neg_idx = torch.randint(0, 2 * B, (B, K, 2), device=device, generator=g)
+
+        def fused():
+            e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+            ops.inbatch_loss(c["model"], c["loss"], e, r, neg_idx, c["reg"]).backward()
+
+        def stock():
+            e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+            ref_port.compute_loss(c["model"], c["loss"], e, r, neg_idx, c["reg"]).backward()
+
+        def wall(fn, n):
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e6
+
+        # raw C-ABI, back to back on the current stream
+        L = _lib.lib()
+        loss = torch.empty((), dtype=torch.float32, device=device)
+        pos = torch.empty(2 * B, dtype=torch.float32, device=device)
+        neg = torch.empty((B, K), dtype=torch.float32, device=device)
+        g_ent, g_rel, one = torch.empty_like(ent), torch.empty(B, D, device=device), torch.ones((), device=device)
+        rel2 = rel.reshape(B, D).contiguous()
+        args = (_lib.MODEL_IDS[c["model"]], _lib.LOSS_IDS[c["loss"]], _lib.DTYPE_NAMES.index(c["dtype"]), 0)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+        def raw():
+            _lib.check(L.blp_inbatch_loss_fwd_t(*args, ent.data_ptr(), rel2.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+                                                loss.data_ptr(), pos.data_ptr(), neg.data_ptr(), device.index, stream), "fwd")
+            _lib.check(L.blp_inbatch_loss_bwd_t(*args, ent.data_ptr(), rel2.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+                                                one.data_ptr(), pos.data_ptr(), neg.data_ptr(), g_ent.data_ptr(), g_rel.data_ptr(),
+                                                device.index, stream), "bwd")
+
+        for _ in range(20):
+            raw()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            raw()
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = {"rel_model": c["model"], "loss": c["loss"], "B": B, "K": K, "D": D, "storage": c["dtype"],
+                     "launches_per_step": 3, "us_per_step_kernels": a.elapsed_time(b) / iters * 1e3,
+                     "us_per_step_autograd": wall(fused, iters), "torch_us_per_step": wall(stock, max(20, iters // 4)),
+                     "pairs_per_step": B * (K + 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -607,6 +684,7 @@ def main():
                 del sub, t, c
                 torch.cuda.empty_cache()
             result["sub_results"] = subs
+            result["inbatch_loss"] = inbatch_bench(device)
         if not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
             result["hbm_probe"] = hbm_probe(device, events)
     if rank == 0:

@@ -241,10 +241,15 @@ int blp_score_bwd(int model, int D, int64_t M0, int64_t M1,
  *   rel_vecs  (B, D)    f32: rel_emb(rels) already gathered (its backward stays in torch)
  *   neg_idx   (B, K, 2) int64, values in [0, 2B): rows of ent_embs.view(2B, D)  (data.py:35-81)
  *   regularizer: models.py:59-60, applied iff > 0
- * fwd: loss (1) f32; pos (B) and neg (B, K) scores are saved for bwd.
- * bwd: grad_ent (2B, D), grad_rel (B, D), both overwritten, scaled by *grad_loss (device scalar).
- *      Deterministic (no float atomics).  margin_loss passes gradient where the hinge is
- *      exactly 0 (models.py:252-253 masks in place).
+ * fwd: loss (1) f32; save_pos (2 B) f32 -- the B positive scores, then B per-row shares of the regulariser -- and
+ *      save_neg (B, K) f32 scores are kept for bwd.  Two launches: scores (16 lanes per pair, wavefront shuffle
+ *      reduction of the elementwise terms), then one block for the loss (f64 accumulation, fixed order).
+ * bwd: grad_ent (2B, D), grad_rel (B, D), both overwritten, scaled by *grad_loss (device scalar).  One launch,
+ *      O(B K) work (a workgroup finds the negatives of its rows with one stable compaction of neg_idx into LDS).
+ *      Deterministic (no float atomics: contributions are added in neg_idx order).  margin_loss passes gradient
+ *      where the hinge is exactly 0 (models.py:252-253 masks in place).
+ * Floating point: the scores are the reference's elementwise terms summed in tree order, so the loss agrees with the
+ * reference to ~1e-6 relative and the gradients to ~1e-5 (the bit-exact score_fn is blp_score_fwd).
  * -------------------------------------------------------------------------------------------- */
 int blp_inbatch_loss_fwd(int model, int loss, const float *ent_embs, const float *rel_vecs,
                          const int64_t *neg_idx, int B, int K, int D, float regularizer,

@@ -125,3 +125,19 @@ def test_metric_sums_buffer_size_matches_the_header():
     from blp_amd import _lib
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "blp_hip.h")).read()
     assert int(re.search(r"#define BLP_METRIC_SUMS_DOUBLES (\d+)", header).group(1)) == _lib.METRIC_SUMS_DOUBLES
+
+
+def test_no_kernel_of_the_in_batch_loss_uses_scratch(built_lib):
+    """Every inbatch_* kernel keeps its working set in registers / LDS: .private_segment_fixed_size == 0 and no spills
+    in the gfx950 code object's notes (tools/kernel_resources.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from blp_amd import build
+    kernels = kernel_resources.kernels_of(os.path.join(build.OBJ, "inbatch_loss.hip.o"))
+    names = [k for k in kernels if "inbatch" in k]
+    assert len(names) >= 3 * 4 * 5 // 2  # scores + grad per (model, storage types), one reduce
+    for name in names:
+        f = kernels[name]
+        # (scalar registers parked in VGPR lanes -- sgpr_spill_count -- touch no memory and are not scratch)
+        assert f["private_segment_fixed_size"] == 0 and f.get("vgpr_spill_count", 0) == 0, (name, f)

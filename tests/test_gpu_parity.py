@@ -792,6 +792,44 @@ def test_inbatch_loss_training_shape_vs_port(ops, model, loss_fn):
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
 
 
+@pytest.mark.default_routing
+@pytest.mark.parametrize("model,B,K,skew", [("transe", 1024, 64, None), ("complex", 1024, 64, None), ("distmult", 300, 7, None),
+                                            ("simple", 200, 33, None), ("transe", 3, 2, None), ("distmult", 64, 80, "two_rows"),
+                                            ("complex", 96, 64, "one_row"), ("transe", 520, 9, "few_rows")])
+def test_inbatch_loss_backward_row_ownership_and_rounds(ops, model, B, K, skew):
+    """The backward's work split (inbatch_loss.hip): a workgroup owns R = 1 ... 16 entity rows and finds their negatives by
+    one stable compaction of neg_idx -- batches of 1 024 (R = 16), sizes that leave a short last workgroup, rows split over
+    waves (R < 4), and negatives that all name one or two rows (more hits than the LDS list holds: several rounds).
+    Against the torch port, the training-shape test's tolerances; and bit-reproducible."""
+    from oracle import ref_port
+    torch.manual_seed(B + K)
+    D = 128
+    ent = torch.randn(B, 2, D) * (1.0 if model == "transe" else 0.4)
+    rel = torch.randn(B, 1, D) * 0.3
+    neg_idx = torch.randint(0, 2 * B, (B, K, 2))
+    if skew == "two_rows":
+        neg_idx = torch.randint(0, 2, (B, K, 2))
+    elif skew == "one_row":
+        neg_idx[..., 0] = 5
+    elif skew == "few_rows":
+        neg_idx = torch.randint(100, 104, (B, K, 2))
+    e_ref, r_ref = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    ref = ref_port.compute_loss(model, "margin", e_ref, r_ref, neg_idx, 1e-3)
+    ref.backward()
+    grads = []
+    for _ in range(2):
+        e, r = ent.cuda().requires_grad_(True), rel.cuda().requires_grad_(True)
+        loss = ops.inbatch_loss(model, "margin", e, r, neg_idx.cuda(), 1e-3)
+        loss.backward()
+        grads.append((e.grad.clone(), r.grad.clone()))
+    assert loss.item() == pytest.approx(ref.item(), rel=2e-6, abs=1e-7)
+    # sums of up to 2 B K signed terms per row: a few ulps of the largest partial sum in absolute terms
+    scale = float(e_ref.grad.abs().max())
+    np.testing.assert_allclose(grads[0][0].cpu().numpy(), e_ref.grad.numpy(), rtol=2e-5, atol=2e-6 * max(scale, 1e-3))
+    np.testing.assert_allclose(grads[0][1].cpu().numpy(), r_ref.grad.numpy(), rtol=2e-5, atol=2e-6 * max(scale, 1e-3))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
 @pytest.mark.parametrize("model,D", [("distmult", 100), ("complex", 200), ("simple", 300), ("transe", 1000),
                                      ("distmult", 1100)])
 @pytest.mark.default_routing

@@ -1,7 +1,9 @@
 """Randomised parity soak: random model / width / sizes / data shapes / filter / true-entity form / slab
 knobs, HIP ranking through the C-ABI against the CPU oracle (test infrastructure), for a wall-clock budget.
-    python tools/fuzz_parity.py [seconds] [seed]
-Prints every mismatch with the seed that reproduces it; exit code 1 if there was one."""
+    python tools/fuzz_parity.py [seconds] [seed] [--shipped]
+Prints every mismatch with the seed that reproduces it; exit code 1 if there was one.
+--shipped: no knobs at all -- the product library at the dispatch it ships with, and block shapes drawn around its
+thresholds (tests/test_gpu_dispatch.py runs a seeded, bounded slice of this mode inside `pytest -m gpu`)."""
 import os
 import sys
 import time
@@ -16,7 +18,33 @@ from oracle import oracle  # noqa: E402
 from test_gpu_parity import oracle_counts, random_csr  # noqa: E402
 
 
-def make_case(rng):
+def shipped_shape(rng, model):
+    """Block shapes for the shipped dispatch: most draws land near one of its thresholds (rank_common.h: 6 M / 4 M pairs
+    for TransE, 0.4 M for the bilinear models, 32 / 64-query floors, <= 4 + 4 queries, 256 / 1 024 tiles)."""
+    u = rng.random()
+    if u < 0.25:   # pairs around the small-block / pre-pass switch
+        N = int(rng.integers(3000, 30000))
+        pairs = rng.uniform(3e6, 9e6) if model == "transe" else rng.uniform(2e5, 1.6e6)
+        Q = max(2, int(pairs / N))
+    elif u < 0.4:  # the query floors of the pre-pass paths on a table that would otherwise qualify
+        N = int(rng.integers(60000, 120000)) if model == "transe" else int(rng.integers(13000, 40000))
+        Q = int(rng.integers(56, 72)) if model == "transe" else int(rng.integers(26, 40))
+    elif u < 0.55:  # <= 4 + 4 queries and just above, short and long tables (streaming kernels / small block / rank_tiles)
+        N = int(rng.choice([int(rng.integers(1, 3000)), int(rng.integers(16000, 17000)), int(rng.integers(60000, 200000))]))
+        Q = int(rng.integers(1, 11))
+    elif u < 0.65:  # tile-count limits of the small-block kernels
+        N = int(rng.choice([16384, 65536])) + int(rng.integers(-70, 71))
+        Q = int(rng.integers(5, 60))
+    else:
+        N = int(rng.integers(1, 2500))
+        Q = int(rng.integers(1, 1000))
+    q_head = int(rng.integers(0, Q + 1))
+    if Q <= 10 and rng.random() < 0.5:
+        q_head = min(Q, int(rng.integers(0, 6)))
+    return N, q_head, Q - q_head
+
+
+def make_case(rng, shipped=False):
     model = rng.choice(["transe", "distmult", "complex", "simple"])
     if model == "transe":
         D = int(rng.choice([64, 128, 256, 300, 100, 768, 36]))
@@ -34,6 +62,10 @@ def make_case(rng):
         q_head, q_tail = int(rng.integers(0, 40)), int(rng.integers(0, 40))
         if rng.random() < 0.4:
             q_head, q_tail = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+    if shipped:
+        N, q_head, q_tail = shipped_shape(rng, model)
+        if N * D > 6_000_000 and D not in (64, 128):  # keep the host-side table generation of a case short
+            D = int(rng.choice([64, 128]))
     if q_head + q_tail == 0:
         q_tail = 1
     g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
@@ -97,17 +129,18 @@ def make_case(rng):
             env["exact_query_chunk"] = int(rng.integers(1, 200))
     if rng.random() < 0.45:
         env["stream_kernel"] = int(rng.choice([2, 2, 3, 4]))  # <= 4 + 4 queries on rank_tiles<STATIC> (2) / TransE's workgroup-tile (3) or ring (4) kernel
+    if shipped:
+        env = {}
     return model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids, (fixed_idx, rel_table)
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def run(budget=60.0, seed0=0, max_cases=None, shipped=False, out=sys.stdout):
+    """Cases seed0, seed0 + 1, ... until the budget (seconds) or max_cases is used up.  Returns (cases, mismatches)."""
     t0, n, bad = time.time(), 0, 0
-    while time.time() - t0 < budget:
+    while (budget is None or time.time() - t0 < budget) and (max_cases is None or n < max_cases):
         seed = seed0 + n
         rng = np.random.default_rng(seed)
-        model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids, (fixed_idx, rel_table) = make_case(rng)
+        model, D, N, q_head, q_tail, kind, table, q_fixed, q_rel, true_row, csr, by_vector, env, rel_ids, (fixed_idx, rel_table) = make_case(rng, shipped)
         if os.environ.get("BLP_FUZZ_TRACE"):  # the last line names the case a crash happened in
             print(f"seed={seed} model={model} D={D} N={N} q=({q_head},{q_tail}) data={kind} csr={csr is not None} "
                   f"by_vector={by_vector} env={env}", file=sys.stderr, flush=True)
@@ -141,9 +174,18 @@ def main():
             rows = np.nonzero((got != want).any(axis=1))[0]
             print(f"MISMATCH seed={seed} model={model} D={D} N={N} q=({q_head},{q_tail}) data={kind} csr={csr is not None} "
                   f"by_vector={by_vector} env={env}: {len(rows)} queries differ, first {rows[:3].tolist()} "
-                  f"got {got[rows[0]].tolist()} want {want[rows[0]].tolist()}", flush=True)
+                  f"got {got[rows[0]].tolist()} want {want[rows[0]].tolist()}", file=out, flush=True)
         n += 1
-    print(f"{n} cases in {time.time() - t0:.0f} s, {bad} mismatches (seeds {seed0}..{seed0 + n - 1})")
+    print(f"{n} cases in {time.time() - t0:.0f} s, {bad} mismatches (seeds {seed0}..{seed0 + n - 1}, "
+          f"{'shipped dispatch' if shipped else 'random knobs'})", file=out)
+    return n, bad
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    budget = float(args[0]) if len(args) > 0 else 60.0
+    seed0 = int(args[1]) if len(args) > 1 else 0
+    n, bad = run(budget, seed0, shipped="--shipped" in sys.argv)
     return 1 if bad else 0
 
 
