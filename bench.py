@@ -539,7 +539,7 @@ def inbatch_bench(device, iters=200):
         # raw C-ABI, back to back on the current stream
         L = _lib.lib()
         loss = torch.empty((), dtype=torch.float32, device=device)
-        pos = torch.empty(2 * B, dtype=torch.float32, device=device)
+        pos = torch.empty(_lib.inbatch_save_pos_floats(B), dtype=torch.float32, device=device)
         neg = torch.empty((B, K), dtype=torch.float32, device=device)
         g_ent, g_rel, one = torch.empty_like(ent), torch.empty(B, D, device=device), torch.ones((), device=device)
         rel2 = rel.reshape(B, D).contiguous()

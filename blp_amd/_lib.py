@@ -33,6 +33,11 @@ KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h
+def inbatch_save_pos_floats(B):
+    """BLP_INBATCH_SAVE_POS_FLOATS(B) of include/blp_hip.h: floats the `save_pos` argument of blp_inbatch_loss_fwd needs."""
+    return 2 * B + 6 * 64 + 2
+
+
 METRIC_SUMS_DOUBLES = 520  # BLP_METRIC_SUMS_DOUBLES: room the `sums` argument of blp_rank_metric_sums needs
 
 

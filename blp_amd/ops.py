@@ -476,7 +476,8 @@ class _InBatchLoss(torch.autograd.Function):
         idx = neg_idx.to(torch.int64).contiguous()
         dev = ent.device
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        pos = torch.empty(2 * B, dtype=torch.float32, device=dev)  # positives' scores, then the rows' regulariser shares
+        # BLP_INBATCH_SAVE_POS_FLOATS(B): positives' scores, the rows' regulariser shares, scratch of the loss reduction
+        pos = torch.empty(_lib.inbatch_save_pos_floats(B), dtype=torch.float32, device=dev)
         neg = torch.empty((B, K), dtype=torch.float32, device=dev)
         status = _lib.lib().blp_inbatch_loss_fwd_t(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
                                                    _ptr(ent), _ptr(rel), _ptr(idx), B, K, D, float(regularizer),

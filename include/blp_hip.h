@@ -241,9 +241,11 @@ int blp_score_bwd(int model, int D, int64_t M0, int64_t M1,
  *   rel_vecs  (B, D)    f32: rel_emb(rels) already gathered (its backward stays in torch)
  *   neg_idx   (B, K, 2) int64, values in [0, 2B): rows of ent_embs.view(2B, D)  (data.py:35-81)
  *   regularizer: models.py:59-60, applied iff > 0
- * fwd: loss (1) f32; save_pos (2 B) f32 -- the B positive scores, then B per-row shares of the regulariser -- and
- *      save_neg (B, K) f32 scores are kept for bwd.  Two launches: scores (16 lanes per pair, wavefront shuffle
- *      reduction of the elementwise terms), then one block for the loss (f64 accumulation, fixed order).
+ * fwd: loss (1) f32; save_pos (BLP_INBATCH_SAVE_POS_FLOATS(B)) f32 -- the B positive scores, B per-row shares of the
+ *      regulariser, then scratch of the loss reduction -- and save_neg (B, K) f32 scores are kept for bwd.  Two launches:
+ *      scores (bilinear models: 32 lanes per pair = torch.sum's 32 running sums, folded by wavefront shuffles; TransE:
+ *      four lanes per pair, the running L1 sum walking through them -- scores bit-identical to the reference at the
+ *      scripts' widths), then the loss (f64 accumulation in a fixed order; the last of up to 64 workgroups adds theirs).
  * bwd: grad_ent (2B, D), grad_rel (B, D), both overwritten, scaled by *grad_loss (device scalar).  One launch,
  *      O(B K) work (a workgroup finds the negatives of its rows with one stable compaction of neg_idx into LDS).
  *      Deterministic (no float atomics: contributions are added in neg_idx order).  margin_loss passes gradient
@@ -251,6 +253,7 @@ int blp_score_bwd(int model, int D, int64_t M0, int64_t M1,
  * Floating point: the scores are the reference's elementwise terms summed in tree order, so the loss agrees with the
  * reference to ~1e-6 relative and the gradients to ~1e-5 (the bit-exact score_fn is blp_score_fwd).
  * -------------------------------------------------------------------------------------------- */
+#define BLP_INBATCH_SAVE_POS_FLOATS(B) (2 * (B) + 6 * 64 + 2)
 int blp_inbatch_loss_fwd(int model, int loss, const float *ent_embs, const float *rel_vecs,
                          const int64_t *neg_idx, int B, int K, int D, float regularizer,
                          float *out_loss, float *save_pos, float *save_neg, int device,
