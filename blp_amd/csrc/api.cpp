@@ -295,6 +295,52 @@ int blp_rank_all_shard(int model, const float* table, int64_t N, int D, int64_t 
                             workspace_bytes, device, stream);
 }
 
+size_t blp_rank_all_batches_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch) {
+    if (!valid_model(model) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0) return 0;
+    return blp::rank_all_batches_workspace_bytes(model, D, N, n_triples, batch);
+}
+
+int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_t ld, const float* source, int64_t S,
+                         int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, int64_t R, const int64_t* rel_id,
+                         const int64_t* true_row, int64_t n_triples, int64_t batch, const blp_filter* filter, int32_t* counts,
+                         void* workspace, size_t workspace_bytes, int device, void* stream) {
+    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: unknown model %d", model);
+    if (n_triples < 0 || batch <= 0 || N < 0 || ld < D)
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: bad sizes (n_triples=%lld batch=%lld N=%lld)", (long long)n_triples,
+                    (long long)batch, (long long)N);
+    if (n_triples == 0) return BLP_OK;
+    if (n_triples <= batch)  // one batch: the plain shard call (its own argument checks)
+        return blp_rank_all_shard(model, table, N, D, ld, source, S, ld_src, fixed_row, rel_emb, R, rel_id, true_row, n_triples,
+                                  n_triples, filter, counts, workspace, workspace_bytes, device, stream);
+    if (!blp_rank_all_supported(model, D, 1, 1))
+        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_rank_all_batches: D = %d not supported (see blp_rank_all_supported)", D);
+    if (n_triples > (1ll << 40) || N >= (1ll << 31)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: n_triples > 2^40 or N >= 2^31");
+    if (!source || !fixed_row || !rel_id || !rel_emb || !true_row || !counts || R <= 0 || S <= 0 || (N > 0 && !table))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: NULL pointer, or R <= 0 / S <= 0");
+    if (!aligned16(table) || !aligned16(source) || !aligned16(rel_emb) || !aligned16(counts) || (ld & 3) || (ld_src & 3) || ld_src < D || (D & 3))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: table / source / rel_emb / counts must be 16-byte aligned, ld %% 4 == 0, D %% 4 == 0");
+    blp::FilterSpec spec;
+    if (filter) {
+        if (!filter->seg_lo || !filter->seg_hi || !filter->values || (filter->ent2idx && filter->ent2idx_len < 0))
+            return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: filter needs seg_lo, seg_hi and values");
+        spec.lo = filter->seg_lo; spec.hi = filter->seg_hi; spec.val = filter->values; spec.exclude = filter->exclude;
+        spec.ent2idx = filter->ent2idx; spec.ent2idx_len = filter->ent2idx ? filter->ent2idx_len : 0;
+        spec.row_base = filter->row_base;
+    }
+    const size_t need = blp::rank_all_batches_workspace_bytes(model, D, N, n_triples, batch);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail(BLP_ERR_WORKSPACE, "blp_rank_all_batches: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", need,
+                    workspace_bytes);
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    int cu = 0;
+    if (int rc = compute_units(device, &cu)) return rc;
+    hipError_t err = blp::launch_rank_all_batches(model, D, table, N, ld, source, ld_src, fixed_row, rel_emb, rel_id, true_row, n_triples,
+                                                  batch, spec, counts, workspace, cu, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_all_batches launch");
+    return BLP_OK;
+}
+
 int blp_rank_all_idx(int model, const float* table, int64_t N, int D, int64_t ld, const int64_t* fixed_row,
                      const float* rel_emb, int64_t R, const int64_t* rel_id, const int64_t* true_row, int64_t q_head,
                      int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace, size_t workspace_bytes,

@@ -200,6 +200,48 @@ def rank_all_shard(rel_model, table, source, fixed_row, rel_emb, rel_ids, q_head
     return counts
 
 
+def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, num_triples, batch, filter=None, out=None, source=None):
+    """Every batch of the reference's evaluation loop in ONE call (blp_rank_all_batches): fixed_row / rel_ids / true_row
+    (2 num_triples,), a SegmentFilter's seg_lo / seg_hi / exclude and the returned counts (2 num_triples, 4) are laid out
+    batch after batch of ``batch`` triples, each batch as [its head queries | its tail queries] -- build_queries'
+    layout with block_size = batch, i.e. what a loop over the reference's DataLoader sees.  Same counts as one
+    rank_all_idx call per batch; the library ranks 65 536 triples at a time."""
+    source = table if source is None else source
+    _require_device(table, source, fixed_row, rel_emb, rel_ids, true_row)
+    table, rel_emb = _f32_rows(table, "table"), _f32_rows(rel_emb, "rel_emb").contiguous()
+    source = table if source is table else _f32_rows(source, "source")
+    N, D = table.shape
+    n, Q = int(num_triples), 2 * int(num_triples)
+    fixed_row, rel_ids, true_row = (x.reshape(-1).to(torch.int64).contiguous() for x in (fixed_row, rel_ids, true_row))
+    if fixed_row.shape[0] != Q or rel_ids.shape[0] != Q or true_row.shape[0] != Q or rel_emb.shape[1] != D or source.shape[1] != D:
+        raise ValueError("fixed_row, rel_ids, true_row need 2 * num_triples entries; rel_emb / source must be (., D)")
+    dev = table.device
+    counts = out if out is not None else torch.empty((Q, 4), dtype=torch.int32, device=dev)
+    if counts.shape != (Q, 4) or counts.dtype != torch.int32 or not counts.is_contiguous():
+        raise ValueError("out must be a contiguous (2 * num_triples, 4) int32 tensor")
+    if Q == 0:
+        return counts
+    L = _lib.lib()
+    model = _lib.MODEL_IDS[rel_model]
+    ws_bytes = L.blp_rank_all_batches_workspace_bytes(model, N, D, n, int(batch))
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    spec = None
+    if filter is not None:
+        seg = [None if x is None else x.to(device=dev, dtype=torch.int64).contiguous()
+               for x in (filter.seg_lo, filter.seg_hi, filter.values, filter.exclude, filter.ent2idx)]
+        if seg[0].shape[0] != Q or seg[1].shape[0] != Q or (seg[3] is not None and seg[3].shape[0] != Q):
+            raise ValueError("SegmentFilter: seg_lo, seg_hi and exclude need one entry per query")
+        spec = ctypes.byref(_lib.BlpFilter(seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr() if seg[2].numel() else seg[0].data_ptr(),
+                                           None if seg[3] is None else seg[3].data_ptr(), None if seg[4] is None else seg[4].data_ptr(),
+                                           0 if seg[4] is None else seg[4].shape[0], int(filter.row_base)))
+    status = L.blp_rank_all_batches(model, _ptr(table), N, D, table.stride(0) if N > 1 else D, _ptr(source), source.shape[0],
+                                    source.stride(0) if source.shape[0] > 1 else D, _ptr(fixed_row), _ptr(rel_emb), rel_emb.shape[0],
+                                    _ptr(rel_ids), _ptr(true_row), n, int(batch), spec, _ptr(counts), _ptr(workspace), ws_bytes,
+                                    dev.index, _stream(dev))
+    _lib.check(status, "blp_rank_all_batches")
+    return counts
+
+
 def gather_triple_vectors(triples, ent2idx, table, row_base=0):
     """(2n, D) f32: row t = the vector of triple t's head, row n + t = of its tail (train.py:141-142 for the whole set),
     for the entities whose global row ent2idx[id] lies in [row_base, row_base + len(table)); zeros for the others, so

@@ -120,3 +120,33 @@ def test_candidate_axis_two_gloo_ranks_take_the_fused_path(model, N, T, block):
         if r["kernels_per_block"] is not None:  # the profiler saw the device activity of this process
             assert 1 <= r["kernels_per_block"] <= limit, (r["kernels_per_block"], r["kernel_names"])
             assert not [k for k in r["kernel_names"] if "at::" in k or "elementwise" in k], r["kernel_names"]
+
+
+@pytest.mark.parametrize("model,N,T,batch", [("transe", 2100, 1000, 64), ("distmult", 2100, 333, 50), ("complex", 40000, 7, 2),
+                                             ("simple", 900, 64, 64), ("transe", 300, 70001, 64)])
+def test_rank_all_batches_equals_per_batch_calls_and_oracle(oracle, model, N, T, batch):
+    """blp_rank_all_batches: the reference's loop layout (train.py:128-157: eval_batch_size triples per batch, each batch
+    [head queries | tail queries]) handed over in one call == one blp_rank_all_idx call per batch == the oracle, raw and
+    filtered; 70 001 triples cross the 65 536-triple block the library ranks at a time."""
+    from blp_amd import ops, utils
+    D, R = 128, 5
+    table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=T % 97)
+    index = utils.FilterIndex(edges, num_relations=R)
+    dev_table, dev_rel, dev_e2i, dev_triples = table.cuda(), rel_w.cuda(), ent2idx.cuda(), triples.cuda()
+    qb = ops.build_queries(dev_triples, dev_e2i, dev_table, dev_rel, batch, index=index, gather=False)
+    got = ops.rank_all_batches(model, dev_table, qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, T, batch, filter=qb.filter)
+    # the loop a maintainer's patch of train.py:128-171 would run (INTEGRATION.md 2), first and last batches
+    for start in list(range(0, T, batch))[:3] + list(range(0, T, batch))[-2:]:
+        b = min(batch, T - start)
+        sl = slice(2 * start, 2 * (start + b))
+        seg = qb.filter._replace(seg_lo=qb.filter.seg_lo[sl], seg_hi=qb.filter.seg_hi[sl], exclude=qb.filter.exclude[sl])
+        one = ops.rank_all_idx(model, dev_table, qb.fixed_row[sl], dev_rel, qb.rel_ids[sl], b, qb.true_row[sl], filter=seg)
+        assert torch.equal(got[sl], one), start
+    if T <= 2000:  # the oracle's order is [all heads | all tails]
+        want = _oracle_counts(oracle, model, table, rel_w, ent2idx, triples, index)
+        idx = torch.arange(T)
+        first = idx // batch * batch
+        nb = torch.clamp(T - first, max=batch)
+        head_pos = 2 * first + (idx - first)
+        assert np.array_equal(got[head_pos].cpu().numpy(), want[:T])
+        assert np.array_equal(got[head_pos + nb].cpu().numpy(), want[T:])
