@@ -121,7 +121,7 @@ def make_filter_index(cfg, heads, tails, rels, seed=3):
         nodes = torch.multinomial(weight, 2 * extra, replacement=True, generator=g).reshape(2, extra)
         rel = torch.randint(0, cfg["R"], (extra,), generator=g)
         test = torch.cat((test, torch.stack((nodes[0], nodes[1], rel), dim=1)))
-    return utils.FilterIndex(test, num_relations=cfg["R"])
+    return utils.FilterIndex(test, num_relations=cfg["R"], device=heads.device)
 
 
 class HipEvents:

@@ -494,7 +494,7 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
 
     if isinstance(model, models.InductiveLinkPrediction):
         if compute_filtered:
-            index = filtering_graph if isinstance(filtering_graph, utils.FilterIndex) else utils.FilterIndex(filtering_graph)
+            index = filtering_graph if isinstance(filtering_graph, utils.FilterIndex) else utils.FilterIndex(filtering_graph, device=device)
             max_ent_id = max(index.max_node, int(entities.max()))
         else:
             index, max_ent_id = None, int(entities.max())
@@ -504,7 +504,7 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
         ent2idx = entities
         index = None
         if compute_filtered:
-            index = filtering_graph if isinstance(filtering_graph, utils.FilterIndex) else utils.FilterIndex(filtering_graph)
+            index = filtering_graph if isinstance(filtering_graph, utils.FilterIndex) else utils.FilterIndex(filtering_graph, device=device)
     num_entities = entities.shape[0]
 
     sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)

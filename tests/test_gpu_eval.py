@@ -535,3 +535,52 @@ def test_rank_all_idx_equals_rank_all_on_gathered_vectors(rel_model, D, n, N, kn
                         filt_col=col[rowptr[lo]:rowptr[hi]].numpy())
         for side, sl, lo, hi in ((orc.SIDE_HEAD, slice(0, n), 0, n), (orc.SIDE_TAIL, slice(n, 2 * n), n, 2 * n))])
     assert np.array_equal(idx.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.default_routing
+def test_filter_index_builds_on_the_device():
+    """utils.FilterIndex(..., device=cuda): the sort / unique of the graph's packed (key, value) pairs runs on the GPU
+    (utils.py:46-83's index, train.py:298-302's graph).  Same arrays as the host build at FB15k-237 size (310 116 edges,
+    parallel edges collapsed), in milliseconds; and a 20 M-edge graph (a Wikidata5M-sized training graph) builds and
+    answers like a brute-force scan."""
+    import time
+    from blp_amd import utils
+    g = torch.Generator().manual_seed(0)
+    N, R, E = 14541, 237, 310116
+    edges = torch.stack((torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g),
+                         torch.randint(0, R, (E,), generator=g)), dim=1)
+    edges[1000:2000] = edges[:1000]  # parallel edges
+    host = utils.FilterIndex(edges, num_relations=R)
+    dev_edges = edges.cuda()
+    utils.FilterIndex(dev_edges, num_relations=R)  # warm-up (the sort's temporary storage)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev = utils.FilterIndex(dev_edges, num_relations=R)
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    for name in ("heads_key", "heads_val", "tails_key", "tails_val"):
+        assert getattr(dev, name).is_cuda and torch.equal(getattr(dev, name).cpu(), getattr(host, name)), name
+    assert dev.R == host.R and dev.max_node == host.max_node and dev.num_edges == host.num_edges
+    assert build_ms < 20.0, build_ms  # (measured ~2 ms; the host build: 75-84 ms)
+    # Wikidata5M scale
+    N, R, E = 4_600_000, 822, 20_000_000
+    gd = torch.Generator(device="cuda").manual_seed(1)
+    big = torch.stack((torch.randint(0, N, (E,), device="cuda", generator=gd), torch.randint(0, N, (E,), device="cuda", generator=gd),
+                       torch.randint(0, R, (E,), device="cuda", generator=gd)), dim=1)
+    t0 = time.perf_counter()
+    index = utils.FilterIndex(big, num_relations=R)
+    torch.cuda.synchronize()
+    big_ms = (time.perf_counter() - t0) * 1e3
+    assert index.num_edges == E and big_ms < 2000.0, big_ms
+    probe = big[:64]
+    ent2idx = torch.arange(N, device="cuda")
+    seg = index.segments(probe, ent2idx, "cuda")
+    for q in range(0, 128, 17):  # head side (q < 64): heads known for (tail, rel); tail side: tails known for (head, rel)
+        t = probe[q % 64]
+        if q < 64:
+            want = torch.unique(big[(big[:, 1] == t[1]) & (big[:, 2] == t[2]), 0])
+        else:
+            want = torch.unique(big[(big[:, 0] == t[0]) & (big[:, 2] == t[2]), 1])
+        got = seg.values[int(seg.seg_lo[q]):int(seg.seg_hi[q])]
+        assert torch.equal(got, want), q

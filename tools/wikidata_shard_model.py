@@ -1,43 +1,64 @@
-# Per-rank time of candidate-axis shards of the Wikidata5M-scale table on ONE GPU (no exchange): the
-# reference's eval batch (2 triples = 4 queries per table pass, 64 passes per step) and the whole test set
-# as one block, against 1/W of the rows.  What the exchange may cost on top: one all-gather of (Q, 4) int32
-# per step.
-import os, sys, time, torch
+"""Per-rank time of candidate-axis shards of the Wikidata5M-scale table on ONE GPU (no exchange), through the calls
+blp_amd.ranking.rank_triples makes on that axis (ops.gather_triple_vectors, ops.build_queries with the shard's row_base,
+one ops.rank_all_shard per block, ops.rank_metric_sums): the reference's eval batch (2 triples = 4 queries per table pass,
+64 passes per step), TransE and ComplEx, and the whole test set as one block -- against 1/W of the rows.  What a real run
+adds on top: one all-reduce of the (2T, D) query vectors and one all-gather of (2T, 4) int32 counts per step
+(bench.py --gpus N reports them as exchange_ms).  W = 1 is the unsharded evaluation (bench.Job.step).
+    python tools/wikidata_shard_model.py [workload ...]"""
+import os
+import sys
+import time
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from blp_amd import ops
-import bench
+import bench  # noqa: E402
+from blp_amd import ops, ranking  # noqa: E402
+
 dev = torch.device("cuda", 0)
-for name in ("wikidata5m-transe", "wikidata5m-transe-block"):
-    cfg = bench.WORKLOADS[name]
-    table, rel_w, heads, tails, rels = bench.make_data(cfg, dev)
-    q_fixed, q_rel, true_row = bench.build_queries(table, rel_w, heads, tails, rels)
-    Tall, N, blk = heads.shape[0], table.shape[0], min(cfg["block"], heads.shape[0])
-    passes = (Tall + blk - 1) // blk
-    q_true_all = table[true_row].contiguous()
-    blocks = []
-    for i in range(passes):  # (q_fixed, q_rel, q_true) of block i: its head-replacing queries, then its tail-replacing ones
-        sl = torch.cat((torch.arange(i * blk, min((i + 1) * blk, Tall)), Tall + torch.arange(i * blk, min((i + 1) * blk, Tall)))).to(dev)
-        blocks.append((q_fixed[sl].contiguous(), q_rel[sl].contiguous(), q_true_all[sl].contiguous()))
-    T = blk
-    out = torch.empty((passes, 2 * T, 4), dtype=torch.int32, device=dev)
-    def timeit(fn, n=5):
-        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(n): fn()
-        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+
+
+def timeit(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for name in (sys.argv[1:] or ["wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-block"]):
+    job = bench.Job(name, dev)
+    cfg, T, N, blk = job.cfg, job.T, job.N, min(job.cfg["block"], job.T)
+    passes = (T + blk - 1) // blk
+    rel_w = job.model.rel_emb.weight.detach()
+    unsharded = timeit(lambda: job.step(True))
+    print(f"{name}: unsharded evaluation (bench.Job.step) {unsharded:8.3f} ms per step ({unsharded / passes * 1e3:7.1f} us per table pass)", flush=True)
     base = None
     for W in (1, 2, 4, 8):
-        shard = table[: (N + W - 1) // W]
-        def step():
-            for i, (qf, qr, qt) in enumerate(blocks):
-                ops.rank_all("transe", shard, qf, qr, qf.shape[0] // 2, q_true=qt, out=out[i, : qf.shape[0]])
+        lo, hi = ranking.shard_bounds(N, W, 0)
+        shard = job.table[lo:hi]
+
+        def step():  # rank 0's share of ranking.rank_triples(axis="candidate"), collectives left out
+            source = ops.gather_triple_vectors(job.triples, job.ent2idx, shard, row_base=lo) if W > 1 else job.table
+            if W > 1:  # (what the all-reduce leaves: here the vectors of the rows this shard does not own stay zero)
+                source = torch.cat((job.table[job.triples[:, 0]], job.table[job.triples[:, 1]])) if step.exact else source
+            qb = ops.build_queries(job.triples, job.ent2idx, source, rel_w, blk, index=job.index, gather=False, row_base=lo,
+                                   by_position=W > 1, num_rows=N)
+            counts = torch.empty((2 * T, 4), dtype=torch.int32, device=dev)
+            for start in range(0, T, blk):
+                b = min(blk, T - start)
+                sl = slice(2 * start, 2 * (start + b))
+                seg = qb.filter._replace(seg_lo=qb.filter.seg_lo[sl], seg_hi=qb.filter.seg_hi[sl], exclude=qb.filter.exclude[sl])
+                ops.rank_all_shard(cfg["model"], shard, source, qb.fixed_row[sl], rel_w, qb.rel_ids[sl], b, qb.true_row[sl],
+                                   filter=seg, out=counts[sl])
+            return ops.rank_metric_sums(counts)
+
+        step.exact = False  # timing: the owner-filled array as it is (same kernels, same traffic)
         ms = timeit(step)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        ms_graph = timeit(graph.replay)
-        base = base or (ms, ms_graph)
-        print(f"{name} W={W}: eager {ms:8.3f} ms per step ({ms / passes * 1e3:7.1f} us per table pass) {base[0] / ms:.2f}x   "
-              f"hipGraph replay {ms_graph:8.3f} ms ({ms_graph / passes * 1e3:7.1f} us per pass) {base[1] / ms_graph:.2f}x", flush=True)
-        del graph
-    del table, q_true_all, blocks
+        base = base or ms
+        print(f"{name} W={W}: {ms:8.3f} ms per step ({ms / passes * 1e3:7.1f} us per table pass)  {base / ms:.2f}x of W=1,  "
+              f"{unsharded / ms:.2f}x of the unsharded evaluation", flush=True)
+    del job
     torch.cuda.empty_cache()

@@ -133,7 +133,7 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
     train_ent = set(train_data.entities.tolist())
     if dataset != 'Wikidata5M':
         graph = utils.FilterIndex(torch.cat((train_data.triples, valid_data.triples, test_data.triples)),
-                                  num_relations=train_data.rel_categories.shape[0])
+                                  num_relations=train_data.rel_categories.shape[0], device=device)
         train_val_ent = set(valid_data.entities.tolist()).union(train_ent)
         train_val_test_ent = set(test_data.entities.tolist()).union(train_val_ent)
         val_new_ents = train_val_ent.difference(train_ent)
@@ -204,12 +204,12 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
         net.load_state_dict(torch.load(checkpoint_file))
 
     if dataset == 'Wikidata5M':
-        graph = utils.FilterIndex(valid_data.triples, num_relations=train_data.rel_categories.shape[0])
+        graph = utils.FilterIndex(valid_data.triples, num_relations=train_data.rel_categories.shape[0], device=device)
     _log.info('Evaluating on validation set (with filtering)')
     eval_link_prediction(net, valid_loader, train_data, train_val_ent, max_epochs + 1, emb_batch_size, _run, _log,
                          prefix='valid', filtering_graph=graph, new_entities=val_new_ents, device=device)
     if dataset == 'Wikidata5M':
-        graph = utils.FilterIndex(test_data.triples, num_relations=train_data.rel_categories.shape[0])
+        graph = utils.FilterIndex(test_data.triples, num_relations=train_data.rel_categories.shape[0], device=device)
     _log.info('Evaluating on test set')
     _, ent_emb = eval_link_prediction(net, test_loader, train_data, train_val_test_ent, max_epochs + 1,
                                       emb_batch_size, _run, _log, prefix='test', filtering_graph=graph,
