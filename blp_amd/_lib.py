@@ -135,9 +135,9 @@ def _load(path, hooks):
     L.blp_rank_all_shard.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
                                      ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
     L.blp_rank_all_batches_workspace_bytes.restype = _sz
-    L.blp_rank_all_batches_workspace_bytes.argtypes = [_i, _i64, _i, _i64, _i64]
+    L.blp_rank_all_batches_workspace_bytes.argtypes = [_i, _i64, _i, _i64, _i64, _i64]
     L.blp_rank_all_batches.restype = _i
-    L.blp_rank_all_batches.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
+    L.blp_rank_all_batches.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64,
                                        ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
     L.blp_gather_triple_vectors.restype = _i
     L.blp_gather_triple_vectors.argtypes = [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _i, _vp]

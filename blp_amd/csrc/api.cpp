@@ -295,17 +295,17 @@ int blp_rank_all_shard(int model, const float* table, int64_t N, int D, int64_t 
                             workspace_bytes, device, stream);
 }
 
-size_t blp_rank_all_batches_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch) {
-    if (!valid_model(model) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0) return 0;
-    return blp::rank_all_batches_workspace_bytes(model, D, N, n_triples, batch);
+size_t blp_rank_all_batches_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch, int64_t block_triples) {
+    if (!valid_model(model) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
+    return blp::rank_all_batches_workspace_bytes(model, D, N, n_triples, batch, block_triples);
 }
 
 int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_t ld, const float* source, int64_t S,
                          int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, int64_t R, const int64_t* rel_id,
-                         const int64_t* true_row, int64_t n_triples, int64_t batch, const blp_filter* filter, int32_t* counts,
-                         void* workspace, size_t workspace_bytes, int device, void* stream) {
+                         const int64_t* true_row, int64_t n_triples, int64_t batch, int64_t block_triples, const blp_filter* filter,
+                         int32_t* counts, void* workspace, size_t workspace_bytes, int device, void* stream) {
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: unknown model %d", model);
-    if (n_triples < 0 || batch <= 0 || N < 0 || ld < D)
+    if (n_triples < 0 || batch <= 0 || block_triples < 0 || N < 0 || ld < D)
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: bad sizes (n_triples=%lld batch=%lld N=%lld)", (long long)n_triples,
                     (long long)batch, (long long)N);
     if (n_triples == 0) return BLP_OK;
@@ -327,7 +327,7 @@ int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_
         spec.ent2idx = filter->ent2idx; spec.ent2idx_len = filter->ent2idx ? filter->ent2idx_len : 0;
         spec.row_base = filter->row_base;
     }
-    const size_t need = blp::rank_all_batches_workspace_bytes(model, D, N, n_triples, batch);
+    const size_t need = blp::rank_all_batches_workspace_bytes(model, D, N, n_triples, batch, block_triples);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail(BLP_ERR_WORKSPACE, "blp_rank_all_batches: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", need,
                     workspace_bytes);
@@ -336,7 +336,7 @@ int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_
     int cu = 0;
     if (int rc = compute_units(device, &cu)) return rc;
     hipError_t err = blp::launch_rank_all_batches(model, D, table, N, ld, source, ld_src, fixed_row, rel_emb, rel_id, true_row, n_triples,
-                                                  batch, spec, counts, workspace, cu, static_cast<hipStream_t>(stream));
+                                                  batch, block_triples, spec, counts, workspace, cu, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all_batches launch");
     return BLP_OK;
 }

@@ -179,30 +179,46 @@ __global__ __launch_bounds__(256) void unpermute_counts_kernel(BatchPerm pm, con
     counts[pm.blocked(j)] = permuted[j];
 }
 
-constexpr int64_t kBatchesSuper = 65536;  // triples ranked as one block (the block size of blp_amd.ranking)
-static int64_t batches_super(int64_t n, int64_t batch) {
+constexpr int64_t kBatchesSuper = 65536;  // triples ranked as one block by default (the block size of blp_amd.ranking)
+// triples per ranking pass: whole batches, up to block_triples (0: kBatchesSuper) -- at least one batch
+static int64_t batches_super(int64_t n, int64_t batch, int64_t block_triples) {
     if (n <= batch) return n;
-    const int64_t s = kBatchesSuper / batch * batch;
+    const int64_t want = block_triples > 0 ? block_triples : kBatchesSuper;
+    const int64_t s = want / batch * batch;
     return s >= batch ? s : batch;
 }
 
-size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch) {
+size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples) {
     if (n <= 0 || batch <= 0) return 0;
-    const int64_t m = batches_super(n, batch) < n ? batches_super(n, batch) : n;
+    const int64_t super = batches_super(n, batch, block_triples), m = super < n ? super : n;
     const size_t inner = rank_all_workspace_bytes(model, D, N, m, m);
-    if (n <= batch) return inner;  // one batch: already [heads | tails]
+    if (super <= batch) return inner;  // a pass per batch: every batch is [heads | tails] already
     return (inner + 255) / 256 * 256 + (size_t)(6 * 2 * m) * 8 + (size_t)(2 * m) * 16;
 }
 
 hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t N, int64_t ld, const float* source, int64_t ld_src,
                                    const int64_t* fixed_row, const float* rel_emb, const int64_t* rel_id, const int64_t* true_row,
-                                   int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts, void* workspace, int n_cu,
-                                   hipStream_t stream) {
+                                   int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter, int32_t* counts,
+                                   void* workspace, int n_cu, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (n <= batch)
-        return launch_rank_all(model, D, table, N, ld, QRows::rows_of(source, fixed_row, ld_src), QRows::rows_of(rel_emb, rel_id, D),
-                               rel_id, QRows::rows_of(source, true_row, ld_src), n, n, filter, counts, workspace, n_cu, stream);
-    const int64_t super = batches_super(n, batch);
+    const int64_t super = batches_super(n, batch, block_triples);
+    if (super <= batch) {  // one ranking pass per batch, as the reference's loop runs them: slices of the loop's layout
+        for (int64_t t0 = 0; t0 < n; t0 += batch) {
+            const int64_t m = n - t0 < batch ? n - t0 : batch, q0 = 2 * t0;
+            FilterSpec f = filter;
+            if (filter.on()) {
+                f.lo = filter.lo + q0;
+                f.hi = filter.hi + q0;
+                f.exclude = filter.exclude ? filter.exclude + q0 : nullptr;
+            }
+            const hipError_t err = launch_rank_all(model, D, table, N, ld, QRows::rows_of(source, fixed_row + q0, ld_src),
+                                                   QRows::rows_of(rel_emb, rel_id + q0, D), rel_id + q0,
+                                                   QRows::rows_of(source, true_row + q0, ld_src), m, m, f, counts + 4 * q0, workspace,
+                                                   n_cu, stream);
+            if (err != hipSuccess) return err;
+        }
+        return hipSuccess;
+    }
     const int64_t m_max = super < n ? super : n;
     const size_t inner = (rank_all_workspace_bytes(model, D, N, m_max, m_max) + 255) / 256 * 256;
     int64_t* perm = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + inner);

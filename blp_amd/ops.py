@@ -200,12 +200,14 @@ def rank_all_shard(rel_model, table, source, fixed_row, rel_emb, rel_ids, q_head
     return counts
 
 
-def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, num_triples, batch, filter=None, out=None, source=None):
+def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, num_triples, batch, filter=None, out=None, source=None,
+                     block_triples=0):
     """Every batch of the reference's evaluation loop in ONE call (blp_rank_all_batches): fixed_row / rel_ids / true_row
     (2 num_triples,), a SegmentFilter's seg_lo / seg_hi / exclude and the returned counts (2 num_triples, 4) are laid out
     batch after batch of ``batch`` triples, each batch as [its head queries | its tail queries] -- build_queries'
     layout with block_size = batch, i.e. what a loop over the reference's DataLoader sees.  Same counts as one
-    rank_all_idx call per batch; the library ranks 65 536 triples at a time."""
+    rank_all_idx call per batch; the library ranks ``block_triples`` triples at a time (0: 65 536; <= batch: one pass per
+    batch, the reference's own pass structure, issued back to back by the library)."""
     source = table if source is None else source
     _require_device(table, source, fixed_row, rel_emb, rel_ids, true_row)
     table, rel_emb = _f32_rows(table, "table"), _f32_rows(rel_emb, "rel_emb").contiguous()
@@ -223,7 +225,7 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
         return counts
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
-    ws_bytes = L.blp_rank_all_batches_workspace_bytes(model, N, D, n, int(batch))
+    ws_bytes = L.blp_rank_all_batches_workspace_bytes(model, N, D, n, int(batch), int(block_triples))
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     spec = None
     if filter is not None:
@@ -236,7 +238,8 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
                                            0 if seg[4] is None else seg[4].shape[0], int(filter.row_base)))
     status = L.blp_rank_all_batches(model, _ptr(table), N, D, table.stride(0) if N > 1 else D, _ptr(source), source.shape[0],
                                     source.stride(0) if source.shape[0] > 1 else D, _ptr(fixed_row), _ptr(rel_emb), rel_emb.shape[0],
-                                    _ptr(rel_ids), _ptr(true_row), n, int(batch), spec, _ptr(counts), _ptr(workspace), ws_bytes,
+                                    _ptr(rel_ids), _ptr(true_row), n, int(batch), int(block_triples), spec, _ptr(counts), _ptr(workspace),
+                                    ws_bytes,
                                     dev.index, _stream(dev))
     _lib.check(status, "blp_rank_all_batches")
     return counts

@@ -300,7 +300,8 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
 
     Everything runs on the table's device without a host round trip: the id lookups (train.py:134-135), the layout of
     the queries -- left as (vector row, relation) index pairs -- and the filter segments are one kernel
-    (ops.build_queries); a block is then ONE library call (blp_rank_all_shard: <= 8 launches, none of them torch's).
+    (ops.build_queries); the blocks are then ONE library call (blp_rank_all_batches: per block <= 8 launches, none of them
+    torch's).
     Collectives: candidate axis -- the vectors the queries are made of are replicated ONCE (the whole table by one
     all-gather when it is smaller than the 2T vectors of the triples, else those vectors by one all-reduce of an
     owner-filled array) and the (2T, 4) counts of every shard are combined by ONE all-gather + sum; query axis -- ONE
@@ -343,15 +344,11 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         qb = ops.build_queries(triples[mine], ent2idx, source, rel_w, block_size, index=index, gather=False, row_base=row_lo,
                                by_position=by_position, num_rows=num_entities)
         ids_ok = qb.ids_min >= 0
-        counts = torch.empty((2 * n, 4), dtype=torch.int32, device=device)
-        for start in range(0, n, block_size):
-            b = min(start + block_size, n) - start
-            sl = slice(2 * start, 2 * (start + b))
-            seg = qb.filter
-            if seg is not None:
-                seg = seg._replace(seg_lo=seg.seg_lo[sl], seg_hi=seg.seg_hi[sl], exclude=seg.exclude[sl])
-            ops.rank_all_shard(model.rel_model, table, source, qb.fixed_row[sl], rel_w, qb.rel_ids[sl], b, qb.true_row[sl],
-                               filter=seg, out=counts[sl])
+        # every block in ONE library call (blp_rank_all_batches with a ranking pass per block: the blocks are issued back to
+        # back by the library -- at the reference's Wikidata5M batching, 2 triples per table pass, a Python-level loop over
+        # the blocks costs as much host time per pass as the pass takes on a 1/8 shard)
+        counts = ops.rank_all_batches(model.rel_model, table, qb.fixed_row, rel_w, qb.rel_ids, qb.true_row, n, block_size,
+                                      filter=qb.filter, source=source, block_triples=block_size)
         if by_candidate:  # ONE all-gather for the whole set; the shards' counts add up exactly
             with _Stopwatch(timing, device):
                 gathered = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=device)

@@ -178,14 +178,17 @@ int blp_rank_all_shard(int model, const float *table, int64_t N, int D, int64_t 
  * of `batch` triples (the last may be short), each batch as [its head-replacing queries | its tail-replacing queries] --
  * exactly what blp_build_queries writes with block = batch.  fixed_row / rel_id / true_row / the filter's seg_lo, seg_hi,
  * exclude and `counts` (2 n_triples, 4) all use that layout; source / S / ld_src as in blp_rank_all_shard (source = table
- * for an unsharded table).  Inside, the queries are ranked as ONE block per 65 536 triples ([all heads | all tails]: the
- * throughput-bound kernels) and the counts scattered back: 3.1 ms instead of 827 calls x 29 us for the FB15k-237 test set.
- * Workspace: blp_rank_all_batches_workspace_bytes(model, N, D, n_triples, batch), 256-B aligned. */
-size_t blp_rank_all_batches_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch);
+ * for an unsharded table).  Inside, the queries are ranked as ONE block per block_triples triples (0 = the default, 65 536;
+ * whole batches; [all heads | all tails]: the throughput-bound kernels) and the counts scattered back: 3.1 ms instead of
+ * 827 calls x 29 us for the FB15k-237 test set.  block_triples <= batch keeps one ranking pass per batch -- the reference's
+ * own pass structure (one read of the table per eval_batch_size triples), issued back to back without a host round trip.
+ * Workspace: blp_rank_all_batches_workspace_bytes(model, N, D, n_triples, batch, block_triples), 256-B aligned. */
+size_t blp_rank_all_batches_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch, int64_t block_triples);
 int blp_rank_all_batches(int model, const float *table, int64_t N, int D, int64_t ld, const float *source, int64_t S,
                          int64_t ld_src, const int64_t *fixed_row, const float *rel_emb, int64_t R, const int64_t *rel_id,
-                         const int64_t *true_row, int64_t n_triples, int64_t batch, const blp_filter *filter, int32_t *counts,
-                         void *workspace, size_t workspace_bytes, int device, void *stream);
+                         const int64_t *true_row, int64_t n_triples, int64_t batch, int64_t block_triples,
+                         const blp_filter *filter, int32_t *counts, void *workspace, size_t workspace_bytes, int device,
+                         void *stream);
 
 /* Producer of `source` for big tables: out (2n, D) f32 contiguous, out[t] = the vector of triple t's head, out[n + t] = of
  * its tail (train.py:141-142's `ent_emb[heads]` / `ent_emb[tails]` for the whole set of triples), filled only for the

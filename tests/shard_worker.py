@@ -21,8 +21,9 @@ FREE_OPS = {"slice", "view", "reshape", "empty", "empty_strided", "alias", "deta
 
 
 class BlockLoopOps(TorchDispatchMode):
-    """Logs the aten ops dispatched while ops.rank_all_shard calls are being issued (the per-block loop) that are not
-    views / allocations -- every one of them would be a torch kernel (a copy included)."""
+    """Logs the aten ops dispatched while the blocks are being ranked (ops.rank_all_batches: one library call for all the
+    blocks of an evaluation) that are not views / allocations -- every one of them would be a torch kernel (a copy
+    included)."""
 
     def __init__(self):
         super().__init__()
@@ -61,7 +62,7 @@ def main():
 
     # (1) which aten ops run while the blocks are issued
     log = BlockLoopOps()
-    real = ops.rank_all_shard
+    real = ops.rank_all_batches
     calls = []
 
     def traced(*a, **k):
@@ -72,12 +73,12 @@ def main():
         finally:
             log.inside = False
 
-    ops.rank_all_shard = traced
+    ops.rank_all_batches = traced
     try:
         with log:
             ranking.rank_triples(model, shard, dev_triples, dev_e2i, index, **kw)
     finally:
-        ops.rank_all_shard = real
+        ops.rank_all_batches = real
     torch.cuda.synchronize()
 
     # (2) the device kernels of ONE block, from the profiler's trace of this process
@@ -100,7 +101,7 @@ def main():
         names = [f"profiler unavailable: {exc!r}"[:200]]
     source = "table" if N <= 2 * T else "vectors"
     print(json.dumps({"rank": rank, "counts_equal_single_process": equal, "ids_ok": bool(ok), "source": source,
-                      "blocks": len(calls), "torch_compute_ops_in_block_loop": sorted(set(log.seen)),
+                      "library_calls_for_all_blocks": len(calls), "torch_compute_ops_in_block_loop": sorted(set(log.seen)),
                       "kernels_per_block": per_block, "kernel_names": names}), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """Per-rank time of candidate-axis shards of the Wikidata5M-scale table on ONE GPU (no exchange), through the calls
 blp_amd.ranking.rank_triples makes on that axis (ops.gather_triple_vectors, ops.build_queries with the shard's row_base,
-one ops.rank_all_shard per block, ops.rank_metric_sums): the reference's eval batch (2 triples = 4 queries per table pass,
+ops.rank_all_batches with one ranking pass per block, ops.rank_metric_sums): the reference's eval batch (2 triples = 4 queries per table pass,
 64 passes per step), TransE and ComplEx, and the whole test set as one block -- against 1/W of the rows.  What a real run
 adds on top: one all-reduce of the (2T, D) query vectors and one all-gather of (2T, 4) int32 counts per step
 (bench.py --gpus N reports them as exchange_ms).  W = 1 is the unsharded evaluation (bench.Job.step).
@@ -46,13 +46,8 @@ for name in (sys.argv[1:] or ["wikidata5m-transe", "wikidata5m-complex", "wikida
                 source = torch.cat((job.table[job.triples[:, 0]], job.table[job.triples[:, 1]])) if step.exact else source
             qb = ops.build_queries(job.triples, job.ent2idx, source, rel_w, blk, index=job.index, gather=False, row_base=lo,
                                    by_position=W > 1, num_rows=N)
-            counts = torch.empty((2 * T, 4), dtype=torch.int32, device=dev)
-            for start in range(0, T, blk):
-                b = min(blk, T - start)
-                sl = slice(2 * start, 2 * (start + b))
-                seg = qb.filter._replace(seg_lo=qb.filter.seg_lo[sl], seg_hi=qb.filter.seg_hi[sl], exclude=qb.filter.exclude[sl])
-                ops.rank_all_shard(cfg["model"], shard, source, qb.fixed_row[sl], rel_w, qb.rel_ids[sl], b, qb.true_row[sl],
-                                   filter=seg, out=counts[sl])
+            counts = ops.rank_all_batches(cfg["model"], shard, qb.fixed_row, rel_w, qb.rel_ids, qb.true_row, T, blk, filter=qb.filter,
+                                          source=source, block_triples=blk)
             return ops.rank_metric_sums(counts)
 
         step.exact = False  # timing: the owner-filled array as it is (same kernels, same traffic)
