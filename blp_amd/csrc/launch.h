@@ -47,15 +47,6 @@ struct FilterSpec {
     __host__ __device__ bool on() const { return lo != nullptr; }
 };
 
-// Side streams for the exact paths' short chains (true keys + coefficients -> ranking kernel -> filter + finalize), used
-// when many small blocks are ranked back to back (blp_rank_all_batches with a pass per batch): the preparation of the
-// next block and the finalisation of the previous one run on their own streams NEXT TO the ranking kernels, which then
-// follow each other on the caller's stream with nothing in between.  Events order the three stages of a block.
-struct StageOverlap {
-    hipStream_t prep, fin;
-    hipEvent_t prep_done, main_done;
-};
-
 bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 
@@ -64,17 +55,14 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
                            const QRows q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
-                           hipEvent_t ev_stop = nullptr, const StageOverlap* overlap = nullptr);
-
-bool rank_all_takes_exact_chain(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
+                           hipEvent_t ev_stop = nullptr);
 
 // queries.hip: every batch of the reference's evaluation loop in one call (include/blp_hip.h: blp_rank_all_batches)
 size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples);
 hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t N, int64_t ld, const float* source, int64_t ld_src,
                                    const int64_t* fixed_row, const float* rel_emb, const int64_t* rel_id, const int64_t* true_row,
                                    int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter, int32_t* counts,
-                                   void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
-                                   hipEvent_t ev_stop = nullptr);
+                                   void* workspace, int n_cu, hipStream_t stream);
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,
                                uint8_t* hits, hipStream_t stream);

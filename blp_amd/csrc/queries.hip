@@ -188,66 +188,22 @@ static int64_t batches_super(int64_t n, int64_t batch, int64_t block_triples) {
     return s >= batch ? s : batch;
 }
 
-constexpr int kPassSlots = 3;  // a pass per batch: workspaces in flight (the next block's preparation, a ranking kernel, the previous block's finalisation)
-
-// Side streams and events of the calling thread for `device` (created on first use, kept for the life of the thread).
-struct PassStreams {
-    hipStream_t prep = nullptr, fin = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, prep_done[kPassSlots] = {}, main_done[kPassSlots] = {}, fin_done[kPassSlots] = {};
-    bool ok = false;
-};
-static PassStreams* pass_streams() {
-    thread_local PassStreams cache[16];
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return nullptr;
-    PassStreams& p = cache[device];
-    if (!p.ok) {
-        bool good = hipStreamCreateWithFlags(&p.prep, hipStreamNonBlocking) == hipSuccess &&
-                    hipStreamCreateWithFlags(&p.fin, hipStreamNonBlocking) == hipSuccess &&
-                    hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&p.join, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < kPassSlots && good; ++i)
-            good = hipEventCreateWithFlags(&p.prep_done[i], hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&p.main_done[i], hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&p.fin_done[i], hipEventDisableTiming) == hipSuccess;
-        if (!good) return nullptr;
-        p.ok = true;
-    }
-    return &p;
-}
-
 size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples) {
     if (n <= 0 || batch <= 0) return 0;
     const int64_t super = batches_super(n, batch, block_triples), m = super < n ? super : n;
     const size_t inner = rank_all_workspace_bytes(model, D, N, m, m);
-    if (super <= batch)  // a pass per batch: every batch is [heads | tails] already; kPassSlots passes in flight
-        return n > batch ? kPassSlots * ((inner + 255) / 256 * 256) : inner;
+    if (super <= batch) return inner;  // a pass per batch: every batch is [heads | tails] already
     return (inner + 255) / 256 * 256 + (size_t)(6 * 2 * m) * 8 + (size_t)(2 * m) * 16;
 }
 
 hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t N, int64_t ld, const float* source, int64_t ld_src,
                                    const int64_t* fixed_row, const float* rel_emb, const int64_t* rel_id, const int64_t* true_row,
                                    int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter, int32_t* counts,
-                                   void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    // (ev_start / ev_stop: blp_profile_next_rank_kernel -- they bracket the FIRST ranking pass of the call)
+                                   void* workspace, int n_cu, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int64_t super = batches_super(n, batch, block_triples);
     if (super <= batch) {  // one ranking pass per batch, as the reference's loop runs them: slices of the loop's layout
-        // Short exact chains (<= 4 + 4 queries against a long table, small blocks): the three stages of consecutive passes
-        // overlap on side streams, so that the ranking kernels follow each other on `stream` with nothing in between
-        // -- a 4-query pass over a 1/8 shard of the Wikidata5M table is 49 us of kernel inside 62 us of chain otherwise.
-        const int64_t m_last = n % batch ? n % batch : batch;
-        PassStreams* ps = nullptr;
-        if (n > batch && rank_all_takes_exact_chain(model, D, N, batch, batch) && rank_all_takes_exact_chain(model, D, N, m_last, m_last))
-            ps = pass_streams();
-        const size_t slot_bytes = (rank_all_workspace_bytes(model, D, N, batch < n ? batch : n, batch < n ? batch : n) + 255) / 256 * 256;
-        if (ps) {  // fork: the side streams start behind everything already queued on `stream`
-            (void)hipEventRecord(ps->fork, stream);
-            (void)hipStreamWaitEvent(ps->prep, ps->fork, 0);
-            (void)hipStreamWaitEvent(ps->fin, ps->fork, 0);
-        }
-        int64_t pass = 0;
-        for (int64_t t0 = 0; t0 < n; t0 += batch, ++pass) {
+        for (int64_t t0 = 0; t0 < n; t0 += batch) {
             const int64_t m = n - t0 < batch ? n - t0 : batch, q0 = 2 * t0;
             FilterSpec f = filter;
             if (filter.on()) {
@@ -255,26 +211,13 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
                 f.hi = filter.hi + q0;
                 f.exclude = filter.exclude ? filter.exclude + q0 : nullptr;
             }
-            const int slot = (int)(pass % kPassSlots);
-            StageOverlap ov;
-            if (ps) {
-                ov = StageOverlap{ps->prep, ps->fin, ps->prep_done[slot], ps->main_done[slot]};
-                if (pass >= kPassSlots) (void)hipStreamWaitEvent(ps->prep, ps->fin_done[slot], 0);  // the slot's previous user is done
-            }
-            void* ws = n > batch ? static_cast<char*>(workspace) + (size_t)slot * slot_bytes : workspace;
             const hipError_t err = launch_rank_all(model, D, table, N, ld, QRows::rows_of(source, fixed_row + q0, ld_src),
                                                    QRows::rows_of(rel_emb, rel_id + q0, D), rel_id + q0,
-                                                   QRows::rows_of(source, true_row + q0, ld_src), m, m, f, counts + 4 * q0, ws,
-                                                   n_cu, stream, t0 == 0 ? ev_start : nullptr, t0 == 0 ? ev_stop : nullptr,
-                                                   ps ? &ov : nullptr);
+                                                   QRows::rows_of(source, true_row + q0, ld_src), m, m, f, counts + 4 * q0, workspace,
+                                                   n_cu, stream);
             if (err != hipSuccess) return err;
-            if (ps) (void)hipEventRecord(ps->fin_done[slot], ps->fin);
         }
-        if (ps) {  // join: the caller's stream continues when the last finalisation is done
-            (void)hipEventRecord(ps->join, ps->fin);
-            (void)hipStreamWaitEvent(stream, ps->join, 0);
-        }
-        return hipGetLastError();
+        return hipSuccess;
     }
     const int64_t m_max = super < n ? super : n;
     const size_t inner = (rank_all_workspace_bytes(model, D, N, m_max, m_max) + 255) / 256 * 256;
@@ -293,8 +236,7 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
         }
         const hipError_t err = launch_rank_all(model, D, table, N, ld, QRows::rows_of(source, perm, ld_src),
                                                QRows::rows_of(rel_emb, perm + Q, D), perm + Q, QRows::rows_of(source, perm + 2 * Q, ld_src),
-                                               m, m, f, reinterpret_cast<int32_t*>(pcounts), workspace, n_cu, stream,
-                                               t0 == 0 ? ev_start : nullptr, t0 == 0 ? ev_stop : nullptr);
+                                               m, m, f, reinterpret_cast<int32_t*>(pcounts), workspace, n_cu, stream);
         if (err != hipSuccess) return err;
         unpermute_counts_kernel<<<blocks, 256, 0, stream>>>(pm, pcounts, reinterpret_cast<int4*>(counts));
     }

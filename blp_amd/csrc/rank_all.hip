@@ -673,40 +673,28 @@ template <int MODEL, int D>
 static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
                                 const QRows q_rel, const int64_t* q_rel_id, const QRows q_true,
                                 int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace,
-                                int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const StageOverlap* ov) {
+                                int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
     if (Q == 0) return hipSuccess;
-    // the three stages of the chain, each on its stream (all `stream` without an overlap): keys + coefficients, the ranking
-    // kernel, filter + finalize
-    const hipStream_t s_prep = ov ? ov->prep : stream, s_fin = ov ? ov->fin : stream;
-    auto prep_done = [&]() {
-        if (ov) { (void)hipEventRecord(ov->prep_done, s_prep); (void)hipStreamWaitEvent(stream, ov->prep_done, 0); }
-    };
-    auto main_done = [&]() {
-        if (ov) { (void)hipEventRecord(ov->main_done, stream); (void)hipStreamWaitEvent(s_fin, ov->main_done, 0); }
-    };
     if (rank_small_applicable(MODEL, D, N, q_head, q_tail)) {  // small block: 3 launches, no coefficient array
         const int slots = rank_small_slots(N);
         RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail, slots);
         const bool coef = rank_small_wants_coef(MODEL, D, N);
         // (tiles sharing slots -- more tiles than slots, the scalar-register kernel only -- add to zeroed counts)
         const bool shared_slots = coef && (N + kTileRows - 1) / kTileRows > slots;
-        launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, s_prep,
+        launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream,
                                   coef ? w.coef_head : nullptr, coef ? w.coef_tail : nullptr, shared_slots ? slots : 0);
-        prep_done();
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.coef_head, w.coef_tail, w.key_true, q_head,
                                                  q_tail, w.acc, n_cu, stream);
         if (err != hipSuccess) return err;
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-        main_done();
         return launch_filter_finalize(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter, w.acc, counts,
-                                      s_fin, slots);
+                                      stream, slots);
     }
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
-    launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, s_prep, w.coef_head,
+    launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
                               w.coef_tail);
-    prep_done();
 
     if (N > 0) {
         const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
@@ -756,20 +744,20 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                 (int)groups, q_chunk, q_rel_id, w.acc);
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
-    main_done();
+
     return launch_filter_finalize(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter, w.acc, counts,
-                                  s_fin);
+                                  stream);
 }
 
 template <int MODEL>
 static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
                                const QRows q_rel, const int64_t* q_rel_id, const QRows q_true,
                                int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace, int n_cu,
-                               hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const StageOverlap* ov) {
+                               hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define BLP_RANK_CASE(DD)                                                                              \
     case DD:                                                                                           \
         return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, \
-                                        filter, counts, workspace, n_cu, stream, ev_start, ev_stop, ov);
+                                        filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (D) {
         BLP_RANK_CASE(64)
         BLP_RANK_CASE(128)
@@ -780,23 +768,13 @@ static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld,
 #undef BLP_RANK_CASE
 }
 
-// true if a block of this shape takes the three-stage exact chain (keys + coefficients, ranking kernel, filter +
-// finalize) that a StageOverlap can spread over streams; the pre-pass paths keep their longer chains on one stream
-bool rank_all_takes_exact_chain(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
-    if (rank_small_applicable(model, D, N, q_head, q_tail)) return true;
-    return !rank_gemm_applicable(model, D, q_head, q_tail) && !rank_sad_wide_applicable(model, D, q_head, q_tail) &&
-           !rank_sad_applicable(model, D, N, q_head, q_tail) && (D == 64 || D == 128 || D == 256);
-}
-
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
                            const QRows q_fixed, const QRows q_rel, const int64_t* q_rel_id,
                            const QRows q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
-                           hipEvent_t ev_stop, const StageOverlap* ov) {
+                           hipEvent_t ev_stop) {
     const bool small = rank_small_applicable(model, D, N, q_head, q_tail);  // a small block: rank_small.hip, below
-    // (the pre-pass paths below keep their whole chain on `stream`: their preparation is not small next to the pass.
-    //  With an overlap they still have to respect the stage streams' ordering: their results are read after a join.)
     if (!small && rank_gemm_applicable(model, D, q_head, q_tail))
         return launch_rank_all_gemm(model, D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail,
                                     filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
@@ -808,10 +786,10 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
                                    counts, workspace, n_cu, stream, ev_start, ev_stop);
     // everything else: the exact f32 kernels (few queries, D = 256 bilinear, or the rank_kernel knob)
     switch (model) {
-    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop, ov);
-    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop, ov);
-    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop, ov);
-    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop, ov);
+    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     default:       return hipErrorInvalidValue;
     }
 }

@@ -136,11 +136,6 @@ def test_rank_all_batches_equals_per_batch_calls_and_oracle(oracle, model, N, T,
     dev_table, dev_rel, dev_e2i, dev_triples = table.cuda(), rel_w.cuda(), ent2idx.cuda(), triples.cuda()
     qb = ops.build_queries(dev_triples, dev_e2i, dev_table, dev_rel, batch, index=index, gather=False)
     got = ops.rank_all_batches(model, dev_table, qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, T, batch, filter=qb.filter)
-    if T // batch <= 1200:  # a ranking pass per batch, issued by the library (three passes' stages in flight on side streams)
-        for _ in range(2):
-            per_pass = ops.rank_all_batches(model, dev_table, qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, T, batch,
-                                            filter=qb.filter, block_triples=batch)
-            assert torch.equal(per_pass, got)
     # the loop a maintainer's patch of train.py:128-171 would run, first and last batches
     for start in list(range(0, T, batch))[:3] + list(range(0, T, batch))[-2:]:
         b = min(batch, T - start)
