@@ -335,8 +335,11 @@ int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
     int cu = 0;
     if (int rc = compute_units(device, &cu)) return rc;
+    hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;  // blp_profile_next_rank_kernel: the first ranking pass of this call
+    g_prof_start = g_prof_stop = nullptr;
     hipError_t err = blp::launch_rank_all_batches(model, D, table, N, ld, source, ld_src, fixed_row, rel_emb, rel_id, true_row, n_triples,
-                                                  batch, block_triples, spec, counts, workspace, cu, static_cast<hipStream_t>(stream));
+                                                  batch, block_triples, spec, counts, workspace, cu, static_cast<hipStream_t>(stream),
+                                                  ev0, ev1);
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all_batches launch");
     return BLP_OK;
 }

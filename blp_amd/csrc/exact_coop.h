@@ -235,4 +235,17 @@ __device__ __forceinline__ void true_key_lane(const float* __restrict__ table, i
                              : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
 }
 
+// the same with the query's side given (the reference loop's layout, where the sides alternate batch by batch)
+template <int MODEL, int D>
+__device__ __forceinline__ void true_key_lane_side(const QRows& q_true, const QRows& q_fixed, const QRows& q_rel, int64_t q, bool head,
+                                                   float* __restrict__ key_true, unsigned long long* __restrict__ acc) {
+    acc[q] = 0;
+    float e[D];
+    load_row<D>(e, q_true.row(q));
+    const float* f = q_fixed.row(q);
+    const float* r = q_rel.row(q);
+    key_true[q] = head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, r})
+                       : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
+}
+
 }  // namespace blp

@@ -57,12 +57,20 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
                            hipEvent_t ev_stop = nullptr);
 
+// rank_all.hip: many passes of <= 4 + 4 queries back to back (one preparation and one finalisation launch for all of them)
+bool rank_static_passes_applicable(int model, int D, int64_t N, int64_t batch);
+size_t rank_static_passes_workspace_bytes(int D, int64_t n);
+hipError_t launch_rank_static_passes(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
+                                     const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts,
+                                     void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 // queries.hip: every batch of the reference's evaluation loop in one call (include/blp_hip.h: blp_rank_all_batches)
 size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples);
 hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t N, int64_t ld, const float* source, int64_t ld_src,
                                    const int64_t* fixed_row, const float* rel_emb, const int64_t* rel_id, const int64_t* true_row,
                                    int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter, int32_t* counts,
-                                   void* workspace, int n_cu, hipStream_t stream);
+                                   void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                                   hipEvent_t ev_stop = nullptr);
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,
                                uint8_t* hits, hipStream_t stream);

@@ -475,12 +475,20 @@ __device__ __forceinline__ unsigned long long sum_partials(const unsigned long l
 // query by a binary search in the scanned lengths.  Entries at or above the true entity are counted per query in
 // LDS; finally thread q writes query q's four counts.  (One wave per query, one lane per entry with its own
 // row-by-row loads: 127 us for the 105 740 queries of the FB15k-237 block, of which 9 % have an entry.)
+// Which side a query replaces: plain blocks -- queries [0, q_head) the head --, or the reference loop's layout
+// (blp_rank_all_batches: batch after batch of `batch` triples, each batch as [its head queries | its tail queries]).
+__host__ __device__ inline bool replaces_head(int64_t q, int64_t q_head, int64_t Q, int64_t batch) {
+    if (batch <= 0) return q < q_head;
+    const int64_t first = q / (2 * batch) * batch, n = Q / 2, nb = n - first < batch ? n - first : batch;
+    return q - 2 * first < nb;
+}
+
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void filter_finalize_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const QRows q_fixed,
     const QRows q_rel, const float* __restrict__ key_true, int64_t q_head,
     int64_t q_tail, const FilterSpec filter, const unsigned long long* __restrict__ acc, int n_partials,
-    int32_t* __restrict__ counts) {
+    int32_t* __restrict__ counts, int64_t batch) {
     __shared__ unsigned long long partial_sums[3][kSweepQueries];
     __shared__ int prefix[kSweepQueries + 1];
     __shared__ unsigned removed[kSweepQueries][2];
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             int64_t q = q_base < Q ? q_base : 0, row = -1;
             int slot = 0;
             if (x < total) locate(x, q, row, slot);
-            const bool live = row >= 0, head = q < q_head;
+            const bool live = row >= 0, head = replaces_head(q, q_head, Q, batch);
             const float key = transe_key_64<D>(table + (live ? row : 0) * ld, frow[slot], rrow[slot], head, slab, lane);
             const float kt = key_true[q];
             if (live && key > kt) atomicAdd(&removed[slot][0], 1u);
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             int64_t q = q_base < Q ? q_base : 0, row = -1;
             int slot = 0;
             if (x < total) locate(x, q, row, slot);
-            const bool live = row >= 0, head = q < q_head;
+            const bool live = row >= 0, head = replaces_head(q, q_head, Q, batch);
             const float* e = table + (live ? row : 0) * ld;
             float key;
             if (head) key = coop_score<MODEL, HEAD, D>(e, frow[slot], rrow[slot], sub);
@@ -669,6 +677,25 @@ size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
     return bytes;
 }
 
+// One ranking pass of <= 4 + 4 queries over the table (the reference's Wikidata5M eval batch): the streaming kernels of
+// rank_stream.hip, or rank_tiles<STATIC> where they do not apply (bilinear models at D = 256; knob stream_kernel = 2).
+// Coefficients, true keys and zeroed accumulators are the caller's.
+template <int MODEL, int D>
+static hipError_t launch_static_pass(const float* table, int64_t N, int64_t ld, const float* coef_head, const float* coef_tail,
+                                     const float* key_true, int q_head, int q_tail, unsigned long long* acc, int n_cu,
+                                     hipStream_t stream) {
+    if (knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(MODEL, D, N, ld, q_head, q_tail))
+        return launch_rank_stream(MODEL, D, table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, acc, n_cu, stream);
+    // one resident set of persistent workgroups that grid-stride over the tile quads with no barrier in the loop, so waves
+    // drift apart and one wave's arithmetic overlaps the others' loads
+    const int64_t n_tiles = (N + kTileRows - 1) / kTileRows, n_quads = (n_tiles + kWaves - 1) / kWaves;
+    const int64_t resident = (int64_t)n_cu * 3, groups = n_quads < resident ? n_quads : resident;
+    const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)2 * kQB * kMaxCoef(D) * 4 + (size_t)kWaves * 2 * kQueryChunk * 4;
+    rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)groups), kWaves * 64, lds, stream>>>(
+        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, (int)n_tiles, (int)groups, kQueryChunk, nullptr, acc);
+    return hipGetLastError();
+}
+
 template <int MODEL, int D>
 static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
                                 const QRows q_rel, const int64_t* q_rel_id, const QRows q_true,
@@ -730,15 +757,11 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                      (size_t)kWaves * 2 * kQueryChunk * 4;
 
         if (ev_start) (void)hipEventRecord(ev_start, stream);
-        if (static_mode && knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(MODEL, D, N, ld, q_head, q_tail)) {
-            const hipError_t err = launch_rank_stream(MODEL, D, table, N, ld, w.coef_head, w.coef_tail, w.key_true, q_head, q_tail,
-                                                      w.acc, n_cu, stream);
+        if (static_mode) {
+            const hipError_t err = launch_static_pass<MODEL, D>(table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head,
+                                                                (int)q_tail, w.acc, n_cu, stream);
             if (err != hipSuccess) return err;
-        } else if (static_mode)
-            rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
-                table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-                (int)groups, q_chunk, q_rel_id, w.acc);
-        else
+        } else
             rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
                 (int)groups, q_chunk, q_rel_id, w.acc);
@@ -809,9 +832,9 @@ template <int MODEL, int D>
 static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
                                        const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                        const FilterSpec& filter, const unsigned long long* acc, int n_partials,
-                                       int32_t* counts, hipStream_t stream) {
+                                       int32_t* counts, hipStream_t stream, int64_t batch = 0) {
     filter_finalize_kernel<MODEL, D><<<(int)((q_head + q_tail + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(
-        table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc, n_partials, counts);
+        table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc, n_partials, counts, batch);
     return hipGetLastError();
 }
 
@@ -849,6 +872,97 @@ hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t 
     }
     BLP_DISPATCH_MODEL_DIM(filter_finalize_impl, table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc,
                            n_partials, counts, stream)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Many passes of <= 4 + 4 queries each over one table, back to back (blp_rank_all_batches with a pass per batch: the
+// reference's Wikidata5M evaluation, eval_batch_size = 2 -- scripts/blp-*-wikidata5m.sh:18, train.py:128-171).  A pass
+// on its own is a chain of three launches (true keys + coefficients -> streaming kernel -> filter + finalize): on a 1/8
+// shard of the 4.6 M-row table the streaming kernel takes 49 us of a 62 us pass.  Here the first and the last stage are
+// done ONCE for all passes -- one launch writes every pass's coefficient rows (in the layout its streaming kernel reads),
+// every query's true key and zeroed accumulator; one launch at the end applies the filter and writes all counts -- and
+// the streaming kernels follow each other with nothing in between.  Queries in the reference loop's layout.
+template <int MODEL, int D>
+__global__ __launch_bounds__(64) void prep_passes_kernel(const QRows q_fixed, const QRows q_rel, const QRows q_true, int64_t n,
+                                                        int64_t batch, float* __restrict__ coef, float* __restrict__ key_true,
+                                                        unsigned long long* __restrict__ acc, unsigned key_blocks) {
+    using SH = Scorer<MODEL, HEAD, D>;
+    using ST = Scorer<MODEL, TAIL, D>;
+    constexpr int CP = SH::C + ST::C, CM = SH::C > ST::C ? SH::C : ST::C;  // floats per triple of a pass / widest row
+    const int64_t Q = 2 * n;
+    if (blockIdx.x < key_blocks) {  // one lane per query: its true key (all of its row loads in flight at once), acc = 0
+        const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        if (q < Q) true_key_lane_side<MODEL, D>(q_true, q_fixed, q_rel, q, replaces_head(q, 0, Q, batch), key_true, acc);
+        return;
+    }
+    for (int64_t i = (int64_t)(blockIdx.x - key_blocks) * 64 + threadIdx.x; i < Q * CM; i += (int64_t)(gridDim.x - key_blocks) * 64) {
+        const int64_t q = i / CM;
+        const int c = (int)(i - q * CM);
+        const int64_t first = q / (2 * batch) * batch, nb = n - first < batch ? n - first : batch, o = q - 2 * first;
+        float* pass = coef + first * CP;  // this pass: nb head rows of SH::C floats, then nb tail rows of ST::C
+        if (o < nb) {
+            if (c < SH::C) pass[o * SH::C + c] = SH::coef(q_fixed.row(q), q_rel.row(q), c);
+        } else if (c < ST::C) {
+            pass[nb * SH::C + (o - nb) * ST::C + c] = ST::coef(q_fixed.row(q), q_rel.row(q), c);
+        }
+    }
+}
+
+struct PassesWorkspace {
+    float* coef;
+    float* key_true;
+    unsigned long long* acc;
+    size_t bytes;
+};
+static PassesWorkspace carve_passes(void* base, int D, int64_t n) {
+    PassesWorkspace w;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    w.coef = reinterpret_cast<float*>(p + off);     off = align_up(off + (size_t)n * 2 * max_coef(D) * 4, 256);
+    w.key_true = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)n * 2 * 4, 256);
+    w.acc = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)n * 2 * 8, 256);
+    w.bytes = off;
+    return w;
+}
+
+bool rank_static_passes_applicable(int model, int D, int64_t N, int64_t batch) {
+    if (batch <= 0 || batch > kQB || N <= 0 || !(D == 64 || D == 128 || D == 256)) return false;
+    return !rank_small_applicable(model, D, N, batch, batch) && knob(KNOB_RANK_KERNEL) != 1;  // i.e. rank_all_impl's static mode
+}
+size_t rank_static_passes_workspace_bytes(int D, int64_t n) { return carve_passes(nullptr, D, n).bytes; }
+
+template <int MODEL, int D>
+static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
+                                     const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts,
+                                     void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    using SH = Scorer<MODEL, HEAD, D>;
+    using ST = Scorer<MODEL, TAIL, D>;
+    const PassesWorkspace w = carve_passes(workspace, D, n);
+    const int64_t Q = 2 * n, key_blocks = (Q + 63) / 64;
+    int64_t coef_blocks = (Q * (SH::C > ST::C ? SH::C : ST::C) + 63) / 64;
+    coef_blocks = coef_blocks > 8192 ? 8192 : coef_blocks;
+    prep_passes_kernel<MODEL, D><<<dim3((unsigned)(key_blocks + coef_blocks)), 64, 0, stream>>>(q_fixed, q_rel, q_true, n, batch, w.coef,
+                                                                                              w.key_true, w.acc, (unsigned)key_blocks);
+    for (int64_t first = 0; first < n; first += batch) {
+        const int nb = (int)(n - first < batch ? n - first : batch);
+        const float* coef_head = w.coef + first * (SH::C + ST::C);
+        if (first == 0 && ev_start) (void)hipEventRecord(ev_start, stream);
+        const hipError_t err = launch_static_pass<MODEL, D>(table, N, ld, coef_head, coef_head + (size_t)nb * SH::C, w.key_true + 2 * first,
+                                                            nb, nb, w.acc + 2 * first, n_cu, stream);
+        if (err != hipSuccess) return err;
+        if (first == 0 && ev_stop) (void)hipEventRecord(ev_stop, stream);
+    }
+    if (filter.on())
+        return filter_finalize_impl<MODEL, D>(table, N, ld, q_fixed, q_rel, w.key_true, n, n, filter, w.acc, 1, counts, stream, batch);
+    finalize_counts_kernel<<<(int)((Q + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(w.acc, 1, Q, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_static_passes(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
+                                     const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts,
+                                     void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    BLP_DISPATCH_MODEL_DIM(static_passes_impl, table, N, ld, q_fixed, q_rel, q_true, n, batch, filter, counts, workspace, n_cu, stream,
+                           ev_start, ev_stop)
 }
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,

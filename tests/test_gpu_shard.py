@@ -124,7 +124,8 @@ def test_candidate_axis_two_gloo_ranks_take_the_fused_path(model, N, T, block):
 
 
 @pytest.mark.parametrize("model,N,T,batch", [("transe", 2100, 1000, 64), ("distmult", 2100, 333, 50), ("complex", 40000, 7, 2),
-                                             ("simple", 900, 64, 64), ("transe", 300, 70001, 64)])
+                                             ("simple", 900, 64, 64), ("transe", 300, 70001, 64), ("transe", 70000, 9, 4),
+                                             ("distmult", 20000, 31, 3), ("simple", 17000, 5, 1)])
 def test_rank_all_batches_equals_per_batch_calls_and_oracle(oracle, model, N, T, batch):
     """blp_rank_all_batches: the reference's loop layout (train.py:128-157: eval_batch_size triples per batch, each batch
     [head queries | tail queries]) handed over in one call == one blp_rank_all_idx call per batch == the oracle, raw and
@@ -136,6 +137,12 @@ def test_rank_all_batches_equals_per_batch_calls_and_oracle(oracle, model, N, T,
     dev_table, dev_rel, dev_e2i, dev_triples = table.cuda(), rel_w.cuda(), ent2idx.cuda(), triples.cuda()
     qb = ops.build_queries(dev_triples, dev_e2i, dev_table, dev_rel, batch, index=index, gather=False)
     got = ops.rank_all_batches(model, dev_table, qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, T, batch, filter=qb.filter)
+    if T // batch <= 1200:  # a ranking pass per batch, issued by the library (<= 4 + 4 queries per pass against a long table:
+        for filt in (qb.filter, None):  # one preparation and one finalisation launch for all the passes)
+            per_pass = ops.rank_all_batches(model, dev_table, qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, T, batch,
+                                            filter=filt, block_triples=batch)
+            assert torch.equal(per_pass, got) if filt is not None else torch.equal(per_pass[:, :2], got[:, :2])
+            assert filt is not None or torch.equal(per_pass[:, 2:], per_pass[:, :2])
     # the loop a maintainer's patch of train.py:128-171 would run, first and last batches
     for start in list(range(0, T, batch))[:3] + list(range(0, T, batch))[-2:]:
         b = min(batch, T - start)
