@@ -272,51 +272,6 @@ __device__ __forceinline__ void score_batch_transe_sgpr(const float (&e)[D], boo
     }
 }
 
-// Head-replacing TransE queries whose relation ids are known: x = (e + r) - t, and e + r depends only on
-// (candidate, relation).  Whenever the relation id changes the wave re-fetches its tile and adds r in
-// place (exactly the reference's first rounding), after which every query of that relation costs the
-// two instructions per element of the tail side (|t - (e + r)| == |(e + r) - t| bit for bit) instead of
-// three.  Callers sort the block by relation (blp_amd.ranking does) so changes are rare; correctness
-// does not depend on the order.  Must run AFTER the tail queries of the tile (e is overwritten).
-template <int D>
-__device__ __forceinline__ void score_batch_transe_head_grouped(float (&e)[D], bool valid, const float* rows, int nq,
-                                                               const float* __restrict__ key_true,
-                                                               const int64_t* __restrict__ rel_id, unsigned* cnt,
-                                                               const float* __restrict__ table, int64_t N, int64_t ld,
-                                                               int64_t row0, float* slab, int wave, int lane) {
-    constexpr int C = 2 * D;  // coefficient row: r (D floats) then t (D floats)
-    if (nq <= 0) return;
-    int64_t cur_rel = rel_id[0] - 1;  // != rel_id[0]
-    bool pristine = true;
-    sf16 a = sload16<D * 4>(rows);    // chunk 0 of t of query 0
-    sdrain(a);
-    for (int j = 0; j < nq; ++j) {
-        const float* row = rows + (size_t)j * C;
-        const int64_t rid = rel_id[j];
-        if (rid != cur_rel) {
-            if (!pristine) load_tile<D, false>(e, table, N, ld, row0, slab, lane);
-            static_for<D / 16>([&](auto kk) {
-                constexpr int k = decltype(kk)::value;
-                sf16 r = sload16<k * 64>(row);
-                sdrain(r);
-                static_for<16>([&](auto ii) { e[16 * k + decltype(ii)::value] = e[16 * k + decltype(ii)::value] + r[decltype(ii)::value]; });
-            });
-            cur_rel = rid;
-            pristine = false;
-        }
-        const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * C;
-        const float* touch_row = ((j & 3) == wave && j + 3 < nq) ? rows + (size_t)(j + 3) * C : row;
-        const float key = transe_tail_sgpr<D>(e, a, row + D, next_row + D, touch_row + D);
-        const float kt = key_true[j];
-        const unsigned gt = __popcll(__ballot(valid && key > kt));
-        const unsigned ge = __popcll(__ballot(valid && key >= kt));
-        if (lane == 0) {
-            __hip_atomic_fetch_add(cnt + 2 * j, gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(cnt + 2 * j + 1, ge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-    }
-}
-
 // Score nq queries of one side against the wave's tile and add the two rank counts of each to the
 // wave's LDS counters.  USE_SGPR = false: coefficient rows are staged in LDS at `cur` (DppCoef).
 // USE_SGPR = true: `cur` is the wave-uniform global address of the rows, so the compiler fetches them
@@ -377,8 +332,9 @@ __device__ __forceinline__ void apply_queries(const float (&e)[D], bool valid, c
 // read as SGPR operands; the waves stream tiles independently, with no workgroup barrier in the loop.
 template <int MODEL, int D, bool STATIC>
 // TransE keeps D + ~35 VGPRs -> 3 waves/SIMD (fewer waves measured slower: 12.2 vs 9.9 ms); the bilinear
-// fallback needs 32 more accumulators -> 2 waves/SIMD.
-__global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_tiles_kernel(
+// fallback needs 32 more accumulators -> 2 waves/SIMD.  D = 256: a row alone is 256 registers -- one wave per SIMD and the
+// accumulator half of the unified register file instead of scratch memory (round 2: 51-732 spilled registers).
+__global__ __launch_bounds__(kWaves * 64, (D == 256 ? 1 : (MODEL == TRANSE ? 3 : 2))) void rank_tiles_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
     int n_tiles, int n_quad_groups, int q_chunk, const int64_t* __restrict__ q_rel_id,
@@ -420,11 +376,9 @@ __global__ __launch_bounds__(kWaves * 64, (MODEL == TRANSE ? 3 : 2)) void rank_t
         } else {
             if constexpr (MODEL == TRANSE) {  // scalar-cache coefficients, hand-pipelined (no barriers)
                 score_batch_transe_sgpr<TAIL, D>(e, valid, ct, t_hi - t_lo, key_true + t_lo, cnt + 2 * (t_lo - qa), wave, lane);
-                if (q_rel_id)  // relation ids known: e + r once per (tile, relation); overwrites e
-                    score_batch_transe_head_grouped<D>(e, valid, ch, h_hi - h_lo, key_true + h_lo, q_rel_id + h_lo,
-                                                       cnt + 2 * (h_lo - qa), table, N, ld, row0, slab, wave, lane);
-                else
-                    score_batch_transe_sgpr<HEAD, D>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), wave, lane);
+                // (until round 3 head queries of one relation could share e + r per tile through q_rel_id: the second copy
+                //  of the tile it kept cost this kernel 147 spilled registers for a case no caller of the package hits)
+                score_batch_transe_sgpr<HEAD, D>(e, valid, ch, h_hi - h_lo, key_true + h_lo, cnt + 2 * (h_lo - qa), wave, lane);
             } else {                          // LDS-staged coefficients + DPP broadcast
                 apply_queries<MODEL, HEAD, D>(e, valid, ch, key_true + h_lo, h_hi - h_lo, cbuf, cnt + 2 * (h_lo - qa), wave, lane);
                 apply_queries<MODEL, TAIL, D>(e, valid, ct, key_true + t_lo, t_hi - t_lo, cbuf, cnt + 2 * (t_lo - qa), wave, lane);

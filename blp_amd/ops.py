@@ -70,8 +70,8 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     true_row (Q,) int64 rows of the true entities in ``table``  -- or -- q_true (Q, D) their vectors
     (sharded ranking).  filt_rowptr (Q+1,), filt_col (nnz,) int64: CSR of filtered rows per query -- or --
     filter: a SegmentFilter (slices of a FilterIndex on the device; no per-batch list).
-    rel_ids (Q,) int64, optional: the relation id of each query (equal id => identical q_rel row); a
-    performance hint for TransE (sort the block by relation to benefit), never changes a result.
+    rel_ids (Q,) int64, optional: the relation id of each query (equal id => identical q_rel row); accepted for
+    compatibility and ignored (include/blp_hip.h: q_rel_id), never changes a result.
     Returns counts (Q, 4) int32: gt, ge, gt_filtered, ge_filtered.
     """
     _require_device(table, q_fixed, q_rel, true_row, q_true, filt_rowptr, filt_col, rel_ids)

@@ -82,10 +82,10 @@ int blp_dim_supported(int model, int D);
  *   q_fixed    (Q, D) f32  the entity kept fixed (tail_embs for head queries, head_embs for tail)
  *   q_rel      (Q, D) f32  rel_emb(rels)
  *   q_rel_id   (Q) int64   OPTIONAL (may be NULL) relation id of each query (`rels`, train.py:132).
- *                          Contract: queries with equal ids have identical q_rel rows.  Lets the
- *                          head-replacing TransE queries of one relation share e + r in the exact f32
- *                          kernel (2 instead of 3 VALU ops per element); sort the block by relation
- *                          to benefit.  Never changes a result; the pre-pass paths ignore it.
+ *                          Contract: queries with equal ids have identical q_rel rows.  Accepted and ignored since
+ *                          version 3.0.0 (rounds 1-2 let head-replacing TransE queries of one relation share e + r in
+ *                          the exact f32 kernel; the second tile copy cost that kernel its registers).  Never changed a
+ *                          result.
  *   true_row   (Q) int64   row of the true entity in `table` (true_ents, train.py:150), or NULL
  *   q_true     (Q, D) f32  the true entity's vector, used when true_row == NULL (candidate-axis
  *                          sharding: the true row may live in another shard).  Exactly one of

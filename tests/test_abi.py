@@ -141,3 +141,24 @@ def test_no_kernel_of_the_in_batch_loss_uses_scratch(built_lib):
         f = kernels[name]
         # (scalar registers parked in VGPR lanes -- sgpr_spill_count -- touch no memory and are not scratch)
         assert f["private_segment_fixed_size"] == 0 and f.get("vgpr_spill_count", 0) == 0, (name, f)
+
+
+def test_no_ranking_kernel_uses_scratch_memory(built_lib):
+    """Every kernel of the product library keeps its working set in registers (the accumulator half of the unified file
+    included: a non-zero vgpr_spill_count next to a zero private segment is parked there, not in memory) and LDS --
+    .private_segment_fixed_size == 0 in the gfx950 code objects' notes -- with ONE named exception: blp_score_fwd's
+    order-exact torch.sum at widths off the 32-grid (score_direct.h: torch_inner_sum_any keeps 128 partial sums in
+    scratch; the bilinear models' scripts never use such a width).  Round 2: rank_tiles_kernel<0,128,false> and every
+    D = 256 instantiation spilled 51-732 registers to scratch."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from blp_amd import build
+    kernels = kernel_resources.kernels_of(build.OBJ)
+    assert len(kernels) > 150
+    nice = dict(zip(kernels, kernel_resources.demangle(list(kernels))))
+    offenders = {nice[k]: f["private_segment_fixed_size"] for k, f in kernels.items()
+                 if f["private_segment_fixed_size"] != 0 and "score_fwd_kernel" not in nice[k]}
+    assert not offenders, offenders
+    exempt = [nice[k] for k, f in kernels.items() if f["private_segment_fixed_size"] != 0]
+    assert all("score_fwd_kernel<" in n and "score_fwd_kernel<0>" not in n for n in exempt), exempt
