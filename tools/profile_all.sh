@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out/r
-for w in ${WORKLOADS:-fb15k237-transe fb15k237-distmult fb15k237-complex fb15k237-simple fb15k237-transe-d768 wikidata5m-transe wikidata5m-transe-block}; do
+for w in ${WORKLOADS:-fb15k237-transe fb15k237-distmult fb15k237-complex fb15k237-simple fb15k237-transe-d768 wikidata5m-transe wikidata5m-complex wikidata5m-transe-block}; do
   mkdir -p gpurun_out/r/$w
   extra="--no-cpu-baseline"
   [ "$w" = "fb15k237-transe" ] && extra=""
