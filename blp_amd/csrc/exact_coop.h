@@ -223,7 +223,7 @@ __device__ __forceinline__ float coop_score(const float* __restrict__ e, const f
 // One lane's true-entity key (and its query's zeroed accumulator): the row in registers, all of its loads in flight at
 // once -- what a launch with few queries wants (rank_all.hip: true_key_lane_kernel; rank_gemm.hip: the bilinear prelude).
 template <int MODEL, int D>
-__device__ __forceinline__ void true_key_lane(const float* __restrict__ table, int64_t ld, const QRows q_true, const QRows& q_fixed, const QRows& q_rel,
+__device__ __forceinline__ void true_key_lane(const QRows& q_true, const QRows& q_fixed, const QRows& q_rel,
                                               int64_t q, int64_t q_head, float* __restrict__ key_true,
                                               unsigned long long* __restrict__ acc) {
     acc[q] = 0;

@@ -77,8 +77,7 @@ __global__ void prep_coef_kernel(const QRows q_fixed, const QRows q_rel,
 // The queries' accumulators start at zero.
 __host__ __device__ constexpr int true_key_queries_per_block(int model) { return model == TRANSE ? 64 : 4; }
 template <int MODEL, int D>
-__global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ table, int64_t ld,
-                                const QRows q_true,
+__global__ __launch_bounds__(64) void true_key_kernel(const QRows q_true,
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc) {
@@ -114,8 +113,7 @@ __global__ __launch_bounds__(64) void true_key_kernel(const float* __restrict__ 
 // query-side launches in one (a 4-query pass over a 1/8 shard of the Wikidata5M table is ~50 us of table read; every
 // launch of the chain is 4-5 us on top).
 template <int MODEL, int D>
-__global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restrict__ table, int64_t ld,
-                                const QRows q_true,
+__global__ __launch_bounds__(64) void true_key_lane_kernel(const QRows q_true,
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc, unsigned key_blocks,
@@ -142,13 +140,13 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const float* __restri
     }
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (q >= q_head + q_tail) return;
-    true_key_lane<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q, q_head, key_true, acc);
+    true_key_lane<MODEL, D>(q_true, q_fixed, q_rel, q, q_head, key_true, acc);
 }
 
 
 // True keys (and zeroed accumulators); with coef_head / coef_tail also the coefficient rows of the exact path.
 template <int MODEL, int D>
-static void launch_true_key(const float* table, int64_t ld, const QRows q_true, const QRows& q_fixed,
+static void launch_true_key(const QRows q_true, const QRows& q_fixed,
                             const QRows& q_rel, int64_t q_head, int64_t q_tail, float* key_true, unsigned long long* acc,
                             hipStream_t stream, float* coef_head = nullptr, float* coef_tail = nullptr, int64_t zero_slots = 0) {
     const int64_t Q = q_head + q_tail;
@@ -157,7 +155,7 @@ static void launch_true_key(const float* table, int64_t ld, const QRows q_true, 
         const int64_t key_blocks = (Q + 63) / 64, work = n_coef > zero_slots * Q ? n_coef : zero_slots * Q, want = (work + 63) / 64,
                       coef_blocks = want < 4096 ? want : 4096;
         true_key_lane_kernel<MODEL, D><<<(unsigned)(key_blocks + coef_blocks), 64, 0, stream>>>(
-            table, ld, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail,
+            q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail,
             zero_slots);
     } else {
         if (zero_slots > 1) (void)hipMemsetAsync(acc + Q, 0, (size_t)(zero_slots - 1) * Q * 8, stream);
@@ -167,7 +165,7 @@ static void launch_true_key(const float* table, int64_t ld, const QRows q_true, 
                                                                                                  coef_head, coef_tail);
         }
         constexpr int QB = true_key_queries_per_block(MODEL);
-        true_key_kernel<MODEL, D><<<(unsigned)((Q + QB - 1) / QB), 64, 0, stream>>>(table, ld, q_true, q_fixed, q_rel,
+        true_key_kernel<MODEL, D><<<(unsigned)((Q + QB - 1) / QB), 64, 0, stream>>>(q_true, q_fixed, q_rel,
                                                                                      q_head, q_tail, key_true, acc);
     }
 }
@@ -663,7 +661,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         const bool coef = rank_small_wants_coef(MODEL, D, N);
         // (tiles sharing slots -- more tiles than slots, the scalar-register kernel only -- add to zeroed counts)
         const bool shared_slots = coef && (N + kTileRows - 1) / kTileRows > slots;
-        launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream,
+        launch_true_key<MODEL, D>(q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream,
                                   coef ? w.coef_head : nullptr, coef ? w.coef_tail : nullptr, shared_slots ? slots : 0);
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         const hipError_t err = launch_rank_small(MODEL, D, table, N, ld, q_fixed, q_rel, w.coef_head, w.coef_tail, w.key_true, q_head,
@@ -674,7 +672,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                                       stream, slots);
     }
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
-    launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
+    launch_true_key<MODEL, D>(q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
                               w.coef_tail);
 
     if (N > 0) {
@@ -776,9 +774,9 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 // accumulators) and the filter / finalize step.  They read the query vectors directly: no coefficient array.
 template <int MODEL, int D>
 static hipError_t true_keys_impl(const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
-                                 const float* table, int64_t ld, const QRows q_true,
+                                 const QRows q_true,
                                  float* key_true, unsigned long long* acc, hipStream_t stream) {
-    launch_true_key<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, stream);
+    launch_true_key<MODEL, D>(q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, stream);
     return hipGetLastError();
 }
 
@@ -810,9 +808,9 @@ static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld
     }
 
 hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
-                            const float* table, int64_t ld, const QRows q_true,
+                            const QRows q_true,
                             float* key_true, unsigned long long* acc, hipStream_t stream) {
-    BLP_DISPATCH_MODEL_DIM(true_keys_impl, q_fixed, q_rel, q_head, q_tail, table, ld, q_true, key_true, acc, stream)
+    BLP_DISPATCH_MODEL_DIM(true_keys_impl, q_fixed, q_rel, q_head, q_tail, q_true, key_true, acc, stream)
 }
 
 hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,

@@ -84,7 +84,7 @@ constexpr int64_t kTrueKeyLaneMaxQueries = 2048;  // up to here true keys are on
 
 // rank_all.hip: true-entity keys by the exact routine (and the Q rank-count accumulators `acc` zeroed on the way)
 hipError_t launch_true_keys(int model, int D, const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
-                            const float* table, int64_t ld, const QRows q_true,
+                            const QRows q_true,
                             float* key_true, unsigned long long* acc, hipStream_t stream);
 
 // rank_small.hip: the exact f32 kernel for small blocks (coefficients computed in the kernel, LDS broadcasts, TransE

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void gemm_prelude_bf16_kernel(
     const int64_t q1 = head ? (q0 + kGQT < q_head ? q0 + kGQT : q_head) : (q0 + kGQT < q_head + q_tail ? q0 + kGQT : q_head + q_tail);
     for (int64_t i = q0 * words + threadIdx.x; i < q1 * words; i += 256) flags[i] = 0;
     if (true_keys && threadIdx.x >= 192 && q0 + (threadIdx.x - 192) < q1)  // (the last wave: kGQT = 32 of its lanes)
-        true_key_lane<MODEL, D>(table, ld, q_true, q_fixed, q_rel, q0 + (threadIdx.x - 192), q_head, key_true, acc);
+        true_key_lane<MODEL, D>(q_true, q_fixed, q_rel, q0 + (threadIdx.x - 192), q_head, key_true, acc);
     prep_query_tile_bf16<MODEL, D>(blockIdx.x, q_fixed, q_rel, q_head, q_tail, img_head, img_tail, eps_q, w_s);
 }
 
@@ -1111,7 +1111,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     const bool keys_in_prelude = !f32_kernel && Q <= kTrueKeyLaneMaxQueries;
     hipError_t err = hipSuccess;
     if (!keys_in_prelude)
-        err = launch_true_keys(MODEL, D, q_fixed, q_rel, q_head, q_tail, table, ld, q_true, w.key_true, w.acc, stream);
+        err = launch_true_keys(MODEL, D, q_fixed, q_rel, q_head, q_tail, q_true, w.key_true, w.acc, stream);
     if (err != hipSuccess) return err;
     const size_t lds_f32 = (size_t)gemm_buf_floats(D) * 4 + (size_t)kGTilesPerChunk * kGQT * 4 + (size_t)kGW * 32 * 4 +
                            (size_t)kPairQuota * 8 + 16;

@@ -567,7 +567,7 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
     SadWorkspace w = carve_sad(workspace, D, N, q_head, q_tail);
     // (the true keys of a small call folded into the range launch, one lane per query: tried -- 2 us slower from 256
     //  queries on, where this path starts)
-    hipError_t err = launch_true_keys(TRANSE, D, q_fixed, q_rel, q_head, q_tail, table, ld, q_true, w.key_true, w.acc,
+    hipError_t err = launch_true_keys(TRANSE, D, q_fixed, q_rel, q_head, q_tail, q_true, w.key_true, w.acc,
                                       stream);
     if (err != hipSuccess) return err;
     if (ev_start) (void)hipEventRecord(ev_start, stream);

@@ -74,7 +74,7 @@ __device__ __forceinline__ float transe_key_rt(const float* __restrict__ e, cons
     return -acc;
 }
 
-__global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restrict__ table, int64_t ld, int D,
+__global__ __launch_bounds__(256) void wide_true_key_kernel(int D,
                                                             const QRows q_fixed,
                                                             const QRows q_rel,
                                                             const QRows q_true, int64_t q_head, int64_t Q,
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void wide_true_key_kernel(const float* __restr
 // coalesced and compute the |differences| -- elementwise, any lane gets the reference's bits -- into LDS, and lane 0 adds
 // them up in the reference's order, left to right.
 constexpr int64_t kWTrueKeyWaveMaxQueries = 2048;
-__global__ __launch_bounds__(256) void wide_true_key_wave_kernel(const float* __restrict__ table, int64_t ld, int D,
+__global__ __launch_bounds__(256) void wide_true_key_wave_kernel(int D,
                                                                  const QRows q_fixed, const QRows q_rel,
                                                                  const QRows q_true, int64_t q_head, int64_t Q,
                                                                  float* __restrict__ key_true,
@@ -602,10 +602,10 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
     const int Dp = padded_width(D);
     WideWorkspace w = carve_wide(workspace, D, N, Q);
     if (Q <= kWTrueKeyWaveMaxQueries)
-        wide_true_key_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, q_true,
+        wide_true_key_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), 256, 0, stream>>>(D, q_fixed, q_rel, q_true,
                                                                                   q_head, Q, w.key_true, w.acc);
     else
-        wide_true_key_kernel<<<dim3((unsigned)((Q + 255) / 256)), 256, 0, stream>>>(table, ld, D, q_fixed, q_rel, q_true,
+        wide_true_key_kernel<<<dim3((unsigned)((Q + 255) / 256)), 256, 0, stream>>>(D, q_fixed, q_rel, q_true,
                                                                                    q_head, Q, w.key_true, w.acc);
     if (ev_start) (void)hipEventRecord(ev_start, stream);
     const int64_t n_tiles = (N + 63) / 64, query_blocks = (Q + 3) / 4;
