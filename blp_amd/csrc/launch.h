@@ -59,7 +59,7 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 
 // rank_all.hip: many passes of <= 4 + 4 queries back to back (one preparation and one finalisation launch for all of them)
 bool rank_static_passes_applicable(int model, int D, int64_t N, int64_t batch);
-size_t rank_static_passes_workspace_bytes(int D, int64_t n);
+size_t rank_static_passes_workspace_bytes(int D, int64_t n, int64_t batch);
 hipError_t launch_rank_static_passes(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
                                      const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts,
                                      void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);

@@ -194,7 +194,7 @@ size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, 
     const size_t inner = rank_all_workspace_bytes(model, D, N, m, m);
     if (super <= batch) {  // a pass per batch: every batch is [heads | tails] already
         if (n > batch && rank_static_passes_applicable(model, D, N, batch)) {
-            const size_t all = rank_static_passes_workspace_bytes(D, n);
+            const size_t all = rank_static_passes_workspace_bytes(D, n, batch);
             return all > inner ? all : inner;
         }
         return inner;

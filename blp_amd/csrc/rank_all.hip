@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include "../../include/blp_hip.h"  // BLP_METRIC_SUMS_DOUBLES
+#include "dot_band.h"
 #include "exact_coop.h"
 #include "knobs.h"
 #include "launch.h"
@@ -106,6 +107,45 @@ __global__ __launch_bounds__(64) void true_key_kernel(const QRows q_true,
     }
 }
 
+// The bilinear models' approximate keys (rank_stream.hip, DOT): the GEMM operand row W_q of one query and its two band
+// factors, by eight neighbouring lanes (`sub` = 0 .. 7; all eight must call).  row: where W_q goes (D floats); band2: eq =
+// C u ||B_q|| -- times ||e|| it bounds |<W_q, e> - S_ref| for any summation order, rank_gemm.hip's header -- and et = the
+// same bound for rows whose squares underflow (||e||^2 < 1e-30: every |e_k| <= 1.0001e-15, T <= ||B_q||_1 max |e_k|).
+template <int MODEL, int D>
+__device__ __forceinline__ void dot_prepare(const float* __restrict__ f, const float* __restrict__ r, bool head, bool live, int sub,
+                                            float* __restrict__ row, float* __restrict__ band2) {
+    float bsq = 0.f, bmax = 0.f, b1 = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i) {
+        float w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 32 * i + 4 * sub + c;
+            float b;
+            if (head) gemm_operand<MODEL, HEAD>(f, r, k, D, w[c], b);
+            else gemm_operand<MODEL, TAIL>(f, r, k, D, w[c], b);
+            bsq += b * b;
+            b1 += b;
+            bad |= !(b <= 3.0e38f);  // NaN too
+            bmax = b > bmax ? b : bmax;
+        }
+        if (live) *reinterpret_cast<float4*>(row + 32 * i + 4 * sub) = make_float4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        bsq += __shfl_xor(bsq, off);
+        b1 += __shfl_xor(b1, off);
+        const float m2 = __shfl_xor(bmax, off);
+        bmax = m2 > bmax ? m2 : bmax;
+        bad |= (bool)__shfl_xor((int)bad, off);
+    }
+    if (sub == 0 && live) {
+        band2[0] = kBandC * 5.9604645e-8f * band_norm(bsq, bad ? __builtin_inff() : bmax);
+        band2[1] = bad ? __builtin_inff() : kBandC * 5.9604645e-8f * 1.1e-15f * b1;
+    }
+}
+
 // Few queries: latency, not throughput, is what a true-key launch costs, and one lane per query with all 96 of its
 // row loads in flight at once is a single memory round trip (the cooperative kernel above walks four chunks one after
 // the other: 128-query call 40 -> 49 us when it replaced this one outright).  Same Scorer<> arithmetic, bit for bit.
@@ -117,17 +157,29 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const QRows q_true,
                                 const QRows q_fixed, const QRows q_rel,
                                 int64_t q_head, int64_t q_tail, float* __restrict__ key_true,
                                 unsigned long long* __restrict__ acc, unsigned key_blocks,
-                                float* __restrict__ coef_head, float* __restrict__ coef_tail, int64_t zero_slots) {
+                                float* __restrict__ coef_head, float* __restrict__ coef_tail, int64_t zero_slots,
+                                unsigned dot_blocks, float* __restrict__ wq, float* __restrict__ band) {
+    if (blockIdx.x >= gridDim.x - dot_blocks) {  // the last dot_blocks workgroups: eight queries' operand rows each (one pass)
+        if constexpr (MODEL != TRANSE) {
+            const int64_t Q = q_head + q_tail, qq = (blockIdx.x - (gridDim.x - dot_blocks)) * 8ll + (threadIdx.x >> 3);
+            const bool live = qq < Q;
+            const int64_t q = live ? qq : Q - 1;
+            dot_prepare<MODEL, D>(q_fixed.row(q), q_rel.row(q), q < q_head, live, threadIdx.x & 7, wq + stream_dot_row((int)q) * D,
+                                  band + 2 * q);
+        }
+        return;
+    }
     if (blockIdx.x >= key_blocks) {
         using SH = Scorer<MODEL, HEAD, D>;
         using ST = Scorer<MODEL, TAIL, D>;
         const int64_t n_head = q_head * SH::C, total = n_head + q_tail * ST::C;
         // (partial counts of slots 1 .. zero_slots - 1, for a kernel that ADDS to them; slot 0 = acc[q]: the key lanes)
+        const int64_t n_fill = gridDim.x - dot_blocks - key_blocks;
         for (int64_t i = (q_head + q_tail) + (blockIdx.x - key_blocks) * 64ll + threadIdx.x; i < zero_slots * (q_head + q_tail);
-             i += (gridDim.x - key_blocks) * 64ll)
+             i += n_fill * 64ll)
             acc[i] = 0;
         if (!coef_head) return;
-        for (int64_t i = (blockIdx.x - key_blocks) * 64ll + threadIdx.x; i < total; i += (gridDim.x - key_blocks) * 64ll) {
+        for (int64_t i = (blockIdx.x - key_blocks) * 64ll + threadIdx.x; i < total; i += n_fill * 64ll) {
             if (i < n_head) {
                 const int64_t q = i / SH::C;
                 coef_head[i] = SH::coef(q_fixed.row(q), q_rel.row(q), (int)(i % SH::C));
@@ -148,15 +200,16 @@ __global__ __launch_bounds__(64) void true_key_lane_kernel(const QRows q_true,
 template <int MODEL, int D>
 static void launch_true_key(const QRows q_true, const QRows& q_fixed,
                             const QRows& q_rel, int64_t q_head, int64_t q_tail, float* key_true, unsigned long long* acc,
-                            hipStream_t stream, float* coef_head = nullptr, float* coef_tail = nullptr, int64_t zero_slots = 0) {
+                            hipStream_t stream, float* coef_head = nullptr, float* coef_tail = nullptr, int64_t zero_slots = 0,
+                            float* wq = nullptr, float* band = nullptr) {
     const int64_t Q = q_head + q_tail;
     const int64_t n_coef = coef_head ? q_head * Scorer<MODEL, HEAD, D>::C + q_tail * Scorer<MODEL, TAIL, D>::C : 0;
     if (Q <= kTrueKeyLaneMaxQueries) {
         const int64_t key_blocks = (Q + 63) / 64, work = n_coef > zero_slots * Q ? n_coef : zero_slots * Q, want = (work + 63) / 64,
-                      coef_blocks = want < 4096 ? want : 4096;
-        true_key_lane_kernel<MODEL, D><<<(unsigned)(key_blocks + coef_blocks), 64, 0, stream>>>(
+                      coef_blocks = want < 4096 ? want : 4096, dot_blocks = wq ? (Q + 7) / 8 : 0;  // (wq: one pass, Q <= 8)
+        true_key_lane_kernel<MODEL, D><<<(unsigned)(key_blocks + coef_blocks + dot_blocks), 64, 0, stream>>>(
             q_true, q_fixed, q_rel, q_head, q_tail, key_true, acc, (unsigned)key_blocks, coef_head, coef_tail,
-            zero_slots);
+            zero_slots, (unsigned)dot_blocks, wq, band);
     } else {
         if (zero_slots > 1) (void)hipMemsetAsync(acc + Q, 0, (size_t)(zero_slots - 1) * Q * 8, stream);
         if (n_coef) {
@@ -601,8 +654,14 @@ struct RankWorkspace {
     float* coef_tail;
     float* key_true;
     unsigned long long* acc;
+    float* wq;    // one pass's operand rows + bands of the bilinear models' approximate keys (rank_stream.hip, DOT)
+    float* band;
     size_t bytes;
 };
+
+// floats of one pass's operand rows / bands (rank_common.h: StreamDot)
+constexpr size_t dot_rows_floats(int D) { return (size_t)kStreamDotRows * D; }
+constexpr size_t dot_band_floats() { return (size_t)2 * kStreamDotRows; }
 
 // partial_slots > 1: the small-block kernel's per-slot partial counts, partial_slots x Q accumulators
 static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t q_tail, int partial_slots = 1) {
@@ -615,6 +674,8 @@ static RankWorkspace carve_workspace(void* base, int D, int64_t q_head, int64_t 
     w.coef_tail = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)q_tail * max_coef(D) * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off);  off = align_up(off + (size_t)Q * 4, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off);   off = align_up(off + (size_t)Q * 8 * partial_slots, 256);
+    w.wq = reinterpret_cast<float*>(p + off);   off = align_up(off + dot_rows_floats(D) * 4, 256);
+    w.band = reinterpret_cast<float*>(p + off); off = align_up(off + dot_band_floats() * 4, 256);
     w.bytes = off;
     return w;
 }
@@ -634,10 +695,10 @@ size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int
 // Coefficients, true keys and zeroed accumulators are the caller's.
 template <int MODEL, int D>
 static hipError_t launch_static_pass(const float* table, int64_t N, int64_t ld, const float* coef_head, const float* coef_tail,
-                                     const float* key_true, int q_head, int q_tail, unsigned long long* acc, int n_cu,
-                                     hipStream_t stream) {
+                                     const float* key_true, int q_head, int q_tail, unsigned long long* acc, const StreamDot& dot,
+                                     int n_cu, hipStream_t stream) {
     if (knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(MODEL, D, N, ld, q_head, q_tail))
-        return launch_rank_stream(MODEL, D, table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, acc, n_cu, stream);
+        return launch_rank_stream(MODEL, D, table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, acc, dot, n_cu, stream);
     // one resident set of persistent workgroups that grid-stride over the tile quads with no barrier in the loop, so waves
     // drift apart and one wave's arithmetic overlaps the others' loads
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows, n_quads = (n_tiles + kWaves - 1) / kWaves;
@@ -672,8 +733,10 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                                       stream, slots);
     }
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
+    // <= 4 + 4 queries of a bilinear model: the streaming kernels take approximate keys first (operand rows + bands)
+    const bool dot_keys = q_head <= kQB && q_tail <= kQB && N > 0 && rank_stream_wants_dot(MODEL, D, N, ld, q_head, q_tail);
     launch_true_key<MODEL, D>(q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
-                              w.coef_tail);
+                              w.coef_tail, 0, dot_keys ? w.wq : nullptr, w.band);
 
     if (N > 0) {
         const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
@@ -710,8 +773,10 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
 
         if (ev_start) (void)hipEventRecord(ev_start, stream);
         if (static_mode) {
+            StreamDot dot;
+            if (dot_keys) { dot.wq = w.wq; dot.band = w.band; dot.q_fixed = q_fixed; dot.q_rel = q_rel; }
             const hipError_t err = launch_static_pass<MODEL, D>(table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head,
-                                                                (int)q_tail, w.acc, n_cu, stream);
+                                                                (int)q_tail, w.acc, dot, n_cu, stream);
             if (err != hipSuccess) return err;
         } else
             rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
@@ -837,7 +902,8 @@ hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t 
 template <int MODEL, int D>
 __global__ __launch_bounds__(64) void prep_passes_kernel(const QRows q_fixed, const QRows q_rel, const QRows q_true, int64_t n,
                                                         int64_t batch, float* __restrict__ coef, float* __restrict__ key_true,
-                                                        unsigned long long* __restrict__ acc, unsigned key_blocks) {
+                                                        unsigned long long* __restrict__ acc, unsigned key_blocks,
+                                                        unsigned dot_blocks, float* __restrict__ wq, float* __restrict__ band) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
     constexpr int CP = SH::C + ST::C, CM = SH::C > ST::C ? SH::C : ST::C;  // floats per triple of a pass / widest row
@@ -847,7 +913,18 @@ __global__ __launch_bounds__(64) void prep_passes_kernel(const QRows q_fixed, co
         if (q < Q) true_key_lane_side<MODEL, D>(q_true, q_fixed, q_rel, q, replaces_head(q, 0, Q, batch), key_true, acc);
         return;
     }
-    for (int64_t i = (int64_t)(blockIdx.x - key_blocks) * 64 + threadIdx.x; i < Q * CM; i += (int64_t)(gridDim.x - key_blocks) * 64) {
+    if (blockIdx.x >= gridDim.x - dot_blocks) {  // the approximate keys' operand rows, eight queries per workgroup
+        if constexpr (MODEL != TRANSE) {
+            const int64_t qq = (blockIdx.x - (gridDim.x - dot_blocks)) * 8ll + (threadIdx.x >> 3);
+            const bool live = qq < Q;
+            const int64_t q = live ? qq : Q - 1, pass = q / (2 * batch), o = q - pass * 2 * batch;  // query o of its pass
+            dot_prepare<MODEL, D>(q_fixed.row(q), q_rel.row(q), replaces_head(q, 0, Q, batch), live, threadIdx.x & 7,
+                                  wq + (pass * kStreamDotRows + stream_dot_row((int)o)) * D, band + 2 * q);
+        }
+        return;
+    }
+    const int64_t n_fill = gridDim.x - dot_blocks - key_blocks;
+    for (int64_t i = (int64_t)(blockIdx.x - key_blocks) * 64 + threadIdx.x; i < Q * CM; i += n_fill * 64) {
         const int64_t q = i / CM;
         const int c = (int)(i - q * CM);
         const int64_t first = q / (2 * batch) * batch, nb = n - first < batch ? n - first : batch, o = q - 2 * first;
@@ -864,15 +941,20 @@ struct PassesWorkspace {
     float* coef;
     float* key_true;
     unsigned long long* acc;
+    float* wq;    // per pass kStreamDotRows operand rows; two band factors per query (rank_stream.hip, DOT)
+    float* band;
     size_t bytes;
 };
-static PassesWorkspace carve_passes(void* base, int D, int64_t n) {
+static PassesWorkspace carve_passes(void* base, int D, int64_t n, int64_t batch) {
     PassesWorkspace w;
     char* p = static_cast<char*>(base);
+    const int64_t passes = batch > 0 ? (n + batch - 1) / batch : 0;
     size_t off = 0;
     w.coef = reinterpret_cast<float*>(p + off);     off = align_up(off + (size_t)n * 2 * max_coef(D) * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)n * 2 * 4, 256);
     w.acc = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)n * 2 * 8, 256);
+    w.wq = reinterpret_cast<float*>(p + off);       off = align_up(off + (size_t)passes * dot_rows_floats(D) * 4, 256);
+    w.band = reinterpret_cast<float*>(p + off);     off = align_up(off + (size_t)n * 2 * 2 * 4, 256);
     w.bytes = off;
     return w;
 }
@@ -881,7 +963,7 @@ bool rank_static_passes_applicable(int model, int D, int64_t N, int64_t batch) {
     if (batch <= 0 || batch > kQB || N <= 0 || !(D == 64 || D == 128 || D == 256)) return false;
     return !rank_small_applicable(model, D, N, batch, batch) && knob(KNOB_RANK_KERNEL) != 1;  // i.e. rank_all_impl's static mode
 }
-size_t rank_static_passes_workspace_bytes(int D, int64_t n) { return carve_passes(nullptr, D, n).bytes; }
+size_t rank_static_passes_workspace_bytes(int D, int64_t n, int64_t batch) { return carve_passes(nullptr, D, n, batch).bytes; }
 
 template <int MODEL, int D>
 static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
@@ -889,18 +971,26 @@ static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, 
                                      void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
-    const PassesWorkspace w = carve_passes(workspace, D, n);
+    const PassesWorkspace w = carve_passes(workspace, D, n, batch);
     const int64_t Q = 2 * n, key_blocks = (Q + 63) / 64;
     int64_t coef_blocks = (Q * (SH::C > ST::C ? SH::C : ST::C) + 63) / 64;
     coef_blocks = coef_blocks > 8192 ? 8192 : coef_blocks;
-    prep_passes_kernel<MODEL, D><<<dim3((unsigned)(key_blocks + coef_blocks)), 64, 0, stream>>>(q_fixed, q_rel, q_true, n, batch, w.coef,
-                                                                                              w.key_true, w.acc, (unsigned)key_blocks);
+    const bool dot_keys = rank_stream_wants_dot(MODEL, D, N, ld, batch, batch);
+    const int64_t dot_blocks = dot_keys ? (Q + 7) / 8 : 0;
+    prep_passes_kernel<MODEL, D><<<dim3((unsigned)(key_blocks + coef_blocks + dot_blocks)), 64, 0, stream>>>(
+        q_fixed, q_rel, q_true, n, batch, w.coef, w.key_true, w.acc, (unsigned)key_blocks, (unsigned)dot_blocks, w.wq, w.band);
     for (int64_t first = 0; first < n; first += batch) {
         const int nb = (int)(n - first < batch ? n - first : batch);
         const float* coef_head = w.coef + first * (SH::C + ST::C);
+        StreamDot dot;
+        if (dot_keys) {
+            dot.wq = w.wq + (first / batch) * dot_rows_floats(D);
+            dot.band = w.band + 2 * 2 * first;
+            dot.q_fixed = q_fixed; dot.q_rel = q_rel; dot.q0 = 2 * first;
+        }
         if (first == 0 && ev_start) (void)hipEventRecord(ev_start, stream);
         const hipError_t err = launch_static_pass<MODEL, D>(table, N, ld, coef_head, coef_head + (size_t)nb * SH::C, w.key_true + 2 * first,
-                                                            nb, nb, w.acc + 2 * first, n_cu, stream);
+                                                            nb, nb, w.acc + 2 * first, dot, n_cu, stream);
         if (err != hipSuccess) return err;
         if (first == 0 && ev_stop) (void)hipEventRecord(ev_stop, stream);
     }

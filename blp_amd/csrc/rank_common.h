@@ -106,9 +106,24 @@ hipError_t launch_rank_small(int model, int D, const float* table, int64_t N, in
 // wave's ring of 32-column pieces; bilinear models: a workgroup's double-buffered LDS tile).  The ranking pass only:
 // coefficients and true keys as for rank_tiles<STATIC>; adds to acc[q].
 bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail);
+// The bilinear models' approximate keys (rank_stream.hip, DOT): per pass kStreamDotRows operand rows W_q of D floats --
+// query q of the pass (heads first) in row stream_dot_row(q): the workgroup-tile kernel's wave w has queries w and w + 4
+// in neighbouring rows -- and two band factors per query, band[2 q] = C u ||B_q|| (times the row's norm) and
+// band[2 q + 1] = the absolute band against rows whose squares underflow; written by rank_all.hip's preparation launch
+// (dot_prepare).  wq == nullptr: order-exact keys only.  The ring kernel re-scores undecided pairs from the queries'
+// own vectors: query q of the pass is q0 + q of q_fixed / q_rel.
+constexpr int kStreamDotRows = 8;
+__host__ __device__ constexpr int stream_dot_row(int q) { return (q % 4) * 2 + q / 4; }
+struct StreamDot {
+    const float* wq = nullptr;
+    const float* band = nullptr;
+    QRows q_fixed, q_rel;
+    int64_t q0 = 0;
+};
+bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail);
 hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                              unsigned long long* acc, int n_cu, hipStream_t stream);
+                              unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream);
 
 // rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
 void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)

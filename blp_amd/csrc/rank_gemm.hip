@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "dot_band.h"
 #include "exact_coop.h"
 #include "knobs.h"
 #include "launch.h"
@@ -49,7 +50,6 @@ constexpr int kGQT = 32;            // queries per tile
 constexpr int kGCT = 32;            // candidates per tile
 constexpr int kGTilesPerChunk = 8;  // query tiles per workgroup
 constexpr int kGSlab = 36;          // dwords, transpose slab row stride
-constexpr float kBandC = 320.0f;    // error-band constant (see header)
 constexpr int kPairQuota = 32;      // undecided (query, candidate) pairs a workgroup can list
 constexpr unsigned kNoPair = 0xFFFFFFFFu;
 
@@ -59,31 +59,6 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // LDS floats shared by the two query-tile buffers and (before any staging) the transpose slabs.
 __host__ __device__ constexpr int gemm_buf_floats(int D) {
     return 2 * (D / 8) * 64 * 4 > kGW * kGCT * kGSlab ? 2 * (D / 8) * 64 * 4 : kGW * kGCT * kGSlab;
-}
-
-// GEMM operand w and its absolute bound b for element k of a query (f = the fixed entity, r = relation).
-template <int MODEL, int SIDE>
-__device__ __forceinline__ void gemm_operand(const float* __restrict__ f, const float* __restrict__ r, int k, int D,
-                                             float& w, float& b) {
-    const int H = D / 2, j = k < H ? k : k - H;
-    if constexpr (MODEL == DISTMULT) {
-        w = f[k] * r[k];
-        b = fabsf(w);
-    } else if constexpr (MODEL == COMPLEX) {
-        const float fr = f[j], fi = f[H + j], rr = r[j], ri = r[H + j];
-        float p, q;
-        if (SIDE == TAIL) {  // f = head:  re: rr*hr - ri*hi ; im: rr*hi + ri*hr
-            if (k < H) { p = rr * fr; q = ri * fi; w = p - q; } else { p = rr * fi; q = ri * fr; w = p + q; }
-        } else {             // f = tail:  re: rr*tr + ri*ti ; im: rr*ti - ri*tr
-            if (k < H) { p = rr * fr; q = ri * fi; w = p + q; } else { p = rr * fi; q = ri * fr; w = p - q; }
-        }
-        b = fabsf(p) + fabsf(q);
-    } else {  // SIMPLE: f = [f_head_role | f_tail_role], r = [ra | rb]
-        if (SIDE == TAIL) w = k < H ? r[H + j] * f[H + j] : f[j] * r[j];      // cand [th | tt]: rb*ht , hh*ra
-        else              w = k < H ? r[j] * f[H + j] : f[j] * r[H + j];      // cand [hh | ht]: ra*tt , th*rb
-        w = w * 0.5f;
-        b = fabsf(w);
-    }
 }
 
 // B-operand image of one 32-query tile: float4 index (g * 64 + l), l = 64-lane id, holds
@@ -321,13 +296,6 @@ constexpr int kBfMaxTilesPerChunk = 64;          // small cost model (see rank_g
 constexpr int kBfResident = 512;                 // workgroups the chip holds (2 per CU)
 constexpr int kBfSetupTiles = 5;                 // a workgroup's set-up, in query tiles of work
 constexpr int kBfQuotaPerTile = 8 * kBfTPW;      // undecided pairs a workgroup can list, per query tile of its chunk
-
-// band factor of a row from its norm / largest magnitude (see above); exact zero rows need no band
-__device__ __forceinline__ float band_norm(float sumsq, float maxabs) {
-    if (maxabs == 0.f) return 0.f;
-    if (!(maxabs >= 1e-18f && maxabs <= 3.0e38f)) return __builtin_inff();  // also NaN
-    return sqrtf(sumsq) * 1.0001f;  // overflow of sumsq gives inf: conservative
-}
 
 // (x0, x1) -> packed bf16 pairs hi, lo (x0 in the low half)
 __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {

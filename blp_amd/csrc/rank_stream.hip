@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dot_band.h"
+#include "exact_coop.h"
 #include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
@@ -235,11 +237,68 @@ __device__ __forceinline__ float score_sgpr_stream(const float (&e)[D], const fl
     return Scorer<MODEL, SIDE, D>::template score<false>(e, c);
 }
 
+// DOT (the bilinear models' default): a key is first taken as the plain dot product <W_q, e> -- one chain of D fused
+// multiply-adds against the query's GEMM operand row (dot_band.h; 128 VALU instructions where the reference's order
+// costs 512 - 790) -- and decided against the exact true key within the band of rank_gemm.hip's f32-chain kernel,
+// eps = C u ||B_q|| ||e|| with ||e|| from the same registers; only when a lane of the tile stays undecided (the true
+// entity itself, near-ties, non-finite values, magnitudes outside the band's premises) does the wave score the tile
+// with the order-exact routine as well, and those lanes count by that key.  Counts are the exact kernels' in every case.
+static_assert(kStreamDotRows == 2 * kStreamQ && kStreamQ == kWaves, "stream_dot_row pairs query w with query w + kWaves");
+struct DotBand {  // one query's band against a row of squared norm ss: see dot_prepare()
+    float kt, eq, et, guard;
+};
+__device__ __forceinline__ DotBand dot_band_of(const float* __restrict__ key_true, const float* __restrict__ band, int q) {
+    DotBand b;
+    b.kt = key_true[q];
+    b.eq = band[2 * q];
+    b.et = band[2 * q + 1];
+    b.guard = fabsf(b.kt) * 2.4e-7f + 1e-35f;  // rounding of kt +- eps themselves; underflowing products
+    return b;
+}
+// certainly above (gt) / certainly below (lt) the true key; neither: undecided.  nrow = ||e|| rounded up, tiny = the
+// squares underflow (every |e_k| <= 1.0001e-15: the band is the absolute one, et); premises broken (overflowing
+// magnitudes, NaN anywhere): eps = inf or NaN, both compares fail.
+__device__ __forceinline__ void dot_decide(float v, const DotBand& b, float nrow, bool tiny, bool& gt, bool& lt) {
+    float eps = tiny ? b.et : b.eq * nrow;
+    eps = eps < 1e30f ? eps + b.guard : __builtin_inff();
+    gt = v > b.kt + eps;
+    lt = v < b.kt - eps;
+#ifdef BLP_DOT_ALL_EXACT  // debugging aid: nothing is decided, every row takes the exact routine
+    gt = lt = false;
+#endif
+}
+
+// The undecided rows `und` (a lane mask) of the tile whose first row is row0, against one query (f, r: its two vectors;
+// kt: its true key), by coop_score -- 32 lanes per pair, the order-exact arithmetic of every other exact path, the row
+// re-read from the cache it has just passed through; two rows per trip, one per 32-lane half (the upper half without a
+// row of its own repeats the lower one's).  Returns the rows at or above the true key as gt | ge << 32.
 template <int MODEL, int D>
+__device__ __forceinline__ unsigned long long exact_undecided(const float* __restrict__ table, int64_t ld, int64_t row0,
+                                                              const float* f, const float* r, bool head,
+                                                              unsigned long long und, float kt, int lane) {
+    const bool upper = lane >= 32;
+    const int sub = lane & 31;
+    unsigned gt = 0, ge = 0;
+    while (und) {
+        const int r0 = __builtin_ctzll(und);
+        und &= und - 1;
+        int r1 = -1;
+        if (und) { r1 = __builtin_ctzll(und); und &= und - 1; }
+        const bool mine = sub == 0 && (!upper || r1 >= 0);
+        const float* e = table + (row0 + (upper && r1 >= 0 ? r1 : r0)) * ld;
+        const float key = head ? coop_score<MODEL, HEAD, D>(e, f, r, sub) : coop_score<MODEL, TAIL, D>(e, f, r, sub);
+        gt += __popcll(__ballot(mine && key > kt));
+        ge += __popcll(__ballot(mine && key >= kt));
+    }
+    return (unsigned long long)gt | ((unsigned long long)ge << 32);
+}
+
+template <int MODEL, int D, bool DOT>
 __global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
-    unsigned long long* __restrict__ acc) {
+    unsigned long long* __restrict__ acc, const float* __restrict__ wq, const float* __restrict__ band, const QRows q_fixed,
+    const QRows q_rel, int64_t q0) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
     constexpr int TS = D + 4;  // row stride of an LDS tile, floats
@@ -283,17 +342,52 @@ __global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
             e[4 * j] = w.x; e[4 * j + 1] = w.y; e[4 * j + 2] = w.z; e[4 * j + 3] = w.w;
         });
         const bool valid = (int64_t)t * kTileRows + lane < N;
-        static_for<2>([&](auto ss) {
-            constexpr int s = decltype(ss)::value;
-            const int q = qw + kWaves * s;
-            if (q < Q) {
-                const float key = q < q_head ? score_sgpr_stream<MODEL, HEAD, D>(e, coef_head + (size_t)q * SH::C)
-                                             : score_sgpr_stream<MODEL, TAIL, D>(e, coef_tail + (size_t)(q - q_head) * ST::C);
-                const float kt = key_true[q];
-                n_gt[s] += __popcll(__ballot(valid && key > kt));
-                n_ge[s] += __popcll(__ballot(valid && key >= kt));
-            }
-        });
+        if constexpr (DOT) {
+            // both queries' chains and the norm's in one walk over the row; the wave's two operand rows are neighbours
+            // in wq (dot_row) and come through one two-stream SGPR ring (a row the pass has no query for: never counted)
+            sf16 ring[2][2];
+            const SgprStreamCoef<D, 2, 16> c{wq + (size_t)stream_dot_row(qw) * D, ring};
+            c.template request<0>();
+            float v0 = 0.f, v1 = 0.f, ssq = 0.f;
+            static_for<D>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                v0 = __builtin_fmaf(e[k], c(ic<k>{}), v0);
+                v1 = __builtin_fmaf(e[k], c(ic<D + k>{}), v1);
+                ssq = __builtin_fmaf(e[k], e[k], ssq);
+            });
+            const float nrow = sqrtf(ssq) * 1.0001f;
+            const bool tiny = ssq < 1e-30f;
+            static_for<2>([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                const int q = qw + kWaves * s;
+                if (q < Q) {
+                    const DotBand b = dot_band_of(key_true, band, q);
+                    bool gt, lt;
+                    dot_decide(s ? v1 : v0, b, nrow, tiny, gt, lt);
+                    const unsigned long long above = __ballot(valid && gt), und = __ballot(valid && !(gt || lt));
+                    n_gt[s] += __popcll(above);
+                    n_ge[s] += __popcll(above);
+                    if (und) {  // wave-uniform, rare (about one (tile, query) in a hundred has an undecided row)
+                        const unsigned long long c = exact_undecided<MODEL, D>(table, ld, (int64_t)t * kTileRows, q_fixed.row(q0 + q),
+                                                                               q_rel.row(q0 + q), q < q_head, und, b.kt, lane);
+                        n_gt[s] += (unsigned)c;
+                        n_ge[s] += (unsigned)(c >> 32);
+                    }
+                }
+            });
+        } else {
+            static_for<2>([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                const int q = qw + kWaves * s;
+                if (q < Q) {
+                    const float key = q < q_head ? score_sgpr_stream<MODEL, HEAD, D>(e, coef_head + (size_t)q * SH::C)
+                                                 : score_sgpr_stream<MODEL, TAIL, D>(e, coef_tail + (size_t)(q - q_head) * ST::C);
+                    const float kt = key_true[q];
+                    n_gt[s] += __popcll(__ballot(valid && key > kt));
+                    n_ge[s] += __popcll(__ballot(valid && key >= kt));
+                }
+            });
+        }
     };
 
     // tiles t0, t0 + G, t0 + 2G, ...: in LDS tile i (buffer i & 1), in ring[(i + 1) & 1] tile i + 1, in ring[i & 1] tile i + 2
@@ -327,47 +421,258 @@ __global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
     }
 }
 
+// ---- the bilinear models on shorter tables: TransE's per-wave ring, approximate keys -----------------------------------
+// The dot product <W_q, e> can be summed in any order -- the band does not care -- so it CAN be carried across 32-column
+// pieces: the bilinear models take the ring kernel's structure (a wave's two pieces in flight across tile boundaries, the
+// pass ramps up and down in a few microseconds: what a 1/8 shard of the Wikidata5M table needs) with D fused multiply-adds
+// per (row, query) and D for the row's squared norm.  Undecided lanes (the true entity, near-ties, non-finite values:
+// about one (tile, query) in a hundred has one) are re-scored on the spot by coop_score -- 32 lanes per pair, the row
+// re-read from the cache it has just passed through, the order-exact arithmetic of every other exact path.
+// The operand rows through the scalar cache, loads issued by hand (left alone the compiler either hoists all NQ x D
+// loop-invariant values out of the tile loop and parks them in VGPR lanes -- a v_readlane per multiply-add -- or, once the
+// pointer is made opaque, falls back to per-lane vector loads): units of 16 columns of one query, the next unit requested
+// before the current one's 16 multiply-adds and drained after them (rank_common.h: sload16 / sdrain; scalar loads return
+// out of order, every wait is a full drain).  Unit u of piece S: query u / 2, columns 32 S + 16 (u % 2) ..; the unit after
+// a tile's last is the next tile's first.  `cur` holds the unit about to be used.
+// Both asm statements carry the unit's running sum as an operand: the request stands before the unit's first
+// multiply-add, the wait behind its last (volatile asm keeps its own order, not its place among the arithmetic --
+// unpinned, the compiler issues every request and wait of a piece up front and parks the values in VGPR lanes all the same).
+template <int OFF>
+__device__ __forceinline__ void sload16_pinned(sf16& v, const float* base, float& pin) {
+    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(v), "+v"(pin) : "s"(base), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin) : : "memory");
+}
+__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin, float& pin2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin), "+v"(pin2) : : "memory");
+}
+// (the squared norm's chain rides along with query 0's two units -- on its own it drifts behind the following pieces and
+//  keeps three pieces' columns alive)
+template <int D, int NQ, int S, int U>
+__device__ __forceinline__ void dot_units(float (&sum)[NQ], float& ssq, const float (&x)[kSubCols], const float* wq, sf16& cur) {
+    if constexpr (U < 2 * NQ) {
+        constexpr int NP = D / kSubCols;
+        constexpr int nu = (U + 1) % (2 * NQ), ns = U + 1 < 2 * NQ ? S : (S + 1) % NP;  // the unit after this one
+        constexpr int q = U / 2, c0 = 16 * (U % 2);
+        sf16 nxt;
+        sload16_pinned<(stream_dot_row(nu / 2) * D + ns * kSubCols + 16 * (nu % 2)) * 4>(nxt, wq, sum[q]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sum[q] = __builtin_fmaf(x[c0 + i], cur[i], sum[q]);
+            if constexpr (q == 0) ssq = __builtin_fmaf(x[c0 + i], x[c0 + i], ssq);
+        }
+        if constexpr (q == 0) sdrain_pinned(nxt, sum[q], ssq);
+        else sdrain_pinned(nxt, sum[q]);
+        cur = nxt;
+        dot_units<D, NQ, S, U + 1>(sum, ssq, x, wq, cur);
+    }
+}
+
+template <int MODEL, int D, int NQ>
+__global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_kernel(
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ wq, const float* __restrict__ band,
+    const float* __restrict__ key_true, const QRows q_fixed, const QRows q_rel, int64_t q0, int q_head, int q_tail,
+    int n_tiles, unsigned long long* __restrict__ acc) {
+    constexpr int NP = D / kSubCols;  // NQ: the pass has at most NQ queries (4: the reference's Wikidata5M batch of two triples)
+    static_assert(NP % 2 == 0, "the ring of two pieces assumes an even number of pieces per tile");
+    static_assert(NQ == 4 || NQ == 2 * kStreamQ, "a pass of up to 4, or up to 4 + 4, queries");
+    __shared__ __attribute__((aligned(16))) float slabs[kWaves * kSlabFloats];
+    __shared__ unsigned long long wg_cnt[NQ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Q = q_head + q_tail;  // the pass's queries, heads first: query q < Q is q0 + q of the call
+    float* slab = slabs + wave * kSlabFloats;
+    const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
+    float* wr = slab + sub_row * kLdsStride + sub_col;
+    const float* rd = slab + lane * kLdsStride;
+    if (tid < NQ) wg_cnt[tid] = 0;
+
+    const int stride = gridDim.x * kWaves;
+    int tile = blockIdx.x * kWaves + wave;
+    unsigned boff[8];
+    auto offsets = [&](int t) {
+        const int64_t left = N - (int64_t)t * kTileRows;
+        const int last = left < kTileRows ? (int)left - 1 : kTileRows - 1;  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * i + sub_row;
+            boff[i] = (unsigned)(((r < last ? r : last) * (int)ld + sub_col) * 4);
+        }
+    };
+    auto tile_base = [&](int t) { return table + (int64_t)t * kTileRows * ld; };
+
+    unsigned n_gt[NQ] = {};           // certainly above the true key (gt and ge alike): wave-uniform, scalar registers
+    unsigned long long ex_cnt = 0;    // lane q: query q's undecided rows at or above it, gt | ge << 32
+    f32x4 ring[2][8];
+    if (tile < n_tiles) {
+        offsets(tile);
+        piece_fetch(ring[0], tile_base(tile), boff, 0);
+        piece_fetch(ring[1], tile_base(tile), boff, 1);
+    }
+    sf16 cur = sload16<stream_dot_row(0) * D * 4>(wq);  // unit 0 of piece 0
+    sdrain(cur);
+    for (; tile < n_tiles; tile += stride) {
+        const int next = tile + stride;
+        const bool more = next < n_tiles;  // wave-uniform
+        const float* base = tile_base(tile);
+        float sum[NQ] = {}, ssq = 0.f;
+        static_for<NP>([&](auto ss) {
+            constexpr int s = decltype(ss)::value, p = s & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(wr + 8 * i * kLdsStride) = ring[p][i];
+            if constexpr (s + 2 < NP) {
+                piece_fetch(ring[p], base, boff, s + 2);
+            } else {
+                if constexpr (s + 2 == NP) {
+                    if (more) offsets(next);
+                }
+                if (more) piece_fetch(ring[p], tile_base(next), boff, s + 2 - NP);
+            }
+            wave_lds_sync();
+            float x[kSubCols];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rd + 4 * j);
+                x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+            }
+            wave_lds_sync();  // the reads are out before the next piece overwrites the slab
+            // (no branch per query: a slot the pass has no query for walks its -- unwritten -- operand row, never counted)
+            dot_units<D, NQ, s, 0>(sum, ssq, x, wq, cur);
+        });
+        const bool valid = (int64_t)tile * kTileRows + lane < N;
+        const float nrow = sqrtf(ssq) * 1.0001f;
+        const bool tiny = ssq < 1e-30f;
+        // lane q parks query q's undecided rows (a mask); the exact routine then runs once, over run-time q
+        unsigned und_lo = 0, und_hi = 0;
+        bool any_und = false;
+        static_for<NQ>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            if (q < Q) {
+                const DotBand b = dot_band_of(key_true, band, q);
+                bool gt, lt;
+                dot_decide(sum[q], b, nrow, tiny, gt, lt);
+                const unsigned long long above = __ballot(valid && gt), und = __ballot(valid && !(gt || lt));
+                n_gt[q] += __popcll(above);
+                if (lane == q) { und_lo = (unsigned)und; und_hi = (unsigned)(und >> 32); }
+                any_und |= und != 0;
+            }
+        });
+        if (any_und) {  // wave-uniform, rare (about one (tile, query) in a hundred has an undecided row)
+            for (int q = 0; q < Q; ++q) {
+                const unsigned long long und = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(und_lo, q) |  // (returns int)
+                                               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(und_hi, q) << 32);
+                if (!und) continue;
+                const unsigned long long c = exact_undecided<MODEL, D>(table, ld, (int64_t)tile * kTileRows, q_fixed.row(q0 + q),
+                                                                       q_rel.row(q0 + q), q < q_head, und, key_true[q], lane);
+                if (lane == q) ex_cnt += c;
+            }
+        }
+    }
+
+    __syncthreads();  // wg_cnt is zero
+    if (lane < NQ) {
+        unsigned above = 0;
+        static_for<NQ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if (lane == j) above = n_gt[j];
+        });
+        const unsigned long long v = ((unsigned long long)above | ((unsigned long long)above << 32)) + ex_cnt;
+        if (v) atomicAdd(&wg_cnt[lane], v);
+    }
+    __syncthreads();
+    if (tid < Q) {
+        const unsigned long long v = wg_cnt[tid];
+        if (v) atomicAdd(acc + tid, v);
+    }
+}
+
 bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
     if (q_head > kStreamQ || q_tail > kStreamQ || N <= 0) return false;
     if (model == TRANSE) return (D == 64 || D == 128 || D == 256) && ld < (1 << 22);  // (32-bit byte offsets inside a tile)
     return D == 64 || D == 128;  // a whole row + 32 sums in registers
 }
 
-template <int MODEL, int D>
+// the bilinear models' approximate keys need the operand rows and bands of rank_all.hip's preparation launch
+bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
+    return model != TRANSE && knob(KNOB_STREAM_KERNEL) != 2 && knob(KNOB_STREAM_KERNEL) != 5 &&
+           rank_stream_applicable(model, D, N, ld, q_head, q_tail);
+}
+
+template <int MODEL, int D, bool DOT>
 static hipError_t launch_stream_wg(const float* table, int64_t N, int64_t ld, const float* coef_head, const float* coef_tail,
                                    const float* key_true, int q_head, int q_tail, int n_tiles, unsigned long long* acc,
-                                   int n_cu, hipStream_t stream) {
+                                   const StreamDot& dot, int n_cu, hipStream_t stream) {
     const size_t lds = (size_t)2 * kTileRows * (D + 4) * 4;
     if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_stream_wg_kernel<MODEL, D>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_stream_wg_kernel<MODEL, D, DOT>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int resident = 2 * n_cu;
-    rank_stream_wg_kernel<MODEL, D><<<(unsigned)(n_tiles < resident ? n_tiles : resident), kWaves * 64, lds, stream>>>(
-        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, n_tiles, acc);
+    rank_stream_wg_kernel<MODEL, D, DOT><<<(unsigned)(n_tiles < resident ? n_tiles : resident), kWaves * 64, lds, stream>>>(
+        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, n_tiles, acc, dot.wq, dot.band, dot.q_fixed, dot.q_rel, dot.q0);
+    return hipGetLastError();
+}
+
+template <int MODEL, int D>
+static hipError_t launch_stream_dot(const float* table, int64_t N, int64_t ld, const StreamDot& dot, const float* key_true,
+                                    int q_head, int q_tail, int n_tiles, unsigned long long* acc, int n_cu, hipStream_t stream) {
+    if (ld >= (1 << 22)) return hipErrorInvalidValue;  // (32-bit byte offsets inside a tile)
+    const int64_t n_rounds = ((int64_t)n_tiles + kWaves - 1) / kWaves;
+    if (q_head + q_tail <= 4) {  // four waves per SIMD
+        const int64_t resident = (int64_t)n_cu * 4;
+        rank_stream_dot_kernel<MODEL, D, 4><<<(unsigned)(n_rounds < resident ? n_rounds : resident), kWaves * 64, 0, stream>>>(
+            table, N, ld, dot.wq, dot.band, key_true, dot.q_fixed, dot.q_rel, dot.q0, q_head, q_tail, n_tiles, acc);
+    } else {  // eight running sums: three
+        const int64_t resident = (int64_t)n_cu * 3;
+        rank_stream_dot_kernel<MODEL, D, 2 * kStreamQ><<<(unsigned)(n_rounds < resident ? n_rounds : resident), kWaves * 64, 0, stream>>>(
+            table, N, ld, dot.wq, dot.band, key_true, dot.q_fixed, dot.q_rel, dot.q0, q_head, q_tail, n_tiles, acc);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                              unsigned long long* acc, int n_cu, hipStream_t stream) {
+                              unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream) {
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
-    // TransE: the per-wave ring ramps up and down faster (1/8 Wikidata5M shard: 58 us against 72), the workgroup-tile kernel
-    // streams a long table better ([measured] 4-query pass: 1.15 M rows 103 / 109, 2.3 M rows 198 / 188, 4.6 M rows 384 / 353 us
-    // = 6.7 TB/s); knob stream_kernel = 3 / 4 forces the workgroup-tile / the ring kernel
+    // The per-wave ring ramps up and down faster (1/8 Wikidata5M shard, TransE: 58 us against 72), the workgroup-tile kernel
+    // streams a long table better ([measured] TransE 4-query pass: 1.15 M rows 103 / 109, 2.3 M rows 198 / 188, 4.6 M rows
+    // 384 / 353 us = 6.7 TB/s); knob stream_kernel = 3 / 4 forces the workgroup-tile / the ring kernel; 5: the bilinear
+    // models' workgroup-tile kernel with order-exact keys only (no approximate keys: the A/B reference of the tests)
     const long long forced = knob(KNOB_STREAM_KERNEL);
-    const bool wg_tile = model != TRANSE || (D != 256 && forced != 4 && (forced == 3 || N >= kStreamWgMinRows));
-    if (wg_tile) {
+    const bool ring_ok = ld < (1 << 22) && D != 256;
+    const bool long_table = forced == 3 || (forced != 4 && N >= kStreamWgMinRows);
+    if (model != TRANSE) {
+        const bool use_dot = dot.wq != nullptr && forced != 5;
+        if (use_dot && ring_ok && !long_table) {
+#define BLP_STREAM_DOT(MM, DD)                                                                                       \
+    if (model == MM && D == DD)                                                                                      \
+        return launch_stream_dot<MM, DD>(table, N, ld, dot, key_true, (int)q_head, (int)q_tail, (int)n_tiles, acc, n_cu, stream);
+            BLP_STREAM_DOT(DISTMULT, 64) BLP_STREAM_DOT(DISTMULT, 128) BLP_STREAM_DOT(COMPLEX, 64) BLP_STREAM_DOT(COMPLEX, 128)
+            BLP_STREAM_DOT(SIMPLE, 64) BLP_STREAM_DOT(SIMPLE, 128)
+#undef BLP_STREAM_DOT
+            return hipErrorInvalidValue;
+        }
 #define BLP_STREAM_WG(MM, DD)                                                                                        \
     if (model == MM && D == DD)                                                                                      \
-        return launch_stream_wg<MM, DD>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,       \
-                                        (int)n_tiles, acc, n_cu, stream);
-        BLP_STREAM_WG(TRANSE, 64) BLP_STREAM_WG(TRANSE, 128) BLP_STREAM_WG(DISTMULT, 64) BLP_STREAM_WG(DISTMULT, 128) BLP_STREAM_WG(COMPLEX, 64) BLP_STREAM_WG(COMPLEX, 128)
+        return use_dot ? launch_stream_wg<MM, DD, true>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head,    \
+                                                        (int)q_tail, (int)n_tiles, acc, dot, n_cu, stream)    \
+                       : launch_stream_wg<MM, DD, false>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head,   \
+                                                         (int)q_tail, (int)n_tiles, acc, StreamDot(), n_cu, stream);
+        BLP_STREAM_WG(DISTMULT, 64) BLP_STREAM_WG(DISTMULT, 128) BLP_STREAM_WG(COMPLEX, 64) BLP_STREAM_WG(COMPLEX, 128)
         BLP_STREAM_WG(SIMPLE, 64) BLP_STREAM_WG(SIMPLE, 128)
 #undef BLP_STREAM_WG
         return hipErrorInvalidValue;
+    }
+    if (D != 256 && long_table) {
+        if (D == 64)
+            return launch_stream_wg<TRANSE, 64, false>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,
+                                                       (int)n_tiles, acc, StreamDot(), n_cu, stream);
+        return launch_stream_wg<TRANSE, 128, false>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,
+                                                    (int)n_tiles, acc, StreamDot(), n_cu, stream);
     }
     const int64_t n_rounds = (n_tiles + kWaves - 1) / kWaves;
     const int64_t resident = (int64_t)n_cu * (D == 256 ? 3 : 4);  // workgroups of four waves per CU: 4 (3) waves per SIMD

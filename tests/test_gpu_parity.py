@@ -269,10 +269,70 @@ def test_stream_kernels_vs_oracle(ops, oracle, knobs, model, D, q_head, q_tail):
         tiles = ops.rank_all(*args, **kw).cpu().numpy()
         assert np.array_equal(got, want), (N, got, want)
         assert np.array_equal(tiles, want)
-        if model == "transe":  # both of its streaming kernels (the library picks by table length)
-            for variant in (3, 4):
-                knobs("stream_kernel", variant)
-                assert np.array_equal(ops.rank_all(*args, **kw).cpu().numpy(), want), (N, variant)
+        # both streaming kernels of the model (the library picks by table length); the bilinear models also with
+        # order-exact keys only (5: no approximate keys)
+        for variant in (3, 4) if model == "transe" else (3, 4, 5):
+            knobs("stream_kernel", variant)
+            assert np.array_equal(ops.rank_all(*args, **kw).cpu().numpy(), want), (N, variant)
+
+
+@pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("kind", ["ties", "near", "scales", "tiny", "zero", "huge", "nonfinite", "constant"])
+def test_stream_dot_band_adversarial(ops, oracle, knobs, model, D, kind):
+    """The bilinear models' approximate keys (rank_stream.hip, DOT: a chain of fused multiply-adds decided against the true
+    key within C u ||B_q|| ||e||, undecided rows re-scored in the reference's order) on inputs built to sit inside or
+    break the band: duplicated rows, rows nudged by one ulp, per-row and per-column scales over 2^-40 .. 2^40, rows whose
+    squares underflow, all-zero rows and queries, magnitudes near overflow, NaN / Inf, a constant table.  Both kernels
+    (workgroup tile, ring), 2 + 2 and 4 + 3 queries, counts against the oracle."""
+    N = 70001 + D
+    for q_head, q_tail in ((2, 2), (4, 3)):
+        table, q_fixed, q_rel, true_row = random_problem(model, N, D, q_head, q_tail, seed=D + q_head + len(kind))
+        g = torch.Generator().manual_seed(7 * D + q_tail)
+        Q = q_head + q_tail
+        if kind == "ties":
+            for q in range(Q):
+                table[torch.randint(0, N, (40,), generator=g)] = table[int(true_row[q])].clone()
+        elif kind == "near":
+            for q in range(Q):
+                rows = torch.randint(0, N, (64,), generator=g)
+                near = table[int(true_row[q])].repeat(64, 1)
+                col = torch.randint(0, D, (64,), generator=g)
+                bits = near[torch.arange(64), col].view(torch.int32) + torch.randint(-2, 3, (64,), generator=g, dtype=torch.int32)
+                near[torch.arange(64), col] = bits.view(torch.float32)
+                table[rows] = near
+        elif kind == "scales":
+            table *= torch.exp2(torch.randint(-40, 41, (N, 1), generator=g).float())
+            table *= torch.exp2(torch.randint(-6, 7, (1, D), generator=g).float())
+            q_rel *= torch.exp2(torch.randint(-20, 21, (Q, 1), generator=g).float())
+            q_fixed = table[torch.randint(0, N, (Q,), generator=g)].clone()
+        elif kind == "tiny":
+            table[::3] *= 1e-17   # squares underflow to denormals / zero
+            table[1::7] *= 1e-24
+            q_fixed[0] *= 1e-20
+        elif kind == "zero":
+            table[::5] = 0.0
+            q_fixed[0] = 0.0
+            q_rel[-1] = 0.0
+            true_row[1] = 5  # a true entity with an all-zero row
+        elif kind == "huge":
+            table[::4] *= 1e18
+            table[2::9] *= 3e19
+            q_rel[0] *= 1e19
+            q_fixed[-1] *= 1e19
+        elif kind == "nonfinite":
+            table[torch.randint(0, N, (50,), generator=g), torch.randint(0, D, (50,), generator=g)] = float("inf")
+            table[torch.randint(0, N, (50,), generator=g), torch.randint(0, D, (50,), generator=g)] = float("nan")
+            q_rel[0, 3] = float("inf")
+            q_fixed[-1, 1] = float("nan")
+        elif kind == "constant":
+            table[:] = 0.25
+        want = oracle_counts(oracle, model, table, q_fixed, q_rel, q_head, true_row=true_row)
+        args = (model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head)
+        for variant in (0, 3, 4):
+            knobs("stream_kernel", variant)
+            got = ops.rank_all(*args, true_row=true_row.cuda()).cpu().numpy()
+            assert np.array_equal(got, want), (kind, variant, q_head, np.nonzero((got != want).any(1))[0][:8])
 
 
 @pytest.mark.parametrize("D", [64, 128, 256])

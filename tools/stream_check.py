@@ -24,14 +24,14 @@ for model, D in (("transe", 64), ("transe", 128), ("transe", 256), ("distmult", 
                 bad += 1; print("MISMATCH", model, D, N, qh, qt, a.tolist(), b.tolist())
 print("mismatches", bad)
 _lib.reset_knobs()
-for N in (575000, 4600000):
+for N in (575000, 1150000, 4600000):
     table = torch.nn.functional.normalize(torch.randn((N, 128), device=dev, generator=g), dim=-1)
     rel = torch.randn((9, 128), device=dev, generator=g) * 0.1
     fixed = torch.randint(0, N, (4,), device=dev, generator=g); true = torch.randint(0, N, (4,), device=dev, generator=g)
     qf, qr, qt = table[fixed].contiguous(), rel[:4].contiguous(), table[true].contiguous()
     out = torch.empty((4, 4), dtype=torch.int32, device=dev)
     for model in ("transe", "distmult", "complex", "simple"):
-        for knob in (0, 2):
+        for knob in ((0, 3, 4, 2) if model == "transe" else (0, 3, 4, 5, 2)):
             _lib.set_knob("stream_kernel", knob)
             def step():
                 for _ in range(64): ops.rank_all(model, table, qf, qr, 2, q_true=qt, out=out)
