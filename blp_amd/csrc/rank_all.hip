@@ -735,8 +735,8 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
     // <= 4 + 4 queries of a bilinear model: the streaming kernels take approximate keys first (operand rows + bands)
     const bool dot_keys = q_head <= kQB && q_tail <= kQB && N > 0 && rank_stream_wants_dot(MODEL, D, N, ld, q_head, q_tail);
-    launch_true_key<MODEL, D>(q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, w.coef_head,
-                              w.coef_tail, 0, dot_keys ? w.wq : nullptr, w.band);
+    launch_true_key<MODEL, D>(q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, dot_keys ? nullptr : w.coef_head,
+                              w.coef_tail, 0, dot_keys ? w.wq : nullptr, w.band);  // (approximate keys: no coefficient rows)
 
     if (N > 0) {
         const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
@@ -977,6 +977,7 @@ static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, 
     coef_blocks = coef_blocks > 8192 ? 8192 : coef_blocks;
     const bool dot_keys = rank_stream_wants_dot(MODEL, D, N, ld, batch, batch);
     const int64_t dot_blocks = dot_keys ? (Q + 7) / 8 : 0;
+    if (dot_keys) coef_blocks = 0;  // the approximate-key kernel reads operand rows, not coefficient rows
     prep_passes_kernel<MODEL, D><<<dim3((unsigned)(key_blocks + coef_blocks + dot_blocks)), 64, 0, stream>>>(
         q_fixed, q_rel, q_true, n, batch, w.coef, w.key_true, w.acc, (unsigned)key_blocks, (unsigned)dot_blocks, w.wq, w.band);
     for (int64_t first = 0; first < n; first += batch) {

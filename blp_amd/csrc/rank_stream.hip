@@ -237,13 +237,12 @@ __device__ __forceinline__ float score_sgpr_stream(const float (&e)[D], const fl
     return Scorer<MODEL, SIDE, D>::template score<false>(e, c);
 }
 
-// DOT (the bilinear models' default): a key is first taken as the plain dot product <W_q, e> -- one chain of D fused
-// multiply-adds against the query's GEMM operand row (dot_band.h; 128 VALU instructions where the reference's order
-// costs 512 - 790) -- and decided against the exact true key within the band of rank_gemm.hip's f32-chain kernel,
-// eps = C u ||B_q|| ||e|| with ||e|| from the same registers; only when a lane of the tile stays undecided (the true
-// entity itself, near-ties, non-finite values, magnitudes outside the band's premises) does the wave score the tile
-// with the order-exact routine as well, and those lanes count by that key.  Counts are the exact kernels' in every case.
-static_assert(kStreamDotRows == 2 * kStreamQ && kStreamQ == kWaves, "stream_dot_row pairs query w with query w + kWaves");
+// The bilinear models' approximate keys (the ring kernel further down): a key is first taken as the plain dot product
+// <W_q, e> -- one chain of D fused multiply-adds against the query's GEMM operand row (dot_band.h; 128 VALU instructions
+// where the reference's order costs 512 - 790) -- and decided against the exact true key within the band of rank_gemm.hip's
+// f32-chain kernel, eps = C u ||B_q|| ||e|| with ||e|| from the same registers; only rows that stay undecided (the true
+// entity itself, near-ties, non-finite values, magnitudes outside the band's premises) are scored by the order-exact
+// routine as well and count by that key.  Counts are the exact kernels' in every case.
 struct DotBand {  // one query's band against a row of squared norm ss: see dot_prepare()
     float kt, eq, et, guard;
 };
@@ -268,6 +267,24 @@ __device__ __forceinline__ void dot_decide(float v, const DotBand& b, float nrow
 #endif
 }
 
+// The operand rows W_q come through the scalar cache, loads issued by hand in units of 16 columns of one query: the next
+// unit is requested before the current one's 16 multiply-adds and drained after them (rank_common.h: sload16 / sdrain;
+// scalar loads return out of order, every wait is a full drain).  Left alone the compiler hoists the loop-invariant
+// values out of the tile loop and parks them in VGPR lanes -- a v_readlane per multiply-add -- or, once the pointer is
+// made opaque, falls back to per-lane vector loads; an SGPR ring behind an accessor (SgprStreamCoef) spills the same way.
+// Both asm statements carry the unit's running sum as an operand: the request stands before the unit's first
+// multiply-add, the wait behind its last (volatile asm keeps its own order, not its place among the arithmetic --
+// unpinned, the compiler issues every request and wait of a piece up front and parks the values in VGPR lanes all the same).
+template <int OFF>
+__device__ __forceinline__ void sload16_pinned(sf16& v, const float* base, float& pin) {
+    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(v), "+v"(pin) : "s"(base), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin) : : "memory");
+}
+__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin, float& pin2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin), "+v"(pin2) : : "memory");
+}
 // The undecided rows `und` (a lane mask) of the tile whose first row is row0, against one query (f, r: its two vectors;
 // kt: its true key), by coop_score -- 32 lanes per pair, the order-exact arithmetic of every other exact path, the row
 // re-read from the cache it has just passed through; two rows per trip, one per 32-lane half (the upper half without a
@@ -293,12 +310,11 @@ __device__ __forceinline__ unsigned long long exact_undecided(const float* __res
     return (unsigned long long)gt | ((unsigned long long)ge << 32);
 }
 
-template <int MODEL, int D, bool DOT>
+template <int MODEL, int D>
 __global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
-    unsigned long long* __restrict__ acc, const float* __restrict__ wq, const float* __restrict__ band, const QRows q_fixed,
-    const QRows q_rel, int64_t q0) {
+    unsigned long long* __restrict__ acc) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
     constexpr int TS = D + 4;  // row stride of an LDS tile, floats
@@ -342,52 +358,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
             e[4 * j] = w.x; e[4 * j + 1] = w.y; e[4 * j + 2] = w.z; e[4 * j + 3] = w.w;
         });
         const bool valid = (int64_t)t * kTileRows + lane < N;
-        if constexpr (DOT) {
-            // both queries' chains and the norm's in one walk over the row; the wave's two operand rows are neighbours
-            // in wq (dot_row) and come through one two-stream SGPR ring (a row the pass has no query for: never counted)
-            sf16 ring[2][2];
-            const SgprStreamCoef<D, 2, 16> c{wq + (size_t)stream_dot_row(qw) * D, ring};
-            c.template request<0>();
-            float v0 = 0.f, v1 = 0.f, ssq = 0.f;
-            static_for<D>([&](auto kk) {
-                constexpr int k = decltype(kk)::value;
-                v0 = __builtin_fmaf(e[k], c(ic<k>{}), v0);
-                v1 = __builtin_fmaf(e[k], c(ic<D + k>{}), v1);
-                ssq = __builtin_fmaf(e[k], e[k], ssq);
-            });
-            const float nrow = sqrtf(ssq) * 1.0001f;
-            const bool tiny = ssq < 1e-30f;
-            static_for<2>([&](auto ss) {
-                constexpr int s = decltype(ss)::value;
-                const int q = qw + kWaves * s;
-                if (q < Q) {
-                    const DotBand b = dot_band_of(key_true, band, q);
-                    bool gt, lt;
-                    dot_decide(s ? v1 : v0, b, nrow, tiny, gt, lt);
-                    const unsigned long long above = __ballot(valid && gt), und = __ballot(valid && !(gt || lt));
-                    n_gt[s] += __popcll(above);
-                    n_ge[s] += __popcll(above);
-                    if (und) {  // wave-uniform, rare (about one (tile, query) in a hundred has an undecided row)
-                        const unsigned long long c = exact_undecided<MODEL, D>(table, ld, (int64_t)t * kTileRows, q_fixed.row(q0 + q),
-                                                                               q_rel.row(q0 + q), q < q_head, und, b.kt, lane);
-                        n_gt[s] += (unsigned)c;
-                        n_ge[s] += (unsigned)(c >> 32);
-                    }
-                }
-            });
-        } else {
-            static_for<2>([&](auto ss) {
-                constexpr int s = decltype(ss)::value;
-                const int q = qw + kWaves * s;
-                if (q < Q) {
-                    const float key = q < q_head ? score_sgpr_stream<MODEL, HEAD, D>(e, coef_head + (size_t)q * SH::C)
-                                                 : score_sgpr_stream<MODEL, TAIL, D>(e, coef_tail + (size_t)(q - q_head) * ST::C);
-                    const float kt = key_true[q];
-                    n_gt[s] += __popcll(__ballot(valid && key > kt));
-                    n_ge[s] += __popcll(__ballot(valid && key >= kt));
-                }
-            });
-        }
+        static_for<2>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            const int q = qw + kWaves * s;
+            if (q < Q) {
+                const float key = q < q_head ? score_sgpr_stream<MODEL, HEAD, D>(e, coef_head + (size_t)q * SH::C)
+                                             : score_sgpr_stream<MODEL, TAIL, D>(e, coef_tail + (size_t)(q - q_head) * ST::C);
+                const float kt = key_true[q];
+                n_gt[s] += __popcll(__ballot(valid && key > kt));
+                n_ge[s] += __popcll(__ballot(valid && key >= kt));
+            }
+        });
     };
 
     // tiles t0, t0 + G, t0 + 2G, ...: in LDS tile i (buffer i & 1), in ring[(i + 1) & 1] tile i + 1, in ring[i & 1] tile i + 2
@@ -428,25 +409,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
 // per (row, query) and D for the row's squared norm.  Undecided lanes (the true entity, near-ties, non-finite values:
 // about one (tile, query) in a hundred has one) are re-scored on the spot by coop_score -- 32 lanes per pair, the row
 // re-read from the cache it has just passed through, the order-exact arithmetic of every other exact path.
-// The operand rows through the scalar cache, loads issued by hand (left alone the compiler either hoists all NQ x D
-// loop-invariant values out of the tile loop and parks them in VGPR lanes -- a v_readlane per multiply-add -- or, once the
-// pointer is made opaque, falls back to per-lane vector loads): units of 16 columns of one query, the next unit requested
-// before the current one's 16 multiply-adds and drained after them (rank_common.h: sload16 / sdrain; scalar loads return
-// out of order, every wait is a full drain).  Unit u of piece S: query u / 2, columns 32 S + 16 (u % 2) ..; the unit after
-// a tile's last is the next tile's first.  `cur` holds the unit about to be used.
-// Both asm statements carry the unit's running sum as an operand: the request stands before the unit's first
-// multiply-add, the wait behind its last (volatile asm keeps its own order, not its place among the arithmetic --
-// unpinned, the compiler issues every request and wait of a piece up front and parks the values in VGPR lanes all the same).
-template <int OFF>
-__device__ __forceinline__ void sload16_pinned(sf16& v, const float* base, float& pin) {
-    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(v), "+v"(pin) : "s"(base), "i"(OFF) : "memory");
-}
-__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin) : : "memory");
-}
-__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin, float& pin2) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin), "+v"(pin2) : : "memory");
-}
+// Operand units as above (sload16_pinned / sdrain_pinned).  Unit u of piece S: query u / 2, columns 32 S + 16 (u % 2) ..; the
+// unit after a tile's last is the next tile's first.  `cur` holds the unit about to be used.
 // (the squared norm's chain rides along with query 0's two units -- on its own it drifts behind the following pieces and
 //  keeps three pieces' columns alive)
 template <int D, int NQ, int S, int U>
@@ -594,32 +558,41 @@ bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_h
     return D == 64 || D == 128;  // a whole row + 32 sums in registers
 }
 
-// the bilinear models' approximate keys need the operand rows and bands of rank_all.hip's preparation launch
+// Which kernel takes a pass of a bilinear model ([measured] 4-query pass, us, ring with approximate keys / workgroup tile
+// with order-exact keys: 575 k rows DistMult 54 / 70, ComplEx 55 / 80, SimplE 53 / 69; 1.15 M rows 101 / 108, 102 / 132,
+// 101 / 108; 4.6 M rows 368 / 355, 369 / 471, 367 / 352): the ring below kStreamWgMinRows rows and for ComplEx at any
+// length; knob stream_kernel = 3 (or 5) / 4 forces the workgroup-tile / the ring kernel.
+static bool bilinear_takes_ring(int model, int64_t N, int64_t ld) {
+    const long long forced = knob(KNOB_STREAM_KERNEL);
+    if (ld >= (1 << 22)) return false;  // (32-bit byte offsets inside a tile)
+    if (forced == 3 || forced == 5) return false;
+    return forced == 4 || model == COMPLEX || N < kStreamWgMinRows;
+}
+// ... and so needs the operand rows and bands of rank_all.hip's preparation launch
 bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
-    return model != TRANSE && knob(KNOB_STREAM_KERNEL) != 2 && knob(KNOB_STREAM_KERNEL) != 5 &&
-           rank_stream_applicable(model, D, N, ld, q_head, q_tail);
+    return model != TRANSE && knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(model, D, N, ld, q_head, q_tail) &&
+           bilinear_takes_ring(model, N, ld);
 }
 
-template <int MODEL, int D, bool DOT>
+template <int MODEL, int D>
 static hipError_t launch_stream_wg(const float* table, int64_t N, int64_t ld, const float* coef_head, const float* coef_tail,
                                    const float* key_true, int q_head, int q_tail, int n_tiles, unsigned long long* acc,
-                                   const StreamDot& dot, int n_cu, hipStream_t stream) {
+                                   int n_cu, hipStream_t stream) {
     const size_t lds = (size_t)2 * kTileRows * (D + 4) * 4;
     if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_stream_wg_kernel<MODEL, D, DOT>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_stream_wg_kernel<MODEL, D>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int resident = 2 * n_cu;
-    rank_stream_wg_kernel<MODEL, D, DOT><<<(unsigned)(n_tiles < resident ? n_tiles : resident), kWaves * 64, lds, stream>>>(
-        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, n_tiles, acc, dot.wq, dot.band, dot.q_fixed, dot.q_rel, dot.q0);
+    rank_stream_wg_kernel<MODEL, D><<<(unsigned)(n_tiles < resident ? n_tiles : resident), kWaves * 64, lds, stream>>>(
+        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, n_tiles, acc);
     return hipGetLastError();
 }
 
 template <int MODEL, int D>
 static hipError_t launch_stream_dot(const float* table, int64_t N, int64_t ld, const StreamDot& dot, const float* key_true,
                                     int q_head, int q_tail, int n_tiles, unsigned long long* acc, int n_cu, hipStream_t stream) {
-    if (ld >= (1 << 22)) return hipErrorInvalidValue;  // (32-bit byte offsets inside a tile)
     const int64_t n_rounds = ((int64_t)n_tiles + kWaves - 1) / kWaves;
     if (q_head + q_tail <= 4) {  // four waves per SIMD
         const int64_t resident = (int64_t)n_cu * 4;
@@ -638,16 +611,8 @@ hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, i
                               unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream) {
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
-    // The per-wave ring ramps up and down faster (1/8 Wikidata5M shard, TransE: 58 us against 72), the workgroup-tile kernel
-    // streams a long table better ([measured] TransE 4-query pass: 1.15 M rows 103 / 109, 2.3 M rows 198 / 188, 4.6 M rows
-    // 384 / 353 us = 6.7 TB/s); knob stream_kernel = 3 / 4 forces the workgroup-tile / the ring kernel; 5: the bilinear
-    // models' workgroup-tile kernel with order-exact keys only (no approximate keys: the A/B reference of the tests)
-    const long long forced = knob(KNOB_STREAM_KERNEL);
-    const bool ring_ok = ld < (1 << 22) && D != 256;
-    const bool long_table = forced == 3 || (forced != 4 && N >= kStreamWgMinRows);
     if (model != TRANSE) {
-        const bool use_dot = dot.wq != nullptr && forced != 5;
-        if (use_dot && ring_ok && !long_table) {
+        if (dot.wq != nullptr && bilinear_takes_ring(model, N, ld)) {
 #define BLP_STREAM_DOT(MM, DD)                                                                                       \
     if (model == MM && D == DD)                                                                                      \
         return launch_stream_dot<MM, DD>(table, N, ld, dot, key_true, (int)q_head, (int)q_tail, (int)n_tiles, acc, n_cu, stream);
@@ -658,22 +623,20 @@ hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, i
         }
 #define BLP_STREAM_WG(MM, DD)                                                                                        \
     if (model == MM && D == DD)                                                                                      \
-        return use_dot ? launch_stream_wg<MM, DD, true>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head,    \
-                                                        (int)q_tail, (int)n_tiles, acc, dot, n_cu, stream)    \
-                       : launch_stream_wg<MM, DD, false>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head,   \
-                                                         (int)q_tail, (int)n_tiles, acc, StreamDot(), n_cu, stream);
+        return launch_stream_wg<MM, DD>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,       \
+                                        (int)n_tiles, acc, n_cu, stream);
         BLP_STREAM_WG(DISTMULT, 64) BLP_STREAM_WG(DISTMULT, 128) BLP_STREAM_WG(COMPLEX, 64) BLP_STREAM_WG(COMPLEX, 128)
         BLP_STREAM_WG(SIMPLE, 64) BLP_STREAM_WG(SIMPLE, 128)
-#undef BLP_STREAM_WG
         return hipErrorInvalidValue;
     }
-    if (D != 256 && long_table) {
-        if (D == 64)
-            return launch_stream_wg<TRANSE, 64, false>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,
-                                                       (int)n_tiles, acc, StreamDot(), n_cu, stream);
-        return launch_stream_wg<TRANSE, 128, false>(table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail,
-                                                    (int)n_tiles, acc, StreamDot(), n_cu, stream);
+    // TransE: the per-wave ring ramps up and down faster (1/8 Wikidata5M shard: 58 us against 72), the workgroup-tile kernel
+    // streams a long table better ([measured] 4-query pass: 1.15 M rows 103 / 109, 2.3 M rows 198 / 188, 4.6 M rows 384 / 353 us
+    // = 6.7 TB/s); knob stream_kernel = 3 / 4 forces the workgroup-tile / the ring kernel
+    const long long forced = knob(KNOB_STREAM_KERNEL);
+    if (D != 256 && forced != 4 && (forced == 3 || N >= kStreamWgMinRows)) {
+        BLP_STREAM_WG(TRANSE, 64) BLP_STREAM_WG(TRANSE, 128)
     }
+#undef BLP_STREAM_WG
     const int64_t n_rounds = (n_tiles + kWaves - 1) / kWaves;
     const int64_t resident = (int64_t)n_cu * (D == 256 ? 3 : 4);  // workgroups of four waves per CU: 4 (3) waves per SIMD
     const unsigned blocks = (unsigned)(n_rounds < resident ? n_rounds : resident);
