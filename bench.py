@@ -250,8 +250,12 @@ class Job:
         transe = model == "transe"
         peak_tf = F32_PEAK_TFLOPS if transe else BF16X3_PEAK_TFLOPS
         if alg_bytes / (HBM_PEAK_GBPS * 1e9) >= alg_flops / (peak_tf * 1e12):
+            ring = not transe and (model == "complex" or n_local < 1_700_000) or transe and n_local < 1_700_000
+            dot = "approximate keys (a chain of fused multiply-adds) decided within a band, undecided rows re-scored in the reference's order; "
             roof = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "kernel": "rank_stream_wg_kernel (exact f32 keys; the table streamed once through workgroup tiles, two tiles in flight per workgroup)"}
+                    "kernel": (("rank_stream_kernel (exact f32 keys; " if transe else "rank_stream_dot_kernel (" + dot) +
+                               "the table streamed once through per-wave rings of 32-column pieces)") if ring else
+                              "rank_stream_wg_kernel (exact f32 keys; the table streamed once through workgroup tiles, two tiles in flight per workgroup)"}
         elif transe:
             wide = D not in (64, 128, 256)
             roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
