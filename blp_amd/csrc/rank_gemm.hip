@@ -160,6 +160,31 @@ __device__ __forceinline__ void stage_gemm_tile(const float4* __restrict__ src, 
     });
 }
 
+// The same staging with the LDS-DMA issued through inline asm.  After a global_load_lds the compiler puts
+// `s_waitcnt vmcnt(0)` in front of the wave's NEXT LDS access of any kind (it cannot tell the DMA's target from the
+// buffer being read): issued at the top of a pipeline stage, the copy of tile t + 2 was waited for -- an L2 round trip --
+// before the stage's first operand read, every stage.  The asm form is invisible to that bookkeeping; the caller waits
+// (vmcnt(0)) and synchronises itself before anyone reads the target.  M0 = the LDS byte address of the wave's 1 KB
+// segment (lane l lands at + 16 l).
+template <int BYTES, int WAVES>
+__device__ __forceinline__ void stage_gemm_tile_async(const float4* __restrict__ src, float* dst, int wave, int lane) {
+    constexpr int ROUNDS = (BYTES + WAVES * 1024 - 1) / (WAVES * 1024);
+    static_assert(BYTES % (WAVES * 1024) == 0, "whole 1 KB segments per wave and round");
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)dst;
+    static_for<ROUNDS>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const int seg = (k * WAVES + wave) * 1024;  // wave-uniform
+        const char* g = reinterpret_cast<const char*>(src) + seg + lane * 16;
+        const unsigned target = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)seg);
+        asm volatile("s_mov_b32 m0, %0\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off"
+                     :
+                     : "s"(target), "v"(g)
+                     : "memory", "m0");
+    });
+}
+
 template <int MODEL, int D>
 __global__ __launch_bounds__(kGW * 64, 2) void rank_gemm_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float4* __restrict__ img_head,
@@ -464,6 +489,7 @@ struct BfHalfInfo { float nmax; unsigned row_mask; };
 // -DBLP_TIMING: per-phase cycle counts of the kernel below, summed over waves (tools/gemm_phase_timing.py)
 #ifdef BLP_TIMING
 __device__ unsigned long long g_bf16_timing[8];
+__device__ unsigned long long g_bf16_trace[3 * 4096];  // per workgroup: start, end (100 MHz wall ticks), HW_ID | XCC_ID << 32
 #define BLP_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
 #else
 #define BLP_T(i) do { } while (0)
@@ -641,6 +667,18 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         }
     });
     const BfHalfInfo* my_info = half_info + wave * kBfTPW * 2 + half;  // [ti * 2]; written by this wave's own lanes
+    // What a stage needs of it, wave-uniform (scalar registers: the vector registers are all taken, and an LDS read at the
+    // top of every stage and two more in its settle step were three exposed round trips per query tile): the larger of a
+    // tile's two band factors serves both halves (a wider band, never a narrower one); a tile with all of its 32 rows
+    // needs no row mask.
+    float nmax_tile[kBfTPW];
+    bool tile_full[kBfTPW];
+    static_for<kBfTPW>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        const float a = cnmax[(ctile0 + t) * 2], b = cnmax[(ctile0 + t) * 2 + 1];
+        nmax_tile[t] = a > b ? a : b;  // (band factors are never NaN: band_norm)
+        tile_full[t] = (int64_t)(ctile0 + t + 1) * kGCT <= n_rows;
+    });
 
     const uint4* img = (head ? img_head : img_tail) + (int64_t)tile0 * (TILE_BYTES / 16);
     unsigned my_pairs = 0;  // entries this wave has listed (wave-uniform)
@@ -706,7 +744,9 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
             unsigned above = q_ok ? __popc(gm[ti]) : 0u;  // rows that do not exist score NaN: never above
-            const unsigned und = q_ok ? ~(gm[ti] | lm[ti]) & my_info[ti * 2].row_mask : 0u;
+            unsigned rows = 0xffffu;
+            if (!tile_full[ti]) rows = my_info[ti * 2].row_mask;  // wave-uniform: the table's last tile only
+            const unsigned und = q_ok ? ~(gm[ti] | lm[ti]) & rows : 0u;
             const unsigned long long listing = __ballot(und != 0);
             if (listing) {  // wave-uniform
                 const unsigned n = __popcll(listing);
@@ -737,13 +777,14 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     // tile t's decision arithmetic (on `cur`), so the vector ALU works in the matrix pipe's shadow.
 #ifdef BLP_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();  // the constant 100 MHz counter: [6] = wall ticks per wave
 #endif
     auto stage = [&](int t, f32x16 (&cur)[kBfTPW], f32x16 (&nxt)[kBfTPW]) {
         const bool more = t + 1 < n_tiles;
         BLP_T(0);
         if (t + 2 < n_tiles)  // buf[t & 1] was last read by the MFMAs of tile t, one barrier ago
-            stage_gemm_tile<TILE_BYTES, kBfW>(reinterpret_cast<const float4*>(img + (int64_t)(t + 2) * (TILE_BYTES / 16)),
-                                              (t & 1) ? buf1 : buf0, wave, lane);
+            stage_gemm_tile_async<TILE_BYTES, kBfW>(reinterpret_cast<const float4*>(img + (int64_t)(t + 2) * (TILE_BYTES / 16)),
+                                                    (t & 1) ? buf1 : buf0, wave, lane);
         const int q_local = (tile0 + t) * kGQT + (lane & 31);
         const bool q_ok = q_local < n_side;
         const int q = q_base + (q_ok ? q_local : n_side - 1);
@@ -754,7 +795,7 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
         float thr_hi[kBfTPW], thr_lo[kBfTPW], eps[kBfTPW];
         static_for<kBfTPW>([&](auto tt) {
             constexpr int ti = decltype(tt)::value;
-            eps[ti] = __builtin_fmaf(eq, my_info[ti * 2].nmax, guard);
+            eps[ti] = __builtin_fmaf(eq, nmax_tile[ti], guard);
             thr_hi[ti] = kt + eps[ti];
             thr_lo[ti] = kt - eps[ti];
             gm[ti] = 0;
@@ -847,6 +888,15 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
     BLP_T(5);
     if (lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&g_bf16_timing[i], tacc[i]);
+        atomicAdd(&g_bf16_timing[6], __builtin_amdgcn_s_memrealtime() - wall0);
+        if (wave == 0 && blockIdx.x < 4096) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_bf16_trace[3 * blockIdx.x] = wall0;
+            g_bf16_trace[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            g_bf16_trace[3 * blockIdx.x + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        }
         atomicAdd(&g_bf16_timing[7], 1ull);
     }
 #endif
@@ -1196,6 +1246,9 @@ hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N,
 }
 
 #ifdef BLP_TIMING
+extern "C" int blp_debug_read_trace(unsigned long long* out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_trace), sizeof(unsigned long long) * 3 * (n_blocks < 4096 ? n_blocks : 4096));
+}
 extern "C" int blp_debug_read_timing(unsigned long long* out) {
     hipError_t err = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_timing), sizeof(g_bf16_timing));
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -63,6 +63,33 @@ for model in models:
         names = ["outside stages (prologue, first tile)", "stage: MFMAs of t+1 + decision of t", "stage: settle (entries / flags / counters)",
                  "stage: wait for the LDS-DMA of t+2", "stage: barrier", "epilogue (flush counters, entries)"]
         total = sum(buf[i] for i in range(6))
-        print(f"  {buf[7]} waves, {total / max(buf[7], 1):.0f} ticks per wave")
+        wall = buf[6] / max(buf[7], 1) / 100.0  # us per wave (s_memrealtime: 100 MHz)
+        print(f"  {buf[7]} waves, {total / max(buf[7], 1):.0f} shader-clock ticks and {wall:.1f} us per wave: "
+              f"{total / max(buf[6], 1) * 0.1:.2f} GHz while the kernel runs")
         for i, n in enumerate(names):
             print(f"    {n:46s} {buf[i] / max(buf[7], 1):10.0f} ticks/wave  {100.0 * buf[i] / max(total, 1):5.1f} %")
+        if hasattr(L, "blp_debug_read_trace"):  # the workgroups' lifetimes: how many run at a time, and where
+            nb = min(int(buf[7]) // 4, 4096)
+            tr = (ctypes.c_ulonglong * (3 * nb))()
+            L.blp_debug_read_trace(tr, nb)
+            import numpy as np
+            a = np.frombuffer(tr, dtype=np.uint64).reshape(nb, 3)
+            start, end = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64)
+            hw, xcc = (a[:, 2] & 0xffffffff).astype(np.int64), (a[:, 2] >> 32).astype(np.int64) & 0xf
+            t0, t1 = start.min(), end.max()
+            span = (t1 - t0) / 100.0
+            life = (end - start) / 100.0
+            cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7
+            where = xcc * 1000 + se * 100 + sh * 10 + cu  # a label per CU
+            print(f"  {nb} workgroups over {span:.1f} us; lifetime mean {life.mean():.1f} us (min {life.min():.1f}, max {life.max():.1f}); "
+                  f"sum of lifetimes / span = {life.sum() / span:.0f} workgroups at a time on {len(np.unique(where))} distinct CU labels")
+            grid = np.linspace(t0, t1, 41)
+            conc = [int(((start <= g) & (end > g)).sum()) for g in grid[:-1]]
+            print("  running at 40 instants:", conc)
+            per_cu = {}
+            for w, st, en in zip(where, start, end):
+                per_cu.setdefault(int(w), []).append((int(st), int(en)))
+            busy = np.array([sum(e - s_ for s_, e in v) / 100.0 for v in per_cu.values()])
+            cnt = np.array([len(v) for v in per_cu.values()])
+            print(f"  per CU: workgroups {cnt.min()} .. {cnt.max()} (mean {cnt.mean():.1f}); sum of lifetimes {busy.min():.0f} .. {busy.max():.0f} us (mean {busy.mean():.0f}); "
+                  f"per XCC workgroups {np.bincount(xcc).tolist()}")
