@@ -215,6 +215,18 @@ struct SadTiles {
 #endif
 constexpr unsigned kSadChunkBlock = BLP_SAD_CHUNK_BLOCK;  // query chunks whose workgroups run together on an XCD
 
+// -DBLP_TIMING: per wave of the kernel below, shader-clock ticks and ticks of the constant 100 MHz counter, summed: their
+// ratio is the clock the kernel ran at (tools/gemm_ab.py --sad)
+#ifdef BLP_TIMING
+__device__ unsigned long long g_sad_timing[4];
+extern "C" int blp_debug_read_sad_timing(unsigned long long* out) {
+    hipError_t err = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sad_timing), sizeof(g_sad_timing));
+    unsigned long long zero[4] = {0, 0, 0, 0};
+    if (err == hipSuccess) err = hipMemcpyToSymbol(HIP_SYMBOL(g_sad_timing), zero, sizeof(zero));
+    return (int)err;
+}
+#endif
+
 template <int D, int TPW>
 __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 128 ? 3 : 2)) void rank_sad_kernel(
     const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups, int q_per_group,
@@ -222,6 +234,9 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     unsigned long long* __restrict__ acc,
     unsigned* __restrict__ flags, uint2* __restrict__ pairs, SadParams* __restrict__ params) {
     if (!sad_scale(params).ok) return;
+#ifdef BLP_TIMING
+    const unsigned long long clk0 = __builtin_readcyclecounter(), wall0 = __builtin_amdgcn_s_memrealtime();
+#endif
     __shared__ int2 thr_s[kSChunk];
     __shared__ unsigned cnt[kSChunk];
     __shared__ uint2 pair_s[kSQuota];
@@ -370,6 +385,13 @@ __global__ __launch_bounds__(kSW * 64, (TPW * D / 2 <= 64 ? 5 : TPW * D / 2 <= 1
     __syncthreads();
     for (int w = 0; w < kSW; ++w)
         for (unsigned i = tid; i < wave_used[w]; i += kSW * 64) pairs[wave_base[w] + i] = pair_s[w * (kSQuota / kSW) + i];
+#ifdef BLP_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_sad_timing[0], __builtin_readcyclecounter() - clk0);
+        atomicAdd(&g_sad_timing[1], __builtin_amdgcn_s_memrealtime() - wall0);
+        atomicAdd(&g_sad_timing[2], 1ull);
+    }
+#endif
 }
 
 // Pass 2a: the listed pairs, 64 per wave, one lane per pair (the L1 sum of a pair is one sequential chain of D

@@ -555,23 +555,24 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_
 bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
     if (q_head > kStreamQ || q_tail > kStreamQ || N <= 0) return false;
     if (model == TRANSE) return (D == 64 || D == 128 || D == 256) && ld < (1 << 22);  // (32-bit byte offsets inside a tile)
-    return D == 64 || D == 128;  // a whole row + 32 sums in registers
+    if (D == 256) return ld < (1 << 22) && knob(KNOB_STREAM_KERNEL) != 3 && knob(KNOB_STREAM_KERNEL) != 5;  // the ring with approximate keys only
+    return D == 64 || D == 128;  // (the workgroup-tile kernel: a whole row + 32 sums in registers)
 }
 
 // Which kernel takes a pass of a bilinear model ([measured] 4-query pass, us, ring with approximate keys / workgroup tile
 // with order-exact keys: 575 k rows DistMult 54 / 70, ComplEx 55 / 80, SimplE 53 / 69; 1.15 M rows 101 / 108, 102 / 132,
 // 101 / 108; 4.6 M rows 368 / 355, 369 / 471, 367 / 352): the ring below kStreamWgMinRows rows and for ComplEx at any
 // length; knob stream_kernel = 3 (or 5) / 4 forces the workgroup-tile / the ring kernel.
-static bool bilinear_takes_ring(int model, int64_t N, int64_t ld) {
+static bool bilinear_takes_ring(int model, int D, int64_t N, int64_t ld) {
     const long long forced = knob(KNOB_STREAM_KERNEL);
     if (ld >= (1 << 22)) return false;  // (32-bit byte offsets inside a tile)
     if (forced == 3 || forced == 5) return false;
-    return forced == 4 || model == COMPLEX || N < kStreamWgMinRows;
+    return forced == 4 || model == COMPLEX || D == 256 || N < kStreamWgMinRows;
 }
 // ... and so needs the operand rows and bands of rank_all.hip's preparation launch
 bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
     return model != TRANSE && knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(model, D, N, ld, q_head, q_tail) &&
-           bilinear_takes_ring(model, N, ld);
+           bilinear_takes_ring(model, D, N, ld);
 }
 
 template <int MODEL, int D>
@@ -612,12 +613,12 @@ hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, i
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
     if (model != TRANSE) {
-        if (dot.wq != nullptr && bilinear_takes_ring(model, N, ld)) {
+        if (dot.wq != nullptr && bilinear_takes_ring(model, D, N, ld)) {
 #define BLP_STREAM_DOT(MM, DD)                                                                                       \
     if (model == MM && D == DD)                                                                                      \
         return launch_stream_dot<MM, DD>(table, N, ld, dot, key_true, (int)q_head, (int)q_tail, (int)n_tiles, acc, n_cu, stream);
-            BLP_STREAM_DOT(DISTMULT, 64) BLP_STREAM_DOT(DISTMULT, 128) BLP_STREAM_DOT(COMPLEX, 64) BLP_STREAM_DOT(COMPLEX, 128)
-            BLP_STREAM_DOT(SIMPLE, 64) BLP_STREAM_DOT(SIMPLE, 128)
+            BLP_STREAM_DOT(DISTMULT, 64) BLP_STREAM_DOT(DISTMULT, 128) BLP_STREAM_DOT(DISTMULT, 256) BLP_STREAM_DOT(COMPLEX, 64)
+            BLP_STREAM_DOT(COMPLEX, 128) BLP_STREAM_DOT(COMPLEX, 256) BLP_STREAM_DOT(SIMPLE, 64) BLP_STREAM_DOT(SIMPLE, 128) BLP_STREAM_DOT(SIMPLE, 256)
 #undef BLP_STREAM_DOT
             return hipErrorInvalidValue;
         }

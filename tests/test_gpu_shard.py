@@ -80,6 +80,37 @@ def test_shards_add_up_to_the_oracle(oracle, model, world, form):
     assert np.array_equal(total.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("model", REL_MODELS)
+def test_reference_batched_shards_of_a_long_table_add_up_to_the_oracle(oracle, model):
+    """The Wikidata5M evaluation as the north_star shards it: the reference's batches of two triples (4 queries per table
+    pass, scripts/blp-*-wikidata5m.sh:18) against candidate shards long enough for the streaming kernels (the bilinear
+    models: approximate keys + band + exact re-scoring, rank_stream.hip), the queries indexing the all-reduced vector
+    array, all passes of a shard in one library call.  The shards' counts add up to the oracle's, raw and filtered."""
+    from blp_amd import ops, ranking, utils
+    N, D, T, R, W, batch = 240017, 128, 9, 5, 2, 2
+    table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=11 + len(model))
+    table[N // 3] = table[int(ent2idx[triples[0, 0]])]  # a tie with a true entity, in the first shard or not
+    table[N - 5, 7] = float("nan")
+    index = utils.FilterIndex(edges, num_relations=R)
+    want = _oracle_counts(oracle, model, table, rel_w, ent2idx, triples, index)
+    dev_table, dev_rel, dev_e2i, dev_triples = table.cuda(), rel_w.cuda(), ent2idx.cuda(), triples.cuda()
+    bounds = [ranking.shard_bounds(N, W, r) for r in range(W)]
+    source = torch.stack([ops.gather_triple_vectors(dev_triples, dev_e2i, dev_table[lo:hi], row_base=lo) for lo, hi in bounds]).sum(dim=0)
+    total = torch.zeros((2 * T, 4), dtype=torch.int32, device="cuda")
+    for lo, hi in bounds:
+        qb = ops.build_queries(dev_triples, dev_e2i, source, dev_rel, batch, index=index, gather=False, row_base=lo,
+                               by_position=True, num_rows=N)
+        total += ops.rank_all_batches(model, dev_table[lo:hi].contiguous(), qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, T, batch,
+                                      filter=qb.filter, source=source, block_triples=batch)
+    idx = torch.arange(T)
+    first = idx // batch * batch
+    nb = torch.clamp(T - first, max=batch)
+    head_pos = 2 * first + (idx - first)
+    got = total.cpu().numpy()
+    assert np.array_equal(got[head_pos], want[:T])
+    assert np.array_equal(got[head_pos + nb], want[T:])
+
+
 @pytest.mark.parametrize("model,T,block", [("transe", 2600, 65536), ("distmult", 500, 65536), ("complex", 37, 2), ("transe", 9, 2)])
 def test_rank_triples_candidate_axis_single_process_equals_unsharded(oracle, model, T, block):
     """world == 1: rank_triples is the same code with source == table -- its counts are the oracle's."""

@@ -21,7 +21,9 @@ if args and args[0].endswith(".so"):
 from blp_amd import ops  # noqa: E402
 import bench  # noqa: E402
 
-models = args or ["distmult", "complex"]
+models = [a for a in args if a != "--sad"] or ["distmult", "complex"]
+if "--sad" in args:  # the TransE pre-pass: which clock does it run at? (a -DBLP_TIMING build)
+    models = ["transe"]
 dev = torch.device("cuda", 0)
 events = bench.HipEvents()
 L = _lib.lib()
@@ -54,7 +56,15 @@ for model in models:
     call = (time.perf_counter() - t0) / 20 * 1e3
     print(f"{model:9s} rank pass median {ms[len(ms) // 2]:.3f} ms (min {ms[0]:.3f}, max {ms[-1]:.3f}); whole call {call:.3f} ms; "
           f"counts == exact kernels: {same}", flush=True)
-    if hasattr(L, "blp_debug_read_timing"):
+    if model == "transe" and hasattr(L, "blp_debug_read_sad_timing"):
+        buf = (ctypes.c_ulonglong * 4)()
+        L.blp_debug_read_sad_timing(buf)
+        ops.rank_all(model, table, q_fixed, q_rel, T, true_row=true_row, out=out)
+        torch.cuda.synchronize()
+        L.blp_debug_read_sad_timing(buf)
+        print(f"  rank_sad_kernel: {buf[2]} waves, {buf[0] / max(buf[2], 1):.0f} shader-clock ticks and {buf[1] / max(buf[2], 1) / 100.0:.1f} us "
+              f"per wave: {buf[0] / max(buf[1], 1) * 0.1:.2f} GHz while the kernel runs")
+    if model != "transe" and hasattr(L, "blp_debug_read_timing"):
         buf = (ctypes.c_ulonglong * 8)()
         L.blp_debug_read_timing(buf)
         ops.rank_all(model, table, q_fixed, q_rel, T, true_row=true_row, out=out)
