@@ -278,6 +278,7 @@ def test_stream_kernels_vs_oracle(ops, oracle, knobs, model, D, q_head, q_tail):
             assert np.array_equal(ops.rank_all(*args, **kw).cpu().numpy(), want), (N, variant)
 
 
+@pytest.mark.default_routing  # (the streaming kernels do not depend on the pre-pass knobs of the `routing` fixture: once is enough)
 @pytest.mark.parametrize("model", ["distmult", "complex", "simple"])
 @pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("kind", ["ties", "near", "scales", "tiny", "zero", "huge", "nonfinite", "constant"])
