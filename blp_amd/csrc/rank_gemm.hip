@@ -316,8 +316,8 @@ constexpr float kBandCBf16 = 620.0f;
 constexpr int kBfW = 4;          // waves per workgroup
 constexpr int kBfTPW = 2;        // candidate tiles per wave (4 at one wave/SIMD spills and runs 1.8x slower)
 constexpr int kBfWavesPerSimd = 2;  // launch bound: <= 256 VGPRs (128 of them hold the A operands)
-constexpr int kBfMinTilesPerChunk = 16;          // query tiles per workgroup: 16 / 32 / 64, chosen per launch by a
-constexpr int kBfMaxTilesPerChunk = 64;          // small cost model (see rank_gemm_impl)
+constexpr int kBfMinTilesPerChunk = 16;          // query tiles per workgroup: 16 / 32 / 64, chosen per launch by a small cost model
+constexpr int kBfMaxTilesPerChunk = 96;          // (rank_gemm_impl); the test knob takes any multiple of 4 up to 96 (from 92 on: one workgroup per CU)
 constexpr int kBfResident = 512;                 // workgroups the chip holds (2 per CU)
 constexpr int kBfSetupTiles = 5;                 // a workgroup's set-up, in query tiles of work
 constexpr int kBfQuotaPerTile = 8 * kBfTPW;      // undecided pairs a workgroup can list, per query tile of its chunk
@@ -1044,10 +1044,9 @@ static int64_t pair_entries(int64_t T, int64_t q_head, int64_t q_tail) {
     auto chunks = [&](int64_t per) { return (th + per - 1) / per + (tt + per - 1) / per; };
     const int64_t f32_kernel = (T + kGW - 1) / kGW * chunks(kGTilesPerChunk) * kPairQuota;
     int64_t most = f32_kernel;
-    for (int per = kBfMinTilesPerChunk; per <= kBfMaxTilesPerChunk; per *= 2) {  // whichever chunking a launch picks
-        const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * chunks(per) * kBfQuotaPerTile * per;
-        most = bf16_kernel > most ? bf16_kernel : most;
-    }
+    // whichever chunking a launch picks: chunks(per) * per <= th + tt + 2 * per
+    const int64_t bf16_kernel = (T + kBfW * kBfTPW - 1) / (kBfW * kBfTPW) * (th + tt + 2 * kBfMaxTilesPerChunk) * kBfQuotaPerTile;
+    most = bf16_kernel > most ? bf16_kernel : most;
     return most;
 }
 
@@ -1174,13 +1173,13 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             // workgroup's set-up (candidate split, LDS tables, pipeline ramp, list write-out) costs about as much
             // as kBfSetupTiles query tiles (fitted on the FB15k-237 block: 1.64 / 1.49 / 1.47 ms at 16 / 32 / 64).
             int64_t best_cost = INT64_MAX;
-            for (int per = kBfMaxTilesPerChunk; per >= kBfMinTilesPerChunk; per /= 2) {
+            for (int per = 64; per >= kBfMinTilesPerChunk; per /= 2) {  // ([measured] 48 .. 88 in steps of 4: 0.998 - 1.035 ms against 1.004 at 64: flat)
                 const int64_t grid = n_groups * ((th + per - 1) / per + (tt + per - 1) / per);
                 const int64_t cost = ((grid + kBfResident - 1) / kBfResident) * (kBfSetupTiles + per);
                 if (cost < best_cost) { best_cost = cost; tiles_per_chunk = per; }
             }
             const int forced = (int)knob(KNOB_GEMM_TILES_PER_CHUNK);  // test knob: long chunks on small problems
-            if (forced == 16 || forced == 32 || forced == 64) tiles_per_chunk = forced;
+            if (forced >= kBfMinTilesPerChunk && forced <= kBfMaxTilesPerChunk && forced % 4 == 0) tiles_per_chunk = forced;
         }
         const int64_t chunks_head = (th + tiles_per_chunk - 1) / tiles_per_chunk;
         const int64_t chunks_tail = (tt + tiles_per_chunk - 1) / tiles_per_chunk;
