@@ -733,6 +733,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
                                       stream, slots);
     }
     RankWorkspace w = carve_workspace(workspace, D, q_head, q_tail);
+    if (q_head <= kQB && q_tail <= kQB) w.coef_tail = w.coef_head + q_head * Scorer<MODEL, HEAD, D>::C;  // (static mode: one array, as a pass of blp_rank_all_batches has it -- the streaming kernels' layout)
     // <= 4 + 4 queries of a bilinear model: the streaming kernels take approximate keys first (operand rows + bands)
     const bool dot_keys = q_head <= kQB && q_tail <= kQB && N > 0 && rank_stream_wants_dot(MODEL, D, N, ld, q_head, q_tail);
     launch_true_key<MODEL, D>(q_true, q_fixed, q_rel, q_head, q_tail, w.key_true, w.acc, stream, dot_keys ? nullptr : w.coef_head,
@@ -903,14 +904,18 @@ template <int MODEL, int D>
 __global__ __launch_bounds__(64) void prep_passes_kernel(const QRows q_fixed, const QRows q_rel, const QRows q_true, int64_t n,
                                                         int64_t batch, float* __restrict__ coef, float* __restrict__ key_true,
                                                         unsigned long long* __restrict__ acc, unsigned key_blocks,
-                                                        unsigned dot_blocks, float* __restrict__ wq, float* __restrict__ band) {
+                                                        unsigned dot_blocks, float* __restrict__ wq, float* __restrict__ band,
+                                                        int acc_slots) {
     using SH = Scorer<MODEL, HEAD, D>;
     using ST = Scorer<MODEL, TAIL, D>;
     constexpr int CP = SH::C + ST::C, CM = SH::C > ST::C ? SH::C : ST::C;  // floats per triple of a pass / widest row
     const int64_t Q = 2 * n;
     if (blockIdx.x < key_blocks) {  // one lane per query: its true key (all of its row loads in flight at once), acc = 0
         const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
-        if (q < Q) true_key_lane_side<MODEL, D>(q_true, q_fixed, q_rel, q, replaces_head(q, 0, Q, batch), key_true, acc);
+        if (q < Q) {
+            true_key_lane_side<MODEL, D>(q_true, q_fixed, q_rel, q, replaces_head(q, 0, Q, batch), key_true, acc);
+            for (int s = 1; s < acc_slots; ++s) acc[(int64_t)s * Q + q] = 0;  // (all passes in one launch: replicated accumulators)
+        }
         return;
     }
     if (blockIdx.x >= gridDim.x - dot_blocks) {  // the approximate keys' operand rows, eight queries per workgroup
@@ -952,7 +957,7 @@ static PassesWorkspace carve_passes(void* base, int D, int64_t n, int64_t batch)
     size_t off = 0;
     w.coef = reinterpret_cast<float*>(p + off);     off = align_up(off + (size_t)n * 2 * max_coef(D) * 4, 256);
     w.key_true = reinterpret_cast<float*>(p + off); off = align_up(off + (size_t)n * 2 * 4, 256);
-    w.acc = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)n * 2 * 8, 256);
+    w.acc = reinterpret_cast<unsigned long long*>(p + off); off = align_up(off + (size_t)n * 2 * 8 * kStreamAccSlots, 256);
     w.wq = reinterpret_cast<float*>(p + off);       off = align_up(off + (size_t)passes * dot_rows_floats(D) * 4, 256);
     w.band = reinterpret_cast<float*>(p + off);     off = align_up(off + (size_t)n * 2 * 2 * 4, 256);
     w.bytes = off;
@@ -975,29 +980,46 @@ static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, 
     const int64_t Q = 2 * n, key_blocks = (Q + 63) / 64;
     int64_t coef_blocks = (Q * (SH::C > ST::C ? SH::C : ST::C) + 63) / 64;
     coef_blocks = coef_blocks > 8192 ? 8192 : coef_blocks;
-    const bool dot_keys = rank_stream_wants_dot(MODEL, D, N, ld, batch, batch);
+    // all passes in one launch of a ring kernel (rank_stream.hip: StreamPasses), or a launch per pass
+    const bool one_launch = knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_takes_passes(MODEL, D, N, ld, batch, n);
+    const bool dot_keys = rank_stream_wants_dot(MODEL, D, N, ld, batch, batch, one_launch);
     const int64_t dot_blocks = dot_keys ? (Q + 7) / 8 : 0;
     if (dot_keys) coef_blocks = 0;  // the approximate-key kernel reads operand rows, not coefficient rows
+    const int acc_slots = one_launch ? kStreamAccSlots : 1;
     prep_passes_kernel<MODEL, D><<<dim3((unsigned)(key_blocks + coef_blocks + dot_blocks)), 64, 0, stream>>>(
-        q_fixed, q_rel, q_true, n, batch, w.coef, w.key_true, w.acc, (unsigned)key_blocks, (unsigned)dot_blocks, w.wq, w.band);
-    for (int64_t first = 0; first < n; first += batch) {
-        const int nb = (int)(n - first < batch ? n - first : batch);
-        const float* coef_head = w.coef + first * (SH::C + ST::C);
+        q_fixed, q_rel, q_true, n, batch, w.coef, w.key_true, w.acc, (unsigned)key_blocks, (unsigned)dot_blocks, w.wq, w.band, acc_slots);
+    if (one_launch) {
+        StreamPasses passes;
+        passes.n_passes = (int)((n + batch - 1) / batch);
+        passes.batch = (int)batch;
+        passes.n = n;
+        passes.acc_slots = acc_slots;
         StreamDot dot;
-        if (dot_keys) {
-            dot.wq = w.wq + (first / batch) * dot_rows_floats(D);
-            dot.band = w.band + 2 * 2 * first;
-            dot.q_fixed = q_fixed; dot.q_rel = q_rel; dot.q0 = 2 * first;
-        }
-        if (first == 0 && ev_start) (void)hipEventRecord(ev_start, stream);
-        const hipError_t err = launch_static_pass<MODEL, D>(table, N, ld, coef_head, coef_head + (size_t)nb * SH::C, w.key_true + 2 * first,
-                                                            nb, nb, w.acc + 2 * first, dot, n_cu, stream);
+        if (dot_keys) { dot.wq = w.wq; dot.band = w.band; dot.q_fixed = q_fixed; dot.q_rel = q_rel; dot.q0 = 0; }
+        if (ev_start) (void)hipEventRecord(ev_start, stream);
+        const hipError_t err = launch_rank_stream(MODEL, D, table, N, ld, w.coef, w.coef, w.key_true, batch, batch, w.acc, dot, n_cu, stream, passes);
         if (err != hipSuccess) return err;
-        if (first == 0 && ev_stop) (void)hipEventRecord(ev_stop, stream);
+        if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+    } else {
+        for (int64_t first = 0; first < n; first += batch) {
+            const int nb = (int)(n - first < batch ? n - first : batch);
+            const float* coef_head = w.coef + first * (SH::C + ST::C);
+            StreamDot dot;
+            if (dot_keys) {
+                dot.wq = w.wq + (first / batch) * dot_rows_floats(D);
+                dot.band = w.band + 2 * 2 * first;
+                dot.q_fixed = q_fixed; dot.q_rel = q_rel; dot.q0 = 2 * first;
+            }
+            if (first == 0 && ev_start) (void)hipEventRecord(ev_start, stream);
+            const hipError_t err = launch_static_pass<MODEL, D>(table, N, ld, coef_head, coef_head + (size_t)nb * SH::C, w.key_true + 2 * first,
+                                                                nb, nb, w.acc + 2 * first, dot, n_cu, stream);
+            if (err != hipSuccess) return err;
+            if (first == 0 && ev_stop) (void)hipEventRecord(ev_stop, stream);
+        }
     }
     if (filter.on())
-        return filter_finalize_impl<MODEL, D>(table, N, ld, q_fixed, q_rel, w.key_true, n, n, filter, w.acc, 1, counts, stream, batch);
-    finalize_counts_kernel<<<(int)((Q + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(w.acc, 1, Q, counts);
+        return filter_finalize_impl<MODEL, D>(table, N, ld, q_fixed, q_rel, w.key_true, n, n, filter, w.acc, acc_slots, counts, stream, batch);
+    finalize_counts_kernel<<<(int)((Q + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(w.acc, acc_slots, Q, counts);
     return hipGetLastError();
 }
 

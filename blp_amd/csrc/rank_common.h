@@ -120,10 +120,23 @@ struct StreamDot {
     QRows q_fixed, q_rel;
     int64_t q0 = 0;
 };
-bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail);
+bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail, bool passes = false);
+// Many passes of `batch` triples each (the last: what is left of n) in ONE launch of a ring kernel, in the layout
+// rank_all.hip's prep_passes_kernel leaves: pass p's queries are 2 p batch .. of the call's key_true / acc / band arrays,
+// its coefficient rows start at (p batch) x (floats per triple), its operand rows at p x kStreamDotRows x D.  acc_slots
+// replicas of the accumulators (slot s of query q: acc[s * 2 n + q]).  n_passes <= 1: the single pass the pointers describe.
+struct StreamPasses {
+    int n_passes = 1;
+    int batch = 0;
+    int64_t n = 0;
+    int acc_slots = 1;
+};
+constexpr int kStreamAccSlots = 16;
+bool rank_stream_takes_passes(int model, int D, int64_t N, int64_t ld, int64_t batch, int64_t n);  // all passes in one launch?
 hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                              unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream);
+                              unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream,
+                              const StreamPasses& passes = StreamPasses());
 
 // rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
 void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)

@@ -46,11 +46,29 @@ __device__ __forceinline__ void piece_fetch(f32x4 (&b)[8], const float* __restri
         b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff[i] + s * (kSubCols * 4)));
 }
 
+// MANY PASSES IN ONE LAUNCH (StreamPasses, rank_common.h; the reference's Wikidata5M evaluation is a pass per two triples).
+// A pass launched on its own ramps up and drains: on a 1/8 shard of the 4.6 M-row table that is several of its ~45 us.
+// The ring kernels take all passes of a call as ONE index space of (pass, round of four tiles), workgroup b walking
+// rounds b, b + gridDim.x, ...: a wave crosses from pass p's last tile to pass p + 1's first with its ring full, and the
+// load pipeline of the chip never drains between passes.  A wave that enters a new pass flushes its counts straight to
+// the accumulators (replicated acc_slots times -- slot = workgroup mod acc_slots -- so that a few thousand waves do not
+// queue on one address; the finalisation adds the slots) and re-derives the pass's pointers; nothing synchronises.
+struct PassView {  // pass p of a call in the layout of rank_all.hip's prep_passes_kernel (or the single pass as given)
+    int q_head, q_tail;
+    int64_t first2;  // queries of the call before this pass (2 x its first triple)
+};
+__device__ __forceinline__ PassView pass_view(const StreamPasses& ps, int p, int q_head, int q_tail) {
+    if (ps.n_passes <= 1) return PassView{q_head, q_tail, 0};
+    const int64_t first = (int64_t)p * ps.batch, left = ps.n - first;
+    const int nb = (int)(left < ps.batch ? left : ps.batch);
+    return PassView{nb, nb, 2 * first};
+}
+
 template <int D>
 __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_kernel(
-    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
-    const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
-    unsigned long long* __restrict__ acc) {
+    const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef,
+    const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
+    unsigned long long* __restrict__ acc, const StreamPasses passes) {
     constexpr int NP = D / kSubCols;  // pieces per tile
     static_assert(NP % 2 == 0, "the ring of two pieces assumes an even number of pieces per tile");
     __shared__ __attribute__((aligned(16))) float slabs[kWaves * kSlabFloats];
@@ -63,9 +81,11 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
     const float* rd = slab + lane * kLdsStride;
     if (tid < 2 * kStreamQ) wg_cnt[tid] = 0;
 
-    // the wave's tiles: four consecutive tiles per workgroup and round, workgroups grid-stride over the rounds
-    const int stride = gridDim.x * kWaves;
-    int tile = blockIdx.x * kWaves + wave;
+    // rounds of four consecutive tiles (one per wave); round r of the launch = round r % n_rounds of pass r / n_rounds.
+    // A wave whose tile of a pass's last round does not exist walks the last tile again, masked when counting.
+    const unsigned n_rounds = (unsigned)(n_tiles + kWaves - 1) / kWaves, total = n_rounds * (unsigned)passes.n_passes;
+    const unsigned long long slot_off = passes.acc_slots > 1 ? (unsigned long long)(blockIdx.x % passes.acc_slots) * (2ull * passes.n) : 0ull;
+    auto tile_of = [&](unsigned r) { return (int)((r % n_rounds) * kWaves) + wave; };  // may be >= n_tiles
 
     // byte offsets of this lane's parts of a tile's rows (rows past the end of the table: the last row, masked later)
     unsigned boff[8];
@@ -79,33 +99,74 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
         }
     };
     auto tile_base = [&](int t) { return table + (int64_t)t * kTileRows * ld; };
+    auto clamp_tile = [&](int t) { return t < n_tiles ? t : n_tiles - 1; };
 
     unsigned n_gt[2 * kStreamQ] = {}, n_ge[2 * kStreamQ] = {};  // wave-uniform: scalar registers
+    // the pass the wave is in: its queries' coefficient rows, true keys, accumulators (prep_passes_kernel's layout)
+    // (one base pointer for the coefficient rows: the pass's head rows, 2 D floats each, then its tail rows, D each -- with
+    //  two, the pass-dependent choice between them costs the compiler the no-alias reasoning that keeps these loads scalar)
+    int cur_p = -1, qh = 0, qt = 0;
+    const float *ch = coef, *ct = coef, *kt = key_true;
+    unsigned long long* acc_p = acc;
+    auto enter = [&](int p) {
+        const PassView v = pass_view(passes, p, q_head, q_tail);
+        qh = v.q_head; qt = v.q_tail;
+        ch = coef + (v.first2 / 2) * (3 * D);  // per triple of the earlier passes: a head row and a tail row
+        ct = ch + (size_t)qh * (2 * D);
+        kt = key_true + v.first2;
+        acc_p = acc + slot_off + v.first2;
+        cur_p = p;
+    };
+    auto flush_wave = [&]() {  // this wave's counts of pass cur_p -> its accumulators; slot j < 4: head query j; 4 + j: tail query j
+        if (lane < 2 * kStreamQ) {
+            unsigned gt = 0, ge = 0;
+            static_for<2 * kStreamQ>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if (lane == j) { gt = n_gt[j]; ge = n_ge[j]; }
+            });
+            const int side_q = lane < kStreamQ ? lane : lane - kStreamQ;
+            const bool live = lane < kStreamQ ? side_q < qh : side_q < qt;
+            const unsigned long long v = (unsigned long long)gt | ((unsigned long long)ge << 32);
+            if (live && v) atomicAdd(acc_p + (lane < kStreamQ ? side_q : qh + side_q), v);
+        }
+        static_for<2 * kStreamQ>([&](auto jj) { n_gt[decltype(jj)::value] = 0; n_ge[decltype(jj)::value] = 0; });
+    };
+
+    unsigned r = blockIdx.x;
     f32x4 ring[2][8];
-    if (tile < n_tiles) {
-        offsets(tile);
-        piece_fetch(ring[0], tile_base(tile), boff, 0);
-        piece_fetch(ring[1], tile_base(tile), boff, 1);
+    if (r < total) {
+        const int t0 = clamp_tile(tile_of(r));
+        offsets(t0);
+        piece_fetch(ring[0], tile_base(t0), boff, 0);
+        piece_fetch(ring[1], tile_base(t0), boff, 1);
+        enter((int)(r / n_rounds));
     }
-    for (; tile < n_tiles; tile += stride) {
-        const int next = tile + stride;
-        const bool more = next < n_tiles;  // wave-uniform
+    for (; r < total; r += gridDim.x) {
+        const int p = (int)(r / n_rounds);
+        if (p != cur_p) {  // wave-uniform
+            flush_wave();
+            enter(p);
+        }
+        const int tile_real = tile_of(r), tile = clamp_tile(tile_real);
+        const unsigned next_r = r + gridDim.x;
+        const bool more = next_r < total;  // wave-uniform
+        const int next = more ? clamp_tile(tile_of(next_r)) : 0;
         const float* base = tile_base(tile);
         float sum[2 * kStreamQ] = {};
         static_for<NP>([&](auto ss) {
-            constexpr int s = decltype(ss)::value, p = s & 1;
+            constexpr int s = decltype(ss)::value, pp = s & 1;
             // piece s: registers -> slab (transposing) ...
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<f32x4*>(wr + 8 * i * kLdsStride) = ring[p][i];
+                *reinterpret_cast<f32x4*>(wr + 8 * i * kLdsStride) = ring[pp][i];
             // ... and its ring slot is refilled with the piece two steps ahead: this tile's, or the next tile's
             if constexpr (s + 2 < NP) {
-                piece_fetch(ring[p], base, boff, s + 2);
+                piece_fetch(ring[pp], base, boff, s + 2);
             } else {
                 if constexpr (s + 2 == NP) {
                     if (more) offsets(next);
                 }
-                if (more) piece_fetch(ring[p], tile_base(next), boff, s + 2 - NP);
+                if (more) piece_fetch(ring[pp], tile_base(next), boff, s + 2 - NP);
             }
             wave_lds_sync();
             float x[kSubCols];
@@ -117,29 +178,30 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
             wave_lds_sync();  // the reads are out before the next piece overwrites the slab
             static_for<kStreamQ>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
-                if (j < q_tail) sum[kStreamQ + j] = transe_piece_sum<TAIL, D, s == 0>(sum[kStreamQ + j], x, coef_tail + j * D + s * kSubCols);
+                if (j < qt) sum[kStreamQ + j] = transe_piece_sum<TAIL, D, s == 0>(sum[kStreamQ + j], x, ct + j * D + s * kSubCols);
             });
             static_for<kStreamQ>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
-                if (j < q_head) sum[j] = transe_piece_sum<HEAD, D, s == 0>(sum[j], x, coef_head + j * 2 * D + s * kSubCols);
+                if (j < qh) sum[j] = transe_piece_sum<HEAD, D, s == 0>(sum[j], x, ch + j * 2 * D + s * kSubCols);
             });
         });
-        const bool valid = (int64_t)tile * kTileRows + lane < N;
+        const bool valid = tile_real < n_tiles && (int64_t)tile * kTileRows + lane < N;
         static_for<kStreamQ>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
-            if (j < q_head) {
-                const float key = -sum[j], kt = key_true[j];
-                n_gt[j] += __popcll(__ballot(valid && key > kt));
-                n_ge[j] += __popcll(__ballot(valid && key >= kt));
+            if (j < qh) {
+                const float key = -sum[j], k_true = kt[j];
+                n_gt[j] += __popcll(__ballot(valid && key > k_true));
+                n_ge[j] += __popcll(__ballot(valid && key >= k_true));
             }
-            if (j < q_tail) {
-                const float key = -sum[kStreamQ + j], kt = key_true[q_head + j];
-                n_gt[kStreamQ + j] += __popcll(__ballot(valid && key > kt));
-                n_ge[kStreamQ + j] += __popcll(__ballot(valid && key >= kt));
+            if (j < qt) {
+                const float key = -sum[kStreamQ + j], k_true = kt[qh + j];
+                n_gt[kStreamQ + j] += __popcll(__ballot(valid && key > k_true));
+                n_ge[kStreamQ + j] += __popcll(__ballot(valid && key >= k_true));
             }
         });
     }
 
+    // the last pass of the workgroup (all of its waves walk the same rounds): summed over its waves in LDS, one atomic per query
     __syncthreads();  // wg_cnt is zero
     if (lane < 2 * kStreamQ) {
         unsigned gt = 0, ge = 0;
@@ -151,11 +213,11 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
         if (v) atomicAdd(&wg_cnt[lane], v);
     }
     __syncthreads();
-    if (tid < 2 * kStreamQ) {  // slot j < 4: head query j; slot 4 + j: tail query j
+    if (tid < 2 * kStreamQ && cur_p >= 0) {  // slot j < 4: head query j; slot 4 + j: tail query j
         const int side_q = tid < kStreamQ ? tid : tid - kStreamQ;
-        const bool live = tid < kStreamQ ? side_q < q_head : side_q < q_tail;
+        const bool live = tid < kStreamQ ? side_q < qh : side_q < qt;
         const unsigned long long v = wg_cnt[tid];
-        if (live && v) atomicAdd(acc + (tid < kStreamQ ? side_q : q_head + side_q), v);
+        if (live && v) atomicAdd(acc_p + (tid < kStreamQ ? side_q : qh + side_q), v);
     }
 }
 
@@ -437,23 +499,24 @@ template <int MODEL, int D, int NQ>
 __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ wq, const float* __restrict__ band,
     const float* __restrict__ key_true, const QRows q_fixed, const QRows q_rel, int64_t q0, int q_head, int q_tail,
-    int n_tiles, unsigned long long* __restrict__ acc) {
-    constexpr int NP = D / kSubCols;  // NQ: the pass has at most NQ queries (4: the reference's Wikidata5M batch of two triples)
+    int n_tiles, unsigned long long* __restrict__ acc, const StreamPasses passes) {
+    constexpr int NP = D / kSubCols;  // NQ: a pass has at most NQ queries (4: the reference's Wikidata5M batch of two triples)
     static_assert(NP % 2 == 0, "the ring of two pieces assumes an even number of pieces per tile");
     static_assert(NQ == 4 || NQ == 2 * kStreamQ, "a pass of up to 4, or up to 4 + 4, queries");
     __shared__ __attribute__((aligned(16))) float slabs[kWaves * kSlabFloats];
     __shared__ unsigned long long wg_cnt[NQ];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Q = q_head + q_tail;  // the pass's queries, heads first: query q < Q is q0 + q of the call
     float* slab = slabs + wave * kSlabFloats;
     const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
     float* wr = slab + sub_row * kLdsStride + sub_col;
     const float* rd = slab + lane * kLdsStride;
     if (tid < NQ) wg_cnt[tid] = 0;
 
-    const int stride = gridDim.x * kWaves;
-    int tile = blockIdx.x * kWaves + wave;
+    // rounds of four tiles over all passes of the launch: see rank_stream_kernel
+    const unsigned n_rounds = (unsigned)(n_tiles + kWaves - 1) / kWaves, total = n_rounds * (unsigned)passes.n_passes;
+    const unsigned long long slot_off = passes.acc_slots > 1 ? (unsigned long long)(blockIdx.x % passes.acc_slots) * (2ull * passes.n) : 0ull;
+    auto tile_of = [&](unsigned r) { return (int)((r % n_rounds) * kWaves) + wave; };  // may be >= n_tiles
     unsigned boff[8];
     auto offsets = [&](int t) {
         const int64_t left = N - (int64_t)t * kTileRows;
@@ -465,34 +528,77 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_
         }
     };
     auto tile_base = [&](int t) { return table + (int64_t)t * kTileRows * ld; };
+    auto clamp_tile = [&](int t) { return t < n_tiles ? t : n_tiles - 1; };
 
     unsigned n_gt[NQ] = {};           // certainly above the true key (gt and ge alike): wave-uniform, scalar registers
     unsigned long long ex_cnt = 0;    // lane q: query q's undecided rows at or above it, gt | ge << 32
+    // the pass the wave is in (queries heads first: query q < Q of the pass is q0_p + q of the call)
+    int cur_p = -1, qh = 0, Q = 0;
+    const float *wq_p = wq, *band_p = band, *kt = key_true;
+    int64_t q0_p = q0;
+    unsigned long long* acc_p = acc;
+    sf16 cur;
+    auto enter = [&](int p) {
+        const PassView v = pass_view(passes, p, q_head, q_tail);
+        qh = v.q_head; Q = v.q_head + v.q_tail;
+        if (passes.n_passes > 1) {
+            wq_p = wq + (size_t)p * (kStreamDotRows * D);
+            band_p = band + 2 * v.first2;
+            kt = key_true + v.first2;
+            q0_p = q0 + v.first2;
+            acc_p = acc + slot_off + v.first2;
+        }
+        cur = sload16<stream_dot_row(0) * D * 4>(wq_p);  // unit 0 of piece 0 of this pass's operands
+        sdrain(cur);
+        cur_p = p;
+    };
+    auto flush_wave = [&]() {
+        if (lane < NQ) {
+            unsigned above = 0;
+            static_for<NQ>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if (lane == j) above = n_gt[j];
+            });
+            const unsigned long long v = ((unsigned long long)above | ((unsigned long long)above << 32)) + ex_cnt;
+            if (lane < Q && v) atomicAdd(acc_p + lane, v);
+        }
+        ex_cnt = 0;
+        static_for<NQ>([&](auto jj) { n_gt[decltype(jj)::value] = 0; });
+    };
+
+    unsigned r = blockIdx.x;
     f32x4 ring[2][8];
-    if (tile < n_tiles) {
-        offsets(tile);
-        piece_fetch(ring[0], tile_base(tile), boff, 0);
-        piece_fetch(ring[1], tile_base(tile), boff, 1);
+    if (r < total) {
+        const int t0 = clamp_tile(tile_of(r));
+        offsets(t0);
+        piece_fetch(ring[0], tile_base(t0), boff, 0);
+        piece_fetch(ring[1], tile_base(t0), boff, 1);
+        enter((int)(r / n_rounds));
     }
-    sf16 cur = sload16<stream_dot_row(0) * D * 4>(wq);  // unit 0 of piece 0
-    sdrain(cur);
-    for (; tile < n_tiles; tile += stride) {
-        const int next = tile + stride;
-        const bool more = next < n_tiles;  // wave-uniform
+    for (; r < total; r += gridDim.x) {
+        const int p = (int)(r / n_rounds);
+        if (p != cur_p) {  // wave-uniform
+            flush_wave();
+            enter(p);
+        }
+        const int tile_real = tile_of(r), tile = clamp_tile(tile_real);
+        const unsigned next_r = r + gridDim.x;
+        const bool more = next_r < total;  // wave-uniform
+        const int next = more ? clamp_tile(tile_of(next_r)) : 0;
         const float* base = tile_base(tile);
         float sum[NQ] = {}, ssq = 0.f;
         static_for<NP>([&](auto ss) {
-            constexpr int s = decltype(ss)::value, p = s & 1;
+            constexpr int s = decltype(ss)::value, pp = s & 1;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<f32x4*>(wr + 8 * i * kLdsStride) = ring[p][i];
+                *reinterpret_cast<f32x4*>(wr + 8 * i * kLdsStride) = ring[pp][i];
             if constexpr (s + 2 < NP) {
-                piece_fetch(ring[p], base, boff, s + 2);
+                piece_fetch(ring[pp], base, boff, s + 2);
             } else {
                 if constexpr (s + 2 == NP) {
                     if (more) offsets(next);
                 }
-                if (more) piece_fetch(ring[p], tile_base(next), boff, s + 2 - NP);
+                if (more) piece_fetch(ring[pp], tile_base(next), boff, s + 2 - NP);
             }
             wave_lds_sync();
             float x[kSubCols];
@@ -503,9 +609,9 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_
             }
             wave_lds_sync();  // the reads are out before the next piece overwrites the slab
             // (no branch per query: a slot the pass has no query for walks its -- unwritten -- operand row, never counted)
-            dot_units<D, NQ, s, 0>(sum, ssq, x, wq, cur);
+            dot_units<D, NQ, s, 0>(sum, ssq, x, wq_p, cur);
         });
-        const bool valid = (int64_t)tile * kTileRows + lane < N;
+        const bool valid = tile_real < n_tiles && (int64_t)tile * kTileRows + lane < N;
         const float nrow = sqrtf(ssq) * 1.0001f;
         const bool tiny = ssq < 1e-30f;
         // lane q parks query q's undecided rows (a mask); the exact routine then runs once, over run-time q
@@ -514,7 +620,7 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_
         static_for<NQ>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
             if (q < Q) {
-                const DotBand b = dot_band_of(key_true, band, q);
+                const DotBand b = dot_band_of(kt, band_p, q);
                 bool gt, lt;
                 dot_decide(sum[q], b, nrow, tiny, gt, lt);
                 const unsigned long long above = __ballot(valid && gt), und = __ballot(valid && !(gt || lt));
@@ -528,13 +634,14 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_
                 const unsigned long long und = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(und_lo, q) |  // (returns int)
                                                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(und_hi, q) << 32);
                 if (!und) continue;
-                const unsigned long long c = exact_undecided<MODEL, D>(table, ld, (int64_t)tile * kTileRows, q_fixed.row(q0 + q),
-                                                                       q_rel.row(q0 + q), q < q_head, und, key_true[q], lane);
+                const unsigned long long c = exact_undecided<MODEL, D>(table, ld, (int64_t)tile * kTileRows, q_fixed.row(q0_p + q),
+                                                                       q_rel.row(q0_p + q), q < qh, und, kt[q], lane);
                 if (lane == q) ex_cnt += c;
             }
         }
     }
 
+    // the last pass of the workgroup (all of its waves walk the same rounds): summed over its waves in LDS, one atomic per query
     __syncthreads();  // wg_cnt is zero
     if (lane < NQ) {
         unsigned above = 0;
@@ -546,9 +653,9 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot_
         if (v) atomicAdd(&wg_cnt[lane], v);
     }
     __syncthreads();
-    if (tid < Q) {
+    if (tid < Q && cur_p >= 0) {
         const unsigned long long v = wg_cnt[tid];
-        if (v) atomicAdd(acc + tid, v);
+        if (v) atomicAdd(acc_p + tid, v);
     }
 }
 
@@ -563,16 +670,18 @@ bool rank_stream_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_h
 // with order-exact keys: 575 k rows DistMult 54 / 70, ComplEx 55 / 80, SimplE 53 / 69; 1.15 M rows 101 / 108, 102 / 132,
 // 101 / 108; 4.6 M rows 368 / 355, 369 / 471, 367 / 352): the ring below kStreamWgMinRows rows and for ComplEx at any
 // length; knob stream_kernel = 3 (or 5) / 4 forces the workgroup-tile / the ring kernel.
-static bool bilinear_takes_ring(int model, int D, int64_t N, int64_t ld) {
+// `passes`: the call is many passes, which the ring kernels take in one launch (below) -- ramps paid once per call, not per
+// pass: [measured, ComplEx] 369 -> 338 us per 4.6 M-row pass, past the workgroup tile's 350 - 355 for DistMult / SimplE.
+static bool bilinear_takes_ring(int model, int D, int64_t N, int64_t ld, bool passes) {
     const long long forced = knob(KNOB_STREAM_KERNEL);
     if (ld >= (1 << 22)) return false;  // (32-bit byte offsets inside a tile)
     if (forced == 3 || forced == 5) return false;
-    return forced == 4 || model == COMPLEX || D == 256 || N < kStreamWgMinRows;
+    return forced == 4 || passes || model == COMPLEX || D == 256 || N < kStreamWgMinRows;
 }
 // ... and so needs the operand rows and bands of rank_all.hip's preparation launch
-bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
+bool rank_stream_wants_dot(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail, bool passes) {
     return model != TRANSE && knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_applicable(model, D, N, ld, q_head, q_tail) &&
-           bilinear_takes_ring(model, D, N, ld);
+           bilinear_takes_ring(model, D, N, ld, passes);
 }
 
 template <int MODEL, int D>
@@ -593,30 +702,53 @@ static hipError_t launch_stream_wg(const float* table, int64_t N, int64_t ld, co
 
 template <int MODEL, int D>
 static hipError_t launch_stream_dot(const float* table, int64_t N, int64_t ld, const StreamDot& dot, const float* key_true,
-                                    int q_head, int q_tail, int n_tiles, unsigned long long* acc, int n_cu, hipStream_t stream) {
-    const int64_t n_rounds = ((int64_t)n_tiles + kWaves - 1) / kWaves;
-    if (q_head + q_tail <= 4) {  // four waves per SIMD
+                                    int q_head, int q_tail, int n_tiles, unsigned long long* acc, int n_cu, hipStream_t stream,
+                                    const StreamPasses& passes) {
+    const int64_t n_rounds = (((int64_t)n_tiles + kWaves - 1) / kWaves) * (passes.n_passes > 1 ? passes.n_passes : 1);
+    const int per_pass = passes.n_passes > 1 ? 2 * passes.batch : q_head + q_tail;
+    if (per_pass <= 4) {  // four waves per SIMD
         const int64_t resident = (int64_t)n_cu * 4;
         rank_stream_dot_kernel<MODEL, D, 4><<<(unsigned)(n_rounds < resident ? n_rounds : resident), kWaves * 64, 0, stream>>>(
-            table, N, ld, dot.wq, dot.band, key_true, dot.q_fixed, dot.q_rel, dot.q0, q_head, q_tail, n_tiles, acc);
+            table, N, ld, dot.wq, dot.band, key_true, dot.q_fixed, dot.q_rel, dot.q0, q_head, q_tail, n_tiles, acc, passes);
     } else {  // eight running sums: three
         const int64_t resident = (int64_t)n_cu * 3;
         rank_stream_dot_kernel<MODEL, D, 2 * kStreamQ><<<(unsigned)(n_rounds < resident ? n_rounds : resident), kWaves * 64, 0, stream>>>(
-            table, N, ld, dot.wq, dot.band, key_true, dot.q_fixed, dot.q_rel, dot.q0, q_head, q_tail, n_tiles, acc);
+            table, N, ld, dot.wq, dot.band, key_true, dot.q_fixed, dot.q_rel, dot.q0, q_head, q_tail, n_tiles, acc, passes);
     }
     return hipGetLastError();
 }
 
+// TransE: the ring or the workgroup-tile kernel ([measured] 4-query pass, ring / workgroup tile: 1.15 M rows 103 / 109,
+// 2.3 M rows 198 / 188, 4.6 M rows 384 / 353 us = 6.7 TB/s; a 1/8 Wikidata5M shard: 58 against 72); knob stream_kernel = 3 / 4
+// forces the workgroup-tile / the ring kernel
+// (many passes in one launch: [measured] ring / workgroup tile 2.3 M rows 176 / 180, 4.6 M rows 355 / 348 us per pass)
+constexpr int64_t kStreamWgMinRowsPasses = 3200000;
+static bool transe_takes_ring(int D, int64_t N, bool passes) {
+    const long long forced = knob(KNOB_STREAM_KERNEL);
+    return !(D != 256 && forced != 4 && (forced == 3 || N >= (passes ? kStreamWgMinRowsPasses : kStreamWgMinRows)));
+}
+
+// All passes of a call in one launch: the ring kernels only (the workgroup-tile kernel's passes are long: their ramps
+// are a per cent of them), and while the rounds of all passes fit the kernels' 32-bit round index.
+bool rank_stream_takes_passes(int model, int D, int64_t N, int64_t ld, int64_t batch, int64_t n) {
+    if (knob(KNOB_STREAM_KERNEL) == 2 || !rank_stream_applicable(model, D, N, ld, batch, batch)) return false;
+    const int64_t n_rounds = ((N + kTileRows - 1) / kTileRows + kWaves - 1) / kWaves, n_passes = (n + batch - 1) / batch;
+    if (n_passes <= 1 || n_rounds * n_passes >= (int64_t)0x7fffffff) return false;
+    return model == TRANSE ? transe_takes_ring(D, N, true) : bilinear_takes_ring(model, D, N, ld, true);
+}
+
 hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, int64_t ld, const float* coef_head,
                               const float* coef_tail, const float* key_true, int64_t q_head, int64_t q_tail,
-                              unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream) {
+                              unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream,
+                              const StreamPasses& passes) {
     const int64_t n_tiles = (N + kTileRows - 1) / kTileRows;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
+    if (passes.n_passes > 1 && !rank_stream_takes_passes(model, D, N, ld, passes.batch, passes.n)) return hipErrorInvalidValue;
     if (model != TRANSE) {
-        if (dot.wq != nullptr && bilinear_takes_ring(model, D, N, ld)) {
+        if (dot.wq != nullptr && bilinear_takes_ring(model, D, N, ld, passes.n_passes > 1)) {
 #define BLP_STREAM_DOT(MM, DD)                                                                                       \
     if (model == MM && D == DD)                                                                                      \
-        return launch_stream_dot<MM, DD>(table, N, ld, dot, key_true, (int)q_head, (int)q_tail, (int)n_tiles, acc, n_cu, stream);
+        return launch_stream_dot<MM, DD>(table, N, ld, dot, key_true, (int)q_head, (int)q_tail, (int)n_tiles, acc, n_cu, stream, passes);
             BLP_STREAM_DOT(DISTMULT, 64) BLP_STREAM_DOT(DISTMULT, 128) BLP_STREAM_DOT(DISTMULT, 256) BLP_STREAM_DOT(COMPLEX, 64)
             BLP_STREAM_DOT(COMPLEX, 128) BLP_STREAM_DOT(COMPLEX, 256) BLP_STREAM_DOT(SIMPLE, 64) BLP_STREAM_DOT(SIMPLE, 128) BLP_STREAM_DOT(SIMPLE, 256)
 #undef BLP_STREAM_DOT
@@ -630,21 +762,19 @@ hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, i
         BLP_STREAM_WG(SIMPLE, 64) BLP_STREAM_WG(SIMPLE, 128)
         return hipErrorInvalidValue;
     }
-    // TransE: the per-wave ring ramps up and down faster (1/8 Wikidata5M shard: 58 us against 72), the workgroup-tile kernel
-    // streams a long table better ([measured] 4-query pass: 1.15 M rows 103 / 109, 2.3 M rows 198 / 188, 4.6 M rows 384 / 353 us
-    // = 6.7 TB/s); knob stream_kernel = 3 / 4 forces the workgroup-tile / the ring kernel
-    const long long forced = knob(KNOB_STREAM_KERNEL);
-    if (D != 256 && forced != 4 && (forced == 3 || N >= kStreamWgMinRows)) {
+    if (!transe_takes_ring(D, N, passes.n_passes > 1)) {
         BLP_STREAM_WG(TRANSE, 64) BLP_STREAM_WG(TRANSE, 128)
     }
 #undef BLP_STREAM_WG
-    const int64_t n_rounds = (n_tiles + kWaves - 1) / kWaves;
+    // (the ring kernel takes ONE coefficient array: a pass's head rows, then its tail rows)
+    if (passes.n_passes <= 1 && q_tail > 0 && coef_tail != coef_head + q_head * 2 * D) return hipErrorInvalidValue;
+    const int64_t n_rounds = ((n_tiles + kWaves - 1) / kWaves) * (passes.n_passes > 1 ? passes.n_passes : 1);
     const int64_t resident = (int64_t)n_cu * (D == 256 ? 3 : 4);  // workgroups of four waves per CU: 4 (3) waves per SIMD
     const unsigned blocks = (unsigned)(n_rounds < resident ? n_rounds : resident);
 #define BLP_STREAM_CASE(DD)                                                                                          \
     case DD:                                                                                                         \
-        rank_stream_kernel<DD><<<blocks, kWaves * 64, 0, stream>>>(table, N, ld, coef_head, coef_tail, key_true,      \
-                                                                   (int)q_head, (int)q_tail, (int)n_tiles, acc);     \
+        rank_stream_kernel<DD><<<blocks, kWaves * 64, 0, stream>>>(table, N, ld, coef_head, key_true, (int)q_head,     \
+                                                                   (int)q_tail, (int)n_tiles, acc, passes);          \
         break;
     switch (D) {
         BLP_STREAM_CASE(64)

@@ -203,7 +203,7 @@ def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["config"]["shard_axis"] == "query" and b["parity_check"].endswith("identical counts")
     assert b["shard_axis"] == "query" and len(b["exchange_ms_per_rank"]) == 2 and b["exchange_ms"] > 0
-    assert set(b["sub_results"]) == {"fb15k237-transe@candidate", "wikidata5m-transe", "wikidata5m-transe-block"}
+    assert set(b["sub_results"]) == {"fb15k237-transe@candidate", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-block"}
     for name, sub in b["sub_results"].items():  # the north_star's axis, with what the exchange cost on every rank
         assert sub["shard_axis"] == "candidate" and sub["ranks"] == 2, name
         assert len(sub["kernel_ms_per_rank"]) == 2 and len(sub["exchange_ms_per_rank"]) == 2 and sub["exchange_ms"] > 0, name

@@ -37,3 +37,22 @@ for N in (575000, 1150000, 4600000):
                 for _ in range(64): ops.rank_all(model, table, qf, qr, 2, q_true=qt, out=out)
             step(); torch.cuda.synchronize(); t0 = time.perf_counter(); step(); step(); torch.cuda.synchronize()
             print(f"{model} N={N} stream_kernel={knob}: {(time.perf_counter() - t0) / 128 * 1e6:.1f} us per pass")
+
+# the same passes as ONE call (blp_rank_all_batches, a pass per batch of two triples: the ring kernels take them in one launch)
+print("reference-batched calls: 64 passes of 2 triples per call, us per pass")
+for N in (575000, 2300000, 4600000):
+    table = torch.nn.functional.normalize(torch.randn((N, 128), device=dev, generator=g), dim=-1)
+    rel = torch.randn((9, 128), device=dev, generator=g) * 0.1
+    T, batch = 128, 2
+    fixed = torch.randint(0, N, (2 * T,), device=dev, generator=g)
+    true = torch.randint(0, N, (2 * T,), device=dev, generator=g)
+    rid = torch.randint(0, 9, (2 * T,), device=dev, generator=g)
+    for model in ("transe", "distmult", "complex", "simple"):
+        for knob in (0, 3, 4):
+            _lib.reset_knobs()
+            if knob: _lib.set_knob("stream_kernel", knob)
+            def step():
+                return ops.rank_all_batches(model, table, fixed, rel, rid, true, T, batch, block_triples=batch)
+            a = step(); torch.cuda.synchronize(); t0 = time.perf_counter(); step(); step(); step(); torch.cuda.synchronize()
+            print(f"{model} N={N} stream_kernel={knob}: {(time.perf_counter() - t0) / 3 / (T // batch) * 1e6:.1f} us per pass")
+_lib.reset_knobs()

@@ -16,6 +16,9 @@ import bench  # noqa: E402
 from blp_amd import ops, ranking  # noqa: E402
 
 dev = torch.device("cuda", 0)
+if os.environ.get("BLP_STREAM_KERNEL"):  # A/B: force a streaming kernel (hooks build; 3: workgroup tile, 4: ring)
+    from blp_amd import _lib
+    _lib.set_knob("stream_kernel", int(os.environ["BLP_STREAM_KERNEL"]))
 
 
 def timeit(fn, n=5):
