@@ -223,7 +223,18 @@ class Job:
             self.step()
             pairs.append((a, b))
         torch.cuda.synchronize()
-        return sum(events.elapsed_ms(a, b) for a, b in pairs) / len(pairs)
+        # a reference-batched evaluation (a table pass per `block` triples) may be ONE launch of a streaming kernel that
+        # walks all its passes: the events then bracket all of them, and one pass is its share
+        return sum(events.elapsed_ms(a, b) for a, b in pairs) / len(pairs) / self.passes_per_launch()
+
+    def passes_per_launch(self):
+        from blp_amd import _lib
+        block = min(self.cfg["block"], self.T)
+        if block >= self.T:
+            return 1
+        n_local = self.hi - self.lo
+        model_id = {"transe": 0, "distmult": 1, "complex": 2, "simple": 3}[self.cfg["model"]]
+        return max(1, int(_lib.lib().blp_rank_all_batches_passes_per_launch(model_id, n_local, self.D, self.D, self.T, block, block)))
 
     def exchange_ms(self, reps):
         """Milliseconds per step inside the collectives of this rank (device events around each exchange on the stream
@@ -251,11 +262,13 @@ class Job:
         transe = model == "transe"
         peak_tf = F32_PEAK_TFLOPS if transe else BF16X3_PEAK_TFLOPS
         if alg_bytes / (HBM_PEAK_GBPS * 1e9) >= alg_flops / (peak_tf * 1e12):
-            ring = not transe and (model == "complex" or n_local < 1_700_000) or transe and n_local < 1_700_000
+            ppl = self.passes_per_launch()
+            ring = ppl > 1 or (not transe and (model == "complex" or n_local < 1_700_000)) or (transe and n_local < 1_700_000)
             dot = "approximate keys (a chain of fused multiply-adds) decided within a band, undecided rows re-scored in the reference's order; "
             roof = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "kernel": (("rank_stream_kernel (exact f32 keys; " if transe else "rank_stream_dot_kernel (" + dot) +
-                               "the table streamed once through per-wave rings of 32-column pieces)") if ring else
+                               "the table streamed once per pass through per-wave rings of 32-column pieces" +
+                               (f"; all {ppl} passes of the step in one launch, kernel_ms = its share of one pass)" if ppl > 1 else ")")) if ring else
                               "rank_stream_wg_kernel (exact f32 keys; the table streamed once through workgroup tiles, two tiles in flight per workgroup)"}
         elif transe:
             wide = D not in (64, 128, 256)
@@ -284,6 +297,7 @@ class Job:
                     "mfma_busy": None}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["kernel_ms"] = kernel_ms
+        roof["passes_per_launch"] = self.passes_per_launch()  # > 1: kernel_ms, traffic and the algorithmic figures are one pass's share
         # HBM bytes / matrix-pipe busy fraction of the dominant kernel come from the committed rocprofv3 PMC passes (a
         # profiler cannot run inside this process): stamped with the round / commit they were taken at, and dropped
         # (null) on more than one GPU or when the profiled kernel no longer looks like the live one.

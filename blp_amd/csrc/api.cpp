@@ -369,6 +369,12 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
                            filt_rowptr ? &csr : nullptr, counts, workspace, workspace_bytes, device, stream);
 }
 
+int64_t blp_rank_all_batches_passes_per_launch(int model, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                               int64_t block_triples) {
+    if (!valid_model(model) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
+    return blp::rank_all_batches_passes_per_launch(model, D, N, ld, n_triples, batch, block_triples);
+}
+
 int blp_profile_next_rank_kernel(void* start_event, void* stop_event) {
     if ((start_event == nullptr) != (stop_event == nullptr))
         return fail(BLP_ERR_BAD_ARG, "blp_profile_next_rank_kernel: give both events or neither");

@@ -66,6 +66,7 @@ hipError_t launch_rank_static_passes(int model, int D, const float* table, int64
 
 // queries.hip: every batch of the reference's evaluation loop in one call (include/blp_hip.h: blp_rank_all_batches)
 size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples);
+int64_t rank_all_batches_passes_per_launch(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples);
 hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t N, int64_t ld, const float* source, int64_t ld_src,
                                    const int64_t* fixed_row, const float* rel_emb, const int64_t* rel_id, const int64_t* true_row,
                                    int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter, int32_t* counts,

@@ -14,7 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "knobs.h"
 #include "launch.h"
+#include "rank_common.h"
 
 namespace blp {
 
@@ -200,6 +202,17 @@ size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, 
         return inner;
     }
     return (inner + 255) / 256 * 256 + (size_t)(6 * 2 * m) * 8 + (size_t)(2 * m) * 16;
+}
+
+// How many of the call's ranking passes the FIRST ranking launch covers (what blp_profile_next_rank_kernel's events bracket):
+// all of them when a ring kernel takes the passes of a reference-batched call in one launch, else one.
+int64_t rank_all_batches_passes_per_launch(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples) {
+    if (n <= 0 || batch <= 0) return 0;
+    const int64_t super = batches_super(n, batch, block_triples);
+    if (super <= batch && n > batch && rank_static_passes_applicable(model, D, N, batch) &&
+        knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_takes_passes(model, D, N, ld, batch, n))
+        return (n + batch - 1) / batch;
+    return 1;
 }
 
 hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t N, int64_t ld, const float* source, int64_t ld_src,

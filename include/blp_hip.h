@@ -205,6 +205,13 @@ int blp_gather_triple_vectors(const int64_t *triples, int64_t n, const int64_t *
  * NULL, NULL cancels.  Has no effect on results. */
 int blp_profile_next_rank_kernel(void *start_event, void *stop_event);
 
+/* Measurement aid (bench.py): the number of table passes the first ranking launch of a blp_rank_all_batches call with these
+ * sizes covers -- every pass of the call when the streaming kernels take the passes of a reference-batched evaluation
+ * (train.py:128-171 with eval_batch_size <= 4) in one launch, else 1 (0: nothing to rank).  What the events of
+ * blp_profile_next_rank_kernel bracket divides by it. */
+int64_t blp_rank_all_batches_passes_per_launch(int model, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                               int64_t block_triples);
+
 /* The same counts from a DENSE score matrix already in HBM: scores (Q, N) f32 with row stride ld, the
  * true entity given per query as a column index (true_idx, the reference's `true_ents`,
  * utils.py:102) or as a score (true_score); exactly one of the two.  Replaces utils.py:103-105 and the

@@ -12,7 +12,7 @@ import subprocess
 
 DOMINANT = {"fb15k237-transe": "rank_sad_kernel", "fb15k237-distmult": "rank_gemm_bf16", "fb15k237-complex": "rank_gemm_bf16",
             "fb15k237-simple": "rank_gemm_bf16", "fb15k237-transe-d768": "wide_rank_sad_kernel",
-            "wikidata5m-transe": "rank_stream_wg_kernel", "wikidata5m-complex": "rank_stream_dot_kernel",
+            "wikidata5m-transe": "rank_stream_wg_kernel", "wikidata5m-complex": "rank_stream_dot_kernel",  # (TransE at 4.6 M rows: the workgroup tile, a launch per pass)
             "wikidata5m-transe-block": "rank_sad_kernel"}
 
 
@@ -50,6 +50,12 @@ def main(root):
         try:
             line = json.load(open(os.path.join(d, "bench.json")))
             entry["bench_pass_ms"] = line["roofline"]["kernel_ms"]
+            ppl = int(line["roofline"].get("passes_per_launch", 1))
+            if ppl > 1:  # one launch walks all passes of the step: the counters of a launch / the passes = one pass's share
+                entry["passes_per_launch"] = ppl
+                for key in ("FETCH_SIZE_KiB_mean", "hbm_bytes_per_launch", "kernel_ns"):
+                    if key in entry:
+                        entry[key] = entry[key] / ppl
         except (OSError, ValueError, KeyError):
             pass
         if len(entry) > 1:
