@@ -721,11 +721,11 @@ static hipError_t launch_stream_dot(const float* table, int64_t N, int64_t ld, c
 // TransE: the ring or the workgroup-tile kernel ([measured] 4-query pass, ring / workgroup tile: 1.15 M rows 103 / 109,
 // 2.3 M rows 198 / 188, 4.6 M rows 384 / 353 us = 6.7 TB/s; a 1/8 Wikidata5M shard: 58 against 72); knob stream_kernel = 3 / 4
 // forces the workgroup-tile / the ring kernel
-// (many passes in one launch: [measured] ring / workgroup tile 2.3 M rows 176 / 180, 4.6 M rows 355 / 348 us per pass)
-constexpr int64_t kStreamWgMinRowsPasses = 3200000;
+// (many passes in one launch: [measured] ring / workgroup tile, a launch per pass: 2.3 M rows 176 - 179 / 180 - 183, 4.6 M rows
+//  346 - 355 / 346 - 348 us per pass; the workgroup-tile kernel walking all passes in one launch was tried: 390)
 static bool transe_takes_ring(int D, int64_t N, bool passes) {
     const long long forced = knob(KNOB_STREAM_KERNEL);
-    return !(D != 256 && forced != 4 && (forced == 3 || N >= (passes ? kStreamWgMinRowsPasses : kStreamWgMinRows)));
+    return !(D != 256 && forced != 4 && (forced == 3 || (!passes && N >= kStreamWgMinRows)));
 }
 
 // All passes of a call in one launch: the ring kernels only (the workgroup-tile kernel's passes are long: their ramps
