@@ -90,6 +90,24 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     assert rc == -1 and b"aligned" in L.blp_last_error()
 
 
+def test_passes_per_launch_is_host_logic(built_lib):
+    """blp_rank_all_batches_passes_per_launch (bench.py's roofline divides a bracketed launch by it): all passes of a
+    reference-batched evaluation against a long table are one launch of a streaming kernel; blocks ranked as blocks, short
+    tables (the small-block kernels) and batches of more than 4 triples are not.  Pure host logic: runs without a GPU."""
+    from blp_amd import _lib
+    L = _lib.lib()
+    f = L.blp_rank_all_batches_passes_per_launch
+    for model in range(4):
+        assert f(model, 4_600_000, 128, 128, 128, 2, 2) == 64      # Wikidata5M, eval_batch_size 2 (scripts/blp-*-wikidata5m.sh:18)
+        assert f(model, 575_000, 128, 128, 9, 4, 4) == 3            # a 1/8 shard, 4 + 4 queries, the last pass one triple
+        assert f(model, 4_600_000, 128, 128, 128, 2, 0) == 1        # the library's own blocking: one block
+        assert f(model, 4_600_000, 128, 128, 128, 64, 64) == 1      # a pass per 64-triple batch: not the streaming kernels
+        assert f(model, 2000, 128, 128, 128, 2, 2) == 1             # short table: the small-block kernels, a launch per pass
+        assert f(model, 4_600_000, 128, 128, 2, 2, 2) == 1          # a single pass
+    assert f(0, 4_600_000, 128, 128, 0, 2, 2) == 0 and f(9, 100, 128, 128, 4, 2, 2) == 0
+    assert f(1, 4_600_000, 256, 256, 128, 2, 2) == 64 and f(1, 4_600_000, 100, 100, 128, 2, 2) == 1
+
+
 def test_project_rows_argument_checks(built_lib):
     from blp_amd import _lib
     L = _lib.lib()
