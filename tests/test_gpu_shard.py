@@ -157,7 +157,8 @@ def test_candidate_axis_two_gloo_ranks_take_the_fused_path(model, N, T, block):
 @pytest.mark.parametrize("model,N,T,batch", [("transe", 2100, 1000, 64), ("distmult", 2100, 333, 50), ("complex", 40000, 7, 2),
                                              ("simple", 900, 64, 64), ("transe", 300, 70001, 64), ("transe", 70000, 9, 4),
                                              ("distmult", 20000, 31, 3), ("simple", 17000, 5, 1), ("complex", 110000, 9, 2),
-                                             ("distmult", 120000, 7, 4), ("simple", 110017, 5, 3)])
+                                             ("distmult", 120000, 7, 4), ("simple", 110017, 5, 3), ("complex", 130001, 301, 2),
+                                             ("transe", 130001, 203, 3)])
 def test_rank_all_batches_equals_per_batch_calls_and_oracle(oracle, model, N, T, batch):
     """blp_rank_all_batches: the reference's loop layout (train.py:128-157: eval_batch_size triples per batch, each batch
     [head queries | tail queries]) handed over in one call == one blp_rank_all_idx call per batch == the oracle, raw and
