@@ -21,7 +21,7 @@ SOURCES = ["rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_gemm.hip",
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "blp_hip.h")
 # -ffp-contract=off: the kernels restate the reference's per-operation rounding; an FMA would change
 # the last bit of a score and with it a rank.  No fast-math for the same reason.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wno-inline-asm",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 

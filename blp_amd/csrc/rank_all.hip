@@ -302,9 +302,16 @@ __device__ __forceinline__ void score_batch_transe_sgpr(const float (&e)[D], boo
                                                         int lane) {
     constexpr int C = Scorer<TRANSE, SIDE, D>::C;
     if (nq <= 0) return;
-    sf16 a = sload16<0>(rows), b = a;
-    if constexpr (SIDE == HEAD) b = sload16<D * 4>(rows);
-    sdrain(a, b);
+    // (no copy of `a` before its wait: between a hand-issued scalar load and its s_waitcnt the registers hold nothing yet --
+    //  tests/test_abi.py reads the disassembly for exactly that)
+    sf16 a = sload16<0>(rows), b;
+    if constexpr (SIDE == HEAD) {
+        b = sload16<D * 4>(rows);
+        sdrain(a, b);
+    } else {
+        sdrain(a);
+        b = a;  // (unused on this side)
+    }
     for (int j = 0; j < nq; ++j) {
         const float* row = rows + (size_t)j * C;
         const float* next_row = rows + (size_t)(j + 1 < nq ? j + 1 : j) * C;

@@ -176,12 +176,15 @@ __device__ __forceinline__ void stage_gemm_tile_async(const float4* __restrict__
         const int seg = (k * WAVES + wave) * 1024;  // wave-uniform
         const char* g = reinterpret_cast<const char*>(src) + seg + lane * 16;
         const unsigned target = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)seg);
-        asm volatile("s_mov_b32 m0, %0\n\t"
+        unsigned saved_m0;  // (M0 is the compiler's own: put back, so that nothing it believes about M0 is wrong afterwards)
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off"
-                     :
+                     "global_load_lds_dwordx4 %2, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(saved_m0)
                      : "s"(target), "v"(g)
-                     : "memory", "m0");
+                     : "memory");
     });
 }
 

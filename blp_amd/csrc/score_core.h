@@ -185,10 +185,13 @@ struct Scorer<COMPLEX, HEAD, D> {  // e = head; coefficients are r then t, uncha
     __device__ __forceinline__ static float score(const float (&e)[D], const CF& c) {
         return torch_inner_sum<H, LZ>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
-            float a = c(ic<j>{}) * e[j];          a = a * c(ic<D + j>{});        // (rr*hr)*tr
-            float b = c(ic<j>{}) * e[H + j];      b = b * c(ic<D + H + j>{});    // (rr*hi)*ti
-            float cc = c(ic<H + j>{}) * e[j];     cc = cc * c(ic<D + H + j>{});  // (ri*hr)*ti
-            float d = c(ic<H + j>{}) * e[H + j];  d = d * c(ic<D + j>{});        // (ri*hi)*tr
+            // (every coefficient is read ONCE: an accessor that prefetches on the first touch of a chunk -- rank_stream.hip's
+            //  SgprStreamCoef -- would otherwise see two first touches, request the next chunk twice and wait for it at once)
+            const float rr = c(ic<j>{}), ri = c(ic<H + j>{}), tr = c(ic<D + j>{}), ti = c(ic<D + H + j>{});
+            float a = rr * e[j];       a = a * tr;    // (rr*hr)*tr
+            float b = rr * e[H + j];   b = b * ti;    // (rr*hi)*ti
+            float cc = ri * e[j];      cc = cc * ti;  // (ri*hr)*ti
+            float d = ri * e[H + j];   d = d * tr;    // (ri*hi)*tr
             float s = a + b;
             s = s + cc;
             return s - d;

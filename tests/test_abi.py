@@ -90,6 +90,25 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     assert rc == -1 and b"aligned" in L.blp_last_error()
 
 
+def test_no_scalar_load_result_is_touched_before_its_wait(built_lib):
+    """The hand-pipelined kernels issue scalar loads and wait for them in SEPARATE asm statements (rank_common.h: sload16 /
+    sdrain; rank_stream.hip: sload16_pinned / sdrain_pinned).  Between the two the destination registers hold nothing yet,
+    but the compiler -- which takes the request's result for available -- is free to copy or spill them there (the hardware
+    has no interlock on scalar-load destinations).  The disassembly of every ranking object must show no instruction that
+    names a destination register of an s_load_dwordx16 before the next full lgkmcnt wait."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from blp_amd import build
+    checked = 0
+    for src in ("rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_gemm.hip"):
+        obj = os.path.join(build.OBJ, src + ".o")
+        bad = kernel_resources.early_uses_of_scalar_loads(obj)
+        assert not bad, (src, bad[:3])
+        checked += sum(1 for l in kernel_resources.disassembly(obj) if l.startswith("s_load_dwordx16"))
+    assert checked > 1000  # (the objects were really disassembled)
+
+
 def test_passes_per_launch_is_host_logic(built_lib):
     """blp_rank_all_batches_passes_per_launch (bench.py's roofline divides a bracketed launch by it): all passes of a
     reference-batched evaluation against a long table are one launch of a streaming kernel; blocks ranked as blocks, short

@@ -50,6 +50,49 @@ def kernels_of(path):
     return result
 
 
+def disassembly(path):
+    """llvm-objdump -d of the gfx950 code objects of one .o / .so: a list of instruction lines (labels included)."""
+    lines = []
+    for blob in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as tmp:
+            tmp.write(blob)
+            tmp.flush()
+            out = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", tmp.name], capture_output=True, text=True).stdout
+        lines += [l.strip() for l in out.splitlines() if l.strip()]
+    return lines
+
+
+def sgprs_of(text):
+    """The scalar registers an instruction's operand text names."""
+    regs = set()
+    for lo, hi in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        regs.update(range(int(lo), int(hi) + 1))
+    regs.update(int(r) for r in re.findall(r"\bs(\d+)\b", text))
+    return regs
+
+
+def early_uses_of_scalar_loads(path):
+    """Hand-issued scalar loads (rank_common.h: sload16 + sdrain, rank_stream.hip: sload16_pinned) are two asm statements:
+    the request, and later the wait.  Between them the destination registers hold nothing yet -- and the compiler, which
+    takes the request's result for available, is free to copy or spill them there.  Returns every instruction between an
+    s_load_dwordx8 / x16 and the next full lgkmcnt wait (straight-line code only) that names one of its destination registers."""
+    bad, lines = [], disassembly(path)
+    for i, line in enumerate(lines):
+        m = re.match(r"s_load_dwordx(?:8|16) s\[(\d+):(\d+)\]", line)
+        if not m:
+            continue
+        dest = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for later in lines[i + 1:i + 400]:
+            if later.endswith(":") or later.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                break
+            if later.startswith("s_waitcnt") and ("lgkmcnt(0)" in later or later.strip() == "s_waitcnt 0"):
+                break
+            if sgprs_of(later.split(" ", 1)[1] if " " in later else "") & dest:
+                bad.append((line, later))
+                break
+    return bad
+
+
 def demangle(names):
     r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
     return r.stdout.splitlines() if r.returncode == 0 else list(names)
