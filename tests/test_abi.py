@@ -109,6 +109,22 @@ def test_no_scalar_load_result_is_touched_before_its_wait(built_lib):
     assert checked > 1000  # (the objects were really disassembled)
 
 
+def test_hand_scheduled_valu_keeps_its_sgpr_wait_states(built_lib):
+    """gfx950: a VALU instruction reading an SGPR pair a VALU instruction wrote needs two wait states in between.  The
+    compiler pads its own code with s_nop; the hand-scheduled K-steps of rank_gemm.hip (v_cmp -> carry pair -> v_addc_co,
+    inline asm) space themselves -- checked here on the disassembly of every ranking object, and the checker on itself
+    (with three wait states demanded it must find the K-steps' pairs)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from blp_amd import build
+    for src in ("rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_gemm.hip"):
+        bad = kernel_resources.valu_sgpr_hazards(os.path.join(build.OBJ, src + ".o"))
+        assert not bad, (src, bad[:3])
+    stricter = kernel_resources.valu_sgpr_hazards(os.path.join(build.OBJ, "rank_gemm.hip.o"), min_gap=3)
+    assert any(w.startswith("v_cmp") and r.startswith("v_addc_co") for w, r, _ in stricter)
+
+
 def test_passes_per_launch_is_host_logic(built_lib):
     """blp_rank_all_batches_passes_per_launch (bench.py's roofline divides a bracketed launch by it): all passes of a
     reference-batched evaluation against a long table are one launch of a streaming kernel; blocks ranked as blocks, short

@@ -93,6 +93,54 @@ def early_uses_of_scalar_loads(path):
     return bad
 
 
+def valu_sgpr_hazards(path, min_gap=2):
+    """gfx950: a VALU instruction that reads an SGPR (pair) written by a VALU instruction needs `min_gap` wait states in
+    between (any instruction is one; s_nop N is N + 1).  The compiler pads its own code; the hand-scheduled K-steps of
+    rank_gemm.hip (inline asm: v_cmp -> SGPR pair -> v_addc_co) must space themselves.  Returns (writer, reader) pairs that
+    are closer, straight-line code only."""
+    bad, lines = [], disassembly(path)
+
+    def split(line):
+        body = line.split("//")[0].strip()
+        mnem, _, ops = body.partition(" ")
+        return mnem, [o.strip() for o in ops.split(",")] if ops else []
+
+    def written(mnem, ops):  # SGPRs a VALU instruction writes
+        if not mnem.startswith("v_") or not ops:
+            return set()
+        if mnem.startswith("v_cmp") and mnem.endswith("_e64"):
+            return sgprs_of(ops[0])
+        if mnem.startswith(("v_addc_co", "v_add_co", "v_subb_co", "v_sub_co", "v_subrev_co", "v_subbrev_co")) and mnem.endswith("_e64") and len(ops) > 1:
+            return sgprs_of(ops[1])
+        if mnem.startswith(("v_readlane", "v_readfirstlane")):
+            return sgprs_of(ops[0])
+        return set()
+
+    for i, line in enumerate(lines):
+        mnem, ops = split(line)
+        w = written(mnem, ops)
+        if not w:
+            continue
+        gap = 0
+        for later in lines[i + 1:i + 1 + min_gap + 2]:
+            lm, lo = split(later)
+            if later.endswith(":") or lm.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")) or gap >= min_gap:
+                break
+            if lm.startswith("v_"):
+                dests = written(lm, lo)
+                reads = set()
+                dest_index = 0 if lm.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) else (1 if dests else -1)
+                for k, o in enumerate(lo):
+                    if k == dest_index:
+                        continue  # a destination (an add-with-carry names its carry pair again, further on, as carry-in)
+                    reads |= sgprs_of(o)
+                if reads & w:
+                    bad.append((line.split("//")[0].strip(), later.split("//")[0].strip(), gap))
+                    break
+            gap += int(lo[0], 0) + 1 if lm == "s_nop" and lo else 1
+    return bad
+
+
 def demangle(names):
     r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
     return r.stdout.splitlines() if r.returncode == 0 else list(names)
