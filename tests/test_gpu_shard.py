@@ -191,3 +191,16 @@ def test_rank_all_batches_equals_per_batch_calls_and_oracle(oracle, model, N, T,
         head_pos = 2 * first + (idx - first)
         assert np.array_equal(got[head_pos].cpu().numpy(), want[:T])
         assert np.array_equal(got[head_pos + nb].cpu().numpy(), want[T:])
+
+
+def test_exchange_helpers_run_through_rccl_on_one_rank():
+    """The collectives this package issues (blp_amd.ranking: one all-reduce of the (2T, D) query vectors, one all-gather of
+    the (2T, 4) int32 counts, the row all-gather of the table build) through backend "nccl" = RCCL, world size 1, on this
+    GPU (tests/rccl_worker.py): the process group comes up on the device and the helpers' tensors go through unchanged.
+    Not a measurement of anything between GPUs -- the multi-rank behaviour is tests/test_sharded_gloo.py and the two-rank
+    gloo runs above."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), "29613"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-3000:]
+    out = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert out == {"backend": "nccl", "world": 1, "all_reduce_exact": True, "all_gather_exact": True, "all_gather_rows_exact": True}
