@@ -107,6 +107,50 @@ def test_wikidata5m_block_prepass_equals_exact_kernel():
     assert torch.equal(counts, exact)
 
 
+@pytest.fixture(scope="module")
+def wikidata_table():
+    g = torch.Generator().manual_seed(46)
+    table = torch.randn(4_600_000, 128, generator=g)
+    table[1_234_567] = table[7]          # an exact tie with a row some query may hold as its true entity
+    table[4_599_999, 5] = float("inf")   # the last row of the last tile
+    return table
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_wikidata5m_scale_passes_equal_the_oracle(oracle, wikidata_table, model):
+    """The WHOLE 4.6 M x 128 table against the CPU oracle (until round 3 the oracle only ever saw 100 - 200 k-row slabs of
+    it): the reference's evaluation batch (2 triples = 4 queries per table pass, scripts/blp-*-wikidata5m.sh:18), three
+    triples -- a pass of two and a pass of one, both in one launch of the streaming kernel -- and the same queries as bare
+    blp_rank_all calls (the workgroup-tile / ring kernels a single call takes); raw counts and a CSR filter."""
+    from blp_amd import ops
+    from test_gpu_parity import oracle_counts, random_csr
+    N, D, T, batch = wikidata_table.shape[0], 128, 3, 2
+    table = torch.nn.functional.normalize(wikidata_table, dim=-1) if model == "transe" else wikidata_table * 0.1
+    g = torch.Generator().manual_seed(len(model))
+    rel_w = (torch.rand(5, D, generator=g) - 0.5) * 0.25
+    heads = torch.tensor([7, 3_000_000, 4_599_990])  # (7: ties with row 1 234 567)
+    tails = torch.randint(0, N, (T,), generator=g)
+    rels = torch.randint(0, 5, (T,), generator=g)
+    # oracle: [all head-replacing queries | all tail-replacing queries]
+    q_fixed = torch.cat((table[tails], table[heads]))
+    q_rel = torch.cat((rel_w[rels], rel_w[rels]))
+    true_row = torch.cat((heads, tails))
+    rowptr, col = random_csr(2 * T, N, true_row.numpy(), seed=9)
+    want = oracle_counts(oracle, model, table, q_fixed, q_rel, T, true_row=true_row, csr=(rowptr, col))
+    dev_table, dev_rel = table.cuda(), rel_w.cuda()
+    # (a) one bare call with all 3 + 3 queries
+    got = ops.rank_all(model, dev_table, q_fixed.cuda(), q_rel.cuda(), T, true_row=true_row.cuda(),
+                       filt_rowptr=torch.from_numpy(rowptr).cuda(), filt_col=torch.from_numpy(col).cuda()).cpu().numpy()
+    assert np.array_equal(got, want)
+    # (b) the reference loop's layout, a pass per batch of two triples: [h0 h1 | t0 t1] [h2 | t2]
+    order = torch.tensor([0, 1, T + 0, T + 1, 2, T + 2])
+    fixed_row = torch.cat((tails, heads))[order].cuda()
+    raw = ops.rank_all_batches(model, dev_table, fixed_row, dev_rel, torch.cat((rels, rels))[order].cuda(), true_row[order].cuda(),
+                               T, batch, block_triples=batch).cpu().numpy()
+    assert np.array_equal(raw[:, :2], want[order.numpy(), :2])
+    assert np.array_equal(raw[:, 2:], raw[:, :2])
+
+
 def _dump_block(bench, model, data):
     """2 048 queries x all 14 541 candidates of the timed block through the bilinear pre-pass in dump mode: the
     kernel's own S~ and eps matrices, plus the inputs.  "scaled": every table element and every relation element
