@@ -1,7 +1,13 @@
 // rank_stream.hip -- a handful of queries against a LONG table (the reference's Wikidata5M evaluation batch:
 // eval_batch_size 2 = 4 queries per pass over 4.6 M rows, scripts/blp-*-wikidata5m.sh:18; train.py:128-171): the
-// pass is one read of the table, HBM-bound, and what matters is that the read never stops.  TransE's per-wave ring first
-// (tables of up to 1.7 M rows); the workgroup-tile kernel (the bilinear models; TransE on longer tables) is further down.
+// pass is one read of the table, HBM-bound, and what matters is that the read never stops.  Three kernels:
+//   rank_stream_kernel       TransE, a per-wave ring of 32-column pieces (single calls on tables of up to 1.7 M rows; every
+//                            reference-batched call: all its passes in one launch, StreamPasses);
+//   rank_stream_wg_kernel    order-exact keys from a workgroup's double-buffered LDS tile (single calls: TransE on longer
+//                            tables, DistMult / SimplE on tables of 1.7 M rows and more; the A/B reference of the tests);
+//   rank_stream_dot_kernel   the bilinear models on the ring: approximate keys (a chain of fused multiply-adds) decided within
+//                            a provable band, undecided rows re-scored in the reference's order on the spot (single calls
+//                            below 1.7 M rows, ComplEx and D = 256 at any length; every reference-batched call).
 //
 // rank_tiles<STATIC> (rank_all.hip) fetches a whole tile (64 rows x D floats, all D/4 loads of a lane at once), then
 // scores it: a wave alternates between a load phase and an arithmetic phase and only the drift between the waves of a
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void rank_stream_wg_kernel(
     }
 }
 
-// ---- the bilinear models on shorter tables: TransE's per-wave ring, approximate keys -----------------------------------
+// ---- the bilinear models on the ring: approximate keys ----------------------------------------------------------------
 // The dot product <W_q, e> can be summed in any order -- the band does not care -- so it CAN be carried across 32-column
 // pieces: the bilinear models take the ring kernel's structure (a wave's two pieces in flight across tile boundaries, the
 // pass ramps up and down in a few microseconds: what a 1/8 shard of the Wikidata5M table needs) with D fused multiply-adds
