@@ -18,7 +18,8 @@ Workloads (synthetic data of the published shapes, seeded; BASELINE.json configs
                     filtering graph of 310 116 edges (the test triples + Zipf(0.8)-popular random edges)
   fb15k237-distmult / -complex / -simple   (configs[2]) same shapes, un-normalised table
   wikidata5m-transe (configs[3]) 4.6 M x 128 table (2.36 GB), reference batching: 2 triples = 4 queries per
-                    table pass (scripts/blp-transe-wikidata5m.sh:18); a step = 64 passes
+                    table pass (scripts/blp-transe-wikidata5m.sh:18); a step = 64 passes (one launch of a streaming
+                    kernel walks them all: roofline.passes_per_launch, kernel_ms = one pass's share)
   wikidata5m-complex   the same batching with ComplEx (BASELINE config 5's model; scripts/blp-complex-wikidata5m.sh:16-18)
   wikidata5m-transe-block / -complex-block   the same table, the 6 894 test triples as ONE query block
 The default single-GPU run also reports fb15k237-distmult, fb15k237-complex, wikidata5m-transe (reference batching, with

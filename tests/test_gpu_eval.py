@@ -275,6 +275,11 @@ def test_bench_line_keeps_the_contract():
         assert sub["roofline"]["bound"] == ("hbm" if hbm else "mfma" if "transe" not in name else "valu"), name
         if hbm:
             assert sub["table_passes_per_step"] == 64 and sub["ms_per_table_pass"] == pytest.approx(sub["ms_per_step"] / 64)
+            # one launch of a ring kernel walks all 64 passes: kernel_ms is ONE pass's share of the bracketed launch
+            assert sub["roofline"]["passes_per_launch"] == 64 and sub["roofline"]["kernel_ms"] <= sub["ms_per_table_pass"] * 1.25, name
+            assert sub["roofline"]["frac"] > 0.6, name  # (the north_star's bar is 0.70 of HBM peak; measured 0.82 - 0.87)
+        else:
+            assert sub["roofline"]["passes_per_launch"] == 1, name
     assert subs["fb15k237-distmult"]["parity_check"].endswith("identical counts")
     assert r["hbm_probe"]["bound"] == "hbm" and 0.0 < r["hbm_probe"]["frac"] < 1.0
 
