@@ -315,6 +315,9 @@ int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_
     if (!blp_rank_all_supported(model, D, 1, 1))
         return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_rank_all_batches: D = %d not supported (see blp_rank_all_supported)", D);
     if (n_triples > (1ll << 40) || N >= (1ll << 31)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: n_triples > 2^40 or N >= 2^31");
+    // a ranking pass holds 2 x block_triples queries: the same 2^30 ceiling blp_rank_all puts on one block
+    if (block_triples > (1ll << 29) || (block_triples == 0 && batch > (1ll << 29)))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: block_triples / batch > 2^29 (a pass ranks 2 x block_triples <= 2^30 queries)");
     if (!source || !fixed_row || !rel_id || !rel_emb || !true_row || !counts || R <= 0 || S <= 0 || (N > 0 && !table))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: NULL pointer, or R <= 0 / S <= 0");
     if (!aligned16(table) || !aligned16(source) || !aligned16(rel_emb) || !aligned16(counts) || (ld & 3) || (ld_src & 3) || ld_src < D || (D & 3))

@@ -190,10 +190,23 @@ static int64_t batches_super(int64_t n, int64_t batch, int64_t block_triples) {
     return s >= batch ? s : batch;
 }
 
+// Workspace of the ranking passes of a call that walks n triples `step` at a time.  rank_all_workspace_bytes is NOT monotone
+// in the query count -- the route changes with Q x N (small slots, fixed-point / MFMA pre-pass, exact tiles) -- so the short
+// last pass can need MORE than a full one: the call's passes share the larger of the two.
+static size_t batches_inner_bytes(int model, int D, int64_t N, int64_t n, int64_t step) {
+    const int64_t m_full = step < n ? step : n, m_tail = n > step ? n % step : 0;
+    size_t inner = rank_all_workspace_bytes(model, D, N, m_full, m_full);
+    if (m_tail > 0) {
+        const size_t tail = rank_all_workspace_bytes(model, D, N, m_tail, m_tail);
+        if (tail > inner) inner = tail;
+    }
+    return inner;
+}
+
 size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples) {
     if (n <= 0 || batch <= 0) return 0;
     const int64_t super = batches_super(n, batch, block_triples), m = super < n ? super : n;
-    const size_t inner = rank_all_workspace_bytes(model, D, N, m, m);
+    const size_t inner = batches_inner_bytes(model, D, N, n, super <= batch ? batch : super);
     if (super <= batch) {  // a pass per batch: every batch is [heads | tails] already
         if (n > batch && rank_static_passes_applicable(model, D, N, batch)) {
             const size_t all = rank_static_passes_workspace_bytes(D, n, batch);
@@ -244,7 +257,8 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
         return hipSuccess;
     }
     const int64_t m_max = super < n ? super : n;
-    const size_t inner = (rank_all_workspace_bytes(model, D, N, m_max, m_max) + 255) / 256 * 256;
+    if ((2 * m_max + 255) / 256 > 0x7fffffff) return hipErrorInvalidValue;  // the permutation kernels' grid
+    const size_t inner = (batches_inner_bytes(model, D, N, n, super) + 255) / 256 * 256;
     int64_t* perm = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + inner);
     int4* pcounts = reinterpret_cast<int4*>(perm + 6 * 2 * m_max);
     for (int64_t t0 = 0; t0 < n; t0 += super) {
@@ -252,6 +266,7 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
         const BatchPerm pm{t0, m, n, batch};
         const unsigned blocks = (unsigned)((Q + 255) / 256);
         permute_batches_kernel<<<blocks, 256, 0, stream>>>(pm, fixed_row, rel_id, true_row, filter.lo, filter.hi, filter.exclude, perm);
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;
         FilterSpec f = filter;
         if (filter.on()) {
             f.lo = perm + 3 * Q;
@@ -264,8 +279,9 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
                                                t0 == 0 ? ev_start : nullptr, t0 == 0 ? ev_stop : nullptr);
         if (err != hipSuccess) return err;
         unpermute_counts_kernel<<<blocks, 256, 0, stream>>>(pm, pcounts, reinterpret_cast<int4*>(counts));
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream) {

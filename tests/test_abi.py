@@ -143,6 +143,47 @@ def test_passes_per_launch_is_host_logic(built_lib):
     assert f(1, 4_600_000, 256, 256, 128, 2, 2) == 64 and f(1, 4_600_000, 100, 100, 128, 2, 2) == 1
 
 
+def test_batches_workspace_covers_every_block_of_the_call(built_lib):
+    """blp_rank_all_workspace_bytes is not monotone in the query count (the route changes with Q x N), so the short LAST
+    block of a blp_rank_all_batches call can need more than a full one (round 3: TransE D = 64, N = 7 400, 65 536 + 54 592
+    triples reported 85 MB where the tail block carved 124 MB -- silent out-of-bounds writes).  The call's workspace must
+    hold every block's own requirement, plus the permutation arrays behind it when batches are merged.  Host logic only."""
+    from blp_amd import _lib
+    L = _lib.lib()
+    one, many = L.blp_rank_all_workspace_bytes, L.blp_rank_all_batches_workspace_bytes
+    cases = 0
+    for model in range(4):
+        for D in (64, 128):
+            for N in (7400, 14541, 40943, 575_000, 4_600_000):
+                for batch, block in ((64, 0), (512, 0), (65536, 0), (64, 64), (2, 2), (64, 4096), (16, 48)):
+                    sup = (block if block else 65536) // batch * batch
+                    sup = max(sup, batch)
+                    for tail in (1, 2, 3, 33, 257, 4097, 54592, 65376, sup - 1):
+                        if not 0 < tail < sup:
+                            continue
+                        for full_blocks in (1, 2):
+                            n = full_blocks * sup + tail
+                            got = many(model, N, D, n, batch, block)
+                            merged = sup > batch
+                            extra = 0
+                            if merged:  # permuted index / segment arrays (6 x 2m int64) + permuted counts (2m x 16 B), 256-aligned
+                                extra = 6 * 2 * sup * 8 + 2 * sup * 16
+                            for m in (sup, tail):
+                                need = one(model, N, D, m, m)
+                                need = (need + 255) // 256 * 256 if merged else need
+                                assert got >= need + extra, (model, D, N, n, batch, block, m, got, need + extra)
+                            cases += 1
+    assert cases > 2000
+    # the reviewer's cases
+    assert many(0, 7400, 64, 65536 + 54592, 65536, 65536) >= one(0, 7400, 64, 54592, 54592)
+    assert many(0, 14541, 64, 512 + 257, 512, 512) >= one(0, 14541, 64, 257, 257)
+    # block sizes whose permutation grid / query count would overflow are refused, not truncated
+    p16 = ctypes.c_void_p(16)
+    rc = L.blp_rank_all_batches(0, p16, 100, 128, 128, p16, 100, 128, p16, p16, 5, p16, p16, 1 << 31, 1 << 30, 1 << 30,
+                                None, p16, p16, 1 << 40, 0, None)
+    assert rc == -1 and b"2^29" in L.blp_last_error()
+
+
 def test_project_rows_argument_checks(built_lib):
     from blp_amd import _lib
     L = _lib.lib()
