@@ -4,6 +4,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started WITHOUT a launcher (no WORLD_SIZE in the environment), `python bench.py --gpus N`
+starts its own N ranks (torch.distributed.run on 127.0.0.1 and a free port), passes rank 0's single JSON line through and
+exits with the launcher's status (non-zero if any rank died).
+
 A "step" is ONE WHOLE EVALUATION of the workload's test triples against the entity table, exactly what
 blp_amd.ranking.eval_link_prediction runs after the table build (it is the same function,
 ranking.rank_triples): id -> row lookups, query gathers (train.py:132-150), the filter
@@ -22,11 +26,19 @@ Workloads (synthetic data of the published shapes, seeded; BASELINE.json configs
                     kernel walks them all: roofline.passes_per_launch, kernel_ms = one pass's share)
   wikidata5m-complex   the same batching with ComplEx (BASELINE config 5's model; scripts/blp-complex-wikidata5m.sh:16-18)
   wikidata5m-transe-block / -complex-block   the same table, the 6 894 test triples as ONE query block
-The default single-GPU run also reports fb15k237-distmult, fb15k237-complex, wikidata5m-transe (reference batching, with
-its filter), wikidata5m-complex and wikidata5m-transe-block as `sub_results` (each with its own roofline), and the
-HBM-bound operating point as `hbm_probe`.  The default N > 1 run reports, next to the FB15k-237 headline on the axis
-ranking.choose_shard_axis picks (query), the north_star's CANDIDATE axis three times: fb15k237-transe, wikidata5m-transe
-(reference batching) and wikidata5m-transe-block -- each with `exchange_ms` (device events around the collectives, per
+  wikidata5m-transe-full / -complex-full     the WHOLE Wikidata5M test evaluation as the reference batches it: 6 894 triples,
+                    2 per table pass = 3 447 passes of the 2.36 GB table per step (~1.2 s: the sustained HBM figure next to
+                    the 64-pass burst above; scripts/blp-transe-wikidata5m.sh:18)
+  wikidata5m-protocol   the reference's OWN Wikidata5M candidate set (train.py:312-314: only the 7 475 entities of the test
+                    split), 6 894 triples; also timed in the reference loop's layout (eval_batch_size = 2: 3 447 batches
+                    through ONE blp_rank_all_batches call, and with a ranking pass per batch)
+The default run reports fb15k237-distmult, fb15k237-complex, wikidata5m-transe (reference batching, with its filter),
+wikidata5m-complex, wikidata5m-transe-block, wikidata5m-complex-block, wikidata5m-transe-full, wikidata5m-complex-full and
+wikidata5m-protocol as `sub_results` (each with its own roofline), the training-side step as `inbatch_loss` and the
+HBM-bound operating point as `hbm_probe` -- THE SAME NAMES for every N, so that the N = 1 line of a scaling run can be held
+against the single-GPU line field by field.  With N > 1 the FB15k-237 workloads run on the axis
+ranking.choose_shard_axis picks (query), everything at Wikidata5M scale on the north_star's CANDIDATE axis, and
+`fb15k237-transe@candidate` is added; each sub-result carries `exchange_ms` (device events around the collectives, per
 rank), `kernel_ms_per_rank` and the ranks the process group reports.
 
 With N > 1 the evaluation is sharded along one axis (blp_amd.ranking.choose_shard_axis, --shard-axis):
@@ -47,6 +59,8 @@ import ctypes
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -76,21 +90,54 @@ WORKLOADS = {
     # the same table with the whole Wikidata5M test set (6 894 triples) as ONE query block
     "wikidata5m-transe-block": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
     "wikidata5m-complex-block": dict(model="complex", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
+    # the WHOLE test evaluation in the reference's batching: 6 894 triples, 2 per table pass -> 3 447 passes, ~1.2 s per step
+    # (sustained; `heavy`: few timed steps inside the default run)
+    "wikidata5m-transe-full": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, block=2, edges=0, heavy=True),
+    "wikidata5m-complex-full": dict(model="complex", N=4_600_000, D=128, R=822, triples=6894, block=2, edges=0, heavy=True),
+    # the reference's own Wikidata5M protocol: candidates = the entities of the evaluated split only (train.py:312-314)
+    "wikidata5m-protocol": dict(model="transe", N=7475, D=128, R=822, triples=6894, block=65536, edges=0, loop_batch=2),
 }
-SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-block")
-# N > 1: (workload, shard axis) next to the headline -- the north_star's candidate axis on all three shapes (BASELINE configs 4 and 5: TransE and ComplEx at Wikidata5M scale)
-SUB_RESULTS_SHARDED = (("fb15k237-transe", "candidate"), ("wikidata5m-transe", "candidate"), ("wikidata5m-complex", "candidate"),
-                       ("wikidata5m-transe-block", "candidate"))
+SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-block",
+               "wikidata5m-complex-block", "wikidata5m-transe-full", "wikidata5m-complex-full", "wikidata5m-protocol")
+# N > 1: the same names on the axis a sharded evaluation of that shape takes ("auto": ranking.choose_shard_axis -> query for the
+# FB15k-237-sized tables; the Wikidata5M-scale table always along the north_star's candidate axis), plus the headline
+# workload on the candidate axis
+SUB_RESULTS_EXTRA_SHARDED = (("fb15k237-transe", "candidate"),)
+TABLE_CHUNK_ROWS = 1 << 16      # a Wikidata5M-scale table is generated in chunks of this many rows, each from its own seed
 
 
-def make_data(cfg, device, seed=1, sort=True):
+def make_table_rows(cfg, device, lo, hi, seed=1):
+    """Rows [lo, hi) of a Wikidata5M-scale synthetic table, the same values whoever generates them: chunk c (rows
+    [c, c + 1) x TABLE_CHUNK_ROWS) comes from its own seeded generator, so a rank of a candidate-axis shard makes ITS rows
+    and nothing else (north_star: the table never moves; round 3 materialised 2.36 GB on every rank and sliced)."""
+    N, D = cfg["N"], cfg["D"]
+    out = torch.empty((hi - lo, D), dtype=torch.float32, device=device)
+    for c in range(lo // TABLE_CHUNK_ROWS, (hi + TABLE_CHUNK_ROWS - 1) // TABLE_CHUNK_ROWS):
+        r0, r1 = c * TABLE_CHUNK_ROWS, min((c + 1) * TABLE_CHUNK_ROWS, N)
+        g = torch.Generator(device=device).manual_seed(seed * 1_000_003 + c + 1)
+        rows = torch.randn(r1 - r0, D, device=device, generator=g)
+        rows = torch.nn.functional.normalize(rows, dim=-1) if cfg["model"] == "transe" else rows * 0.1
+        a, b = max(r0, lo), min(r1, hi)
+        out[a - lo:b - lo] = rows[a - r0:b - r0]
+    return out
+
+
+def make_data(cfg, device, seed=1, sort=True, rows=None):
     """Synthetic FB15k-237 / Wikidata5M-shaped inputs: table rows L2-normalised for
     TransE (models.py:40-41), 0.1 * randn otherwise; rel_emb Xavier-uniform (models.py:28-29).  ``sort``:
-    triples grouped by relation (tools that call ops.rank_all directly); the bench step takes them as they come."""
+    triples grouped by relation (tools that call ops.rank_all directly); the bench step takes them as they come.
+    ``rows`` = (lo, hi): only these table rows are generated (tables of more than a million rows come in seeded chunks,
+    make_table_rows; smaller ones are generated whole and sliced)."""
     g = torch.Generator(device=device).manual_seed(seed)
     N, D, R, T = cfg["N"], cfg["D"], cfg["R"], cfg["triples"]
-    table = torch.randn(N, D, device=device, generator=g)
-    table = torch.nn.functional.normalize(table, dim=-1) if cfg["model"] == "transe" else table * 0.1
+    lo, hi = rows if rows is not None else (0, N)
+    if N > 1_000_000:
+        table = make_table_rows(cfg, device, lo, hi, seed)
+    else:
+        table = torch.randn(N, D, device=device, generator=g)
+        table = torch.nn.functional.normalize(table, dim=-1) if cfg["model"] == "transe" else table * 0.1
+        if rows is not None:
+            table = table[lo:hi].contiguous()
     bound = (6.0 / (R + D)) ** 0.5
     rel_w = (torch.rand(R, D, device=device, generator=g) * 2 - 1) * bound
     heads = torch.randint(0, N, (T,), device=device, generator=g)
@@ -156,15 +203,7 @@ class Job:
         from blp_amd import models, ranking
         self.name, self.cfg, self.device, self.world, self.rank, self.backend = name, WORKLOADS[name], device, world, rank, backend
         cfg = self.cfg
-        table, rel_w, heads, tails, rels = make_data(cfg, device, sort=False)
         self.N, self.D, self.T = cfg["N"], cfg["D"], cfg["triples"]
-        self.model = models.LinkPrediction(cfg["D"], cfg["model"], "margin", cfg["R"], 0)
-        self.model.rel_emb.weight.data = rel_w.cpu()
-        self.model = self.model.to(device)
-        self.triples = torch.stack((heads, tails, rels), dim=1).contiguous()   # (T, 3) entity / relation ids
-        self.ent2idx = torch.arange(self.N, device=device)                    # ids are table rows in the synthetic sets
-        self.index = make_filter_index(cfg, heads, tails, rels)
-        self.index.segments(self.triples[:1], self.ent2idx, device)           # sorted arrays resident before the clock starts
         axis = ranking.choose_shard_axis(self.N, self.D, 2 * self.T, world)
         if world > 1 and cfg["N"] > 1_000_000:
             axis = "candidate"  # north_star: the 4.6 M-entity ranking is sharded along the candidate axis
@@ -172,13 +211,28 @@ class Job:
             axis = shard_axis
         self.axis = axis if world > 1 else "none"
         self.lo, self.hi = ranking.shard_bounds(self.N, world, rank) if self.axis == "candidate" else (0, self.N)
-        self.full_table = table if rank == 0 or self.axis != "candidate" else None  # rank 0 keeps it for the parity check
-        self.table = table[self.lo:self.hi].contiguous() if self.axis == "candidate" else table
+        # a candidate shard of a Wikidata5M-scale table generates its own rows only; small tables are made whole (rank 0
+        # keeps the whole one for the parity spot check) and sliced
+        local_only = self.axis == "candidate" and self.N > 1_000_000
+        table, rel_w, heads, tails, rels = make_data(cfg, device, sort=False, rows=(self.lo, self.hi) if local_only else None)
+        self.model = models.LinkPrediction(cfg["D"], cfg["model"], "margin", cfg["R"], 0)
+        self.model.rel_emb.weight.data = rel_w.cpu()
+        self.model = self.model.to(device)
+        self.triples = torch.stack((heads, tails, rels), dim=1).contiguous()   # (T, 3) entity / relation ids
+        self.ent2idx = torch.arange(self.N, device=device)                    # ids are table rows in the synthetic sets
+        self.index = make_filter_index(cfg, heads, tails, rels)
+        self.index.segments(self.triples[:1], self.ent2idx, device)           # sorted arrays resident before the clock starts
+        if local_only:
+            self.full_table, self.table = None, table
+        else:
+            self.full_table = table if rank == 0 or self.axis != "candidate" else None  # rank 0 keeps it for the parity check
+            self.table = table[self.lo:self.hi].contiguous() if self.axis == "candidate" else table
         del table
         self.ranking = ranking
+        self.heavy = bool(cfg.get("heavy"))
         # Initialisation, not warm-up: the first two evaluations of a process load the kernels' code objects and grow
         # the caching allocator to its steady state (a one-off of tens of ms shows up in the SECOND evaluation).
-        for filtered in (True, True, False):
+        for filtered in ((True,) if self.heavy else (True, True, False)):
             self.step(filtered)
         self.fence()
 
@@ -250,6 +304,32 @@ class Job:
             total += self.ranking.exchange_ms(timing)
         return total / reps
 
+    def loop_layout(self, reps=5):
+        """The same evaluation handed over in the REFERENCE LOOP's layout (train.py:128-157: batch after batch of
+        eval_batch_size = cfg['loop_batch'] triples, each [its head queries | its tail queries]): one blp_build_queries +
+        ONE blp_rank_all_batches call for all batches (the library merges them into blocks), and the same call with a
+        ranking pass per batch (block_triples = batch: the reference's pass structure, 3 launches per batch)."""
+        from blp_amd import ops
+        b, rel_w = self.cfg["loop_batch"], self.model.rel_emb.weight
+
+        def run(block_triples):
+            qb = ops.build_queries(self.triples, self.ent2idx, self.table, rel_w, b, index=self.index, gather=False, num_rows=self.N)
+            counts = ops.rank_all_batches(self.cfg["model"], self.table, qb.fixed_row, rel_w, qb.rel_ids, qb.true_row, self.T, b,
+                                          filter=qb.filter, block_triples=block_triples)
+            return ops.rank_metric_sums(counts)
+
+        out = {"eval_batch_size": b, "batches": -(-self.T // b)}
+        for key, block_triples, n in (("ms_one_call_all_batches", 0, reps), ("ms_one_call_pass_per_batch", b, 2)):
+            run(block_triples)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                sums = run(block_triples)
+            torch.cuda.synchronize()
+            out[key] = (time.perf_counter() - t0) / n * 1e3
+            out[key.replace("ms_", "mrr_")] = sums[0].item() / (2 * self.T)
+        return out
+
     def roofline(self, kernel_ms):
         """Roof of the dominant kernel: algorithmic work of ONE ranking launch on this rank / its time."""
         model, D, Q = self.cfg["model"], self.D, 2 * min(self.T, self.cfg["block"])
@@ -267,6 +347,9 @@ class Job:
             ring = ppl > 1 or (not transe and (model == "complex" or n_local < 1_700_000)) or (transe and n_local < 1_700_000)
             dot = "approximate keys (a chain of fused multiply-adds) decided within a band, undecided rows re-scored in the reference's order; "
             roof = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "arith": ("f32, the reference's operations in its order (2-3 VALU operations per element and query)" if transe or not ring else
+                              "f32 fused multiply-add chain per (row, query) decided within a proven band against the exact true key; "
+                              "undecided rows re-scored in the reference's f32 order"),
                     "kernel": (("rank_stream_kernel (exact f32 keys; " if transe else "rank_stream_dot_kernel (" + dot) +
                                "the table streamed once per pass through per-wave rings of 32-column pieces" +
                                (f"; all {ppl} passes of the step in one launch, kernel_ms = its share of one pass)" if ppl > 1 else ")")) if ring else
@@ -274,6 +357,11 @@ class Job:
         elif transe:
             wide = D not in (64, 128, 256)
             roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "arith": "u16 fixed-point v_sad_u16 pre-pass (decides >= 99.5 % of the pairs within a proven band) + exact f32 "
+                             "re-scoring of the rest in the reference's order; NOT the reference's f32 lane-ops",
+                    "peak_source": "builder-measured v_sad_u16 issue rate, tools/sad_ubench.hip -> profiles/r04/sad_ubench.log "
+                                   "(4 cycles per instruction and SIMD: 2 elements x 2 ops x 64 lanes x 1024 SIMDs x 2.4 GHz / 4 = "
+                                   "157.3 Tops/s); numerically equal to the guide's f32 vector-FMA peak, not taken from it",
                     "kernel": ("wide_rank_sad_kernel + wide_refine_* (any-width u16 v_sad_u16 pre-pass)" if wide else
                                "rank_sad_kernel<128> + sad_refine_* (u16 fixed-point v_sad_u16 pre-pass + band + exact f32 "
                                "refinement; range / quantise kernels included)"),
@@ -290,6 +378,8 @@ class Job:
                                            "frac": 2.5 * n_local * D * Q / t_k / 1e12 / (F32_PEAK_TFLOPS / 2)}}
         else:
             roof = {"bound": "mfma", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "arith": "bf16 x 3 split products on v_mfma_f32_32x32x16_bf16 (f32 accumulate) decided within a band + exact "
+                             "f32 re-scoring of the undecided pairs in the reference's order",
                     "kernel": f"rank_gemm_bf16_kernel<{model.upper()},128> + refine_* (bf16 x 3 split MFMA GEMM + band + exact "
                               "f32 refinement)",
                     "note": "achieved = 2 flops x D x Q x N (the f32 GEMM the reference's scores amount to) / time of GEMM "
@@ -315,10 +405,13 @@ class Job:
 
     def measure(self, steps, warmup, events):
         """The JSON fields of this workload: whole evaluation (raw + filtered) and raw-only, the roofline."""
+        if self.heavy:  # a step takes seconds: two timed steps, one of everything else
+            steps, warmup = min(steps, 2), min(warmup, 1)
+        raw_steps = 1 if self.heavy else max(1, min(steps, 5))
         elapsed, (triples, counts, sums) = self.timed(steps, warmup, filtered=True)
-        raw_elapsed, _ = self.timed(max(1, min(steps, 5)), 1, filtered=False)
-        kernel_ms = self.kernel_ms(events, max(1, min(steps, 10)))
-        exchange = self.exchange_ms(max(1, min(steps, 5)))
+        raw_elapsed, _ = self.timed(raw_steps, 0 if self.heavy else 1, filtered=False)
+        kernel_ms = self.kernel_ms(events, 1 if self.heavy else max(1, min(steps, 10)))
+        exchange = self.exchange_ms(1 if self.heavy else max(1, min(steps, 5)))
         scored = 2.0 * self.T * self.N
         per_rank, exchange_per_rank = [kernel_ms], [exchange]
         if self.world > 1:
@@ -329,7 +422,7 @@ class Job:
         out = {
             "value": scored * steps / elapsed,
             "ms_per_step": elapsed / steps * 1e3,
-            "ms_per_step_raw_only": raw_elapsed / max(1, min(steps, 5)) * 1e3,
+            "ms_per_step_raw_only": raw_elapsed / raw_steps * 1e3, "timed_steps": steps,
             "mrr": sums[0].item() / (2 * self.T), "mrr_filtered": sums[1].item() / (2 * self.T),
             "hits@1,3,10": [x.item() / (2 * self.T) for x in sums[2:5]],
             "hits@1,3,10_filtered": [x.item() / (2 * self.T) for x in sums[5:8]],
@@ -588,6 +681,47 @@ def inbatch_bench(device, iters=200):
     return out
 
 
+def relaunch_with_ranks(n_gpus):
+    """`python bench.py --gpus N` started without a launcher: start the N ranks ourselves (one process per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1 and a free port), hand rank 0's single JSON line through on stdout and
+    return the launcher's exit status -- non-zero if any rank died."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")       # (the launcher would set 1 and say so on stderr; the CPU side is tiny either way)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def sub_result(name, axis, device, world, rank, backend, steps, events):
+    """One sub-result: the workload prepared, measured (the better of two timed runs on one GPU) and torn down."""
+    sub = Job(name, device, world, rank, axis, backend)
+    k_sub = max(2, min(steps, 5))
+    # best of two timed runs of K steps: a one-off stall (a code object loaded on first use, the allocator growing)
+    # inside a 5-step run once made a 1.2 ms evaluation read as 16 ms
+    f, t, c = sub.measure(k_sub, 3 if world == 1 else 1, events)
+    runs = 1
+    if world == 1 and not sub.heavy:
+        f2, t2, c2 = sub.measure(k_sub, 1, events)
+        runs = 2
+        if f2["ms_per_step"] < f["ms_per_step"]:
+            f, t, c = f2, t2, c2
+    f["steps"], f["timed_runs"], f["unit"] = f.pop("timed_steps"), runs, "scored triples/s"
+    if rank == 0:
+        f["parity_check"] = parity_spot_check(sub, t, c)
+    if sub.cfg["block"] < sub.T:  # reference batching: a step is several table passes
+        passes = -(-sub.T // sub.cfg["block"])
+        f["table_passes_per_step"], f["ms_per_table_pass"] = passes, f["ms_per_step"] / passes
+    if "loop_batch" in sub.cfg and world == 1:
+        f["reference_loop_layout"] = sub.loop_layout()
+    del sub, t, c
+    torch.cuda.empty_cache()
+    return f
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -602,12 +736,12 @@ def main():
                          "table always along the candidate axis)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch_with_ranks(args.gpus))  # no launcher around us: be our own
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the measured path)")
@@ -616,6 +750,8 @@ def main():
     backend = os.environ.get("BLP_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"--gpus {args.gpus}: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     ranks_seen = 1
@@ -630,7 +766,9 @@ def main():
     events = HipEvents()
     job = Job(args.workload, device, world, rank, args.shard_axis, backend)
     fields, triples, counts = job.measure(args.steps, args.warmup, events)
+    fields.pop("timed_steps")
     cfg = job.cfg
+    result = None
     if rank == 0:
         result = {
             "metric": "scored triples/sec, all-entity eval (raw + filtered ranks, MRR + Hits@k)",
@@ -644,6 +782,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
+            "arith": fields["roofline"]["arith"],
             "data": "synthetic (seeded randn table, Xavier rel_emb, uniform random test triples, Zipf(0.8) filtering graph)",
             "config": {"workload": args.workload, "rel_model": cfg["model"], "entities": cfg["N"], "dim": cfg["D"],
                        "queries_per_step": 2 * cfg["triples"], "triples_per_ranking_call": min(cfg["triples"], cfg["block"]),
@@ -658,54 +797,28 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(job)
             result["torch_gpu_baseline"] = torch_gpu_baseline(job)
-    del triples, counts
-    if world > 1 and not args.no_sub_results and args.workload == "fb15k237-transe":
-        # The north_star's axis next to the headline's: the CANDIDATE axis on the FB15k-237 table, on the Wikidata5M-scale
-        # table as the reference batches it (2 triples per table pass) and on the same table with the test set as one
-        # block.  Every rank takes part: each step has its exchanges (replicated query vectors, one all-gather of counts).
-        del job
-        torch.cuda.empty_cache()
+    del triples, counts, job
+    torch.cuda.empty_cache()
+    default_line = args.workload == "fb15k237-transe"
+    if not args.no_sub_results and default_line:
+        # The same names for every N (SCALE's N = 1 line against BENCH, field by field).  N > 1: every rank takes part in
+        # every sub-result -- each step has its exchanges (replicated query vectors, one all-gather of counts).
         subs = {}
-        for name, axis in SUB_RESULTS_SHARDED:
-            sub = Job(name, device, world, rank, axis, backend)
-            k_sub = max(2, min(args.steps, 5))
-            f, t, c = sub.measure(k_sub, 1, events)
-            if rank == 0:
-                f["steps"], f["unit"] = k_sub, "scored triples/s"
-                f["parity_check"] = parity_spot_check(sub, t, c)
-                subs[f"{name}@{axis}" if name == args.workload else name] = f
-            del sub, t, c
-            torch.cuda.empty_cache()
+        todo = [(name, "auto", name) for name in SUB_RESULTS]
+        if world > 1:
+            todo += [(name, axis, f"{name}@{axis}") for name, axis in SUB_RESULTS_EXTRA_SHARDED]
+        for name, axis, key in todo:
+            f = sub_result(name, axis, device, world, rank, backend, args.steps, events)
+            if world == 1:
+                for k in ("kernel_ms_per_rank", "exchange_ms", "exchange_ms_per_rank", "shard_axis", "ranks"):
+                    f.pop(k)
+            subs[key] = f
+        # the training-side scoring is replicas only: every rank runs the same step, rank 0 reports its own
+        inbatch = inbatch_bench(device)
         if rank == 0:
-            result["sub_results"] = subs
-    if world == 1:
-        subs = {}
-        if not args.no_sub_results and args.workload == "fb15k237-transe":
-            del job
-            torch.cuda.empty_cache()
-            for name in SUB_RESULTS:
-                sub = Job(name, device)
-                # best of two timed runs of K steps: a one-off stall (a code object loaded on first use, the allocator growing)
-                # inside a 5-step run once made a 1.2 ms evaluation read as 16 ms
-                k_sub = max(2, min(args.steps, 5))
-                f, t, c = sub.measure(k_sub, 3, events)
-                f2, t2, c2 = sub.measure(k_sub, 1, events)
-                if f2["ms_per_step"] < f["ms_per_step"]:
-                    f, t, c = f2, t2, c2
-                f["steps"], f["timed_runs"] = k_sub, 2
-                f["unit"] = "scored triples/s"
-                f["parity_check"] = parity_spot_check(sub, t, c)
-                for key in ("kernel_ms_per_rank", "exchange_ms", "exchange_ms_per_rank", "shard_axis", "ranks"):
-                    f.pop(key)
-                if sub.cfg["block"] < sub.T:  # reference batching: a step is several table passes
-                    passes = -(-sub.T // sub.cfg["block"])
-                    f["table_passes_per_step"], f["ms_per_table_pass"] = passes, f["ms_per_step"] / passes
-                subs[name] = f
-                del sub, t, c
-                torch.cuda.empty_cache()
-            result["sub_results"] = subs
-            result["inbatch_loss"] = inbatch_bench(device)
-        if not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
+            result["sub_results"], result["inbatch_loss"] = subs, inbatch
+    if not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
+        if rank == 0:  # one GPU's HBM-bound operating point (the other ranks wait at the barrier below)
             result["hbm_probe"] = hbm_probe(device, events)
     if rank == 0:
         print(json.dumps(result), flush=True)

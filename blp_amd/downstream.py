@@ -36,11 +36,12 @@ def load_labelled_split(path, ent_ids, ent2idx, classes):
 
 
 def _classifier(c):
+    import sklearn
     from sklearn.linear_model import LogisticRegression
-    try:
-        return LogisticRegression(C=c, multi_class="multinomial", max_iter=1000)
-    except TypeError:  # newer scikit-learn: multinomial is the only behaviour for multi-class problems
+    major, minor = (int(x) for x in sklearn.__version__.split(".")[:2])
+    if (major, minor) >= (1, 5):  # multinomial is the only behaviour for multi-class problems (the keyword warns, then goes)
         return LogisticRegression(C=c, max_iter=1000)
+    return LogisticRegression(C=c, multi_class="multinomial", max_iter=1000)
 
 
 def classify_nodes(dataset, checkpoint, log, data_root="data", output_dir="output"):
@@ -62,6 +63,9 @@ def classify_nodes(dataset, checkpoint, log, data_root="data", output_dir="outpu
         log.info(f"{c:.3f} - {dev_acc:.3f}")
         if dev_acc > best_dev:
             best_c, best_dev = c, dev_acc
+    if best_c == 0:  # (the reference would go on to fit with C = 0 and fail inside scikit-learn, train.py:452-460)
+        raise ValueError("node_classification: no regularisation coefficient reached a dev accuracy above 0 -- "
+                         "check the class files and the embeddings")
     log.info(f"Best regularization coefficient: {best_c:.4f}")
 
     x_fit, y_fit = np.concatenate((x_train, x_dev)), np.concatenate((y_train, y_dev))

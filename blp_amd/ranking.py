@@ -314,9 +314,9 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     t_lo, t_hi = shard_bounds(num_triples, world, rank) if by_query else (0, num_triples)
     n = t_hi - t_lo
     mine = slice(t_lo, t_hi)
-    tail_block = n % block_size or min(block_size, n)  # the last block may be short: it must take the same route
-    fused = (n > 0 and model.rel_emb.weight.dtype == torch.float32
-             and fused_ranking_takes(model, table, 2 * min(block_size, n)) and fused_ranking_takes(model, table, 2 * tail_block))
+    # (whether the fused path takes a block depends on the model and the width only; WHICH kernels rank it is decided per
+    # block inside blp_rank_all_batches -- the short last block of a call may well take another route than the full ones)
+    fused = n > 0 and model.rel_emb.weight.dtype == torch.float32 and fused_ranking_takes(model, table, 2 * min(block_size, n))
     row_lo = shard_bounds(num_entities, world, rank)[0] if by_candidate else 0
     head_pos = tail_pos = None
 
@@ -382,6 +382,7 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         q_rel = model.rel_emb(rel_ids)
         q_true = source[true_src] if by_candidate else None
         seg = None
+        tail_block = n % block_size or min(block_size, n)  # rank_block decides per block: both shapes must take segments
         if index is not None and n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n)) \
                 and fused_ranking_takes(model, table, 2 * tail_block):  # slices of the sorted index: nothing is listed per batch
             seg = index.segments(triples[mine], ent2idx, device)
@@ -474,15 +475,16 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
 def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, emb_batch_size, _run, _log,
                          prefix="", max_num_batches=None, filtering_graph=None, new_entities=None,
                          return_embeddings=False, device=None, group=None, block_size=65536, shard_axis="auto",
-                         eval_mode=True):
+                         eval_mode=False):
     """Drop-in for train.eval_link_prediction (same positional arguments, metric names and return
     value).  ``device`` defaults to the model's device; ``group`` (or an initialised default process
     group) shards the evaluation, along ``shard_axis`` = "candidate" | "query" | "auto".
 
-    One deliberate deviation: the reference never leaves train mode (train.py:57-121 has no model.eval()), so its
-    entity table is built with BERT's dropout active and its metrics are not reproducible run to run.  Here the
-    encoder is put in eval mode for the table build and restored afterwards; ``eval_mode=False`` keeps whatever
-    mode the model is in, i.e. the reference's behaviour."""
+    ``eval_mode``: the reference never leaves train mode (train.py:57-121 has no model.eval()), so its entity table is
+    built with BERT's dropout active and its metrics differ run to run.  The default (False) keeps whatever mode the
+    model is in -- the reference's behaviour, so that this function drops in without changing a result's law;
+    ``eval_mode=True`` puts the encoder in eval mode for the table build and restores it afterwards (deterministic
+    tables; train.py's config key ``eval_dropout=False``)."""
     model = _module(model)
     if device is None:
         device = next(model.parameters()).device

@@ -8,7 +8,7 @@ ents-{id}.pt) and log-scalar names, with
     candidate-axis sharding when launched under torch.distributed.run),
   * Sacred itself if installed, otherwise blp_amd.sacred_shim.
 Extra, optional config keys: data_root (default 'data'), seed (default None = unseeded, like the
-reference).
+reference), amp, device_sampler, eval_dropout (default True: the reference's train-mode table build).
 """
 import os
 import os.path as osp
@@ -62,6 +62,8 @@ def config():
     seed = None
     amp = None  # None | 'fp16' | 'bf16': autocast the training step (BASELINE config 5; not in the reference)
     device_sampler = False  # draw the in-batch negative indices on the GPU (same law as data.py:35-81, other RNG stream)
+    eval_dropout = True  # the reference builds its entity tables in train mode (train.py:57-121 never calls model.eval()):
+    #                      True reproduces that; False puts the encoder in eval mode for the table build (deterministic metrics)
 
 
 def _linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps):
@@ -93,7 +95,7 @@ def _get_model(model, dim, rel_model, loss_fn, num_entities, num_relations, enco
 @ex.command
 def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_name, regularizer, max_len,
                     num_negatives, lr, use_scheduler, batch_size, emb_batch_size, eval_batch_size, max_epochs,
-                    checkpoint, use_cached_text, data_root, seed, amp, device_sampler, _run, _log):
+                    checkpoint, use_cached_text, data_root, seed, amp, device_sampler, eval_dropout, _run, _log):
     if amp not in (None, 'fp16', 'bf16'):
         raise ValueError(f'Unknown amp mode {amp}')
     if seed is not None:
@@ -188,10 +190,10 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
         if dataset != 'Wikidata5M':
             _log.info('Evaluating on sample of training set')
             eval_link_prediction(net, train_eval_loader, train_data, train_ent, epoch, emb_batch_size, _run, _log,
-                                 prefix='train', max_num_batches=len(valid_loader), device=device)
+                                 prefix='train', max_num_batches=len(valid_loader), device=device, eval_mode=not eval_dropout)
         _log.info('Evaluating on validation set')
         val_mrr, _ = eval_link_prediction(net, valid_loader, train_data, train_val_ent, epoch, emb_batch_size,
-                                          _run, _log, prefix='valid', device=device)
+                                          _run, _log, prefix='valid', device=device, eval_mode=not eval_dropout)
         if val_mrr > best_valid_mrr:  # best checkpoint by raw validation MRR
             best_valid_mrr = val_mrr
             torch.save(net.state_dict(), checkpoint_file)
@@ -207,13 +209,15 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
         graph = utils.FilterIndex(valid_data.triples, num_relations=train_data.rel_categories.shape[0], device=device)
     _log.info('Evaluating on validation set (with filtering)')
     eval_link_prediction(net, valid_loader, train_data, train_val_ent, max_epochs + 1, emb_batch_size, _run, _log,
-                         prefix='valid', filtering_graph=graph, new_entities=val_new_ents, device=device)
+                         prefix='valid', filtering_graph=graph, new_entities=val_new_ents, device=device,
+                         eval_mode=not eval_dropout)
     if dataset == 'Wikidata5M':
         graph = utils.FilterIndex(test_data.triples, num_relations=train_data.rel_categories.shape[0], device=device)
     _log.info('Evaluating on test set')
     _, ent_emb = eval_link_prediction(net, test_loader, train_data, train_val_test_ent, max_epochs + 1,
                                       emb_batch_size, _run, _log, prefix='test', filtering_graph=graph,
-                                      new_entities=test_new_ents, return_embeddings=True, device=device)
+                                      new_entities=test_new_ents, return_embeddings=True, device=device,
+                                      eval_mode=not eval_dropout)
 
     torch.save(ent_emb, osp.join(OUT_PATH, f'ent_emb-{_run._id}.pt'))
     torch.save(train_val_test_ent, osp.join(OUT_PATH, f'ents-{_run._id}.pt'))
