@@ -25,6 +25,35 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
+GLUE_SRC = os.path.join(CSRC, "torch_glue.cpp")
+GLUE_LIB = os.path.join(HERE, "_torch_glue.so")
+
+
+def build_glue(force=False, verbose=False):
+    """Compile blp_amd/_torch_glue.so: the C++ autograd plumbing around the C-ABI's in-batch loss (torch_glue.cpp: no
+    kernels, no HIP calls -- host compiler only, against the installed torch).  In-tree, so it travels with the snapshot."""
+    import sysconfig
+
+    import pybind11
+    import torch
+    from torch.utils import cpp_extension as ce
+    if not force and os.path.exists(GLUE_LIB) and os.path.getmtime(GLUE_LIB) >= max(os.path.getmtime(GLUE_SRC), os.path.getmtime(__file__)):
+        return GLUE_LIB
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no host C++ compiler (g++) for blp_amd/_torch_glue.so")
+    inc = [*ce.include_paths(), sysconfig.get_paths()["include"], pybind11.get_include()]
+    libdir = ce.library_paths()[0]
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DTORCH_EXTENSION_NAME=_torch_glue",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           *[f"-I{i}" for i in inc], GLUE_SRC, "-o", GLUE_LIB, f"-L{libdir}", "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python",
+           f"-Wl,-rpath,{libdir}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return GLUE_LIB
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):
@@ -82,5 +111,6 @@ def _build(force, verbose, OBJ, LIB, variant_flags):
 
 
 if __name__ == "__main__":
+    build_glue(verbose=True)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_hooks(force="--force" in sys.argv, verbose=True))

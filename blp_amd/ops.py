@@ -20,7 +20,9 @@ _K_VALUES = (ctypes.c_int32 * 3)
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    # (the raw hipStream_t of torch's current stream on `device`; the public torch.cuda.current_stream() builds a Stream
+    # object around the same handle at ~2 us per call)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(device.index))
 
 
 def _ptr(t):
@@ -548,6 +550,31 @@ class _InBatchLoss(torch.autograd.Function):
         return None, None, None, grad_ent, grad_rel.reshape(rel_shape), None
 
 
+_glue_module = False  # False: not looked for yet; None: not available (the Python autograd.Function serves)
+
+
+def torch_glue():
+    """blp_amd/_torch_glue.so (csrc/torch_glue.cpp: the in-batch loss's autograd plumbing as a torch::autograd::Function, no
+    kernels) bound to the product library's entry points -- or None when it is not built / not loadable with this torch,
+    in which case _InBatchLoss above does the same job from Python (same C-ABI calls, ~100 us more host time per step)."""
+    global _glue_module
+    if _glue_module is False:
+        try:
+            from . import _torch_glue as g
+            L = _lib.lib()
+            g.bind(*(ctypes.cast(fn, ctypes.c_void_p).value for fn in (L.blp_inbatch_loss_fwd_t, L.blp_inbatch_loss_bwd_t, L.blp_last_error)))
+            assert g.save_pos_extra_floats + 2 == _lib.inbatch_save_pos_floats(1)
+            _glue_module = g
+        except ImportError:
+            _glue_module = None
+    return _glue_module
+
+
 def inbatch_loss(rel_model, loss_fn, ent_embs, rel_vecs, neg_idx, regularizer=0.0):
     """compute_loss on in-batch negatives (fused forward + deterministic backward)."""
-    return _InBatchLoss.apply(rel_model, loss_fn, regularizer, ent_embs, rel_vecs, neg_idx)
+    glue = torch_glue()
+    if glue is None:
+        return _InBatchLoss.apply(rel_model, loss_fn, regularizer, ent_embs, rel_vecs, neg_idx)
+    _require_device(ent_embs, rel_vecs, neg_idx)
+    return glue.inbatch_loss(ent_embs, rel_vecs, neg_idx, _lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], float(regularizer),
+                             torch._C._cuda_getCurrentRawStream(ent_embs.device.index))

@@ -221,6 +221,23 @@ def test_metric_sums_buffer_size_matches_the_header():
     assert int(re.search(r"#define BLP_METRIC_SUMS_DOUBLES (\d+)", header).group(1)) == _lib.METRIC_SUMS_DOUBLES
 
 
+def test_torch_glue_builds_loads_and_agrees_with_the_header(built_lib):
+    """blp_amd/_torch_glue.so (csrc/torch_glue.cpp: the in-batch loss's autograd plumbing as a C++ torch extension -- host
+    code only) builds against the installed torch, imports, binds the product library's entry points and sizes `save_pos`
+    as include/blp_hip.h's BLP_INBATCH_SAVE_POS_FLOATS does; it refuses CPU tensors like the Python plumbing."""
+    import torch
+    from blp_amd import _lib, build, ops
+    assert os.path.exists(build.build_glue())
+    glue = ops.torch_glue()
+    assert glue is not None and glue.__file__.endswith("_torch_glue.so")
+    header = open(os.path.join(ROOT, "include", "blp_hip.h")).read()
+    macro = re.search(r"#define BLP_INBATCH_SAVE_POS_FLOATS\(B\)\s+\((.*)\)", header).group(1)
+    for B in (1, 64, 1024):
+        assert eval(macro, {"B": B}) == 2 * B + glue.save_pos_extra_floats == _lib.inbatch_save_pos_floats(B)
+    with pytest.raises(RuntimeError, match="HIP device tensors only"):
+        glue.inbatch_loss(torch.zeros(4, 2, 8), torch.zeros(4, 1, 8), torch.zeros(4, 3, 2, dtype=torch.long), 0, 0, 0.0, 0)
+
+
 def test_no_kernel_of_the_in_batch_loss_uses_scratch(built_lib):
     """Every inbatch_* kernel keeps its working set in registers / LDS: .private_segment_fixed_size == 0 and no spills
     in the gfx950 code object's notes (tools/kernel_resources.py)."""
