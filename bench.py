@@ -676,6 +676,8 @@ def inbatch_bench(device, iters=200):
         torch.cuda.synchronize()
         out[name] = {"rel_model": c["model"], "loss": c["loss"], "B": B, "K": K, "D": D, "storage": c["dtype"],
                      "launches_per_step": 3, "us_per_step_kernels": a.elapsed_time(b) / iters * 1e3,
+                     "autograd_plumbing": "C++ torch::autograd::Function (blp_amd/_torch_glue.so)" if ops.torch_glue() is not None
+                                          else "Python autograd.Function + ctypes",
                      "us_per_step_autograd": wall(fused, iters), "torch_us_per_step": wall(stock, max(20, iters // 4)),
                      "pairs_per_step": B * (K + 1)}
     return out
@@ -720,6 +722,46 @@ def sub_result(name, axis, device, world, rank, backend, steps, events):
     del sub, t, c
     torch.cuda.empty_cache()
     return f
+
+
+def call_overhead(device, iters=3000):
+    """Host time per call of the Python layer around the library, on a problem so small (8 queries x 640 rows) that the GPU
+    keeps up: `ops_rank_all_us` = one ops.rank_all call issued (argument checks, workspace, marshalling AND the library's
+    three launches); `library_call_us` = the same blp_rank_all call with its arguments prepared once (what the launch chain
+    itself costs the host); their difference is the Python wrapper.  And one 128-query call (the reference's eval batch
+    against the FB15k-237 table): wall time per call, completed."""
+    from blp_amd import _lib, ops
+    g = torch.Generator(device=device).manual_seed(11)
+    table = torch.nn.functional.normalize(torch.randn(640, 128, device=device, generator=g), dim=-1)
+    qf, qr = torch.randn(8, 128, device=device, generator=g), torch.randn(8, 128, device=device, generator=g)
+    true = torch.zeros(8, dtype=torch.int64, device=device)
+    out = torch.empty((8, 4), dtype=torch.int32, device=device)
+
+    def host_us(fn, n):
+        for _ in range(200):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        return (t1 - t0) / n * 1e6, (time.perf_counter() - t0) / n * 1e6
+
+    wrapped, _ = host_us(lambda: ops.rank_all("transe", table, qf, qr, 4, true_row=true, out=out), iters)
+    L = _lib.lib()
+    ws_bytes = L.blp_rank_all_workspace_bytes(0, 640, 128, 4, 4)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    stream = torch._C._cuda_getCurrentRawStream(device.index)
+    args = (0, table.data_ptr(), 640, 128, 128, qf.data_ptr(), qr.data_ptr(), None, true.data_ptr(), None, 4, 4, None, None,
+            out.data_ptr(), ws.data_ptr(), ws_bytes, device.index, stream)
+    raw, _ = host_us(lambda: L.blp_rank_all(*args), iters)
+    cfg = WORKLOADS["fb15k237-transe"]
+    big, rel_w, heads, tails, rels = make_data(cfg, device)
+    q_fixed, q_rel, true_row = build_queries(big, rel_w, heads[:64], tails[:64], rels[:64])
+    _, call128 = host_us(lambda: ops.rank_all("transe", big, q_fixed, q_rel, 64, true_row=true_row), 500)
+    return {"ops_rank_all_us": wrapped, "library_call_us": raw, "python_wrapper_us": wrapped - raw,
+            "launches_per_call": 3, "rank_all_128_queries_fb15k237_us": call128}
 
 
 def main():
@@ -817,6 +859,7 @@ def main():
         inbatch = inbatch_bench(device)
         if rank == 0:
             result["sub_results"], result["inbatch_loss"] = subs, inbatch
+            result["call_overhead"] = call_overhead(device)
     if not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
         if rank == 0:  # one GPU's HBM-bound operating point (the other ranks wait at the barrier below)
             result["hbm_probe"] = hbm_probe(device, events)

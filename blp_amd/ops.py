@@ -29,6 +29,69 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _addr(t):
+    """The device address as a plain int (what a c_void_p argument takes without building a ctypes object), None = NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def _filter_spec(filter, Q, dev):
+    """SegmentFilter -> byref(blp_filter) (the tensors stay referenced by the caller's ``filter`` for the duration of the call)."""
+    seg = [None if x is None else (x if x.dtype is torch.int64 and x.device == dev and x.is_contiguous()
+                                   else x.to(device=dev, dtype=torch.int64).contiguous())
+           for x in (filter.seg_lo, filter.seg_hi, filter.values, filter.exclude, filter.ent2idx)]
+    if seg[0].shape[0] != Q or seg[1].shape[0] != Q or (seg[3] is not None and seg[3].shape[0] != Q):
+        raise ValueError("SegmentFilter: seg_lo, seg_hi and exclude need one entry per query")
+    spec = _lib.BlpFilter(seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr() if seg[2].numel() else seg[0].data_ptr(),
+                          None if seg[3] is None else seg[3].data_ptr(), None if seg[4] is None else seg[4].data_ptr(),
+                          0 if seg[4] is None else seg[4].shape[0], int(filter.row_base))
+    spec._keep = seg  # converted copies must outlive the (asynchronous) call's argument marshalling
+    return ctypes.byref(spec)
+
+
+# Ranking workspaces, one per (device, stream), grown on demand and kept: every kernel of a call runs on the caller's stream,
+# so the next call on that stream is ordered behind it and may reuse the buffer (a torch.empty + a size query per call were
+# ~4 us of a 20 us small call).  The sizes come from the library (blp_rank_all*_workspace_bytes), memoised per shape.
+_workspaces = {}
+_ws_bytes_memo = {}
+
+
+def _workspace(dev, stream, nbytes):
+    key = (dev.index, stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _workspaces[key] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    return buf
+
+
+def release_workspaces():
+    """Drop the cached ranking workspaces (they hold the largest requirement seen per stream)."""
+    _workspaces.clear()
+
+
+def _rank_ws_bytes(L, model, N, D, q_head, q_tail):
+    key = (id(L), model, N, D, q_head, q_tail)
+    n = _ws_bytes_memo.get(key)
+    if n is None:
+        if len(_ws_bytes_memo) > 4096:
+            _ws_bytes_memo.clear()
+        n = _ws_bytes_memo[key] = L.blp_rank_all_workspace_bytes(model, N, D, q_head, q_tail)
+    return n
+
+
+def _i64_vector(t):
+    """(Q,) int64, contiguous -- as given when it already is."""
+    if t.dtype is torch.int64 and t.dim() == 1 and t.is_contiguous():
+        return t
+    return t.reshape(-1).to(torch.int64).contiguous()
+
+
+def _f32_matrix(t, D, name):
+    """(Q, D) float32, contiguous -- as given when it already is."""
+    if t.dtype is torch.float32 and t.dim() == 2 and t.shape[1] == D and t.is_contiguous():
+        return t
+    return _f32_rows(t, name).reshape(-1, D).contiguous()
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -81,8 +144,8 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     if table.dim() != 2:
         raise ValueError(f"table must be (N, D), got {tuple(table.shape)}")
     N, D = table.shape
-    q_fixed = _f32_rows(q_fixed, "q_fixed").reshape(-1, D).contiguous()
-    q_rel = _f32_rows(q_rel, "q_rel").reshape(-1, D).contiguous()
+    q_fixed = _f32_matrix(q_fixed, D, "q_fixed")
+    q_rel = _f32_matrix(q_rel, D, "q_rel")
     Q = q_fixed.shape[0]
     if q_rel.shape[0] != Q:
         raise ValueError("q_fixed and q_rel must have the same number of rows")
@@ -91,15 +154,15 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     if (true_row is None) == (q_true is None):
         raise ValueError("give exactly one of true_row / q_true")
     if true_row is not None:
-        true_row = true_row.reshape(-1).to(torch.int64).contiguous()
+        true_row = _i64_vector(true_row)
         if true_row.shape[0] != Q:
             raise ValueError("true_row must have one entry per query")
     else:
-        q_true = _f32_rows(q_true, "q_true").reshape(-1, D).contiguous()
+        q_true = _f32_matrix(q_true, D, "q_true")
         if q_true.shape[0] != Q:
             raise ValueError("q_true must have one row per query")
     if rel_ids is not None:
-        rel_ids = rel_ids.reshape(-1).to(torch.int64).contiguous()
+        rel_ids = _i64_vector(rel_ids)
         if rel_ids.shape[0] != Q:
             raise ValueError("rel_ids must have one entry per query")
     if (filt_rowptr is None) != (filt_col is None):
@@ -121,25 +184,20 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
         return counts
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
-    ws_bytes = L.blp_rank_all_workspace_bytes(model, N, D, q_head, Q - q_head)
-    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws_bytes = _rank_ws_bytes(L, model, N, D, q_head, Q - q_head)
+    stream = torch._C._cuda_getCurrentRawStream(dev.index)
+    workspace = _workspace(dev, stream, ws_bytes)
     if filter is not None:
-        seg = [None if x is None else x.to(device=dev, dtype=torch.int64).contiguous()
-               for x in (filter.seg_lo, filter.seg_hi, filter.values, filter.exclude, filter.ent2idx)]
-        if seg[0].shape[0] != Q or seg[1].shape[0] != Q or (seg[3] is not None and seg[3].shape[0] != Q):
-            raise ValueError("SegmentFilter: seg_lo, seg_hi and exclude need one entry per query")
-        spec = _lib.BlpFilter(seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr() if seg[2].numel() else seg[0].data_ptr(),
-                              None if seg[3] is None else seg[3].data_ptr(), None if seg[4] is None else seg[4].data_ptr(),
-                              0 if seg[4] is None else seg[4].shape[0], int(filter.row_base))
-        status = L.blp_rank_all_ex(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
-                                   _ptr(q_rel), _ptr(rel_ids), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
-                                   ctypes.byref(spec), _ptr(counts), _ptr(workspace), ws_bytes, dev.index, _stream(dev))
+        status = L.blp_rank_all_ex(model, table.data_ptr(), N, D, table.stride(0) if N > 0 else D, q_fixed.data_ptr(),
+                                   q_rel.data_ptr(), _addr(rel_ids), _addr(true_row), _addr(q_true), q_head, Q - q_head,
+                                   _filter_spec(filter, Q, dev), counts.data_ptr(), workspace.data_ptr(), ws_bytes, dev.index, stream)
     else:
-        status = L.blp_rank_all(model, _ptr(table), N, D, table.stride(0) if N > 0 else D, _ptr(q_fixed),
-                                _ptr(q_rel), _ptr(rel_ids), _ptr(true_row), _ptr(q_true), q_head, Q - q_head,
-                                _ptr(filt_rowptr), _ptr(filt_col), _ptr(counts), _ptr(workspace), ws_bytes,
-                                dev.index, _stream(dev))
-    _lib.check(status, "blp_rank_all")
+        status = L.blp_rank_all(model, table.data_ptr(), N, D, table.stride(0) if N > 0 else D, q_fixed.data_ptr(),
+                                q_rel.data_ptr(), _addr(rel_ids), _addr(true_row), _addr(q_true), q_head, Q - q_head,
+                                _addr(filt_rowptr), _addr(filt_col), counts.data_ptr(), workspace.data_ptr(), ws_bytes,
+                                dev.index, stream)
+    if status:
+        _lib.check(status, "blp_rank_all")
     return counts
 
 
@@ -165,9 +223,7 @@ def rank_all_shard(rel_model, table, source, fixed_row, rel_emb, rel_ids, q_head
     N, D = table.shape
     if source.dim() != 2 or source.shape[1] != D:
         raise ValueError(f"source must be (S, {D}), got {tuple(source.shape)}")
-    fixed_row = fixed_row.reshape(-1).to(torch.int64).contiguous()
-    rel_ids = rel_ids.reshape(-1).to(torch.int64).contiguous()
-    true_row = true_row.reshape(-1).to(torch.int64).contiguous()
+    fixed_row, rel_ids, true_row = _i64_vector(fixed_row), _i64_vector(rel_ids), _i64_vector(true_row)
     Q = fixed_row.shape[0]
     if rel_ids.shape[0] != Q or true_row.shape[0] != Q or rel_emb.shape[1] != D:
         raise ValueError("fixed_row, rel_ids and true_row need one entry per query; rel_emb must be (R, D)")
@@ -181,24 +237,16 @@ def rank_all_shard(rel_model, table, source, fixed_row, rel_emb, rel_ids, q_head
         return counts
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
-    ws_bytes = L.blp_rank_all_workspace_bytes(model, N, D, q_head, Q - q_head)
-    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    spec = None
-    if filter is not None:
-        seg = [None if x is None else x.to(device=dev, dtype=torch.int64).contiguous()
-               for x in (filter.seg_lo, filter.seg_hi, filter.values, filter.exclude, filter.ent2idx)]
-        if seg[0].shape[0] != Q or seg[1].shape[0] != Q or (seg[3] is not None and seg[3].shape[0] != Q):
-            raise ValueError("SegmentFilter: seg_lo, seg_hi and exclude need one entry per query")
-        spec = ctypes.byref(_lib.BlpFilter(seg[0].data_ptr(), seg[1].data_ptr(),
-                                           seg[2].data_ptr() if seg[2].numel() else seg[0].data_ptr(),
-                                           None if seg[3] is None else seg[3].data_ptr(),
-                                           None if seg[4] is None else seg[4].data_ptr(),
-                                           0 if seg[4] is None else seg[4].shape[0], int(filter.row_base)))
-    status = L.blp_rank_all_shard(model, _ptr(table), N, D, table.stride(0) if N > 1 else D, _ptr(source), source.shape[0],
-                                  source.stride(0) if source.shape[0] > 1 else D, _ptr(fixed_row), _ptr(rel_emb),
-                                  rel_emb.shape[0], _ptr(rel_ids), _ptr(true_row), q_head, Q - q_head, spec, _ptr(counts),
-                                  _ptr(workspace), ws_bytes, dev.index, _stream(dev))
-    _lib.check(status, "blp_rank_all_shard")
+    ws_bytes = _rank_ws_bytes(L, model, N, D, q_head, Q - q_head)
+    stream = torch._C._cuda_getCurrentRawStream(dev.index)
+    workspace = _workspace(dev, stream, ws_bytes)
+    spec = None if filter is None else _filter_spec(filter, Q, dev)
+    status = L.blp_rank_all_shard(model, table.data_ptr(), N, D, table.stride(0) if N > 1 else D, source.data_ptr(), source.shape[0],
+                                  source.stride(0) if source.shape[0] > 1 else D, fixed_row.data_ptr(), rel_emb.data_ptr(),
+                                  rel_emb.shape[0], rel_ids.data_ptr(), true_row.data_ptr(), q_head, Q - q_head, spec, counts.data_ptr(),
+                                  workspace.data_ptr(), ws_bytes, dev.index, stream)
+    if status:
+        _lib.check(status, "blp_rank_all_shard")
     return counts
 
 
@@ -216,7 +264,7 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
     source = table if source is table else _f32_rows(source, "source")
     N, D = table.shape
     n, Q = int(num_triples), 2 * int(num_triples)
-    fixed_row, rel_ids, true_row = (x.reshape(-1).to(torch.int64).contiguous() for x in (fixed_row, rel_ids, true_row))
+    fixed_row, rel_ids, true_row = _i64_vector(fixed_row), _i64_vector(rel_ids), _i64_vector(true_row)
     if fixed_row.shape[0] != Q or rel_ids.shape[0] != Q or true_row.shape[0] != Q or rel_emb.shape[1] != D or source.shape[1] != D:
         raise ValueError("fixed_row, rel_ids, true_row need 2 * num_triples entries; rel_emb / source must be (., D)")
     dev = table.device
@@ -228,22 +276,15 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
     ws_bytes = L.blp_rank_all_batches_workspace_bytes(model, N, D, n, int(batch), int(block_triples))
-    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    spec = None
-    if filter is not None:
-        seg = [None if x is None else x.to(device=dev, dtype=torch.int64).contiguous()
-               for x in (filter.seg_lo, filter.seg_hi, filter.values, filter.exclude, filter.ent2idx)]
-        if seg[0].shape[0] != Q or seg[1].shape[0] != Q or (seg[3] is not None and seg[3].shape[0] != Q):
-            raise ValueError("SegmentFilter: seg_lo, seg_hi and exclude need one entry per query")
-        spec = ctypes.byref(_lib.BlpFilter(seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr() if seg[2].numel() else seg[0].data_ptr(),
-                                           None if seg[3] is None else seg[3].data_ptr(), None if seg[4] is None else seg[4].data_ptr(),
-                                           0 if seg[4] is None else seg[4].shape[0], int(filter.row_base)))
-    status = L.blp_rank_all_batches(model, _ptr(table), N, D, table.stride(0) if N > 1 else D, _ptr(source), source.shape[0],
-                                    source.stride(0) if source.shape[0] > 1 else D, _ptr(fixed_row), _ptr(rel_emb), rel_emb.shape[0],
-                                    _ptr(rel_ids), _ptr(true_row), n, int(batch), int(block_triples), spec, _ptr(counts), _ptr(workspace),
-                                    ws_bytes,
-                                    dev.index, _stream(dev))
-    _lib.check(status, "blp_rank_all_batches")
+    stream = torch._C._cuda_getCurrentRawStream(dev.index)
+    workspace = _workspace(dev, stream, ws_bytes)
+    spec = None if filter is None else _filter_spec(filter, Q, dev)
+    status = L.blp_rank_all_batches(model, table.data_ptr(), N, D, table.stride(0) if N > 1 else D, source.data_ptr(), source.shape[0],
+                                    source.stride(0) if source.shape[0] > 1 else D, fixed_row.data_ptr(), rel_emb.data_ptr(), rel_emb.shape[0],
+                                    rel_ids.data_ptr(), true_row.data_ptr(), n, int(batch), int(block_triples), spec, counts.data_ptr(),
+                                    workspace.data_ptr(), ws_bytes, dev.index, stream)
+    if status:
+        _lib.check(status, "blp_rank_all_batches")
     return counts
 
 
