@@ -631,13 +631,25 @@ def inbatch_bench(device, iters=200):
         rel = torch.randn(B, 1, D, device=device, generator=g) * 0.3
         neg_idx = torch.randint(0, 2 * B, (B, K, 2), device=device, generator=g)
 
+        # leaves made once; a step = forward + backward into fresh .grad tensors (what compute_loss(...).backward() costs the
+        # caller -- round 3 also timed two clone kernels per step here)
+        e_leaf, r_leaf = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+
         def fused():
-            e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
-            ops.inbatch_loss(c["model"], c["loss"], e, r, neg_idx, c["reg"]).backward()
+            e_leaf.grad = r_leaf.grad = None
+            ops.inbatch_loss(c["model"], c["loss"], e_leaf, r_leaf, neg_idx, c["reg"]).backward()
+
+        def forward_only():
+            with torch.no_grad():
+                ops.inbatch_loss(c["model"], c["loss"], e_leaf, r_leaf, neg_idx, c["reg"])
+
+        def floor():  # a node of the same shape that launches nothing: autograd's own cost per step on this host
+            e_leaf.grad = r_leaf.grad = None
+            ops.torch_glue().autograd_floor(e_leaf, r_leaf, neg_idx).backward()
 
         def stock():
-            e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
-            ref_port.compute_loss(c["model"], c["loss"], e, r, neg_idx, c["reg"]).backward()
+            e_leaf.grad = r_leaf.grad = None
+            ref_port.compute_loss(c["model"], c["loss"], e_leaf, r_leaf, neg_idx, c["reg"]).backward()
 
         def wall(fn, n):
             for _ in range(20):
@@ -678,7 +690,9 @@ def inbatch_bench(device, iters=200):
                      "launches_per_step": 3, "us_per_step_kernels": a.elapsed_time(b) / iters * 1e3,
                      "autograd_plumbing": "C++ torch::autograd::Function (blp_amd/_torch_glue.so)" if ops.torch_glue() is not None
                                           else "Python autograd.Function + ctypes",
-                     "us_per_step_autograd": wall(fused, iters), "torch_us_per_step": wall(stock, max(20, iters // 4)),
+                     "us_per_step_autograd": wall(fused, iters), "us_forward_no_grad": wall(forward_only, iters),
+                     "us_autograd_floor_no_kernels": wall(floor, iters) if ops.torch_glue() is not None else None,
+                     "torch_us_per_step": wall(stock, max(20, iters // 4)),
                      "pairs_per_step": B * (K + 1)}
     return out
 
@@ -737,18 +751,26 @@ def call_overhead(device, iters=3000):
     true = torch.zeros(8, dtype=torch.int64, device=device)
     out = torch.empty((8, 4), dtype=torch.int32, device=device)
 
-    def host_us(fn, n):
+    def host_us(fn, n, burst=32):
+        """(host us per call ISSUED -- bursts of `burst` calls into an idle queue, so that the host never waits for the
+        device --, wall us per call completed back to back)"""
         for _ in range(200):
             fn()
+        issued = 0.0
+        for _ in range(max(1, n // burst)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(burst):
+                fn()
+            issued += time.perf_counter() - t0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
-        t1 = time.perf_counter()
         torch.cuda.synchronize()
-        return (t1 - t0) / n * 1e6, (time.perf_counter() - t0) / n * 1e6
+        return issued / (max(1, n // burst) * burst) * 1e6, (time.perf_counter() - t0) / n * 1e6
 
-    wrapped, _ = host_us(lambda: ops.rank_all("transe", table, qf, qr, 4, true_row=true, out=out), iters)
+    wrapped, wrapped_done = host_us(lambda: ops.rank_all("transe", table, qf, qr, 4, true_row=true, out=out), iters)
     L = _lib.lib()
     ws_bytes = L.blp_rank_all_workspace_bytes(0, 640, 128, 4, 4)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
@@ -761,7 +783,7 @@ def call_overhead(device, iters=3000):
     q_fixed, q_rel, true_row = build_queries(big, rel_w, heads[:64], tails[:64], rels[:64])
     _, call128 = host_us(lambda: ops.rank_all("transe", big, q_fixed, q_rel, 64, true_row=true_row), 500)
     return {"ops_rank_all_us": wrapped, "library_call_us": raw, "python_wrapper_us": wrapped - raw,
-            "launches_per_call": 3, "rank_all_128_queries_fb15k237_us": call128}
+            "ops_rank_all_completed_us": wrapped_done, "launches_per_call": 3, "rank_all_128_queries_fb15k237_us": call128}
 
 
 def main():

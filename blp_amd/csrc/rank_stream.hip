@@ -70,7 +70,63 @@ __device__ __forceinline__ PassView pass_view(const StreamPasses& ps, int p, int
     return PassView{nb, nb, 2 * first};
 }
 
-template <int D>
+// Hand-issued scalar loads whose place among the arithmetic is pinned by an operand (see the approximate-key kernel below).
+template <int OFF>
+__device__ __forceinline__ void sload16_pinned(sf16& v, const float* base, float& pin) {
+    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(v), "+v"(pin) : "s"(base), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin) : : "memory");
+}
+__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin, float& pin2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin), "+v"(pin2) : : "memory");
+}
+__device__ __forceinline__ void sdrain_pinned2(sf16& a, sf16& b, float& pin) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+v"(pin) : : "memory");
+}
+
+// The coefficient rows come through the scalar cache in UNITS of 16 columns of one query (tail side: one s_load_dwordx16 of
+// h + r; head side: two, r and t), requested by hand one unit ahead of their use and drained after the arithmetic of the unit
+// before -- as the approximate-key kernel further down does (sload16_pinned / sdrain_pinned).  Left to the compiler (rounds
+// 2-3) every one of a tile's 32 scalar loads was followed by its wait on the spot: 32 exposed scalar-cache round trips per
+// tile and wave, and a pass of 2 + 2 queries ran 2 % behind the bilinear models' ring (346 against 339 us per 4.6 M rows).
+// Units of a piece: the NQ tail-side queries' (two each), then the NQ head-side queries'; the unit after a piece's last is the
+// next piece's first, after a tile's last the first of the same rows again (the next tile; a new pass reloads in enter()).
+// NQ = queries per side the kernel is compiled for: a side with fewer repeats its last row (sums computed, never counted).
+// Sums start at 0: 0 + |d| == |d| bit for bit (|d| is +0, positive or NaN), so the chain is score<false>'s.
+template <int D, int NQ, int S, int U>
+__device__ __forceinline__ void transe_units(float (&sum)[2 * NQ], const float (&x)[kSubCols], const float* const (&row)[2 * NQ],
+                                             sf16& cur_a, sf16& cur_b) {
+    if constexpr (U < 4 * NQ) {
+        constexpr int NP = D / kSubCols;
+        constexpr bool head = U >= 2 * NQ;
+        constexpr int q = (head ? U - 2 * NQ : U) / 2, c0 = 16 * (U % 2), slot = head ? q : NQ + q;  // sum[0 .. NQ): head, [NQ .. 2 NQ): tail
+        constexpr int nu = (U + 1) % (4 * NQ), ns = U + 1 < 4 * NQ ? S : (S + 1) % NP;                // the unit after this one
+        constexpr bool nhead = nu >= 2 * NQ;
+        constexpr int nq = (nhead ? nu - 2 * NQ : nu) / 2, nslot = nhead ? nq : NQ + nq, noff = (ns * kSubCols + 16 * (nu % 2)) * 4;
+        sf16 nxt_a, nxt_b;
+        sload16_pinned<noff>(nxt_a, row[nslot], sum[slot]);
+        if constexpr (nhead) sload16_pinned<noff + D * 4>(nxt_b, row[nslot], sum[slot]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float d;
+            if constexpr (!head) {
+                d = cur_a[k] - x[c0 + k];              // (h + r) - e, h + r hoisted
+            } else {
+                const float y = x[c0 + k] + cur_a[k];  // (e + r) - t
+                d = y - cur_b[k];
+            }
+            sum[slot] = sum[slot] + fabsf(d);
+        }
+        if constexpr (nhead) sdrain_pinned2(nxt_a, nxt_b, sum[slot]);
+        else sdrain_pinned(nxt_a, sum[slot]);
+        cur_a = nxt_a;
+        if constexpr (nhead) cur_b = nxt_b;
+        transe_units<D, NQ, S, U + 1>(sum, x, row, cur_a, cur_b);
+    }
+}
+
+template <int D, int NQ>
 __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef,
     const float* __restrict__ key_true, int q_head, int q_tail, int n_tiles,
@@ -107,13 +163,16 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
     auto tile_base = [&](int t) { return table + (int64_t)t * kTileRows * ld; };
     auto clamp_tile = [&](int t) { return t < n_tiles ? t : n_tiles - 1; };
 
-    unsigned n_gt[2 * kStreamQ] = {}, n_ge[2 * kStreamQ] = {};  // wave-uniform: scalar registers
+    static_assert(NQ >= 1 && NQ <= kStreamQ, "queries per side");
+    unsigned n_gt[2 * kStreamQ] = {}, n_ge[2 * kStreamQ] = {};  // wave-uniform: scalar registers (slots past NQ per side stay 0)
     // the pass the wave is in: its queries' coefficient rows, true keys, accumulators (prep_passes_kernel's layout)
     // (one base pointer for the coefficient rows: the pass's head rows, 2 D floats each, then its tail rows, D each -- with
     //  two, the pass-dependent choice between them costs the compiler the no-alias reasoning that keeps these loads scalar)
     int cur_p = -1, qh = 0, qt = 0;
     const float *ch = coef, *ct = coef, *kt = key_true;
     unsigned long long* acc_p = acc;
+    const float* row[2 * NQ];  // the coefficient rows the units walk: [0, NQ) head side, [NQ, 2 NQ) tail side
+    sf16 cur_a, cur_b;         // the unit about to be used (cur_b: the t half of a head-side unit)
     auto enter = [&](int p) {
         const PassView v = pass_view(passes, p, q_head, q_tail);
         qh = v.q_head; qt = v.q_tail;
@@ -122,6 +181,15 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
         kt = key_true + v.first2;
         acc_p = acc + slot_off + v.first2;
         cur_p = p;
+        // a side with fewer than NQ queries repeats its last row; a side with none walks a row of the other side (in bounds:
+        // both sides' rows are carved 2 D floats wide, rank_all.hip: carve_workspace / carve_passes) -- never counted
+        static_for<NQ>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            row[j] = qh > 0 ? ch + (size_t)(j < qh ? j : qh - 1) * (2 * D) : ct;
+            row[NQ + j] = qt > 0 ? ct + (size_t)(j < qt ? j : qt - 1) * D : ch;
+        });
+        cur_a = sload16<0>(row[NQ]);  // unit 0 of piece 0: the first tail-side row's columns 0 .. 15
+        sdrain(cur_a);
     };
     auto flush_wave = [&]() {  // this wave's counts of pass cur_p -> its accumulators; slot j < 4: head query j; 4 + j: tail query j
         if (lane < 2 * kStreamQ) {
@@ -158,7 +226,7 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
         const bool more = next_r < total;  // wave-uniform
         const int next = more ? clamp_tile(tile_of(next_r)) : 0;
         const float* base = tile_base(tile);
-        float sum[2 * kStreamQ] = {};
+        float sum[2 * NQ] = {};
         static_for<NP>([&](auto ss) {
             constexpr int s = decltype(ss)::value, pp = s & 1;
             // piece s: registers -> slab (transposing) ...
@@ -182,17 +250,10 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
                 x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
             }
             wave_lds_sync();  // the reads are out before the next piece overwrites the slab
-            static_for<kStreamQ>([&](auto jj) {
-                constexpr int j = decltype(jj)::value;
-                if (j < qt) sum[kStreamQ + j] = transe_piece_sum<TAIL, D, s == 0>(sum[kStreamQ + j], x, ct + j * D + s * kSubCols);
-            });
-            static_for<kStreamQ>([&](auto jj) {
-                constexpr int j = decltype(jj)::value;
-                if (j < qh) sum[j] = transe_piece_sum<HEAD, D, s == 0>(sum[j], x, ch + j * 2 * D + s * kSubCols);
-            });
+            transe_units<D, NQ, s, 0>(sum, x, row, cur_a, cur_b);
         });
         const bool valid = tile_real < n_tiles && (int64_t)tile * kTileRows + lane < N;
-        static_for<kStreamQ>([&](auto jj) {
+        static_for<NQ>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
             if (j < qh) {
                 const float key = -sum[j], k_true = kt[j];
@@ -200,7 +261,7 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
                 n_ge[j] += __popcll(__ballot(valid && key >= k_true));
             }
             if (j < qt) {
-                const float key = -sum[kStreamQ + j], k_true = kt[qh + j];
+                const float key = -sum[NQ + j], k_true = kt[qh + j];
                 n_gt[kStreamQ + j] += __popcll(__ballot(valid && key > k_true));
                 n_ge[kStreamQ + j] += __popcll(__ballot(valid && key >= k_true));
             }
@@ -343,16 +404,6 @@ __device__ __forceinline__ void dot_decide(float v, const DotBand& b, float nrow
 // Both asm statements carry the unit's running sum as an operand: the request stands before the unit's first
 // multiply-add, the wait behind its last (volatile asm keeps its own order, not its place among the arithmetic --
 // unpinned, the compiler issues every request and wait of a piece up front and parks the values in VGPR lanes all the same).
-template <int OFF>
-__device__ __forceinline__ void sload16_pinned(sf16& v, const float* base, float& pin) {
-    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(v), "+v"(pin) : "s"(base), "i"(OFF) : "memory");
-}
-__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin) : : "memory");
-}
-__device__ __forceinline__ void sdrain_pinned(sf16& a, float& pin, float& pin2) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin), "+v"(pin2) : : "memory");
-}
 // The undecided rows `und` (a lane mask) of the tile whose first row is row0, against one query (f, r: its two vectors;
 // kt: its true key), by coop_score -- 32 lanes per pair, the order-exact arithmetic of every other exact path, the row
 // re-read from the cache it has just passed through; two rows per trip, one per 32-lane half (the upper half without a
@@ -777,15 +828,17 @@ hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, i
     const int64_t n_rounds = ((n_tiles + kWaves - 1) / kWaves) * (passes.n_passes > 1 ? passes.n_passes : 1);
     const int64_t resident = (int64_t)n_cu * (D == 256 ? 3 : 4);  // workgroups of four waves per CU: 4 (3) waves per SIMD
     const unsigned blocks = (unsigned)(n_rounds < resident ? n_rounds : resident);
-#define BLP_STREAM_CASE(DD)                                                                                          \
-    case DD:                                                                                                         \
-        rank_stream_kernel<DD><<<blocks, kWaves * 64, 0, stream>>>(table, N, ld, coef_head, key_true, (int)q_head,     \
-                                                                   (int)q_tail, (int)n_tiles, acc, passes);          \
+    // queries per side the kernel is compiled for: a pass's batch, or the larger side of a single call
+    const int64_t per_side = passes.n_passes > 1 ? passes.batch : (q_head > q_tail ? q_head : q_tail);
+#define BLP_STREAM_CASE(DD, QQ)                                                                                      \
+    case DD * 8 + QQ:                                                                                                \
+        rank_stream_kernel<DD, QQ><<<blocks, kWaves * 64, 0, stream>>>(table, N, ld, coef_head, key_true, (int)q_head, \
+                                                                       (int)q_tail, (int)n_tiles, acc, passes);      \
         break;
-    switch (D) {
-        BLP_STREAM_CASE(64)
-        BLP_STREAM_CASE(128)
-        BLP_STREAM_CASE(256)
+    switch (D * 8 + (int)per_side) {
+        BLP_STREAM_CASE(64, 1) BLP_STREAM_CASE(64, 2) BLP_STREAM_CASE(64, 3) BLP_STREAM_CASE(64, 4)
+        BLP_STREAM_CASE(128, 1) BLP_STREAM_CASE(128, 2) BLP_STREAM_CASE(128, 3) BLP_STREAM_CASE(128, 4)
+        BLP_STREAM_CASE(256, 1) BLP_STREAM_CASE(256, 2) BLP_STREAM_CASE(256, 3) BLP_STREAM_CASE(256, 4)
     default: return hipErrorInvalidValue;
     }
 #undef BLP_STREAM_CASE

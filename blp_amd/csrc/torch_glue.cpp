@@ -93,6 +93,28 @@ struct InBatchLoss : public torch::autograd::Function<InBatchLoss> {
     }
 };
 
+// What the autograd machinery itself costs around a fused loss of this shape: the same allocations, the same saved tensors, the
+// same engine round trip -- and no kernel at all.  bench.py times it next to the real function; the difference is what the
+// C-ABI calls (argument checks + three launches) add on the host.
+struct AutogradFloor : public torch::autograd::Function<AutogradFloor> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& ent_embs, const at::Tensor& rel_vecs,
+                              const at::Tensor& neg_idx) {
+        const int64_t B = ent_embs.size(0), K = neg_idx.size(1);
+        const auto f32 = ent_embs.options().dtype(at::kFloat);
+        at::Tensor loss = at::empty({}, f32), pos = at::empty({2 * B + kSavePosExtra}, f32), neg = at::empty({B, K}, f32);
+        ctx->save_for_backward({ent_embs, rel_vecs, neg_idx, pos, neg});
+        return loss;
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        return {at::empty_like(saved[0]), at::empty_like(saved[1]), at::Tensor()};
+    }
+};
+
+at::Tensor autograd_floor(const at::Tensor& ent_embs, const at::Tensor& rel_vecs, const at::Tensor& neg_idx) {
+    return AutogradFloor::apply(ent_embs, rel_vecs, neg_idx);
+}
+
 void bind(uintptr_t fwd, uintptr_t bwd, uintptr_t err) {
     g_fwd = reinterpret_cast<fwd_fn>(fwd);
     g_bwd = reinterpret_cast<bwd_fn>(bwd);
@@ -111,5 +133,7 @@ PYBIND11_MODULE(_torch_glue, m) {
     m.def("bind", &bind, "hand over the addresses of blp_inbatch_loss_fwd_t, blp_inbatch_loss_bwd_t, blp_last_error");
     m.def("inbatch_loss", &inbatch_loss, py::call_guard<py::gil_scoped_release>(),
           "compute_loss on in-batch negatives: (ent_embs, rel_vecs, neg_idx, model_id, loss_id, regularizer, raw_stream) -> loss");
+    m.def("autograd_floor", &autograd_floor, py::call_guard<py::gil_scoped_release>(),
+          "a node of the same shape that launches nothing (bench.py: what autograd itself costs per step)");
     m.attr("save_pos_extra_floats") = kSavePosExtra;
 }

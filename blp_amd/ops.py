@@ -69,7 +69,9 @@ def release_workspaces():
 
 
 def _rank_ws_bytes(L, model, N, D, q_head, q_tail):
-    key = (id(L), model, N, D, q_head, q_tail)
+    if L is not _lib._product:  # the hooks build (tests, tools): its routing -- hence the size -- moves with the knobs
+        return L.blp_rank_all_workspace_bytes(model, N, D, q_head, q_tail)
+    key = (model, N, D, q_head, q_tail)
     n = _ws_bytes_memo.get(key)
     if n is None:
         if len(_ws_bytes_memo) > 4096:

@@ -90,7 +90,8 @@ def test_link_prediction_module_on_gpu_uses_fused_loss(name):
     model = model.cuda()
     ent = torch.from_numpy(g["ent_embs"]).cuda().requires_grad_(True)
     loss = model.compute_loss(ent, torch.from_numpy(g["rels"]).cuda(), torch.from_numpy(g["neg_idx"]).cuda())
-    assert loss.grad_fn is not None and "InBatchLoss" in type(loss.grad_fn).__name__
+    # (one fused node -- the C++ torch::autograd::Function of blp_amd/_torch_glue.so, or the Python one without it)
+    assert loss.grad_fn is not None and "InBatchLoss" in loss.grad_fn.name()
     loss.backward()
     assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-6, abs=1e-7)
     np.testing.assert_allclose(ent.grad.cpu().numpy(), g["grad_ent"], rtol=1e-5, atol=1e-7)
