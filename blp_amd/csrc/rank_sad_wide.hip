@@ -26,10 +26,19 @@ namespace blp {
 
 constexpr int kWChunk = 32;    // queries per workgroup (their partial SADs live in LDS: 8 KB per wave)
 constexpr int kWQuota = 128;   // undecided pairs a workgroup can list (4 per query)
+// Which workgroups run together on an XCD (its L2 holds 4 MB): windows of kWideGroupBlock candidate groups x kWideChunkBlock
+// query chunks -- at D = 768 a group's four tile images are 393 KB, a chunk's query images 49 KB.  Rounds 2-3 walked ALL
+// groups of a block of 4 chunks in turn: the ~128 workgroups an XCD holds at a time covered 32 groups x 4 chunks = 12.8 MB of
+// distinct data, and 19 GB per launch went over the fabric for 83 GB read from the L2s (algorithmic: 0.7 GB).  A window of
+// 4 groups x 32 chunks is 3.1 MB of distinct data for the same 128 workgroups.
 #ifndef BLP_WIDE_CHUNK_BLOCK
-#define BLP_WIDE_CHUNK_BLOCK 4  // D = 768 block, ranking pass: 4: 21.33 ms, 8: 21.45, 16: 21.39, 32: 21.48, 64: 22.0 (group-major order: 24.07)
+#define BLP_WIDE_CHUNK_BLOCK 32
 #endif
-constexpr unsigned kWideChunkBlock = BLP_WIDE_CHUNK_BLOCK;  // query chunks whose workgroups run together on an XCD
+#ifndef BLP_WIDE_GROUP_BLOCK
+#define BLP_WIDE_GROUP_BLOCK 4
+#endif
+constexpr unsigned kWideChunkBlock = BLP_WIDE_CHUNK_BLOCK;  // query chunks ...
+constexpr unsigned kWideGroupBlock = BLP_WIDE_GROUP_BLOCK;  // ... x candidate groups whose workgroups run together on an XCD
 constexpr int kWMaxD = 1024;
 
 // models.py:222-223 for one (candidate, query) pair, any width: ((h + r) - t), |.|, sequential f32 sum
@@ -294,10 +303,12 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     const unsigned n_blocks = gridDim.x, xcd = blockIdx.x & 7u, per_xcd = n_blocks >> 3, rem_b = n_blocks & 7u;
     const unsigned logical = (xcd < rem_b ? xcd * (per_xcd + 1) : rem_b * (per_xcd + 1) + (xcd - rem_b) * per_xcd) + (blockIdx.x >> 3);
     const unsigned n_chunks_all = n_blocks / (unsigned)n_groups;
+    // logical index = (block of kWideChunkBlock chunks) x (block of kWideGroupBlock groups) x (group of the block) x (chunk of the block)
     const unsigned per_cb = (unsigned)n_groups * kWideChunkBlock, cb = logical / per_cb, in_cb = logical % per_cb;
     const unsigned chunks_here = n_chunks_all - cb * kWideChunkBlock < kWideChunkBlock ? n_chunks_all - cb * kWideChunkBlock : kWideChunkBlock;
-    const int group = (int)(in_cb / chunks_here);
-    const int64_t q0 = (int64_t)(cb * kWideChunkBlock + in_cb % chunks_here) * q_per_wg;
+    const unsigned per_gb = kWideGroupBlock * chunks_here, gb = in_cb / per_gb, in_gb = in_cb % per_gb;
+    const int group = (int)(gb * kWideGroupBlock + in_gb / chunks_here);  // (the last block of groups may be short: in_gb stops early)
+    const int64_t q0 = (int64_t)(cb * kWideChunkBlock + in_gb % chunks_here) * q_per_wg;
     const int nq = (int)(Q - q0 < q_per_wg ? Q - q0 : q_per_wg);
 
     if (tid < kWChunk) {
