@@ -146,6 +146,81 @@ __device__ __forceinline__ float transe_key_64_rt(const float* pe, const float* 
     return -sum;
 }
 
+// 64 candidates against ONE query at a run-time width: what a refinement that has its pairs grouped by query calls
+// (rank_sad_wide.hip).  The query side is staged ONCE per wave in LDS by the caller (stage_query_rt: qa = h + r for a
+// tail-replacing query; qa = r, qb = t for a head-replacing one) and read back as broadcasts -- through the scalar cache the
+// two 3-KB vectors of a new query every task were a cold miss per 32-column chunk (5.7 ms for the D = 768 block's pairs).  The
+// candidate rows go through a ring of four 32-column chunks, three requested ahead of the one being summed.  Same operations
+// in the same order as transe_key_64_rt -- models.py:222-223 -- so the keys are the true-entity keys' bit for bit.
+__device__ __forceinline__ void stage_query_rt(const float* __restrict__ f, const float* __restrict__ r, int D, bool head,
+                                               float* qa, float* qb, int lane) {
+    for (int c = 4 * lane; c < D; c += 256) {
+        const float4 fv = *reinterpret_cast<const float4*>(f + c);
+        const float4 rv = *reinterpret_cast<const float4*>(r + c);
+        if (head) {
+            *reinterpret_cast<float4*>(qa + c) = rv;
+            *reinterpret_cast<float4*>(qb + c) = fv;
+        } else {  // (h + r), rounded once, exactly as the reference's first operation
+            *reinterpret_cast<float4*>(qa + c) = make_float4(fv.x + rv.x, fv.y + rv.y, fv.z + rv.z, fv.w + rv.w);
+        }
+    }
+}
+
+__device__ __forceinline__ float transe_key_64_one_query_rt(const float* pe, const float* qa, const float* qb, int D, bool head,
+                                                            float* slab, int lane) {
+    const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
+    const float* ge[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ge[k] = shfl_ptr(pe, 8 * k + sub_row) + sub_col;
+    float sum = 0.0f;
+    const int n_chunks = (D + 31) / 32;  // the last one may be partial (D = 300: 12 columns)
+    float ring[4][32];
+    auto issue = [&](float (&x)[32], int s) {
+        const int rest = D - 32 * s;
+        gather_issue_rt(x, ge, s, rest < 32 ? rest : 32, lane);
+    };
+    auto consume = [&](float (&x)[32], int s) {
+        gather_transpose(x, slab, lane);
+        const float* a = qa + 32 * s;
+        const float* b = qb + 32 * s;
+        const int cols = D - 32 * s;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            if (4 * k4 < cols) {  // wave-uniform (D % 4 == 0: four columns exist together)
+                const float4 av = *reinterpret_cast<const float4*>(a + 4 * k4);  // every lane the same address: a broadcast
+                const float as[4] = {av.x, av.y, av.z, av.w};
+                if (head) {
+                    const float4 bv = *reinterpret_cast<const float4*>(b + 4 * k4);
+                    const float bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = x[4 * k4 + i] + as[i];  // (e + r) - t
+                        v = v - bs[i];
+                        sum = sum + fabsf(v);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum = sum + fabsf(as[i] - x[4 * k4 + i]);  // (h + r) - e
+                }
+            }
+        }
+    };
+    if (0 < n_chunks) issue(ring[0], 0);
+    if (1 < n_chunks) issue(ring[1], 1);
+    if (2 < n_chunks) issue(ring[2], 2);
+    for (int s0 = 0; s0 < n_chunks; s0 += 4) {
+        static_for<4>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const int s = s0 + i;
+            if (s < n_chunks) {
+                if (s + 3 < n_chunks) issue(ring[(i + 3) % 4], s + 3);
+                consume(ring[i], s);
+            }
+        });
+    }
+    return -sum;
+}
+
 // ---------------------------------------------------------------- bilinear models: 32 lanes per pair
 // Term i of the reference's sum for candidate row e and the query's vectors f (the entity kept fixed) and r (the
 // relation): the arithmetic of Scorer<MODEL, SIDE, D>::score (score_core.h) for one summand with its coefficients

@@ -283,13 +283,13 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
     const uint4* __restrict__ cimg, const unsigned* __restrict__ resid, int64_t n_rows, int n_groups,
     const unsigned* __restrict__ qimg, const int2* __restrict__ thr, int64_t Q, int Dp, int words_per_query,
     unsigned long long* __restrict__ acc, unsigned* __restrict__ flags, uint2* __restrict__ pairs,
-    SadParams* __restrict__ params, int q_per_wg) {  // q_per_wg <= kWChunk: wide_chunk_queries()
+    unsigned* __restrict__ pair_cnt, SadParams* __restrict__ params, int q_per_wg) {  // q_per_wg <= kWChunk: wide_chunk_queries()
     if (!sad_scale(params).ok) return;
     __shared__ unsigned psum[kSW][kWChunk][64];
     __shared__ int2 thr_s[kWChunk];
     __shared__ unsigned cnt[kWChunk];
     __shared__ uint2 pair_s[kWQuota];
-    __shared__ unsigned pair_n, pair_base;
+    __shared__ unsigned pair_n;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -396,35 +396,102 @@ __global__ __launch_bounds__(kSW * 64, 4) void wide_rank_sad_kernel(
         const unsigned long long c = cnt[tid];
         if (c) atomicAdd(acc + q0 + tid, c | (c << 32));  // certainly above: gt and ge
     }
+    // the workgroup's pairs go to ITS region of the list -- (query chunk, candidate group), kWQuota slots, the fill beside it --
+    // so that the refinement finds a chunk's pairs together and can group them by query (wide_refine_chunks_kernel)
     const unsigned used = pair_n < (unsigned)kWQuota ? pair_n : (unsigned)kWQuota;
-    if (tid == 0 && used) pair_base = atomicAdd(&params->n_pairs, used);
-    __syncthreads();
-    for (unsigned i = tid; i < used; i += kSW * 64) pairs[pair_base + i] = pair_s[i];
+    const size_t region = (size_t)(q0 / q_per_wg) * n_groups + group;
+    if (tid == 0) pair_cnt[region] = used;
+    for (unsigned i = tid; i < used; i += kSW * 64) pairs[region * kWQuota + i] = pair_s[i];
 }
 
-// Pass 2a: the listed pairs, 64 per single-wave workgroup and step, one lane per pair; the rows are gathered in
-// whole cache lines and transposed through LDS (exact_coop.h: transe_key_64_rt) instead of every lane reading its
-// own three rows 16 bytes at a time.
-__global__ __launch_bounds__(64) void wide_refine_pairs_kernel(const float* __restrict__ table, int64_t ld, int D,
-                                                               const QRows q_fixed,
-                                                               const QRows q_rel,
-                                                               const float* __restrict__ key_true, int64_t q_head,
-                                                               const uint2* __restrict__ pairs,
-                                                               const SadParams* __restrict__ params,
-                                                               unsigned long long* __restrict__ acc) {
-    __shared__ __attribute__((aligned(16))) float slab[64 * kRefStride];
-    const int lane = threadIdx.x;
-    const int64_t n = params->n_pairs;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {  // wave-uniform
-        const int64_t i = base + lane;
-        const uint2 p = i < n ? pairs[i] : make_uint2(kSNoPair, 0u);
-        const bool live = p.x != kSNoPair;
-        const int64_t q = live ? p.x : 0;
-        const float key = transe_key_64_rt(table + (live ? (int64_t)p.y : 0) * ld, q_fixed.row(q), q_rel.row(q), D,
-                                           q < q_head, slab, lane);
-        const float kt = key_true[q];
-        const unsigned long long gt = live && key > kt, ge = live && key >= kt;
-        if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
+// Pass 2a: the listed pairs, grouped by query.  Rounds 2-3 re-scored the pairs in the order the pre-pass listed them, one
+// lane per pair, every lane gathering its candidate row AND its query's two vectors: three 3-KB rows per pair at D = 768,
+// 26 GB over the fabric per launch -- 3.5 ms at 7.4 TB/s, bandwidth-bound.  A workgroup now takes the pairs of ONE query chunk
+// (<= 32 queries) from kWSliceGroups candidate groups' regions, sorts them by query in LDS (a histogram, a scan, a scatter of
+// the candidate rows), and its waves then re-score 64 candidates of one query at a time: the query's vectors come through
+// the scalar cache once per wave (exact_coop.h: transe_key_64_one_query_rt), only the candidate rows are gathered.
+constexpr int kWSliceGroups = 32;                       // regions a workgroup sorts at a time ...
+constexpr int kWSliceCap = kWSliceGroups * kWQuota;     // ... i.e. at most this many pairs (16 KB of LDS)
+__global__ __launch_bounds__(256) void wide_refine_chunks_kernel(const float* __restrict__ table, int64_t ld, int D,
+                                                                const QRows q_fixed, const QRows q_rel,
+                                                                const float* __restrict__ key_true, int64_t q_head, int64_t Q,
+                                                                const uint2* __restrict__ pairs, const unsigned* __restrict__ pair_cnt,
+                                                                int n_groups, int n_slices, int q_per_wg,
+                                                                const SadParams* __restrict__ params,
+                                                                unsigned long long* __restrict__ acc) {
+    if (!sad_scale(params).ok) return;  // the pre-pass did not run: nothing was listed (the tile sweep takes every query)
+    __shared__ __attribute__((aligned(16))) float slabs[4][64 * kRefStride];
+    extern __shared__ __attribute__((aligned(16))) float qvec[];  // per wave: 2 x Dp floats, the query side of its current task
+    __shared__ unsigned sorted[kWSliceCap];
+    __shared__ unsigned hist[kWChunk], start[kWChunk + 1], cnt_s[kWSliceGroups];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t chunk = blockIdx.x / n_slices;
+    const int g0 = (int)(blockIdx.x % n_slices) * kWSliceGroups;
+    const int ng = n_groups - g0 < kWSliceGroups ? n_groups - g0 : kWSliceGroups;
+    const int64_t q0 = chunk * q_per_wg;
+    const size_t region0 = (size_t)chunk * n_groups + g0;
+    if (tid < kWChunk) hist[tid] = 0;
+    if (tid < kWSliceGroups) cnt_s[tid] = tid < ng ? pair_cnt[region0 + tid] : 0u;
+    __syncthreads();
+    // 1. histogram over the chunk's queries; a thread keeps its <= 16 pairs and their ranks inside their bins
+    constexpr int kSlots = kWSliceCap / 256;
+    unsigned cand[kSlots], where[kSlots];
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) {
+        const int slot = tid + 256 * k, r = slot / kWQuota, i = slot % kWQuota;
+        where[k] = 0xFFFFFFFFu;
+        cand[k] = 0;
+        if (i < (int)cnt_s[r]) {  // (cnt_s[r] == 0 for r >= ng)
+            const uint2 p = pairs[(region0 + r) * kWQuota + i];
+            const unsigned ql = p.x - (unsigned)q0;
+            if (ql < (unsigned)kWChunk) {
+                cand[k] = p.y;
+                where[k] = (ql << 16) | atomicAdd(&hist[ql], 1u);  // (at most kWSliceCap = 4 096 per bin)
+            }
+        }
+    }
+    __syncthreads();
+    // 2. exclusive scan of the 32 bins
+    if (tid < 64) {
+        unsigned incl = lane < kWChunk ? hist[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < kWChunk; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane < kWChunk) start[lane + 1] = incl;
+        if (lane == 0) start[0] = 0;
+    }
+    __syncthreads();
+    // 3. the candidate rows, sorted by query
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k)
+        if (where[k] != 0xFFFFFFFFu) sorted[start[where[k] >> 16] + (where[k] & 0xFFFFu)] = cand[k];
+    __syncthreads();
+    // 4. tasks (query, 64 of its candidates), round-robin over the waves
+    float* slab = slabs[wave];
+    const int Dp = (D + 127) / 128 * 128;
+    float* qa = qvec + (size_t)wave * 2 * Dp;
+    float* qb = qa + Dp;
+    int task = 0;
+    for (int j = 0; j < kWChunk; ++j) {  // wave-uniform throughout
+        const unsigned lo = start[j], hi = start[j + 1];
+        if (lo == hi) continue;
+        const int64_t q = q0 + j;
+        for (unsigned b = lo; b < hi; b += 64, ++task) {
+            if ((task & 3) != wave) continue;
+            const bool live = b + lane < hi;
+            const unsigned row = sorted[live ? b + lane : lo];
+            const bool head = q < q_head;
+            wave_lds_sync();  // the previous task's reads of the query side are done
+            stage_query_rt(q_fixed.row(q), q_rel.row(q), D, head, qa, qb, lane);
+            wave_lds_sync();
+            const float key = transe_key_64_one_query_rt(table + (int64_t)row * ld, qa, qb, D, head, slab, lane);
+            const float kt = key_true[q];
+            const unsigned long long gt = __popcll(__ballot(live && key > kt)), ge = __popcll(__ballot(live && key >= kt));
+            if (lane == 0 && ge) atomicAdd(acc + q, gt | (ge << 32));
+        }
     }
 }
 
@@ -537,6 +604,7 @@ struct WideWorkspace {
     unsigned long long* acc;
     SadParams* params; SadParams* partial; int2* thr; unsigned* qimg; uint4* cimg; unsigned* resid; unsigned* flags;
     uint2* pairs;
+    unsigned* pair_cnt;  // fill of every (query chunk, candidate group) region of `pairs`
     int64_t pass_groups;
     size_t bytes;
 };
@@ -588,6 +656,8 @@ static WideWorkspace carve_wide(void* base, int D, int64_t N, int64_t Q) {
     w.pairs = reinterpret_cast<uint2*>(p + off);
     const int cs = wide_chunk_queries(N, Q);
     off = align_up(off + (size_t)w.pass_groups * ((Q + cs - 1) / cs) * kWQuota * 8, 256);
+    w.pair_cnt = reinterpret_cast<unsigned*>(p + off);
+    off = align_up(off + (size_t)w.pass_groups * ((Q + cs - 1) / cs) * 4, 256);
     w.bytes = off;
     return w;
 }
@@ -655,10 +725,12 @@ hipError_t launch_rank_all_sad_wide(int D, const float* table, int64_t N, int64_
         const float* slab = table + slab0 * ld;
         wide_rank_sad_kernel<<<dim3((unsigned)n_blocks), kSW * 64, 0, stream>>>(
             w.cimg + (slab0 / 64) * (Dp / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, w.qimg, w.thr, Q, Dp, words, w.acc,
-            w.flags, w.pairs, w.params, q_per_wg);
-        const int64_t pair_blocks = (n_blocks * kWQuota + 63) / 64;
-        wide_refine_pairs_kernel<<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 40 ? pair_blocks : (int64_t)n_cu * 40)), 64, 0,
-                                   stream>>>(slab, ld, D, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc);
+            w.flags, w.pairs, w.pair_cnt, w.params, q_per_wg);
+        const int64_t n_slices = (n_groups + kWSliceGroups - 1) / kWSliceGroups;
+        if (n_chunks * n_slices > 0x7fffffff) return hipErrorInvalidValue;
+        wide_refine_chunks_kernel<<<dim3((unsigned)(n_chunks * n_slices)), 256, (size_t)4 * 2 * Dp * 4, stream>>>(
+            slab, ld, D, q_fixed, q_rel, w.key_true, q_head, Q, w.pairs, w.pair_cnt, (int)n_groups, (int)n_slices, q_per_wg, w.params,
+            w.acc);
         wide_refine_tiles_kernel<<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
             slab, n_rows, ld, D, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
     }
