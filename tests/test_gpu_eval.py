@@ -621,3 +621,32 @@ def test_filter_index_builds_on_the_device():
             want = torch.unique(big[(big[:, 0] == t[0]) & (big[:, 2] == t[2]), 1])
         got = seg.values[int(seg.seg_lo[q]):int(seg.seg_hi[q])]
         assert torch.equal(got, want), q
+
+
+@pytest.mark.default_routing
+def test_integration_md_stub_is_runnable():
+    """The ctypes stub INTEGRATION.md section 2 tells a maintainer of the reference to add (the DEFAULT patch: all batches of the
+    evaluation loop in one blp_rank_all_batches call) is executed as printed -- only the library path is made absolute -- and
+    gives the counts of blp_amd.ops.rank_all_batches, which the parity tests hold against the oracle."""
+    import os
+    import re
+    import types
+    from blp_amd import _lib, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# blp_hip\.py.*?)```", text, flags=re.S).group(1)
+    assert "blp_rank_all_batches" in block
+    stub = types.ModuleType("blp_hip_stub")
+    exec(block.replace('"libblp_hip.so"', repr(_lib.LIB_PATH)), stub.__dict__)
+    g = torch.Generator().manual_seed(12)
+    N, D, R, T, batch = 3001, 128, 9, 150, 64
+    for rel_model in ("transe", "complex"):
+        table = torch.randn(N, D, generator=g)
+        table = (torch.nn.functional.normalize(table, dim=-1) if rel_model == "transe" else table * 0.1).cuda()
+        rel_w = (torch.randn(R, D, generator=g) * 0.1).cuda()
+        fixed = torch.randint(0, N, (2 * T,), generator=g).cuda()
+        rid = torch.randint(0, R, (2 * T,), generator=g).cuda()
+        true = torch.randint(0, N, (2 * T,), generator=g).cuda()
+        got = stub.rank_all_batches(rel_model, table, fixed, rel_w, rid, true, T, batch)
+        want = ops.rank_all_batches(rel_model, table, fixed, rel_w, rid, true, T, batch)
+        assert got.shape == (2 * T, 4) and torch.equal(got, want)

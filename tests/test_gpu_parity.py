@@ -451,6 +451,33 @@ def test_transe_any_width_prepass(ops, oracle, D, knobs):
     assert (want[:, 1] - want[:, 0]).max() > 1
 
 
+@pytest.mark.default_routing
+@pytest.mark.parametrize("D,N,q_head,q_tail", [(300, 9100, 40, 37), (768, 16500, 70, 61), (100, 8300, 5, 3)])
+def test_transe_any_width_refinement_across_group_slices(ops, oracle, D, N, q_head, q_tail):
+    """The any-width refinement (rank_sad_wide.hip: wide_refine_chunks_kernel) sorts a query chunk's undecided pairs by query
+    in LDS, 32 candidate groups' regions at a time: tables of more than 32 groups (8 192 rows) take several slices per chunk.
+    Near-duplicate rows (a few ulps off their neighbours: the fixed-point band cannot separate them) fill the regions --
+    past their quota in places, which sends those tiles to the flag sweep -- and exact duplicates pin the tie rule; counts
+    identical to the oracle, raw and with a CSR filter."""
+    table, q_fixed, q_rel, true_row = random_problem("transe", N, D, q_head, q_tail, seed=N + D)
+    g = torch.Generator().manual_seed(D)
+    # clusters of near-identical candidates around some of the true entities
+    for t in true_row[::3].tolist():
+        rows = torch.randint(0, N, (180,), generator=g)
+        table[rows] = table[t] * (1.0 + 1e-7 * torch.randn(180, 1, generator=g))
+    table[5::1000] = table[4::1000][: table[5::1000].shape[0]]  # exact ties
+    # ... and 200 CONSECUTIVE near-copies of one true entity: more undecided pairs than one (chunk, group) region lists
+    t0 = int(true_row[1])
+    base = (t0 + 1000) % (N - 300)
+    table[base:base + 200] = table[t0] * (1.0 + 1e-7 * torch.randn(200, 1, generator=g))
+    rowptr, col = random_csr(q_head + q_tail, N, true_row.numpy(), seed=D + 5)
+    want = oracle_counts(oracle, "transe", table, q_fixed, q_rel, q_head, true_row=true_row, csr=(rowptr, col))
+    got = ops.rank_all("transe", table.cuda(), q_fixed.cuda(), q_rel.cuda(), q_head, true_row=true_row.cuda(),
+                       filt_rowptr=dev(rowptr), filt_col=dev(col)).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert (want[:, 1] - want[:, 0]).max() >= 1
+
+
 @pytest.mark.parametrize("case", ["nan", "constant", "huge"])
 def test_transe_any_width_degenerate_inputs(ops, oracle, case):
     D, N, q_head, q_tail = 300, 500, 130, 140
