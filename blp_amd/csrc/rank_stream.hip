@@ -47,9 +47,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // part of rows 8i .. 8i + 7, clamped to the table by the caller).  Streamed once: non-temporal.
 template <class Off>
 __device__ __forceinline__ void piece_fetch(f32x4 (&b)[8], const float* __restrict__ base, const Off (&boff)[8], int s) {
+#ifdef BLP_STREAM_CONTIG  // experiment (with BLP_STREAM_NULL): a piece = 8 KB contiguous -- 16 whole rows -- instead of 64 rows x 128 B
+    constexpr int kPieceStep = 8192;
+#else
+    constexpr int kPieceStep = kSubCols * 4;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff[i] + s * (kSubCols * 4)));
+        b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff[i] + s * kPieceStep));
 }
 
 // MANY PASSES IN ONE LAUNCH (StreamPasses, rank_common.h; the reference's Wikidata5M evaluation is a pass per two triples).
@@ -107,6 +112,9 @@ __device__ __forceinline__ void transe_units(float (&sum)[2 * NQ], const float (
         sf16 nxt_a, nxt_b;
         sload16_pinned<noff>(nxt_a, row[nslot], sum[slot]);
         if constexpr (nhead) sload16_pinned<noff + D * 4>(nxt_b, row[nslot], sum[slot]);
+#ifdef BLP_STREAM_NULL  // experiment (tools/step_ab.py): the ring with (almost) no arithmetic -- what the access pattern alone streams at
+        sum[slot] = sum[slot] + x[c0] * cur_a[0];
+#else
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             float d;
@@ -118,6 +126,7 @@ __device__ __forceinline__ void transe_units(float (&sum)[2 * NQ], const float (
             }
             sum[slot] = sum[slot] + fabsf(d);
         }
+#endif
         if constexpr (nhead) sdrain_pinned2(nxt_a, nxt_b, sum[slot]);
         else sdrain_pinned(nxt_a, sum[slot]);
         cur_a = nxt_a;
@@ -158,6 +167,9 @@ __global__ __launch_bounds__(kWaves * 64, D == 256 ? 3 : 4) void rank_stream_ker
         for (int i = 0; i < 8; ++i) {
             const int r = 8 * i + sub_row;
             boff[i] = (unsigned)(((r < last ? r : last) * (int)ld + sub_col) * 4);
+#ifdef BLP_STREAM_CONTIG
+            boff[i] = (unsigned)((i * 256 + lane * 4) * 4);  // (experiment: full tiles only)
+#endif
         }
     };
     auto tile_base = [&](int t) { return table + (int64_t)t * kTileRows * ld; };
