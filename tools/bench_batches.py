@@ -36,7 +36,8 @@ for name in ("fb15k237-transe", "fb15k237-distmult"):
         return job.step(True)[1]
 
     def ms(fn, n):
-        fn()
+        for _ in range(3):  # (one warm-up call left the first timed loop of a process 25 % slow: round 4, tools/per_batch_probe.py)
+            fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
