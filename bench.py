@@ -557,8 +557,10 @@ def load_pmc(workload, live_pass_ms=None):
         doc = json.load(open(path))
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
-    # (the whole-evaluation workloads run the very launch of the 64-pass ones, 3 447 passes long: one pass's share is the same)
-    workload = workload[:-5] if workload.endswith("-full") else workload
+    # (the whole-evaluation workloads run the very launch of the 64-pass ones, 3 447 passes long: without counters of their
+    #  own, one pass's share of the 64-pass launch is the same figure)
+    if workload.endswith("-full") and workload not in doc:
+        workload = workload[:-5]
     entry, stamp = doc.get(workload), doc.get("_profile", {})
     where = f"profiles/{stamp.get('round', '?')}/{workload} (rocprofv3 --pmc, commit {stamp.get('commit', '?')})"
     if not entry:
