@@ -1181,6 +1181,9 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                 const int64_t cost = ((grid + kBfResident - 1) / kBfResident) * (kBfSetupTiles + per);
                 if (cost < best_cost) { best_cost = cost; tiles_per_chunk = per; }
             }
+#ifdef BLP_GEMM_FORCE_TILES  // experiment builds (tools/step_ab.py): query tiles per workgroup whatever the cost model says
+            tiles_per_chunk = BLP_GEMM_FORCE_TILES;
+#endif
             const int forced = (int)knob(KNOB_GEMM_TILES_PER_CHUNK);  // test knob: long chunks on small problems
             if (forced >= kBfMinTilesPerChunk && forced <= kBfMaxTilesPerChunk && forced % 4 == 0) tiles_per_chunk = forced;
         }
