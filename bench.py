@@ -486,7 +486,43 @@ def cpu_baseline(job, budget_s=10.0):
     torch.set_num_threads(all_threads)
     best = max(legs, key=lambda k: legs[k][0])
     value, done, el = legs[best]
-    return {"value": value, "unit": "scored triples/s", "cores": best,
+
+    # A second CPU figure, for scale: the order-exact C oracle (oracle/blp_oracle.c: scalar loops in the reference's operation
+    # order, OpenMP over the queries of a side, CSR filter) on the same batches -- NOT what the reference runs (its CPU path is
+    # the torch expressions above), but what a plain C restatement of it reaches on these host cores.
+    def c_oracle_leg(budget):
+        import numpy as np
+        from oracle import oracle as orc
+        tab_np, rw_np = tab.numpy(), rw.numpy()
+
+        def cbatch(i):
+            lo = (i * B) % max(T - B + 1, 1)
+            t = trip[lo:lo + B]
+            rowptr, col = job.index.csr(t, ent2idx)
+            b = t.shape[0]
+            rel = rw_np[t[:, 2].numpy()]
+            orc.rank_counts(cfg["model"], orc.SIDE_HEAD, tab_np, tab_np[t[:, 1].numpy()], rel, true_row=t[:, 0].numpy(),
+                            filt_rowptr=rowptr[:b + 1].numpy(), filt_col=col[:rowptr[b]].numpy())
+            orc.rank_counts(cfg["model"], orc.SIDE_TAIL, tab_np, tab_np[t[:, 0].numpy()], rel, true_row=t[:, 1].numpy(),
+                            filt_rowptr=(rowptr[b:] - rowptr[b]).numpy(), filt_col=col[rowptr[b]:].numpy())
+
+        cbatch(0)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            cbatch(n + 1)
+            n += 1
+            e = time.perf_counter() - t0
+            if e >= budget or n >= 256:
+                break
+        return {"value": 2.0 * B * cfg["N"] * n / e, "unit": "scored triples/s", "threads": min(B, os.cpu_count() or 1),
+                "kind": "port: oracle/blp_oracle.c (scalar C in the reference's operation order, OpenMP over the <= "
+                        f"{B} queries of a side; CSR filter)", "sample": f"{n} reference batches of {B} triples, {e:.1f} s"}
+
+    try:
+        c_leg = c_oracle_leg(3.0)
+    except Exception as exc:  # (a baseline beside the baseline: never the reason a bench line is lost)
+        c_leg = {"error": repr(exc)}
+    return {"value": value, "unit": "scored triples/s", "cores": best, "c_oracle": c_leg,
             "kind": "port, vectorised filter (the reference's own networkx walk adds ~190 ms per batch: SURVEY.md 8a)",
             "value_by_threads": {str(k): v[0] for k, v in legs.items()}, "value_1_thread": legs[1][0],
             "cpu_model": cpu_model_name(), "logical_cpus": os.cpu_count(),

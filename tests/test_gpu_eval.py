@@ -281,6 +281,8 @@ def test_bench_line_keeps_the_contract():
     # the best of a few thread counts (an oversubscribed all-threads run was the slower one), thread count stated
     assert "1" in cpu["value_by_threads"] and cpu["value"] == max(cpu["value_by_threads"].values())
     assert cpu["value"] == cpu["value_by_threads"][str(cpu["cores"])]
+    # beside it, for scale: the order-exact C oracle on the same batches (OpenMP over a side's queries)
+    assert cpu["c_oracle"]["value"] > 0 and cpu["c_oracle"]["threads"] >= 1 and "blp_oracle.c" in cpu["c_oracle"]["kind"]
     assert r["parity_check"].endswith("identical counts")
     subs = r["sub_results"]
     import bench
