@@ -179,6 +179,23 @@ int blp_project_rows(const float* x, int64_t n, int64_t ldx, const float* w, int
     return BLP_OK;
 }
 
+int blp_bow_rows_supported(int E) { return blp::bow_rows_supported(E) ? 1 : 0; }
+
+int blp_bow_rows(const int64_t* tok, const float* mask, int64_t n, int L, const float* emb, int64_t V, int E, int normalize,
+                 float* out, int64_t ldo, int32_t* bad_tok, int device, void* stream) {
+    if (n < 0 || L < 0 || V < 0) return fail(BLP_ERR_BAD_ARG, "blp_bow_rows: negative size");
+    if (!blp::bow_rows_supported(E)) return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_bow_rows: E = %d (needs E %% 4 == 0, E <= 1024)", E);
+    if (n == 0) return BLP_OK;
+    if (!out || !bad_tok || (L > 0 && (!tok || !emb || V == 0))) return fail(BLP_ERR_BAD_ARG, "blp_bow_rows: NULL pointer or empty embedding table");
+    if (!aligned16(emb) || !aligned16(out) || (ldo & 3) || ldo < E)
+        return fail(BLP_ERR_BAD_ARG, "blp_bow_rows: emb / out must be 16-byte aligned, ldo %% 4 == 0, ldo >= E");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    hipError_t err = blp::launch_bow_rows(tok, mask, n, L, emb, V, E, normalize, out, ldo, bad_tok, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_bow_rows launch");
+    return BLP_OK;
+}
+
 int blp_version(void) { return BLP_HIP_VERSION; }
 
 const char* blp_last_error(void) { return g_error; }

@@ -103,6 +103,10 @@ bool project_rows_supported(int E, int D);
 hipError_t launch_project_rows(const float* x, int64_t n, int64_t ldx, const float* w, int E, int D, int normalize,
                                float* out, int64_t ldo, hipStream_t stream);
 
+bool bow_rows_supported(int E);
+hipError_t launch_bow_rows(const int64_t* tok, const float* mask, int64_t n, int L, const float* emb, int64_t V, int E,
+                           int normalize, float* out, int64_t ldo, int* bad_tok, hipStream_t stream);
+
 struct StridedRows {  // row(i0, i1) = base + i0 * s0 + i1 * s1   (strides in floats)
     const float* base;
     int64_t s0, s1;

@@ -267,6 +267,29 @@ class BOW(WordEmbeddingsLP):
         embs = torch.sum(text_mask.unsqueeze(dim=-1) * embs, dim=1)
         return embs / lengths
 
+    def encode_into(self, out, text_tok, text_mask=None):
+        """Table build (train.py:96-121): on a HIP device and outside autograd the lookup, the masked mean, F.normalize and
+        the row assignment are one kernel that reads every gathered word vector once (ops.bow_rows -> blp_bow_rows); the
+        stock modules stream the (B, L, E) gather three times."""
+        weight = self.embeddings.weight
+        if out.is_cuda and not torch.is_grad_enabled() and out.dtype == torch.float32 and weight.dtype == torch.float32 \
+                and text_tok.dim() == 2 and out.stride(1) == 1 and ops.bow_rows_supported(weight.shape[1]) \
+                and type(self.embeddings) is nn.Embedding and self.embeddings.max_norm is None:  # (padding_idx: gradients only)
+            flag = self.__dict__.get("_bow_bad_tok")  # (a plain attribute: not a buffer, not in the state_dict)
+            if flag is None or flag.device != out.device:
+                flag = self.__dict__["_bow_bad_tok"] = torch.zeros((), dtype=torch.int32, device=out.device)
+            return ops.bow_rows(text_tok, text_mask, weight, out, self.normalize_embs, bad_flag=flag)
+        return super().encode_into(out, text_tok, text_mask)
+
+    def check_tokens(self):
+        """Raise IndexError if a fused encode_into since the last check saw a token id outside the embedding table (the
+        kernel reads row 0 for it and sets a device flag; nn.Embedding's own device-side assert surfaces as late as this).
+        ranking.build_entity_table calls it once after its last chunk: one host read per table, none per chunk."""
+        flag = self.__dict__.get("_bow_bad_tok")
+        if flag is not None and flag.item() < 0:
+            flag.zero_()
+            raise IndexError("a token id is outside the embedding table")
+
 
 class DKRL(WordEmbeddingsLP):
     """DKRL two-layer CNN description encoder (models.py:158-204)."""

@@ -452,6 +452,45 @@ def project_rows(x, weight, out, normalize):
     return out
 
 
+def bow_rows_supported(embedding_dim):
+    """True if blp_bow_rows takes word vectors of this width."""
+    return bool(_lib.lib().blp_bow_rows_supported(int(embedding_dim)))
+
+
+def bow_rows(text_tok, text_mask, weight, out, normalize, bad_flag=None):
+    """out[i] = sum_l mask[i, l] * weight[tok[i, l]] / sum_l mask[i, l], L2-normalised if ``normalize`` -- the bag-of-words
+    encoder (models.py:143-155) + F.normalize (models.py:40-41) + the row assignment into the entity table
+    (train.py:109-113) in one kernel that reads every gathered word vector once (blp_bow_rows).  text_tok (n, L) int64,
+    text_mask (n, L) float or None (all ones), weight (V, E) f32 (embeddings.weight), out (n, E) f32 rows of the table.
+    Inference only (no autograd).  Token ids outside [0, V) raise IndexError, as nn.Embedding does -- checked after the
+    launch with one host read of a flag, or, with ``bad_flag`` (a 0-dim int32 device tensor the caller zeroed once), left to
+    the caller: the kernel sets it to -1 and nothing synchronises here (models.BOW.check_tokens reads it after a table build)."""
+    _require_device(text_tok, text_mask, weight, out)
+    if weight.dtype != torch.float32 or out.dtype != torch.float32:
+        raise TypeError("bow_rows works on float32 tables")
+    if text_tok.dim() != 2 or weight.dim() != 2 or out.dim() != 2 or out.shape != (text_tok.shape[0], weight.shape[1]):
+        raise ValueError(f"shapes do not match: tok {tuple(text_tok.shape)}, weight {tuple(weight.shape)}, out {tuple(out.shape)}")
+    if out.stride(1) != 1:
+        raise ValueError("out must have contiguous rows")
+    tok = text_tok if text_tok.dtype is torch.int64 and text_tok.is_contiguous() else text_tok.to(torch.int64).contiguous()
+    mask = None
+    if text_mask is not None:
+        if text_mask.shape != text_tok.shape:
+            raise ValueError("text_mask must have text_tok's shape")
+        mask = text_mask if text_mask.dtype is torch.float32 and text_mask.is_contiguous() else text_mask.to(torch.float32).contiguous()
+    weight = weight.contiguous()
+    n, L = tok.shape
+    dev = out.device
+    bad = bad_flag if bad_flag is not None else torch.zeros((), dtype=torch.int32, device=dev)
+    status = _lib.lib().blp_bow_rows(tok.data_ptr(), _addr(mask), n, L, weight.data_ptr(), weight.shape[0], weight.shape[1],
+                                     int(bool(normalize)), out.data_ptr(), out.stride(0) if n > 1 else weight.shape[1],
+                                     bad.data_ptr(), dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+    _lib.check(status, "blp_bow_rows")
+    if bad_flag is None and bad.item() < 0:
+        raise IndexError("bow_rows: a token id is outside the embedding table")
+    return out
+
+
 # ------------------------------------------------------------------------------------- score_fn
 def _collapse(sizes, strides):
     """Collapse a group of dims into (size, stride) or None if not expressible with one stride."""

@@ -468,6 +468,8 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
             table[idx: idx + batch_ents.shape[0]] = model(batch_ents.to(device))
         if log is not None and (it + 1) % report == 0:
             log.info(f"[{idx + batch_ents.shape[0]:,}/{n:,}]")
+    if hasattr(model, "check_tokens"):  # the fused bag-of-words build leaves its token-id check on the device until here
+        model.check_tokens()
     return table
 
 

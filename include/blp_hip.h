@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 300 /* major*10000 + minor*100 + patch */
+#define BLP_HIP_VERSION 400 /* major*10000 + minor*100 + patch */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -364,6 +364,29 @@ int blp_build_queries(const blp_queries *q, int device, void *stream);
 int blp_project_rows_supported(int E, int D);
 int blp_project_rows(const float *x, int64_t n, int64_t ldx, const float *w, int E, int D, int normalize,
                      float *out, int64_t ldo, int device, void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Entity-table build for the bag-of-words encoder (models.py:143-155; the glove-bow / bert-bow scripts), with the steps
+ * that follow it:
+ *
+ *   embs = self.embeddings(text_tok); lengths = torch.sum(text_mask, dim=-1, keepdim=True)      models.py:150-151
+ *   embs = torch.sum(text_mask.unsqueeze(dim=-1) * embs, dim=1) / lengths                       models.py:152-153
+ *   ent_emb = F.normalize(ent_emb, dim=-1)    models.py:40-41 (iff normalize != 0)
+ *   ent_emb[idx:idx + batch] = batch_emb      train.py:109-113
+ *
+ *   out[i, :] = (sum_l mask[i, l] * emb[tok[i, l], :]) / (sum_l mask[i, l])  [ / max(||.||_2, 1e-12) ]      i < n
+ *
+ *   tok   (n, L) int64 token ids, row-major;  mask (n, L) f32 or NULL (all ones: models.py:147-148);
+ *   emb   (V, E) f32 row-major (embeddings.weight);  out (n, E) f32, row stride ldo: rows of the table shard;
+ *   bad_tok  int32 on the device, set to -1 if a token id was outside [0, V) (row 0 is read for it; nn.Embedding would
+ *            raise) and left alone otherwise: the caller initialises it to 0 and reads it when convenient.
+ * No (n, L, E) temporary: every gathered row is read once.  Floating point (tokens summed in order, product and sum rounded
+ * separately): agrees with the torch expression to ~1e-6 relative, not bit for bit.
+ * blp_bow_rows_supported: E % 4 == 0, E <= 1024; emb, out 16-byte aligned, ldo % 4 == 0, ldo >= E.
+ * -------------------------------------------------------------------------------------------- */
+int blp_bow_rows_supported(int E);
+int blp_bow_rows(const int64_t *tok, const float *mask, int64_t n, int L, const float *emb, int64_t V, int E,
+                 int normalize, float *out, int64_t ldo, int32_t *bad_tok, int device, void *stream);
 
 /* --------------------------------------------------------------------------------------------
  * Test / A-B hooks -- NOT part of the production library.  They are compiled only with -DBLP_TEST_HOOKS, into a second

@@ -49,7 +49,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     L = _lib.lib()
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.blp_version() == 300
+    assert L.blp_version() == 400
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 8)  # coefficients, key, accumulator
@@ -194,6 +194,20 @@ def test_project_rows_argument_checks(built_lib):
     assert L.blp_project_rows(None, 4, 768, None, 768, 96, 1, None, 96, 0, None) == -2
     assert L.blp_project_rows(None, -1, 768, None, 768, 128, 1, None, 128, 0, None) == -1
     assert b"blp_project_rows" in L.blp_last_error()
+
+
+def test_bow_rows_argument_checks(built_lib):
+    from blp_amd import _lib
+    L = _lib.lib()
+    assert L.blp_bow_rows_supported(300) == 1 and L.blp_bow_rows_supported(768) == 1 and L.blp_bow_rows_supported(1024) == 1
+    assert L.blp_bow_rows_supported(302) == 0 and L.blp_bow_rows_supported(1028) == 0 and L.blp_bow_rows_supported(0) == 0
+    p16 = ctypes.c_void_p(16)
+    assert L.blp_bow_rows(None, None, 0, 32, None, 100, 300, 1, None, 300, None, 0, None) == _lib.BLP_OK     # nothing to do
+    assert L.blp_bow_rows(None, None, 4, 32, p16, 100, 300, 1, p16, 300, p16, 0, None) == -1               # no tokens
+    assert L.blp_bow_rows(p16, None, 4, 32, p16, 100, 302, 1, p16, 304, p16, 0, None) == -2
+    assert L.blp_bow_rows(p16, None, 4, 32, ctypes.c_void_p(20), 100, 300, 1, p16, 300, p16, 0, None) == -1  # alignment
+    assert L.blp_bow_rows(p16, None, 4, 32, p16, 100, 300, 1, p16, 296, p16, 0, None) == -1                # ldo < E
+    assert b"blp_bow_rows" in L.blp_last_error()
 
 
 def test_knobs_are_named_and_reset(built_lib):

@@ -482,6 +482,64 @@ def test_bert_table_build_uses_the_fused_epilogue(rel_model, monkeypatch):
 
 @pytest.mark.default_routing
 @pytest.mark.gpu
+@pytest.mark.parametrize("rel_model,E,V,L", [("transe", 300, 5000, 32), ("transe", 768, 3000, 64), ("distmult", 300, 700, 7),
+                                             ("transe", 1024, 90, 1), ("transe", 8, 40, 33)])
+def test_bow_table_build_is_one_kernel(rel_model, E, V, L, monkeypatch):
+    """models.BOW.encode_into (what ranking.build_entity_table calls per chunk for the glove-bow / bert-bow scripts) ==
+    the reference's BOW encoder + F.normalize (models.py:143-155, 40-41), through blp_bow_rows: masked mean of the word
+    vectors with zero-masked padding tokens, mask None, every chunk written into its own rows, shard rows equal the full
+    table's; under autograd (training) the stock modules serve; a token id outside the table raises like nn.Embedding."""
+    from blp_amd import models, ops, ranking
+    g = torch.Generator().manual_seed(E + L)
+    weight = torch.randn(V, E, generator=g) * 0.3
+    model = models.BOW(rel_model, "margin", 5, 0, embeddings=weight).cuda()
+    calls = []
+    real = ops.bow_rows
+    monkeypatch.setattr(ops, "bow_rows", lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1])
+
+    class Text:
+        def __init__(self, n):
+            self.tok = torch.randint(0, V, (n, L), generator=g)
+            lengths = torch.randint(1, L + 1, (n,), generator=g)
+            self.mask = (torch.arange(L).unsqueeze(0) < lengths.unsqueeze(1)).float()
+            self.tok = self.tok * self.mask.long()  # padding token 0, as data.TextGraphDataset pads
+        def get_entity_description(self, ents):
+            return self.tok[ents], self.mask[ents], None
+    text = Text(53)
+    entities = torch.arange(53)
+    table = ranking.build_entity_table(model, text, entities, 16, torch.device("cuda"))
+    assert calls == [16, 16, 16, 5]
+    with torch.no_grad():
+        want = model.encode(text.tok.cuda(), text.mask.cuda())  # the stock modules: embedding, masked sum, division, normalise
+    assert torch.allclose(table, want, rtol=2e-6, atol=1e-7)
+    if rel_model == "transe":
+        assert torch.allclose(table.norm(dim=1), torch.ones(53, device="cuda"), atol=1e-6)
+    shard = ranking.build_entity_table(model, text, entities, 16, torch.device("cuda"), rows=(20, 45))
+    assert torch.allclose(shard, table[20:45], rtol=1e-6, atol=1e-7)
+    out = torch.full((4, E), 7.0, device="cuda")                      # mask None: every token counts (models.py:147-148)
+    with torch.no_grad():
+        model.encode_into(out, text.tok[:4].cuda(), None)
+        assert torch.allclose(out, model.encode(text.tok[:4].cuda(), None), rtol=2e-6, atol=1e-7)
+    with torch.enable_grad():                                          # training keeps the stock modules (autograd)
+        n_before = len(calls)
+        model.encode_into(out, text.tok[:4].cuda(), text.mask[:4].cuda())
+        assert len(calls) == n_before
+    bad = text.tok[:4].clone()
+    bad[2, 0] = V
+    with torch.no_grad():
+        model.encode_into(out, bad.cuda(), text.mask[:4].cuda())   # (no host sync per chunk: the flag waits on the device)
+        with pytest.raises(IndexError):
+            model.check_tokens()
+        model.check_tokens()                                        # the flag was reset
+        with pytest.raises(IndexError):                             # the bare op checks on the spot
+            ops.bow_rows(bad.cuda(), text.mask[:4].cuda(), model.embeddings.weight, out, True)
+    text.tok[7, 0] = V
+    with pytest.raises(IndexError):                                 # ... and a table build checks once, after its last chunk
+        ranking.build_entity_table(model, text, entities, 16, torch.device("cuda"))
+
+
+@pytest.mark.default_routing
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,block,D", [(1, 64, 128), (100, 64, 128), (128, 64, 64), (333, 50, 300), (70, 1000, 768)])
 def test_build_queries_equals_the_torch_prelude(n, block, D):
     """blp_build_queries (train.py:132-145 + utils.py:46-83 for a whole set of triples, one kernel) against the same
