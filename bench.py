@@ -826,6 +826,48 @@ def call_overhead(device, iters=3000):
             "ops_rank_all_completed_us": wrapped_done, "launches_per_call": 3, "rank_all_128_queries_fb15k237_us": call128}
 
 
+def table_build_bench(device):
+    """The step BEFORE the path: the entity-table build's fused pieces against the stock PyTorch-ROCm
+    modules, per emb_batch_size chunk -- the bag-of-words encoder's whole build (models.py:143-155 + F.normalize + the row
+    assignment: blp_bow_rows) at the BERT word-embedding table's size, and the BERT encoders' last step (enc_linear +
+    F.normalize + row assignment, models.py:110-111: blp_project_rows).  Floating point (tolerance in the tests); us per chunk."""
+    from blp_amd import models, ops
+    g = torch.Generator(device=device).manual_seed(21)
+    out = {}
+
+    def us(fn, n=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    V, E = 28996, 768  # bert-base-cased word embeddings
+    model = models.BOW("transe", "margin", 5, 0, embeddings=torch.randn(V, E) * 0.1).to(device)
+    for name, n, L in (("bert-bow, 512 entities x 32 tokens (scripts/bert-bow-fb15k237.sh)", 512, 32),
+                       ("bert-bow, 12 288 entities x 64 tokens (scripts/bert-bow-wikidata5m.sh)", 12288, 64)):
+        tok = torch.randint(1, V, (n, L), device=device, generator=g)
+        lengths = torch.randint(L // 2, L + 1, (n, 1), device=device, generator=g)
+        mask = (torch.arange(L, device=device).unsqueeze(0) < lengths).float()
+        rows = torch.empty(n, E, device=device)
+        with torch.no_grad():
+            stock = us(lambda: rows.copy_(model.encode(tok, mask)))
+            fused = us(lambda: model.encode_into(rows, tok, mask))
+        model.check_tokens()
+        out[name] = {"stock_us": stock, "fused_us": fused, "gathered_GBps": n * L * E * 4 / fused / 1e3, "kernel": "blp_bow_rows"}
+    x = torch.randn(14541, 768, device=device, generator=g)
+    w = torch.randn(128, 768, device=device, generator=g) * 0.03
+    rows = torch.empty(14541, 128, device=device)
+    with torch.no_grad():
+        stock = us(lambda: rows.copy_(torch.nn.functional.normalize(torch.nn.functional.linear(x, w), dim=-1)))
+        fused = us(lambda: ops.project_rows(x, w, rows, True))
+    out["bert [CLS] rows 14 541 x 768 -> 128, normalised"] = {"stock_us": stock, "fused_us": fused, "kernel": "blp_project_rows"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -922,6 +964,7 @@ def main():
         if rank == 0:
             result["sub_results"], result["inbatch_loss"] = subs, inbatch
             result["call_overhead"] = call_overhead(device)
+            result["table_build"] = table_build_bench(device)
     if not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
         if rank == 0:  # one GPU's HBM-bound operating point (the other ranks wait at the barrier below)
             result["hbm_probe"] = hbm_probe(device, events)

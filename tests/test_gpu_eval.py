@@ -316,6 +316,11 @@ def test_bench_line_keeps_the_contract():
     assert proto["mrr_one_call_pass_per_batch"] == pytest.approx(subs["wikidata5m-protocol"]["mrr"], abs=1e-12)
     assert subs["fb15k237-distmult"]["parity_check"].endswith("identical counts")
     assert r["hbm_probe"]["bound"] == "hbm" and 0.0 < r["hbm_probe"]["frac"] < 1.0
+    # the step before the path: the fused table-build kernels beat the stock modules they replace
+    for name, tb in r["table_build"].items():
+        assert 0 < tb["fused_us"] < tb["stock_us"], (name, tb)
+    co = r["call_overhead"]
+    assert co["python_wrapper_us"] < 8.0 and co["library_call_us"] > 0 and co["launches_per_call"] == 3
 
 
 @pytest.mark.parametrize("rel_model,D", [("transe", 300), ("transe", 768), ("distmult", 96), ("complex", 192),
