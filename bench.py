@@ -87,6 +87,11 @@ WORKLOADS = {
     # Wikidata5M filtering graph is the evaluated split's own triples (train.py:381-393)
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0),
     "wikidata5m-complex": dict(model="complex", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0),
+    # the same batching against the 16-bit COPY of the table (include/blp_hip.h: blp_rank_all_batches_t; SURVEY 8f row 2: "emit
+    # fp16 copy"): the candidates are the table's rows rounded to IEEE half, scored in f32 in the reference's order -- a
+    # different INPUT, the same arithmetic; the pass reads half the bytes
+    "wikidata5m-transe-f16": dict(model="transe", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0, table_dtype="float16"),
+    "wikidata5m-complex-f16": dict(model="complex", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0, table_dtype="float16"),
     # the same table with the whole Wikidata5M test set (6 894 triples) as ONE query block
     "wikidata5m-transe-block": dict(model="transe", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
     "wikidata5m-complex-block": dict(model="complex", N=4_600_000, D=128, R=822, triples=6894, block=65536, edges=0),
@@ -97,7 +102,8 @@ WORKLOADS = {
     # the reference's own Wikidata5M protocol: candidates = the entities of the evaluated split only (train.py:312-314)
     "wikidata5m-protocol": dict(model="transe", N=7475, D=128, R=822, triples=6894, block=65536, edges=0, loop_batch=2),
 }
-SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-block",
+SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-f16",
+               "wikidata5m-complex-f16", "wikidata5m-transe-block",
                "wikidata5m-complex-block", "wikidata5m-transe-full", "wikidata5m-complex-full", "wikidata5m-protocol")
 # N > 1: the same names on the axis a sharded evaluation of that shape takes ("auto": ranking.choose_shard_axis -> query for the
 # FB15k-237-sized tables; the Wikidata5M-scale table always along the north_star's candidate axis), plus the headline
@@ -222,8 +228,14 @@ class Job:
         self.ent2idx = torch.arange(self.N, device=device)                    # ids are table rows in the synthetic sets
         self.index = make_filter_index(cfg, heads, tails, rels)
         self.index.segments(self.triples[:1], self.ent2idx, device)           # sorted arrays resident before the clock starts
+        self.table_dtype = getattr(torch, cfg["table_dtype"]) if cfg.get("table_dtype") else torch.float32
+        if self.table_dtype != torch.float32:  # the 16-bit copy IS the table of this workload; checks see it widened (exact)
+            table = table.to(self.table_dtype)
         if local_only:
             self.full_table, self.table = None, table
+        elif self.table_dtype != torch.float32:
+            self.full_table = table.float() if self.N <= 100_000 and (rank == 0 or self.axis != "candidate") else None  # (the oracle's spot check only)
+            self.table = table[self.lo:self.hi].contiguous() if self.axis == "candidate" else table
         else:
             self.full_table = table if rank == 0 or self.axis != "candidate" else None  # rank 0 keeps it for the parity check
             self.table = table[self.lo:self.hi].contiguous() if self.axis == "candidate" else table
@@ -289,7 +301,9 @@ class Job:
             return 1
         n_local = self.hi - self.lo
         model_id = {"transe": 0, "distmult": 1, "complex": 2, "simple": 3}[self.cfg["model"]]
-        return max(1, int(_lib.lib().blp_rank_all_batches_passes_per_launch(model_id, n_local, self.D, self.D, self.T, block, block)))
+        from blp_amd import ops
+        return max(1, int(_lib.lib().blp_rank_all_batches_t_passes_per_launch(model_id, ops.TABLE_DTYPES[self.table_dtype], n_local, self.D,
+                                                                               self.D, self.T, block, block)))
 
     def exchange_ms(self, reps):
         """Milliseconds per step inside the collectives of this rank (device events around each exchange on the stream
@@ -338,7 +352,7 @@ class Job:
             Q = 2 * (t_hi - t_lo)
         n_local = self.hi - self.lo
         alg_flops = 2.0 * n_local * D * Q          # TransE: subtract + |.|-accumulate per element; bilinear: the GEMM
-        alg_bytes = n_local * D * 4 + Q * (2 * D * 4 + 24)
+        alg_bytes = n_local * D * self.table.element_size() + Q * (2 * D * 4 + 24)
         t_k = kernel_ms * 1e-3
         transe = model == "transe"
         peak_tf = F32_PEAK_TFLOPS if transe else BF16X3_PEAK_TFLOPS
@@ -350,7 +364,8 @@ class Job:
                     "arith": ("f32, the reference's operations in its order (2-3 VALU operations per element and query)" if transe or not ring else
                               "f32 fused multiply-add chain per (row, query) decided within a proven band against the exact true key; "
                               "undecided rows re-scored in the reference's f32 order"),
-                    "kernel": (("rank_stream_kernel (exact f32 keys; " if transe else "rank_stream_dot_kernel (" + dot) +
+                    "kernel": (((("rank_stream16_kernel" if transe else "rank_stream_dot16_kernel") + f" [a {self.cfg['table_dtype']} table, widened exactly] (" if self.table.element_size() == 2 else "") +
+                               ("rank_stream_kernel (exact f32 keys; " if transe else "rank_stream_dot_kernel (" + dot)) +
                                "the table streamed once per pass through per-wave rings of 32-column pieces" +
                                (f"; all {ppl} passes of the step in one launch, kernel_ms = its share of one pass)" if ppl > 1 else ")")) if ring else
                               "rank_stream_wg_kernel (exact f32 keys; the table streamed once through workgroup tiles, two tiles in flight per workgroup)"}

@@ -23,7 +23,8 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
            "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex", "blp_rank_all_idx",
            "blp_rank_all_shard", "blp_gather_triple_vectors", "blp_rank_all_batches", "blp_rank_all_batches_workspace_bytes",
-           "blp_rank_all_batches_passes_per_launch", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
+           "blp_rank_all_batches_passes_per_launch", "blp_rank_all_batches_t", "blp_rank_all_batches_t_workspace_bytes",
+           "blp_rank_all_batches_t_passes_per_launch", "blp_gather_triple_vectors_t", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows",
            "blp_build_queries")
@@ -144,6 +145,15 @@ def _load(path, hooks):
                                        ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
     L.blp_gather_triple_vectors.restype = _i
     L.blp_gather_triple_vectors.argtypes = [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _i, _vp]
+    L.blp_gather_triple_vectors_t.restype = _i
+    L.blp_gather_triple_vectors_t.argtypes = [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _vp, _i, _vp]
+    L.blp_rank_all_batches_t_workspace_bytes.restype = _sz
+    L.blp_rank_all_batches_t_workspace_bytes.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
+    L.blp_rank_all_batches_t_passes_per_launch.restype = _i64
+    L.blp_rank_all_batches_t_passes_per_launch.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
+    L.blp_rank_all_batches_t.restype = _i
+    L.blp_rank_all_batches_t.argtypes = [_i, _vp, _i, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64,
+                                         ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
     L.blp_profile_next_rank_kernel.restype = _i
     L.blp_profile_next_rank_kernel.argtypes = [_vp, _vp]
     L.blp_rank_from_scores.restype = _i

@@ -145,20 +145,32 @@ int blp_build_queries(const blp_queries* q, int device, void* stream) {
     return BLP_OK;
 }
 
-int blp_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len, const float* table,
-                              int64_t N, int D, int64_t ld, int64_t row_base, float* out, int device, void* stream) {
-    if (n < 0 || N < 0 || D <= 0 || (D & 3) || (ld & 3) || ld < D || n > (1ll << 40) || (ent2idx && ent2idx_len < 0))
+static bool valid_table_dtype(int dtype) { return dtype == BLP_DTYPE_F32 || dtype == BLP_DTYPE_F16 || dtype == BLP_DTYPE_BF16; }
+// rows of a table of this storage type start on 16-byte boundaries
+static bool table_rows_aligned(const void* table, int dtype, int64_t ld) {
+    return aligned16(table) && (ld & (dtype == BLP_DTYPE_F32 ? 3 : 7)) == 0;
+}
+
+int blp_gather_triple_vectors_t(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len, const void* table,
+                                int table_dtype, int64_t N, int D, int64_t ld, int64_t row_base, float* out, int device, void* stream) {
+    if (!valid_table_dtype(table_dtype)) return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: unknown table dtype %d", table_dtype);
+    if (n < 0 || N < 0 || D <= 0 || (D & 3) || ld < D || n > (1ll << 40) || (ent2idx && ent2idx_len < 0))
         return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: bad sizes (n=%lld N=%lld D=%d ld=%lld)", (long long)n, (long long)N, D, (long long)ld);
     if (n == 0) return BLP_OK;
     if (!triples || !out || (N > 0 && !table)) return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: NULL pointer");
-    if (!aligned16(table) || !aligned16(out))
-        return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: table / out must be 16-byte aligned");
+    if (!table_rows_aligned(table, table_dtype, ld) || !aligned16(out))
+        return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: table rows / out must be 16-byte aligned (ld %% 4 == 0; a 16-bit table: ld %% 8 == 0)");
     DeviceGuard guard(device);
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
-    hipError_t err = blp::launch_gather_triple_vectors(triples, n, ent2idx, ent2idx_len, table, N, D, ld, row_base, out,
+    hipError_t err = blp::launch_gather_triple_vectors(triples, n, ent2idx, ent2idx_len, table, table_dtype, N, D, ld, row_base, out,
                                                        static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_gather_triple_vectors launch");
     return BLP_OK;
+}
+
+int blp_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len, const float* table,
+                              int64_t N, int D, int64_t ld, int64_t row_base, float* out, int device, void* stream) {
+    return blp_gather_triple_vectors_t(triples, n, ent2idx, ent2idx_len, table, BLP_DTYPE_F32, N, D, ld, row_base, out, device, stream);
 }
 
 int blp_project_rows_supported(int E, int D) { return blp::project_rows_supported(E, D) ? 1 : 0; }
@@ -361,6 +373,71 @@ int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_
                                                   batch, block_triples, spec, counts, workspace, cu, static_cast<hipStream_t>(stream),
                                                   ev0, ev1);
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all_batches launch");
+    return BLP_OK;
+}
+
+size_t blp_rank_all_batches_t_workspace_bytes(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                              int64_t block_triples) {
+    if (table_dtype == BLP_DTYPE_F32) return blp_rank_all_batches_workspace_bytes(model, N, D, n_triples, batch, block_triples);
+    if (!valid_model(model) || !valid_table_dtype(table_dtype) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
+    return blp::rank_all_batches16_workspace_bytes(model, D, N, ld, n_triples, batch, block_triples);
+}
+
+int64_t blp_rank_all_batches_t_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                                 int64_t block_triples) {
+    if (table_dtype == BLP_DTYPE_F32) return blp_rank_all_batches_passes_per_launch(model, N, D, ld, n_triples, batch, block_triples);
+    if (!valid_model(model) || !valid_table_dtype(table_dtype) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
+    if (blp::rank_all_batches_native16(model, D, N, ld, n_triples, batch, block_triples)) return (n_triples + batch - 1) / batch;
+    return n_triples <= batch ? 1 : blp::rank_all_batches_passes_per_launch(model, D, N, D, n_triples, batch, block_triples);
+}
+
+int blp_rank_all_batches_t(int model, const void* table, int table_dtype, int64_t N, int D, int64_t ld, const float* source, int64_t S,
+                           int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, int64_t R, const int64_t* rel_id,
+                           const int64_t* true_row, int64_t n_triples, int64_t batch, int64_t block_triples, const blp_filter* filter,
+                           int32_t* counts, void* workspace, size_t workspace_bytes, int device, void* stream) {
+    if (table_dtype == BLP_DTYPE_F32)
+        return blp_rank_all_batches(model, static_cast<const float*>(table), N, D, ld, source, S, ld_src, fixed_row, rel_emb, R, rel_id,
+                                    true_row, n_triples, batch, block_triples, filter, counts, workspace, workspace_bytes, device, stream);
+    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: unknown model %d", model);
+    if (!valid_table_dtype(table_dtype)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: unknown table dtype %d", table_dtype);
+    if (n_triples < 0 || batch <= 0 || block_triples < 0 || N < 0 || ld < D)
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: bad sizes (n_triples=%lld batch=%lld N=%lld)", (long long)n_triples,
+                    (long long)batch, (long long)N);
+    if (n_triples == 0) return BLP_OK;
+    const int64_t per_block = n_triples <= batch ? n_triples : 1;
+    if (!blp_rank_all_supported(model, D, per_block, per_block))
+        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_rank_all_batches_t: D = %d not supported (see blp_rank_all_supported)", D);
+    if (n_triples > (1ll << 40) || N >= (1ll << 31)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: n_triples > 2^40 or N >= 2^31");
+    if (block_triples > (1ll << 29) || (block_triples == 0 && batch > (1ll << 29)) || (n_triples <= batch && n_triples > (1ll << 29)))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: block_triples / batch > 2^29 (a pass ranks 2 x block_triples <= 2^30 queries)");
+    if (!source || !fixed_row || !rel_id || !rel_emb || !true_row || !counts || R <= 0 || S <= 0 || (N > 0 && !table))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: NULL pointer, or R <= 0 / S <= 0");
+    if (!table_rows_aligned(table, table_dtype, ld) || !aligned16(source) || !aligned16(rel_emb) || !aligned16(counts) || (ld_src & 3) ||
+        ld_src < D || (D & 3))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: table rows (a 16-bit table: ld %% 8 == 0) / source / rel_emb / counts must be "
+                                     "16-byte aligned, D %% 4 == 0");
+    blp::FilterSpec spec;
+    if (filter) {
+        if (!filter->seg_lo || !filter->seg_hi || !filter->values || (filter->ent2idx && filter->ent2idx_len < 0))
+            return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: filter needs seg_lo, seg_hi and values");
+        spec.lo = filter->seg_lo; spec.hi = filter->seg_hi; spec.val = filter->values; spec.exclude = filter->exclude;
+        spec.ent2idx = filter->ent2idx; spec.ent2idx_len = filter->ent2idx ? filter->ent2idx_len : 0;
+        spec.row_base = filter->row_base;
+    }
+    const size_t need = blp::rank_all_batches16_workspace_bytes(model, D, N, ld, n_triples, batch, block_triples);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail(BLP_ERR_WORKSPACE, "blp_rank_all_batches_t: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", need,
+                    workspace_bytes);
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    int cu = 0;
+    if (int rc = compute_units(device, &cu)) return rc;
+    hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;  // blp_profile_next_rank_kernel: the first ranking pass of this call
+    g_prof_start = g_prof_stop = nullptr;
+    hipError_t err = blp::launch_rank_all_batches16(model, D, table, table_dtype, N, ld, source, ld_src, fixed_row, rel_emb, rel_id, true_row,
+                                                    n_triples, batch, block_triples, spec, counts, workspace, cu,
+                                                    static_cast<hipStream_t>(stream), ev0, ev1);
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_all_batches_t launch");
     return BLP_OK;
 }
 

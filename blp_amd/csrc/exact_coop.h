@@ -10,6 +10,7 @@
 
 #include "rank_common.h"
 #include "score_core.h"
+#include "table_elem.h"
 
 #pragma clang fp contract(off)
 
@@ -23,18 +24,27 @@ namespace blp {
 // through per-lane pointers instead of being consecutive.
 constexpr int kRefStride = 36;  // dwords per slab row: conflict-free for the 16-byte reads of 16 consecutive lanes
 
-__device__ __forceinline__ const float* shfl_ptr(const float* p, int src) {
+// A candidate row in its storage type TE (float, _Float16, __bf16: table_elem.h): element k widened to f32, exactly.
+template <class TE>
+struct RowOf {
+    const TE* p;
+    __device__ __forceinline__ float operator[](int k) const { return (float)p[k]; }
+};
+
+template <class T>
+__device__ __forceinline__ const T* shfl_ptr(const T* p, int src) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
-    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
 }
 
 // columns [32 s, 32 s + 32) of the 64 gathered rows: g[i] = start of row (8 i + sub_row) + sub_col, x[k] <- own row
-__device__ __forceinline__ void gather_chunk(float (&x)[32], const float* const (&g)[8], int s, float* slab, int lane) {
+template <class T>
+__device__ __forceinline__ void gather_chunk(float (&x)[32], const T* const (&g)[8], int s, float* slab, int lane) {
     // the loads land in x[] in the coalesced layout first (plain scalars: they stay in registers across the fences)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(g[i] + 32 * s);
+        const float4 v = load4<T>(g[i] + 32 * s);  // (a 16-bit row: widened here, exactly)
         x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
     }
     float* wr = slab + (lane >> 3) * kRefStride + (lane & 7) * 4;
@@ -55,10 +65,10 @@ __device__ __forceinline__ void gather_chunk(float (&x)[32], const float* const 
 // key of lane's pair straight from the vectors: pe = its candidate row, pf = the query's fixed entity, pr = its
 // relation; head-replacing query (e + r) - f, tail-replacing (f + r) - e (models.py:222-223; Scorer<TRANSE, *, D>
 // computes the same operations, with f + r hoisted).  Every lane must pass readable pointers.
-template <int D>
-__device__ __forceinline__ float transe_key_64(const float* pe, const float* pf, const float* pr, bool head, float* slab, int lane) {
+template <int D, class TE = float>
+__device__ __forceinline__ float transe_key_64(const TE* pe, const float* pf, const float* pr, bool head, float* slab, int lane) {
     const int sub_row = lane >> 3, sub_col = (lane & 7) * 4;
-    const float* ge[8];
+    const TE* ge[8];
     const float* gf[8];
     const float* gr[8];
 #pragma unroll
@@ -225,10 +235,12 @@ __device__ __forceinline__ float transe_key_64_one_query_rt(const float* pe, con
 // Term i of the reference's sum for candidate row e and the query's vectors f (the entity kept fixed) and r (the
 // relation): the arithmetic of Scorer<MODEL, SIDE, D>::score (score_core.h) for one summand with its coefficients
 // (Scorer<>::coef) computed in place, addressed at run time.
-template <int MODEL, int SIDE, int D>
-__device__ __forceinline__ float score_term(const float* __restrict__ e, const float* __restrict__ f,
+template <int MODEL, int SIDE, int D, class TE>
+__device__ __forceinline__ float score_term(const TE* __restrict__ ep, const float* __restrict__ f,
                                             const float* __restrict__ r, int i) {
     constexpr int H = D / 2;
+    (void)H;
+    const RowOf<TE> e{ep};  // e[k]: element k of the candidate row, widened (exact) from its storage type
     if constexpr (MODEL == DISTMULT) {
         if constexpr (SIDE == TAIL) {  // (h * r) * e
             const float c = f[i] * r[i];
@@ -278,8 +290,8 @@ __device__ __forceinline__ float score_term(const float* __restrict__ e, const f
 // order -- then V[l] = ((A[l] + A[8 + l]) + A[16 + l]) + A[24 + l] and the eight V left to right.  Every load is 32
 // consecutive floats (one 128-B line) instead of 64 lanes gathering 16 bytes each from 64 different rows.
 // `sub` = lane & 31; both 32-lane halves of a wave work on their own pair.  Result valid in every lane of the half.
-template <int MODEL, int SIDE, int D>
-__device__ __forceinline__ float coop_score(const float* __restrict__ e, const float* __restrict__ f,
+template <int MODEL, int SIDE, int D, class TE = float>
+__device__ __forceinline__ float coop_score(const TE* __restrict__ e, const float* __restrict__ f,
                                             const float* __restrict__ r, int sub) {
     constexpr int NT = MODEL == DISTMULT ? D : D / 2;
     float a = score_term<MODEL, SIDE, D>(e, f, r, sub);

@@ -60,9 +60,11 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 // rank_all.hip: many passes of <= 4 + 4 queries back to back (one preparation and one finalisation launch for all of them)
 bool rank_static_passes_applicable(int model, int D, int64_t N, int64_t batch);
 size_t rank_static_passes_workspace_bytes(int D, int64_t n, int64_t batch);
-hipError_t launch_rank_static_passes(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
-                                     const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts,
-                                     void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+// (table: f32, or a 16-bit table -- dtype: table_elem.h -- when rank_stream16_takes_passes says so)
+hipError_t launch_rank_static_passes(int model, int D, const void* table, int dtype, int64_t N, int64_t ld, const QRows q_fixed,
+                                     const QRows q_rel, const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter,
+                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                                     hipEvent_t ev_stop);
 
 // queries.hip: every batch of the reference's evaluation loop in one call (include/blp_hip.h: blp_rank_all_batches)
 size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples);
@@ -72,6 +74,15 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
                                    int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter, int32_t* counts,
                                    void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
                                    hipEvent_t ev_stop = nullptr);
+
+// ... with the candidate table in a 16-bit storage type (include/blp_hip.h: blp_rank_all_batches_t)
+bool rank_all_batches_native16(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples);
+size_t rank_all_batches16_workspace_bytes(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples);
+hipError_t launch_rank_all_batches16(int model, int D, const void* table, int dtype, int64_t N, int64_t ld, const float* source,
+                                     int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, const int64_t* rel_id,
+                                     const int64_t* true_row, int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter,
+                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                                     hipEvent_t ev_stop = nullptr);
 
 hipError_t launch_rank_metrics(const int32_t* counts, int64_t Q, const int32_t* k, float* rr,
                                uint8_t* hits, hipStream_t stream);
@@ -96,7 +107,7 @@ struct QueryBuild {
 };
 hipError_t launch_build_queries(const QueryBuild& a, hipStream_t stream);
 hipError_t launch_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len,
-                                        const float* table, int64_t N, int D, int64_t ld, int64_t row_base, float* out,
+                                        const void* table, int dtype, int64_t N, int D, int64_t ld, int64_t row_base, float* out,
                                         hipStream_t stream);
 
 bool project_rows_supported(int E, int D);

@@ -17,6 +17,7 @@
 #include "knobs.h"
 #include "launch.h"
 #include "rank_common.h"
+#include "table_elem.h"
 
 namespace blp {
 
@@ -110,9 +111,10 @@ __global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a, unsign
 // blp_gather_triple_vectors: out[t] = the head's vector of triple t, out[n + t] = its tail's, for the rows this shard owns
 // (global row - row_base in [0, N)); zeros otherwise, so that one all-reduce over the ranks replicates every vector.
 // 32 lanes per vector, 16 bytes per lane and sweep.
+template <class TE>  // TE: the table's storage type (table_elem.h); the vectors come out in f32 (widened exactly)
 __global__ __launch_bounds__(256) void gather_triple_vectors_kernel(const int64_t* __restrict__ triples, int64_t n,
                                                                     const int64_t* __restrict__ ent2idx, int64_t ent2idx_len,
-                                                                    const float* __restrict__ table, int64_t N, int D, int64_t ld,
+                                                                    const TE* __restrict__ table, int64_t N, int D, int64_t ld,
                                                                     int64_t row_base, float* __restrict__ out) {
     const int sub = threadIdx.x & 31;
     const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -122,23 +124,57 @@ __global__ __launch_bounds__(256) void gather_triple_vectors_kernel(const int64_
     if (ent2idx) row = (uint64_t)id < (uint64_t)ent2idx_len ? ent2idx[id] : -1;
     row = row < 0 ? -1 : row - row_base;
     const bool mine = (uint64_t)row < (uint64_t)N;
-    const float* src = table + (mine ? row : 0) * ld;
+    const TE* src = table + (mine ? row : 0) * ld;
     float* dst = out + p * D;
     for (int c = 4 * sub; c < D; c += 128) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mine) v = *reinterpret_cast<const float4*>(src + c);
+        if (mine) v = load4<TE>(src + c);
         *reinterpret_cast<float4*>(dst + c) = v;
     }
 }
 
 hipError_t launch_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len,
-                                        const float* table, int64_t N, int D, int64_t ld, int64_t row_base, float* out,
+                                        const void* table, int dtype, int64_t N, int D, int64_t ld, int64_t row_base, float* out,
                                         hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const int64_t blocks = (2 * n + 7) / 8;
     if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    gather_triple_vectors_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(triples, n, ent2idx, ent2idx_len, table, N, D, ld,
-                                                                             row_base, out);
+    const dim3 grid((unsigned)blocks);
+    if (dtype == kTableF32)
+        gather_triple_vectors_kernel<float><<<grid, 256, 0, stream>>>(triples, n, ent2idx, ent2idx_len, static_cast<const float*>(table), N,
+                                                                      D, ld, row_base, out);
+    else if (dtype == kTableF16)
+        gather_triple_vectors_kernel<_Float16><<<grid, 256, 0, stream>>>(triples, n, ent2idx, ent2idx_len,
+                                                                         static_cast<const _Float16*>(table), N, D, ld, row_base, out);
+    else if (dtype == kTableBF16)
+        gather_triple_vectors_kernel<__bf16><<<grid, 256, 0, stream>>>(triples, n, ent2idx, ent2idx_len, static_cast<const __bf16*>(table),
+                                                                       N, D, ld, row_base, out);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// A 16-bit table widened into a packed (N, D) f32 copy: what every route but the few-queries ring kernels ranks a 16-bit table
+// through (they are bound by arithmetic, not by the table read; their operand images are made from f32 rows).
+template <class TE>
+__global__ __launch_bounds__(256) void widen_table_kernel(const TE* __restrict__ table, int64_t N, int D, int64_t ld,
+                                                          float* __restrict__ out) {
+    const int64_t quads = N * (D / 4), stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += stride) {
+        const int64_t r = i / (D / 4), c = (i - r * (D / 4)) * 4;
+        *reinterpret_cast<float4*>(out + r * D + c) = load4<TE>(table + r * ld + c);
+    }
+}
+static hipError_t launch_widen_table(const void* table, int dtype, int64_t N, int D, int64_t ld, float* out, hipStream_t stream) {
+    if (N == 0) return hipSuccess;
+    const int64_t want = (N * (D / 4) + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 16384 ? want : 16384);
+    if (dtype == kTableF16)
+        widen_table_kernel<_Float16><<<blocks, 256, 0, stream>>>(static_cast<const _Float16*>(table), N, D, ld, out);
+    else if (dtype == kTableBF16)
+        widen_table_kernel<__bf16><<<blocks, 256, 0, stream>>>(static_cast<const __bf16*>(table), N, D, ld, out);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -217,6 +253,41 @@ size_t rank_all_batches_workspace_bytes(int model, int D, int64_t N, int64_t n, 
     return (inner + 255) / 256 * 256 + (size_t)(6 * 2 * m) * 8 + (size_t)(2 * m) * 16;
 }
 
+// A 16-BIT TABLE (table_elem.h).  The reference-batched passes of <= 4 + 4 queries over a long table read it as it is
+// (rank_stream16.hip); any other shape of call ranks a widened f32 copy kept at the end of the workspace.
+bool rank_all_batches_native16(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples) {
+    if (n <= 0 || batch <= 0) return false;
+    return batches_super(n, batch, block_triples) <= batch && rank_static_passes_applicable(model, D, N, batch) &&
+           knob(KNOB_STREAM_KERNEL) != 2 && rank_stream16_takes_passes(model, D, N, ld, batch, n);
+}
+static size_t batches_front_bytes(int model, int D, int64_t N, int64_t n, int64_t batch, int64_t block_triples) {
+    const size_t b = n <= batch ? rank_all_workspace_bytes(model, D, N, n, n) : rank_all_batches_workspace_bytes(model, D, N, n, batch, block_triples);
+    return (b + 255) / 256 * 256;
+}
+size_t rank_all_batches16_workspace_bytes(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples) {
+    if (n <= 0 || batch <= 0) return 0;
+    if (rank_all_batches_native16(model, D, N, ld, n, batch, block_triples)) return rank_static_passes_workspace_bytes(D, n, batch);
+    return batches_front_bytes(model, D, N, n, batch, block_triples) + (size_t)N * D * 4;
+}
+hipError_t launch_rank_all_batches16(int model, int D, const void* table, int dtype, int64_t N, int64_t ld, const float* source,
+                                     int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, const int64_t* rel_id,
+                                     const int64_t* true_row, int64_t n, int64_t batch, int64_t block_triples, const FilterSpec& filter,
+                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                                     hipEvent_t ev_stop) {
+    if (n <= 0) return hipSuccess;
+    if (rank_all_batches_native16(model, D, N, ld, n, batch, block_triples))
+        return launch_rank_static_passes(model, D, table, dtype, N, ld, QRows::rows_of(source, fixed_row, ld_src),
+                                         QRows::rows_of(rel_emb, rel_id, D), QRows::rows_of(source, true_row, ld_src), n, batch, filter,
+                                         counts, workspace, n_cu, stream, ev_start, ev_stop);
+    float* wide = reinterpret_cast<float*>(static_cast<char*>(workspace) + batches_front_bytes(model, D, N, n, batch, block_triples));
+    if (const hipError_t e = launch_widen_table(table, dtype, N, D, ld, wide, stream); e != hipSuccess) return e;
+    if (n <= batch)  // one batch: one block of [heads | tails]
+        return launch_rank_all(model, D, wide, N, D, QRows::rows_of(source, fixed_row, ld_src), QRows::rows_of(rel_emb, rel_id, D), rel_id,
+                               QRows::rows_of(source, true_row, ld_src), n, n, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    return launch_rank_all_batches(model, D, wide, N, D, source, ld_src, fixed_row, rel_emb, rel_id, true_row, n, batch, block_triples,
+                                   filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+}
+
 // How many of the call's ranking passes the FIRST ranking launch covers (what blp_profile_next_rank_kernel's events bracket):
 // all of them when a ring kernel takes the passes of a reference-batched call in one launch, else one.
 int64_t rank_all_batches_passes_per_launch(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples) {
@@ -237,7 +308,7 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
     const int64_t super = batches_super(n, batch, block_triples);
     if (super <= batch) {  // one ranking pass per batch, as the reference's loop runs them: slices of the loop's layout
         if (n > batch && rank_static_passes_applicable(model, D, N, batch))  // <= 4 + 4 queries per pass: one prep, one finalize for all
-            return launch_rank_static_passes(model, D, table, N, ld, QRows::rows_of(source, fixed_row, ld_src),
+            return launch_rank_static_passes(model, D, table, kTableF32, N, ld, QRows::rows_of(source, fixed_row, ld_src),
                                              QRows::rows_of(rel_emb, rel_id, D), QRows::rows_of(source, true_row, ld_src), n, batch,
                                              filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
         for (int64_t t0 = 0; t0 < n; t0 += batch) {

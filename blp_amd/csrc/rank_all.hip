@@ -495,9 +495,9 @@ __host__ __device__ inline bool replaces_head(int64_t q, int64_t q_head, int64_t
     return q - 2 * first < nb;
 }
 
-template <int MODEL, int D>
+template <int MODEL, int D, class TE = float>  // TE: the candidate table's storage type (table_elem.h)
 __global__ __launch_bounds__(256) void filter_finalize_kernel(
-    const float* __restrict__ table, int64_t N, int64_t ld, const QRows q_fixed,
+    const TE* __restrict__ table, int64_t N, int64_t ld, const QRows q_fixed,
     const QRows q_rel, const float* __restrict__ key_true, int64_t q_head,
     int64_t q_tail, const FilterSpec filter, const unsigned long long* __restrict__ acc, int n_partials,
     int32_t* __restrict__ counts, int64_t batch) {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             int slot = 0;
             if (x < total) locate(x, q, row, slot);
             const bool live = row >= 0, head = replaces_head(q, q_head, Q, batch);
-            const float key = transe_key_64<D>(table + (live ? row : 0) * ld, frow[slot], rrow[slot], head, slab, lane);
+            const float key = transe_key_64<D, TE>(table + (live ? row : 0) * ld, frow[slot], rrow[slot], head, slab, lane);
             const float kt = key_true[q];
             if (live && key > kt) atomicAdd(&removed[slot][0], 1u);
             if (live && key >= kt) atomicAdd(&removed[slot][1], 1u);
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void filter_finalize_kernel(
             int slot = 0;
             if (x < total) locate(x, q, row, slot);
             const bool live = row >= 0, head = replaces_head(q, q_head, Q, batch);
-            const float* e = table + (live ? row : 0) * ld;
+            const TE* e = table + (live ? row : 0) * ld;
             float key;
             if (head) key = coop_score<MODEL, HEAD, D>(e, frow[slot], rrow[slot], sub);
             else key = coop_score<MODEL, TAIL, D>(e, frow[slot], rrow[slot], sub);
@@ -853,12 +853,12 @@ static hipError_t true_keys_impl(const QRows q_fixed, const QRows q_rel, int64_t
     return hipGetLastError();
 }
 
-template <int MODEL, int D>
-static hipError_t filter_finalize_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
+template <int MODEL, int D, class TE = float>
+static hipError_t filter_finalize_impl(const TE* table, int64_t N, int64_t ld, const QRows q_fixed,
                                        const QRows q_rel, const float* key_true, int64_t q_head, int64_t q_tail,
                                        const FilterSpec& filter, const unsigned long long* acc, int n_partials,
                                        int32_t* counts, hipStream_t stream, int64_t batch = 0) {
-    filter_finalize_kernel<MODEL, D><<<(int)((q_head + q_tail + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(
+    filter_finalize_kernel<MODEL, D, TE><<<(int)((q_head + q_tail + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(
         table, N, ld, q_fixed, q_rel, key_true, q_head, q_tail, filter, acc, n_partials, counts, batch);
     return hipGetLastError();
 }
@@ -978,7 +978,7 @@ bool rank_static_passes_applicable(int model, int D, int64_t N, int64_t batch) {
 size_t rank_static_passes_workspace_bytes(int D, int64_t n, int64_t batch) { return carve_passes(nullptr, D, n, batch).bytes; }
 
 template <int MODEL, int D>
-static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
+static hipError_t static_passes_impl(const void* table_any, int dtype, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
                                      const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts,
                                      void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     using SH = Scorer<MODEL, HEAD, D>;
@@ -987,6 +987,44 @@ static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, 
     const int64_t Q = 2 * n, key_blocks = (Q + 63) / 64;
     int64_t coef_blocks = (Q * (SH::C > ST::C ? SH::C : ST::C) + 63) / 64;
     coef_blocks = coef_blocks > 8192 ? 8192 : coef_blocks;
+    const float* table = static_cast<const float*>(table_any);  // (an f32 table; a 16-bit one: the branch right below)
+    if (dtype != kTableF32) {
+        // A 16-BIT TABLE (table_elem.h): the ring kernels of rank_stream16.hip, all passes in one launch, the bilinear models
+        // with approximate keys; the queries' own vectors (q_fixed / q_true index an f32 `source`) and everything derived
+        // from them -- coefficient rows, operand rows, true keys -- are what the f32 path makes; the filter's rows are read
+        // from the 16-bit table and widened.
+        if constexpr (D == 64) {
+            return hipErrorInvalidValue;
+        } else {
+            if (!rank_stream16_takes_passes(MODEL, D, N, ld, batch, n)) return hipErrorInvalidValue;
+            const bool dot16 = MODEL != TRANSE;
+            prep_passes_kernel<MODEL, D><<<dim3((unsigned)(key_blocks + (dot16 ? 0 : coef_blocks) + (dot16 ? (Q + 7) / 8 : 0))), 64, 0, stream>>>(
+                q_fixed, q_rel, q_true, n, batch, w.coef, w.key_true, w.acc, (unsigned)key_blocks, (unsigned)(dot16 ? (Q + 7) / 8 : 0), w.wq,
+                w.band, kStreamAccSlots);
+            StreamPasses passes;
+            passes.n_passes = (int)((n + batch - 1) / batch);
+            passes.batch = (int)batch;
+            passes.n = n;
+            passes.acc_slots = kStreamAccSlots;
+            StreamDot dot;
+            if (dot16) { dot.wq = w.wq; dot.band = w.band; dot.q_fixed = q_fixed; dot.q_rel = q_rel; dot.q0 = 0; }
+            if (ev_start) (void)hipEventRecord(ev_start, stream);
+            const int64_t per_side = n < batch ? n : batch;  // (a single short pass is described by these, not by passes.batch)
+            const hipError_t err = launch_rank_stream16(MODEL, D, dtype, table_any, N, ld, w.coef, w.key_true, per_side, per_side, w.acc, dot,
+                                                        n_cu, stream, passes);
+            if (err != hipSuccess) return err;
+            if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+            if (filter.on()) {
+                if (dtype == kTableF16)
+                    return filter_finalize_impl<MODEL, D, _Float16>(static_cast<const _Float16*>(table_any), N, ld, q_fixed, q_rel, w.key_true,
+                                                                    n, n, filter, w.acc, kStreamAccSlots, counts, stream, batch);
+                return filter_finalize_impl<MODEL, D, __bf16>(static_cast<const __bf16*>(table_any), N, ld, q_fixed, q_rel, w.key_true, n, n,
+                                                              filter, w.acc, kStreamAccSlots, counts, stream, batch);
+            }
+            finalize_counts_kernel<<<(int)((Q + kSweepQueries - 1) / kSweepQueries), 256, 0, stream>>>(w.acc, kStreamAccSlots, Q, counts);
+            return hipGetLastError();
+        }
+    }
     // all passes in one launch of a ring kernel (rank_stream.hip: StreamPasses), or a launch per pass
     const bool one_launch = knob(KNOB_STREAM_KERNEL) != 2 && rank_stream_takes_passes(MODEL, D, N, ld, batch, n);
     const bool dot_keys = rank_stream_wants_dot(MODEL, D, N, ld, batch, batch, one_launch);
@@ -1030,10 +1068,11 @@ static hipError_t static_passes_impl(const float* table, int64_t N, int64_t ld, 
     return hipGetLastError();
 }
 
-hipError_t launch_rank_static_passes(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
-                                     const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter, int32_t* counts,
-                                     void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    BLP_DISPATCH_MODEL_DIM(static_passes_impl, table, N, ld, q_fixed, q_rel, q_true, n, batch, filter, counts, workspace, n_cu, stream,
+hipError_t launch_rank_static_passes(int model, int D, const void* table, int dtype, int64_t N, int64_t ld, const QRows q_fixed,
+                                     const QRows q_rel, const QRows q_true, int64_t n, int64_t batch, const FilterSpec& filter,
+                                     int32_t* counts, void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
+                                     hipEvent_t ev_stop) {
+    BLP_DISPATCH_MODEL_DIM(static_passes_impl, table, dtype, N, ld, q_fixed, q_rel, q_true, n, batch, filter, counts, workspace, n_cu, stream,
                            ev_start, ev_stop)
 }
 

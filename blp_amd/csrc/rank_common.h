@@ -138,6 +138,13 @@ hipError_t launch_rank_stream(int model, int D, const float* table, int64_t N, i
                               unsigned long long* acc, const StreamDot& dot, int n_cu, hipStream_t stream,
                               const StreamPasses& passes = StreamPasses());
 
+// rank_stream16.hip: the ring kernels over a 16-bit candidate table (table_elem.h: dtype), every pass of a call in one launch
+// (n_passes >= 1); the bilinear models with approximate keys (dot.wq) always.  D = 128 or 256.
+bool rank_stream16_takes_passes(int model, int D, int64_t N, int64_t ld, int64_t batch, int64_t n);
+hipError_t launch_rank_stream16(int model, int D, int dtype, const void* table, int64_t N, int64_t ld, const float* coef,
+                                const float* key_true, int64_t q_head, int64_t q_tail, unsigned long long* acc,
+                                const StreamDot& dot, int n_cu, hipStream_t stream, const StreamPasses& passes);
+
 // rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
 void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail);

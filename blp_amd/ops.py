@@ -110,6 +110,24 @@ def _f32_rows(t, name):
     return t
 
 
+TABLE_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}  # BLP_DTYPE_* of include/blp_hip.h
+
+
+def _table_rows(t, name):
+    """A candidate table: float32, or the 16-bit copy the table build can emit next to it (float16 / bfloat16: rows start on
+    16-byte boundaries); unit stride along the last dim."""
+    if t.dtype not in TABLE_DTYPES:
+        raise TypeError(f"{name} must be float32, float16 or bfloat16, got {t.dtype}")
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        t = t.contiguous()
+    if t.dtype != torch.float32 and t.dim() == 2 and (t.stride(0) % 8 or t.data_ptr() % 16):
+        # (a width that is not a multiple of 8 -- the bag-of-words 300 --: rows padded to the next multiple, a copy)
+        wide = torch.zeros((t.shape[0], (t.shape[1] + 7) // 8 * 8), dtype=t.dtype, device=t.device)
+        wide[:, :t.shape[1]] = t
+        t = wide[:, :t.shape[1]]
+    return t
+
+
 # The filtered setting as segments of a sorted index of the filtering graph (include/blp_hip.h: blp_filter;
 # built by blp_amd.utils.FilterIndex.segments): seg_lo, seg_hi (Q,) int64 slices of `values` (entity ids),
 # exclude (Q,) the triple's own entity, ent2idx the id -> table row map (None: values are rows), row_base the
@@ -262,9 +280,15 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
     batch, the reference's own pass structure, issued back to back by the library)."""
     source = table if source is None else source
     _require_device(table, source, fixed_row, rel_emb, rel_ids, true_row)
-    table, rel_emb = _f32_rows(table, "table"), _f32_rows(rel_emb, "rel_emb").contiguous()
+    # (a 16-bit table -- float16 / bfloat16, blp_rank_all_batches_t --: the candidates only; `source`, the queries' own
+    #  vectors, is float32: gather_triple_vectors widens them)
+    table, rel_emb = _table_rows(table, "table"), _f32_rows(rel_emb, "rel_emb").contiguous()
+    if source is table and table.dtype != torch.float32:
+        raise TypeError("a 16-bit table needs a float32 `source` for the queries' vectors (ops.gather_triple_vectors + build_queries(by_position=True))")
     source = table if source is table else _f32_rows(source, "source")
     N, D = table.shape
+    tdt = TABLE_DTYPES[table.dtype]
+    ld = table.stride(0) if tdt or N > 1 else D
     n, Q = int(num_triples), 2 * int(num_triples)
     fixed_row, rel_ids, true_row = _i64_vector(fixed_row), _i64_vector(rel_ids), _i64_vector(true_row)
     if fixed_row.shape[0] != Q or rel_ids.shape[0] != Q or true_row.shape[0] != Q or rel_emb.shape[1] != D or source.shape[1] != D:
@@ -277,16 +301,16 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
         return counts
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
-    ws_bytes = L.blp_rank_all_batches_workspace_bytes(model, N, D, n, int(batch), int(block_triples))
+    ws_bytes = L.blp_rank_all_batches_t_workspace_bytes(model, tdt, N, D, ld, n, int(batch), int(block_triples))
     stream = torch._C._cuda_getCurrentRawStream(dev.index)
     workspace = _workspace(dev, stream, ws_bytes)
     spec = None if filter is None else _filter_spec(filter, Q, dev)
-    status = L.blp_rank_all_batches(model, table.data_ptr(), N, D, table.stride(0) if N > 1 else D, source.data_ptr(), source.shape[0],
-                                    source.stride(0) if source.shape[0] > 1 else D, fixed_row.data_ptr(), rel_emb.data_ptr(), rel_emb.shape[0],
-                                    rel_ids.data_ptr(), true_row.data_ptr(), n, int(batch), int(block_triples), spec, counts.data_ptr(),
-                                    workspace.data_ptr(), ws_bytes, dev.index, stream)
+    status = L.blp_rank_all_batches_t(model, table.data_ptr(), tdt, N, D, ld, source.data_ptr(), source.shape[0],
+                                      source.stride(0) if source.shape[0] > 1 else D, fixed_row.data_ptr(), rel_emb.data_ptr(), rel_emb.shape[0],
+                                      rel_ids.data_ptr(), true_row.data_ptr(), n, int(batch), int(block_triples), spec, counts.data_ptr(),
+                                      workspace.data_ptr(), ws_bytes, dev.index, stream)
     if status:
-        _lib.check(status, "blp_rank_all_batches")
+        _lib.check(status, "blp_rank_all_batches_t")
     return counts
 
 
@@ -295,15 +319,17 @@ def gather_triple_vectors(triples, ent2idx, table, row_base=0):
     for the entities whose global row ent2idx[id] lies in [row_base, row_base + len(table)); zeros for the others, so
     that ONE all-reduce over the ranks of a candidate-axis shard replicates every vector (blp_gather_triple_vectors)."""
     _require_device(triples, ent2idx, table)
-    table = _f32_rows(table, "table")
+    table = _table_rows(table, "table")  # (float16 / bfloat16 rows come out widened, exactly: the result is float32 always)
     triples = triples.to(torch.int64).contiguous()
     n, (N, D) = triples.shape[0], table.shape
+    tdt = TABLE_DTYPES[table.dtype]
     out = torch.empty((2 * n, D), dtype=torch.float32, device=table.device)
     if ent2idx is not None:
         ent2idx = ent2idx.to(torch.int64).contiguous()
-    status = _lib.lib().blp_gather_triple_vectors(_ptr(triples), n, _ptr(ent2idx), 0 if ent2idx is None else ent2idx.shape[0],
-                                                  _ptr(table), N, D, table.stride(0) if N > 1 else D, int(row_base), _ptr(out),
-                                                  table.device.index, _stream(table.device))
+    ld = table.stride(0) if tdt or N > 1 else D
+    status = _lib.lib().blp_gather_triple_vectors_t(_ptr(triples), n, _ptr(ent2idx), 0 if ent2idx is None else ent2idx.shape[0],
+                                                    _ptr(table), tdt, N, D, ld, int(row_base), _ptr(out),
+                                                    table.device.index, _stream(table.device))
     _lib.check(status, "blp_gather_triple_vectors")
     return out
 

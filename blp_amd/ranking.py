@@ -332,13 +332,17 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         # triples need from the other shards.
         rel_w = model.rel_emb.weight
         source, by_position = table, False
-        if by_candidate and num_entities <= 2 * num_triples:      # small table: all of it, one all-gather
+        half_table = table.dtype != torch.float32  # the 16-bit copy of the table (ops.rank_all_batches): candidates only
+        if by_candidate and num_entities <= 2 * num_triples and not half_table:  # small table: all of it, one all-gather
             with _Stopwatch(timing, device):
                 source = all_gather_rows(table, num_entities, world, group)
-        elif by_candidate:                                        # big table: the 2T vectors of the triples, one all-reduce
-            source = ops.gather_triple_vectors(triples, ent2idx, table, row_base=row_lo)
-            with _Stopwatch(timing, device):
-                _all_reduce(source, group)
+        elif by_candidate or half_table:                          # big table: the 2T vectors of the triples, one all-reduce
+            # (a 16-bit table on any axis: the queries' own vectors are its rows WIDENED to float32 -- exactly --, which this
+            #  gather does on the way; nothing to exchange unless the candidate axis is sharded)
+            source = ops.gather_triple_vectors(triples[mine], ent2idx, table, row_base=row_lo)
+            if by_candidate:
+                with _Stopwatch(timing, device):
+                    _all_reduce(source, group)
             by_position = True
         # one kernel (blp_build_queries) instead of ~35 small torch kernels: lookups, layout, binary searches
         qb = ops.build_queries(triples[mine], ent2idx, source, rel_w, block_size, index=index, gather=False, row_base=row_lo,
@@ -357,6 +361,8 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
     else:
         # CPU tensors, half-precision relation tables, widths the fused kernels do not take: the torch prelude and
         # gathered query vectors (dense routes; a CSR filter per block).
+        if table.dtype != torch.float32:
+            table = table.float()  # (a 16-bit table on a dense route: widened once, exactly)
         ranker = ShardedRanker(model, table, num_entities, group) if by_candidate else None
         heads = ent2idx[triples[:, 0]]
         tails = ent2idx[triples[:, 1]]
@@ -477,7 +483,7 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
 def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, emb_batch_size, _run, _log,
                          prefix="", max_num_batches=None, filtering_graph=None, new_entities=None,
                          return_embeddings=False, device=None, group=None, block_size=65536, shard_axis="auto",
-                         eval_mode=False):
+                         eval_mode=False, rank_table_dtype=None):
     """Drop-in for train.eval_link_prediction (same positional arguments, metric names and return
     value).  ``device`` defaults to the model's device; ``group`` (or an initialised default process
     group) shards the evaluation, along ``shard_axis`` = "candidate" | "query" | "auto".
@@ -486,7 +492,12 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     built with BERT's dropout active and its metrics differ run to run.  The default (False) keeps whatever mode the
     model is in -- the reference's behaviour, so that this function drops in without changing a result's law;
     ``eval_mode=True`` puts the encoder in eval mode for the table build and restores it afterwards (deterministic
-    tables; train.py's config key ``eval_dropout=False``)."""
+    tables; train.py's config key ``eval_dropout=False``).
+
+    ``rank_table_dtype`` (torch.float16 / torch.bfloat16; default None = the reference's float32): rank against a 16-bit COPY of
+    the table ("emit fp16 copy").  A deliberate change of the INPUT, not of the arithmetic: the candidates are
+    the rounded rows, scored in f32 in the reference's order (counts = the reference's on the rounded table, bit for bit); at
+    the reference's Wikidata5M batching the passes over the table read half the bytes.  The returned embeddings stay float32."""
     model = _module(model)
     if device is None:
         device = next(model.parameters()).device
@@ -523,8 +534,10 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     axis = shard_axis if shard_axis != "auto" else choose_shard_axis(num_entities, table.shape[1], 2 * num_triples, world)
     if sharded and world > 1 and axis == "query":  # full table everywhere, each rank takes a slice of the triples
         table = all_gather_rows(table, num_entities, world, group)
-    triples, counts, ids_ok = rank_triples(model, table, triples, ent2idx.to(device), index, num_entities=num_entities,
+    rank_table = table if rank_table_dtype in (None, torch.float32) or not table.is_cuda else table.to(rank_table_dtype)
+    triples, counts, ids_ok = rank_triples(model, rank_table, triples, ent2idx.to(device), index, num_entities=num_entities,
                                            group=group, world=world, rank=rank, axis=axis, block_size=block_size)
+    del rank_table
     rr, hits = metrics_from_counts(counts)
     num_predictions = 2 * num_triples
     _log.info(f"The total number of predictions is {num_predictions:,}")

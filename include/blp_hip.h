@@ -57,6 +57,10 @@ typedef struct blp_caps {
 int blp_version(void);
 const char *blp_last_error(void);
 int blp_device_caps(int device, blp_caps *out);
+/* storage types of the arrays that may come in 16 bits (the in-batch loss' embeddings; the candidate table of
+ * blp_rank_all_batches_t) */
+enum { BLP_DTYPE_F32 = 0, BLP_DTYPE_F16 = 1, BLP_DTYPE_BF16 = 2 };
+
 /* 1 if kernels are compiled for embedding width D of `model` (D % 32 == 0, D <= 256; the
  * half-width models complex / simple additionally need D % 64 == 0). */
 int blp_dim_supported(int model, int D);
@@ -190,6 +194,26 @@ int blp_rank_all_batches(int model, const float *table, int64_t N, int D, int64_
                          const blp_filter *filter, int32_t *counts, void *workspace, size_t workspace_bytes, int device,
                          void *stream);
 
+/* THE SAME WITH THE CANDIDATE TABLE IN A 16-BIT STORAGE TYPE.  The table build can emit a half-precision copy of the entity
+ * table next to the f32 one (train.py:96-121 builds `ent_emb` once per evaluation); `table` (N, D) is then IEEE half
+ * (BLP_DTYPE_F16) or bfloat16 (BLP_DTYPE_BF16), row stride ld ELEMENTS, ld % 8 == 0, 16-byte aligned; BLP_DTYPE_F32 is
+ * blp_rank_all_batches itself.  A 16-bit element widens to f32 exactly: every kernel widens first and then runs the f32
+ * arithmetic of the reference in the reference's order, so the counts are what blp_rank_all_batches returns for the table
+ * widened to f32, bit for bit.  `source` stays f32 -- the queries' own vectors, which the caller widens along with gathering
+ * them (blp_gather_triple_vectors_t; they are a few thousand rows) -- as does everything else.
+ * What the 16-bit copy buys: the reference's Wikidata5M batching (eval_batch_size = 2: 4 queries per pass over 4.6 M rows,
+ * scripts/blp-*-wikidata5m.sh:18) is one read of the table per batch, HBM-bound; with block_triples <= batch <= 4 and
+ * D = 128 or 256 the passes read the 16-bit table AS IT IS (half the bytes per pass; all passes in one launch).  Any other
+ * shape of call -- bound by arithmetic, not by the table read -- ranks a widened f32 copy made inside the call (the workspace
+ * holds it: N x D x 4 bytes more).  Workspace: blp_rank_all_batches_t_workspace_bytes(...), 256-B aligned. */
+size_t blp_rank_all_batches_t_workspace_bytes(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
+                                              int64_t batch, int64_t block_triples);
+int blp_rank_all_batches_t(int model, const void *table, int table_dtype, int64_t N, int D, int64_t ld, const float *source,
+                           int64_t S, int64_t ld_src, const int64_t *fixed_row, const float *rel_emb, int64_t R,
+                           const int64_t *rel_id, const int64_t *true_row, int64_t n_triples, int64_t batch,
+                           int64_t block_triples, const blp_filter *filter, int32_t *counts, void *workspace,
+                           size_t workspace_bytes, int device, void *stream);
+
 /* Producer of `source` for big tables: out (2n, D) f32 contiguous, out[t] = the vector of triple t's head, out[n + t] = of
  * its tail (train.py:141-142's `ent_emb[heads]` / `ent_emb[tails]` for the whole set of triples), filled only for the
  * entities whose global row ent2idx[id] (NULL: the id itself) lies in this shard's [row_base, row_base + N) and ZERO
@@ -198,6 +222,11 @@ int blp_rank_all_batches(int model, const float *table, int64_t N, int D, int64_
 int blp_gather_triple_vectors(const int64_t *triples, int64_t n, const int64_t *ent2idx, int64_t ent2idx_len,
                               const float *table, int64_t N, int D, int64_t ld, int64_t row_base, float *out, int device,
                               void *stream);
+/* ... from a table of any storage type (table_dtype: BLP_DTYPE_*; a 16-bit table: ld % 8 == 0); out stays f32: the
+ * vectors are widened exactly. */
+int blp_gather_triple_vectors_t(const int64_t *triples, int64_t n, const int64_t *ent2idx, int64_t ent2idx_len,
+                                const void *table, int table_dtype, int64_t N, int D, int64_t ld, int64_t row_base, float *out,
+                                int device, void *stream);
 
 /* Measurement aid (bench.py): the NEXT blp_rank_all issued by the calling thread records the two
  * hipEvent_t (created by the caller with timing enabled) on its stream immediately before and after
@@ -211,6 +240,8 @@ int blp_profile_next_rank_kernel(void *start_event, void *stop_event);
  * blp_profile_next_rank_kernel bracket divides by it. */
 int64_t blp_rank_all_batches_passes_per_launch(int model, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
                                                int64_t block_triples);
+int64_t blp_rank_all_batches_t_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
+                                                 int64_t batch, int64_t block_triples);
 
 /* The same counts from a DENSE score matrix already in HBM: scores (Q, N) f32 with row stride ld, the
  * true entity given per query as a column index (true_idx, the reference's `true_ents`,
@@ -295,7 +326,6 @@ int blp_inbatch_loss_bwd(int model, int loss, const float *ent_embs, const float
  * the reference (f32 accumulate); loss and the saved scores stay f32; gradients are rounded once on
  * store.  The reference has no half path: parity is a tolerance against the f32 oracle on the
  * widened inputs (tests/test_gpu_parity.py::test_inbatch_loss_half_*). */
-enum { BLP_DTYPE_F32 = 0, BLP_DTYPE_F16 = 1, BLP_DTYPE_BF16 = 2 };
 int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
                            const void *rel_vecs, const int64_t *neg_idx, int B, int K, int D,
                            float regularizer, float *out_loss, float *save_pos, float *save_neg,

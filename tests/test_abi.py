@@ -101,7 +101,7 @@ def test_no_scalar_load_result_is_touched_before_its_wait(built_lib):
     import kernel_resources
     from blp_amd import build
     checked = 0
-    for src in ("rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_gemm.hip"):
+    for src in ("rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_stream16.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_gemm.hip"):
         obj = os.path.join(build.OBJ, src + ".o")
         bad = kernel_resources.early_uses_of_scalar_loads(obj)
         assert not bad, (src, bad[:3])
@@ -118,7 +118,7 @@ def test_hand_scheduled_valu_keeps_its_sgpr_wait_states(built_lib):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
     from blp_amd import build
-    for src in ("rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_gemm.hip"):
+    for src in ("rank_all.hip", "rank_small.hip", "rank_stream.hip", "rank_stream16.hip", "rank_sad.hip", "rank_sad_wide.hip", "rank_gemm.hip"):
         bad = kernel_resources.valu_sgpr_hazards(os.path.join(build.OBJ, src + ".o"))
         assert not bad, (src, bad[:3])
     stricter = kernel_resources.valu_sgpr_hazards(os.path.join(build.OBJ, "rank_gemm.hip.o"), min_gap=4)
@@ -141,6 +141,29 @@ def test_passes_per_launch_is_host_logic(built_lib):
         assert f(model, 4_600_000, 128, 128, 2, 2, 2) == 1          # a single pass
     assert f(0, 4_600_000, 128, 128, 0, 2, 2) == 0 and f(9, 100, 128, 128, 4, 2, 2) == 0
     assert f(1, 4_600_000, 256, 256, 128, 2, 2) == 64 and f(1, 4_600_000, 100, 100, 128, 2, 2) == 1
+
+
+def test_typed_batches_routes_and_workspace_are_host_logic(built_lib):
+    """blp_rank_all_batches_t with a 16-bit table: the reference-batched passes over a long table read it as it is (every pass
+    in one launch, the workspace of the passes only); every other shape of call holds a widened float32 copy at the end of its
+    workspace (N x D x 4 bytes on top of what the float32 call needs); BLP_DTYPE_F32 is the float32 entry.  No GPU needed."""
+    from blp_amd import _lib
+    L = _lib.lib()
+    ws, ppl = L.blp_rank_all_batches_t_workspace_bytes, L.blp_rank_all_batches_t_passes_per_launch
+    f32 = L.blp_rank_all_batches_workspace_bytes
+    for model in range(4):
+        for dt in (1, 2):
+            assert ppl(model, dt, 4_600_000, 128, 128, 128, 2, 2) == 64 and ppl(model, dt, 4_600_000, 256, 256, 9, 4, 4) == 3
+            assert ppl(model, dt, 4_600_000, 128, 128, 2, 2, 2) == 1       # a single pass: the ring all the same (one pass per launch)
+            assert ws(model, dt, 4_600_000, 128, 128, 128, 2, 2) < (1 << 20)  # no widened copy
+            assert ppl(model, dt, 4_600_000, 128, 128, 128, 2, 0) == 1     # one block: a widened copy
+            assert ws(model, dt, 4_600_000, 128, 128, 128, 2, 0) >= f32(model, 4_600_000, 128, 128, 2, 0) + 4_600_000 * 128 * 4
+            assert ws(model, dt, 2000, 128, 128, 128, 2, 2) >= 2000 * 128 * 4   # short table: small-block kernels on the copy
+            assert ws(model, dt, 4_600_000, 64, 64, 128, 2, 2) >= 4_600_000 * 64 * 4  # D = 64: not the 16-bit ring
+            assert ws(model, dt, 4_600_000, 128, 132, 128, 2, 2) >= 4_600_000 * 128 * 4  # (ld % 8 != 0 is refused by the call itself)
+        assert ws(model, 0, 4_600_000, 128, 128, 128, 2, 2) == f32(model, 4_600_000, 128, 128, 2, 2)
+        assert ppl(model, 0, 4_600_000, 128, 128, 128, 2, 2) == 64
+    assert ws(0, 5, 100, 128, 128, 4, 2, 2) == 0 and ppl(0, 5, 100, 128, 128, 4, 2, 2) == 0
 
 
 def test_batches_workspace_covers_every_block_of_the_call(built_lib):

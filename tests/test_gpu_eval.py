@@ -287,8 +287,9 @@ def test_bench_line_keeps_the_contract():
     subs = r["sub_results"]
     import bench
     assert set(subs) == set(bench.SUB_RESULTS) == {
-        "fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-block",
-        "wikidata5m-complex-block", "wikidata5m-transe-full", "wikidata5m-complex-full", "wikidata5m-protocol"}
+        "fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-f16",
+        "wikidata5m-complex-f16", "wikidata5m-transe-block", "wikidata5m-complex-block", "wikidata5m-transe-full",
+        "wikidata5m-complex-full", "wikidata5m-protocol"}
     assert "arith" in r and r["arith"] == roof["arith"] and "v_sad_u16" in roof["arith"] and "sad_ubench" in roof["peak_source"]
     for name, sub in subs.items():
         assert sub["value"] > 0 and sub["ms_per_step"] > 0 and sub["ms_per_step_raw_only"] > 0, name
@@ -302,7 +303,12 @@ def test_bench_line_keeps_the_contract():
             assert sub["table_passes_per_step"] == passes and sub["ms_per_table_pass"] == pytest.approx(sub["ms_per_step"] / passes)
             # one launch of a ring kernel walks all passes: kernel_ms is ONE pass's share of the bracketed launch
             assert sub["roofline"]["passes_per_launch"] == passes and sub["roofline"]["kernel_ms"] <= sub["ms_per_table_pass"] * 1.25, name
-            assert sub["roofline"]["frac"] > 0.6, name  # (the north_star's bar is 0.70 of HBM peak; measured 0.82 - 0.87)
+            half = bench.WORKLOADS[name].get("table_dtype") == "float16"  # the 16-bit copy of the table: half the bytes per pass,
+            assert sub["roofline"]["frac"] > (0.5 if half else 0.6), name  # the arithmetic no longer hidden (measured 0.72 - 0.79; f32: the north_star's bar is 0.70 of HBM peak, measured 0.82 - 0.87)
+            if half:
+                f32 = subs[name[:-4]]
+                assert sub["ms_per_table_pass"] < 0.75 * f32["ms_per_table_pass"], name
+                assert "rank_stream" in sub["roofline"]["kernel"] and "16" in sub["roofline"]["kernel"], name
         else:
             assert sub["roofline"]["passes_per_launch"] == 1, name
     # sustained (3 447 passes, > 1 s) against the 64-pass burst: within a few per cent of each other

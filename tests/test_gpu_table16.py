@@ -1,0 +1,156 @@
+"""GPU: the candidate table in a 16-bit storage type (blp_rank_all_batches_t / blp_gather_triple_vectors_t; include/blp_hip.h,
+blp_amd/csrc/table_elem.h, rank_stream16.hip) -- the half-precision copy the table build can emit.  The
+reference has no such table (train.py:96-97 keeps `ent_emb` in float32); what has to hold is that a 16-bit table is ranked as
+the reference ranks the SAME VALUES in float32: every test compares with the CPU oracle on the table widened to float32
+(exact) and with the library's own float32 path on that widened table -- counts identical, raw and filtered."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import REL_MODELS
+from test_gpu_shard import _oracle_counts, _problem
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _loop_positions(T, batch):
+    idx = torch.arange(T)
+    first = idx // batch * batch
+    nb = torch.clamp(T - first, max=batch)
+    head_pos = 2 * first + (idx - first)
+    return head_pos, head_pos + nb
+
+
+def _rank16(model, table16, rel_w, ent2idx, triples, index, batch, block_triples, filtered=True):
+    from blp_amd import ops
+    dev_rel, dev_e2i, dev_triples = rel_w.cuda(), ent2idx.cuda(), triples.cuda()
+    T = triples.shape[0]
+    source = ops.gather_triple_vectors(dev_triples, dev_e2i, table16)  # float32, widened exactly
+    qb = ops.build_queries(dev_triples, dev_e2i, source, dev_rel, batch, index=index, gather=False, by_position=True,
+                           num_rows=table16.shape[0])
+    return ops.rank_all_batches(model, table16, qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, T, batch,
+                                filter=qb.filter if filtered else None, source=source, block_triples=block_triples)
+
+
+def _rank32(model, table32, rel_w, ent2idx, triples, index, batch, block_triples):
+    from blp_amd import ops
+    dev_rel, dev_e2i, dev_triples = rel_w.cuda(), ent2idx.cuda(), triples.cuda()
+    qb = ops.build_queries(dev_triples, dev_e2i, table32, dev_rel, batch, index=index, gather=False)
+    return ops.rank_all_batches(model, table32, qb.fixed_row, dev_rel, qb.rel_ids, qb.true_row, triples.shape[0], batch,
+                                filter=qb.filter, block_triples=block_triples)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("model,N,T,batch,D", [("transe", 70000, 9, 2, 128), ("transe", 130001, 41, 4, 128), ("transe", 66000, 7, 3, 256),
+                                               ("transe", 75000, 5, 1, 128), ("distmult", 120000, 7, 4, 128), ("complex", 110000, 9, 2, 128),
+                                               ("simple", 110017, 5, 3, 128), ("complex", 70001, 6, 2, 256), ("distmult", 66000, 5, 1, 256),
+                                               ("simple", 80000, 1, 2, 128)])
+def test_reference_batched_passes_read_the_16_bit_table(oracle, model, N, T, batch, D, dtype):
+    """eval_batch_size <= 4 against a long table (scripts/blp-*-wikidata5m.sh:18; train.py:128-171): the ring kernels read the
+    16-bit table as it is, every pass in one launch (blp_rank_all_batches_t_passes_per_launch says so); counts == the oracle's
+    on the widened table == the float32 path's on the widened table, raw and filtered; T = 1 / a short last batch included."""
+    from blp_amd import _lib, utils
+    R = 5
+    table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=T + N % 89)
+    table16 = table.to(dtype).cuda()
+    wide = table16.float()  # exact
+    index = utils.FilterIndex(edges, num_relations=R)
+    L, mid = _lib.lib(), _lib.MODEL_IDS[model]
+    assert L.blp_rank_all_batches_t_passes_per_launch(mid, {torch.float16: 1, torch.bfloat16: 2}[dtype], N, D, D, T, batch, batch) == -(-T // batch)
+    got = _rank16(model, table16, rel_w, ent2idx, triples, index, batch, batch)
+    ref32 = _rank32(model, wide, rel_w, ent2idx, triples, index, batch, batch)
+    assert torch.equal(got, ref32)
+    raw = _rank16(model, table16, rel_w, ent2idx, triples, index, batch, batch, filtered=False)
+    assert torch.equal(raw[:, :2], got[:, :2]) and torch.equal(raw[:, 2:], raw[:, :2])
+    want = _oracle_counts(oracle, model, wide.cpu(), rel_w, ent2idx, triples, index)
+    head_pos, tail_pos = _loop_positions(T, batch)
+    assert np.array_equal(got[head_pos].cpu().numpy(), want[:T])
+    assert np.array_equal(got[tail_pos].cpu().numpy(), want[T:])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("model,N,T,batch,block,D", [("transe", 2100, 700, 64, 0, 128), ("distmult", 2100, 333, 50, 0, 128),
+                                                     ("complex", 900, 64, 64, 0, 64), ("simple", 20000, 31, 3, 0, 128),
+                                                     ("transe", 1500, 300, 16, 0, 300), ("transe", 300, 40, 2, 2, 128),
+                                                     ("distmult", 3000, 9, 2, 2, 64), ("transe", 70000, 9, 2, 2, 64),
+                                                     ("transe", 16500, 64, 64, 64, 128)])
+def test_other_shapes_rank_a_widened_copy(oracle, model, N, T, batch, block, D, dtype):
+    """Blocks of many queries (the pre-pass paths), short tables (the small-block kernels), widths the ring does not take
+    (64; the bag-of-words 300): the call widens the table into its workspace and ranks that -- the same counts again."""
+    from blp_amd import utils
+    R = 5
+    table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=N % 53 + T)
+    table16 = table.to(dtype).cuda()
+    wide = table16.float()
+    index = utils.FilterIndex(edges, num_relations=R)
+    got = _rank16(model, table16, rel_w, ent2idx, triples, index, batch, block)
+    assert torch.equal(got, _rank32(model, wide, rel_w, ent2idx, triples, index, batch, block))
+    want = _oracle_counts(oracle, model, wide.cpu(), rel_w, ent2idx, triples, index)
+    head_pos, tail_pos = _loop_positions(T, batch)
+    assert np.array_equal(got[head_pos].cpu().numpy(), want[:T])
+    assert np.array_equal(got[tail_pos].cpu().numpy(), want[T:])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_padded_rows_special_values_and_ties(oracle, dtype):
+    """A 16-bit table with a row stride above D (ld % 8 == 0), duplicate rows of the true entity (ties: gt vs ge), an
+    all-zero row, infinities and a NaN in candidate rows (widened exactly; the oracle sees the same values)."""
+    from blp_amd import utils
+    N, D, T, R, batch = 66000, 128, 6, 3, 2
+    for model in REL_MODELS:
+        table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=11)
+        rows = ent2idx[triples[:, 0]]
+        table[5] = table[rows[0]]            # a tie with a true entity
+        table[6] = 0.0
+        table[7, 3] = float("inf")
+        table[8, 100] = float("-inf")
+        table[9, 64] = float("nan")
+        backing = torch.zeros(N, D + 24, dtype=dtype, device="cuda")
+        backing[:, :D] = table.to(dtype).cuda()
+        table16 = backing[:, :D]             # stride D + 24 elements
+        assert table16.stride(0) == D + 24
+        wide = table16.float().contiguous()
+        index = utils.FilterIndex(edges, num_relations=R)
+        got = _rank16(model, table16, rel_w, ent2idx, triples, index, batch, batch)
+        assert torch.equal(got, _rank32(model, wide, rel_w, ent2idx, triples, index, batch, batch)), model
+        want = _oracle_counts(oracle, model, wide.cpu(), rel_w, ent2idx, triples, index)
+        head_pos, tail_pos = _loop_positions(T, batch)
+        assert np.array_equal(got[head_pos].cpu().numpy(), want[:T]), model
+        assert np.array_equal(got[tail_pos].cpu().numpy(), want[T:]), model
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("model", ["transe", "complex"])
+def test_rank_triples_takes_a_16_bit_table(oracle, model, dtype):
+    """blp_amd.ranking.rank_triples (the evaluation loop body, train.py:128-171) with the 16-bit copy of the table, at the
+    reference's Wikidata5M batching (block_size = 2) and as one block: counts == the oracle's on the widened table."""
+    from blp_amd import models, ranking, utils
+    N, D, T, R = 70000, 128, 11, 5
+    table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=3)
+    m = models.LinkPrediction(D, model, "margin", R, 0).cuda()
+    with torch.no_grad():
+        m.rel_emb.weight.copy_(rel_w.cuda())
+    table16 = table.to(dtype).cuda()
+    index = utils.FilterIndex(edges, num_relations=R)
+    want = _oracle_counts(oracle, model, table16.float().cpu(), rel_w, ent2idx, triples, index)
+    for block_size in (2, 65536):
+        _, counts, ids_ok = ranking.rank_triples(m, table16, triples.cuda(), ent2idx.cuda(), index, block_size=block_size)
+        assert bool(ids_ok)
+        assert np.array_equal(counts.cpu().numpy(), want), block_size
+
+
+def test_bad_arguments_of_the_typed_entries():
+    """Unknown dtype, a 16-bit row stride that is not a multiple of 8, a short workspace: status codes, nothing launched."""
+    import ctypes
+    from blp_amd import _lib
+    L = _lib.lib()
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = buf.data_ptr()
+    args = lambda dt, ld, ws: (0, p, dt, 100, 128, ld, p, 100, 128, p, p, 5, p, p, 4, 2, 2, None, p, p, ws, 0, None)
+    assert L.blp_rank_all_batches_t(*args(7, 128, 1 << 16)) == -1
+    assert L.blp_rank_all_batches_t(*args(1, 132, 1 << 16)) == -1          # ld % 8 != 0
+    assert L.blp_rank_all_batches_t(*args(1, 128, 16)) == -4                # workspace
+    assert b"workspace" in L.blp_last_error()
+    assert L.blp_gather_triple_vectors_t(p, 4, None, 0, p, 9, 100, 128, 128, 0, p, 0, None) == -1
+    assert L.blp_rank_all_batches_t_workspace_bytes(0, 1, 100, 128, 128, 4, 2, 2) > 0
