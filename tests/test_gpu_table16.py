@@ -154,3 +154,31 @@ def test_bad_arguments_of_the_typed_entries():
     assert b"workspace" in L.blp_last_error()
     assert L.blp_gather_triple_vectors_t(p, 4, None, 0, p, 9, 100, 128, 128, 0, p, 0, None) == -1
     assert L.blp_rank_all_batches_t_workspace_bytes(0, 1, 100, 128, 128, 4, 2, 2) > 0
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_seeded_random_cases(oracle, seed):
+    """A seeded slice of random shapes around the routes of a 16-bit call: the ring (long tables, <= 4 triples per pass), the
+    widened copy (short tables, blocks, D = 64), row strides above D, with and without a filter."""
+    from blp_amd import utils
+    rng = np.random.default_rng(1000 + seed)
+    model = REL_MODELS[seed % 4]
+    dtype = DTYPES[(seed // 4) % 2]
+    D = int(rng.choice([128, 128, 256, 64]))
+    N = int(rng.choice([rng.integers(200, 3000), rng.integers(16000, 20000), rng.integers(65000, 140000)]))
+    batch = int(rng.integers(1, 5))
+    T = int(rng.integers(1, 40))
+    block = int(rng.choice([batch, batch, 0]))
+    R = 4
+    table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=seed)
+    pad = int(rng.choice([0, 8, 40]))
+    backing = torch.zeros(N, D + pad, dtype=dtype, device="cuda")
+    backing[:, :D] = table.to(dtype).cuda()
+    table16 = backing[:, :D]
+    wide = table16.float().contiguous()
+    index = utils.FilterIndex(edges, num_relations=R)
+    got = _rank16(model, table16, rel_w, ent2idx, triples, index, batch, block)
+    assert torch.equal(got, _rank32(model, wide, rel_w, ent2idx, triples, index, batch, block)), (model, dtype, D, N, T, batch, block, pad)
+    want = _oracle_counts(oracle, model, wide.cpu(), rel_w, ent2idx, triples, index)
+    head_pos, tail_pos = _loop_positions(T, batch)
+    assert np.array_equal(got[head_pos].cpu().numpy(), want[:T]) and np.array_equal(got[tail_pos].cpu().numpy(), want[T:])

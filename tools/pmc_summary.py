@@ -15,7 +15,8 @@ DOMINANT = {"fb15k237-transe": "rank_sad_kernel", "fb15k237-distmult": "rank_gem
             "wikidata5m-transe": "rank_stream_kernel", "wikidata5m-complex": "rank_stream_dot_kernel",  # (the ring kernels: all passes of a step in one launch)
             "wikidata5m-transe-block": "rank_sad_kernel", "wikidata5m-complex-block": "rank_gemm_bf16",
             "wikidata5m-protocol": "rank_sad_kernel",
-            "wikidata5m-transe-full": "rank_stream_kernel", "wikidata5m-complex-full": "rank_stream_dot_kernel"}  # (3 447 passes in one launch)
+            "wikidata5m-transe-full": "rank_stream_kernel", "wikidata5m-complex-full": "rank_stream_dot_kernel",  # (3 447 passes in one launch)
+            "wikidata5m-transe-f16": "rank_stream16_kernel", "wikidata5m-complex-f16": "rank_stream_dot16_kernel"}  # (the 16-bit copy of the table)
 
 
 def rows(path):
