@@ -844,7 +844,7 @@ def call_overhead(device, iters=3000):
 def table_build_bench(device):
     """The step BEFORE the path: the entity-table build's fused pieces against the stock PyTorch-ROCm
     modules, per emb_batch_size chunk -- the bag-of-words encoder's whole build (models.py:143-155 + F.normalize + the row
-    assignment: blp_bow_rows) at the BERT word-embedding table's size, and the BERT encoders' last step (enc_linear +
+    assignment: blp_bow_rows) at the BERT word-embedding table's size, the DKRL encoder's whole build (blp_dkrl_rows), and the BERT encoders' last step (enc_linear +
     F.normalize + row assignment, models.py:110-111: blp_project_rows).  Floating point (tolerance in the tests); us per chunk."""
     from blp_amd import models, ops
     g = torch.Generator(device=device).manual_seed(21)
@@ -873,6 +873,24 @@ def table_build_bench(device):
             fused = us(lambda: model.encode_into(rows, tok, mask))
         model.check_tokens()
         out[name] = {"stock_us": stock, "fused_us": fused, "gathered_GBps": n * L * E * 4 / fused / 1e3, "kernel": "blp_bow_rows"}
+    # the DKRL encoder's whole build (models.py:158-204 + F.normalize + the row assignment: blp_dkrl_rows; conv1 on the
+    # matrix cores with f32 operands: `conv_TFLOPs` = its arithmetic against the 157.3 TF f32 MFMA peak)
+    dkrl = models.DKRL(128, "transe", "margin", 5, 0, embeddings=model.embeddings.weight.detach().cpu()).to(device)
+    for name, n, L in (("bert-dkrl, 512 entities x 32 tokens (scripts/bert-dkrl-fb15k237.sh)", 512, 32),
+                       ("bert-dkrl, 12 288 entities x 64 tokens (scripts/bert-dkrl-wikidata5m.sh)", 12288, 64)):
+        tok = torch.randint(1, V, (n, L), device=device, generator=g)
+        lengths = torch.randint(L // 2, L + 1, (n, 1), device=device, generator=g)
+        lengths[0] = L
+        mask = (torch.arange(L, device=device).unsqueeze(0) < lengths).float()
+        rows = torch.empty(n, 128, device=device)
+        with torch.no_grad():
+            stock = us(lambda: rows.copy_(dkrl.encode(tok, mask)), 10)
+            fused = us(lambda: dkrl.encode_into(rows, tok, mask), 10)
+        dkrl.check_tokens()
+        flops = 2.0 * n * L * 2 * E * 128
+        out[name] = {"stock_us": stock, "fused_us": fused, "conv_TFLOPs": flops / fused / 1e6, "frac_of_f32_mfma_peak": flops / fused / 1e6 / F32_PEAK_TFLOPS,
+                     "kernel": "blp_dkrl_rows"}
+    del dkrl
     x = torch.randn(14541, 768, device=device, generator=g)
     w = torch.randn(128, 768, device=device, generator=g) * 0.03
     rows = torch.empty(14541, 128, device=device)

@@ -26,12 +26,12 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supporte
            "blp_rank_all_batches_passes_per_launch", "blp_rank_all_batches_t", "blp_rank_all_batches_t_workspace_bytes",
            "blp_rank_all_batches_t_passes_per_launch", "blp_gather_triple_vectors_t", "blp_profile_next_rank_kernel", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
-           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows",
+           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows", "blp_dkrl_rows_supported", "blp_dkrl_rows",
            "blp_build_queries")
 HOOK_SYMBOLS = ("blp_debug_set_knob", "blp_debug_gemm_dump")  # libblp_hip.hooks.so only
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
          "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
-         "small_kernel", "stream_kernel")  # blp_amd/csrc/knobs.h
+         "small_kernel", "stream_kernel", "dkrl_split")  # blp_amd/csrc/knobs.h
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h
@@ -188,6 +188,10 @@ def _load(path, hooks):
     L.blp_bow_rows_supported.argtypes = [_i]
     L.blp_bow_rows.restype = _i
     L.blp_bow_rows.argtypes = [_vp, _vp, _i64, _i, _vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp]
+    L.blp_dkrl_rows_supported.restype = _i
+    L.blp_dkrl_rows_supported.argtypes = [_i, _i, _i]
+    L.blp_dkrl_rows.restype = _i
+    L.blp_dkrl_rows.argtypes = [_vp, _vp, _i64, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp, _i, _vp]
     if hooks:
         L.blp_debug_gemm_dump.restype = _i
         L.blp_debug_gemm_dump.argtypes = [_vp, _vp]

@@ -88,7 +88,7 @@ std::atomic<long long> g_knobs[blp::KNOB_COUNT];  // zero-initialised: every kno
 const char* const kKnobNames[blp::KNOB_COUNT] = {"rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups",
                                                  "sad_min_queries", "gemm_pass_words", "gemm_tiles_per_chunk",
                                                  "exact_query_chunk", "small_kernel",
-                                                 "stream_kernel"};
+                                                 "stream_kernel", "dkrl_split"};
 #endif
 
 }  // namespace
@@ -205,6 +205,29 @@ int blp_bow_rows(const int64_t* tok, const float* mask, int64_t n, int L, const 
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
     hipError_t err = blp::launch_bow_rows(tok, mask, n, L, emb, V, E, normalize, out, ldo, bad_tok, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_bow_rows launch");
+    return BLP_OK;
+}
+
+int blp_dkrl_rows_supported(int E, int D, int L) { return blp::dkrl_rows_supported(E, D, L) ? 1 : 0; }
+
+int blp_dkrl_rows(const int64_t* tok, const float* mask, int64_t n, int L, const float* emb, int64_t V, int E, const float* w1,
+                  const float* b1, const float* w2, const float* b2, int D, int normalize, float* out, int64_t ldo, int32_t* bad_tok,
+                  int device, void* stream) {
+    if (n < 0 || V < 0) return fail(BLP_ERR_BAD_ARG, "blp_dkrl_rows: negative size");
+    if (!blp::dkrl_rows_supported(E, D, L))
+        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_dkrl_rows: E = %d (needs E %% 4 == 0), dim = %d (needs 128), L = %d (needs 4 .. 64)", E, D, L);
+    if (n == 0) return BLP_OK;
+    if (!tok || !emb || !w1 || !b1 || !w2 || !b2 || !out || !bad_tok || V == 0)
+        return fail(BLP_ERR_BAD_ARG, "blp_dkrl_rows: NULL pointer or empty embedding table");
+    if (!aligned16(emb) || !aligned16(w1) || !aligned16(w2) || ldo < D)
+        return fail(BLP_ERR_BAD_ARG, "blp_dkrl_rows: emb / w1 / w2 must be 16-byte aligned, ldo >= dim");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    int cu = 0;
+    if (int rc = compute_units(device, &cu)) return rc;
+    hipError_t err = blp::launch_dkrl_rows(tok, mask, n, L, emb, V, E, w1, b1, w2, b2, normalize, out, ldo, bad_tok, cu,
+                                           static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_dkrl_rows launch");
     return BLP_OK;
 }
 

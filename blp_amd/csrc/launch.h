@@ -118,6 +118,11 @@ bool bow_rows_supported(int E);
 hipError_t launch_bow_rows(const int64_t* tok, const float* mask, int64_t n, int L, const float* emb, int64_t V, int E,
                            int normalize, float* out, int64_t ldo, int* bad_tok, hipStream_t stream);
 
+bool dkrl_rows_supported(int E, int D, int L);
+hipError_t launch_dkrl_rows(const int64_t* tok, const float* mask, int64_t n, int L, const float* emb, int64_t V, int E,
+                            const float* w1, const float* b1, const float* w2, const float* b2, int normalize, float* out,
+                            int64_t ldo, int* bad_tok, int n_cu, hipStream_t stream);
+
 struct StridedRows {  // row(i0, i1) = base + i0 * s0 + i1 * s1   (strides in floats)
     const float* base;
     int64_t s0, s1;

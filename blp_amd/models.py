@@ -315,6 +315,31 @@ class DKRL(WordEmbeddingsLP):
         lengths = torch.sum(text_mask, dim=-1)
         return torch.tanh(torch.sum(embs * text_mask, dim=-1) / lengths)
 
+    def encode_into(self, out, text_tok, text_mask=None):
+        """Table build (train.py:96-121): on a HIP device and outside autograd the whole encoder, F.normalize and the row
+        assignment are one kernel (ops.dkrl_rows -> blp_dkrl_rows: conv1 on the matrix cores in f32, pooling and tanh in its
+        accumulators, conv2 folded into the masked mean); the stock modules run a gather, two transposes, two convolutions, two
+        poolings and five elementwise kernels over (B, L, E) / (B, dim, L) temporaries."""
+        weight = self.embeddings.weight
+        if out.is_cuda and not torch.is_grad_enabled() and out.dtype == torch.float32 and weight.dtype == torch.float32 \
+                and self.conv1.weight.dtype == torch.float32 and text_tok.dim() == 2 and out.stride(1) == 1 \
+                and type(self.embeddings) is nn.Embedding and self.embeddings.max_norm is None \
+                and type(self.conv1) is nn.Conv1d and type(self.conv2) is nn.Conv1d and self.conv1.bias is not None \
+                and self.conv2.bias is not None and ops.dkrl_rows_supported(weight.shape[1], self.dim, text_tok.shape[1]):
+            flag = self.__dict__.get("_dkrl_bad_tok")  # (a plain attribute: not a buffer, not in the state_dict)
+            if flag is None or flag.device != out.device:
+                flag = self.__dict__["_dkrl_bad_tok"] = torch.zeros((), dtype=torch.int32, device=out.device)
+            return ops.dkrl_rows(text_tok, text_mask, weight, self.conv1, self.conv2, out, self.normalize_embs, bad_flag=flag)
+        return super().encode_into(out, text_tok, text_mask)
+
+    def check_tokens(self):
+        """As BOW.check_tokens: raise IndexError if a fused encode_into since the last check saw a token id outside the
+        embedding table (ranking.build_entity_table calls it once after its last chunk)."""
+        flag = self.__dict__.get("_dkrl_bad_tok")
+        if flag is not None and flag.item() < 0:
+            flag.zero_()
+            raise IndexError("a token id is outside the embedding table")
+
 
 class TransductiveLinkPrediction(LinkPrediction):
     """Entity lookup table instead of a text encoder (models.py:207-219)."""

@@ -517,6 +517,43 @@ def bow_rows(text_tok, text_mask, weight, out, normalize, bad_flag=None):
     return out
 
 
+def dkrl_rows_supported(embedding_dim, dim, num_tokens):
+    """True if blp_dkrl_rows takes word vectors of this width, this output width and descriptions of this many tokens."""
+    return bool(_lib.lib().blp_dkrl_rows_supported(int(embedding_dim), int(dim), int(num_tokens)))
+
+
+def dkrl_rows(text_tok, text_mask, weight, conv1, conv2, out, normalize, bad_flag=None):
+    """The DKRL encoder (models.py:158-204: lookup, Conv1d(E, dim, 2), mask, max-pool 4, tanh, Conv1d(dim, dim, 2), masked
+    mean, tanh) + F.normalize (models.py:40-41) + the row assignment into the entity table (train.py:109-113) in one kernel
+    (blp_dkrl_rows).  text_tok (n, L) int64, text_mask (n, L) float or None, weight (V, E) f32 (embeddings.weight), conv1 /
+    conv2 the two nn.Conv1d modules (f32), out (n, dim) f32 rows of the table.  Inference only.  bad_flag as for bow_rows."""
+    _require_device(text_tok, text_mask, weight, out)
+    w1, b1, w2, b2 = conv1.weight, conv1.bias, conv2.weight, conv2.bias
+    if any(t.dtype != torch.float32 for t in (weight, w1, b1, w2, b2, out)):
+        raise TypeError("dkrl_rows works on float32 tables and weights")
+    n, L = text_tok.shape
+    dim, E = w1.shape[0], weight.shape[1]
+    if w1.shape != (dim, E, 2) or w2.shape != (dim, dim, 2) or out.shape != (n, dim) or out.stride(1) != 1:
+        raise ValueError(f"shapes do not match: conv1 {tuple(w1.shape)}, conv2 {tuple(w2.shape)}, weight {tuple(weight.shape)}, out {tuple(out.shape)}")
+    tok = text_tok if text_tok.dtype is torch.int64 and text_tok.is_contiguous() else text_tok.to(torch.int64).contiguous()
+    mask = None
+    if text_mask is not None:
+        if text_mask.shape != text_tok.shape:
+            raise ValueError("text_mask must have text_tok's shape")
+        mask = text_mask if text_mask.dtype is torch.float32 and text_mask.is_contiguous() else text_mask.to(torch.float32).contiguous()
+    weight, w1, b1, w2, b2 = weight.contiguous(), w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+    dev = out.device
+    bad = bad_flag if bad_flag is not None else torch.zeros((), dtype=torch.int32, device=dev)
+    status = _lib.lib().blp_dkrl_rows(tok.data_ptr(), _addr(mask), n, L, weight.data_ptr(), weight.shape[0], E, w1.data_ptr(),
+                                      b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), dim, int(bool(normalize)), out.data_ptr(),
+                                      out.stride(0) if n > 1 else dim, bad.data_ptr(), dev.index,
+                                      torch._C._cuda_getCurrentRawStream(dev.index))
+    _lib.check(status, "blp_dkrl_rows")
+    if bad_flag is None and bad.item() < 0:
+        raise IndexError("dkrl_rows: a token id is outside the embedding table")
+    return out
+
+
 # ------------------------------------------------------------------------------------- score_fn
 def _collapse(sizes, strides):
     """Collapse a group of dims into (size, stride) or None if not expressible with one stride."""

@@ -419,6 +419,34 @@ int blp_bow_rows(const int64_t *tok, const float *mask, int64_t n, int L, const 
                  int normalize, float *out, int64_t ldo, int32_t *bad_tok, int device, void *stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Entity-table build for the DKRL encoder (models.py:158-204; the bert-dkrl / glove-dkrl scripts), with the steps that
+ * follow it:
+ *
+ *   embs = self.embeddings(text_tok) * text_mask.unsqueeze(-1)                                    models.py:177
+ *   embs = self.conv1(F.pad(embs.transpose(1, 2), [0, 1])) * text_mask          Conv1d(E, dim, 2)  models.py:180-187
+ *   embs = F.max_pool1d(embs, 4); text_mask = F.max_pool1d(text_mask, 4)        (L >= 4)           models.py:188-195
+ *   embs = self.conv2(F.pad(torch.tanh(embs), [0, 1]))                          Conv1d(dim, dim, 2) models.py:196-198
+ *   embs = torch.tanh(torch.sum(embs * text_mask, dim=-1) / lengths)                               models.py:199-202
+ *   ent_emb = F.normalize(ent_emb, dim=-1)    models.py:40-41 (iff normalize != 0)
+ *   ent_emb[idx:idx + batch] = batch_emb      train.py:109-113
+ *
+ *   tok (n, L) int64, mask (n, L) f32 or NULL (all ones), emb (V, E) f32 as for blp_bow_rows;
+ *   w1 (dim, E, 2), b1 (dim): conv1.weight / .bias;  w2 (dim, dim, 2), b2 (dim): conv2.weight / .bias, contiguous f32;
+ *   out (n, dim) f32, row stride ldo: rows of the table shard;  bad_tok as for blp_bow_rows.
+ * One kernel, nothing materialised: conv1 on the matrix cores with f32 operands (v_mfma_f32_32x32x2_f32), bias / mask /
+ * max-pool / tanh in the accumulator registers, conv2 + masked mean folded into two 128-vectors per entity (they are linear
+ * in the pooled activations).  A masked position contributes exact zeros (the stock expression multiplies the gathered
+ * row by 0: the same unless the embedding row holds Inf / NaN).  Floating point: agrees with the stock modules to ~1e-6,
+ * not bit for bit (the reduction orders differ from the convolution library's).
+ * blp_dkrl_rows_supported: E % 4 == 0, dim == 128 (every DKRL script's), 4 <= L <= 64 (max_len 32 / 64; shorter chunks
+ * change the pooling window, models.py:188-193, and stay with the stock modules); emb, w1, w2 16-byte aligned, ldo >= dim.
+ * -------------------------------------------------------------------------------------------- */
+int blp_dkrl_rows_supported(int E, int D, int L);
+int blp_dkrl_rows(const int64_t *tok, const float *mask, int64_t n, int L, const float *emb, int64_t V, int E,
+                  const float *w1, const float *b1, const float *w2, const float *b2, int D, int normalize, float *out,
+                  int64_t ldo, int32_t *bad_tok, int device, void *stream);
+
+/* --------------------------------------------------------------------------------------------
  * Test / A-B hooks -- NOT part of the production library.  They are compiled only with -DBLP_TEST_HOOKS, into a second
  * library (blp_amd/libblp_hip.hooks.so) that tests/ and tools/ load; libblp_hip.so exports neither symbol and has no
  * mutable process-wide state.  The library never reads the environment; the kernel-selection and slab-size overrides the

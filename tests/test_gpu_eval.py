@@ -551,6 +551,85 @@ def test_bow_table_build_is_one_kernel(rel_model, E, V, L, monkeypatch):
 
 @pytest.mark.default_routing
 @pytest.mark.gpu
+@pytest.mark.parametrize("rel_model,E,V,L", [("transe", 300, 5000, 32), ("transe", 768, 3000, 64), ("distmult", 300, 700, 7),
+                                             ("transe", 768, 900, 33), ("transe", 8, 40, 4), ("transe", 100, 200, 19),
+                                             ("complex", 44, 90, 61)])
+def test_dkrl_table_build_is_one_kernel(rel_model, E, V, L, monkeypatch):
+    """models.DKRL.encode_into (what ranking.build_entity_table calls per chunk for the bert-dkrl / glove-dkrl scripts) == the
+    reference's DKRL encoder + F.normalize (models.py:158-204, 40-41) through blp_dkrl_rows -- against the stock modules in
+    FLOAT64 (the kernel must be at least as close to them as the stock float32 path is, up to a small factor) and in float32:
+    padded descriptions of every length 1 .. L, mask None, every chunk into its own rows, shard rows equal the full table's;
+    descriptions shorter than four tokens per chunk and training keep the stock modules; a bad token id raises."""
+    import copy
+    from blp_amd import models, ops, ranking
+    g = torch.Generator().manual_seed(E + L)
+    weight = torch.randn(V, E, generator=g) * 0.3
+    model = models.DKRL(128, rel_model, "margin", 5, 0, embeddings=weight).cuda()
+    with torch.no_grad():  # (biases that matter)
+        model.conv1.bias.uniform_(-0.2, 0.2, generator=None)
+        model.conv2.bias.uniform_(-0.2, 0.2, generator=None)
+    calls = []
+    real = ops.dkrl_rows
+    monkeypatch.setattr(ops, "dkrl_rows", lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1])
+
+    class Text:
+        def __init__(self, n):
+            self.tok = torch.randint(0, V, (n, L), generator=g)
+            lengths = torch.randint(1, L + 1, (n,), generator=g)
+            lengths[0] = L  # (data.TextGraphDataset cuts a chunk at its longest description)
+            self.mask = (torch.arange(L).unsqueeze(0) < lengths.unsqueeze(1)).float()
+            self.tok = self.tok * self.mask.long()  # padding token 0
+        def get_entity_description(self, ents):
+            return self.tok[ents], self.mask[ents], None
+    text = Text(53)
+    entities = torch.arange(53)
+    table = ranking.build_entity_table(model, text, entities, 16, torch.device("cuda"))
+    assert calls == [16, 16, 16, 5]
+    with torch.no_grad():
+        stock32 = model.encode(text.tok.cuda(), text.mask.cuda())
+        m64 = copy.deepcopy(model).double()
+        want = m64.encode(text.tok.cuda(), text.mask.cuda().double())
+    err_fused = (table.double() - want).abs().max().item()
+    err_stock = (stock32.double() - want).abs().max().item()
+    assert err_fused <= max(4 * err_stock, 2e-6), (err_fused, err_stock)
+    assert torch.allclose(table, stock32, rtol=2e-5, atol=2e-6)
+    if rel_model == "transe":
+        assert torch.allclose(table.norm(dim=1), torch.ones(53, device="cuda"), atol=1e-6)
+    shard = ranking.build_entity_table(model, text, entities, 16, torch.device("cuda"), rows=(20, 45))
+    assert torch.allclose(shard, table[20:45], rtol=1e-6, atol=1e-7)
+    from blp_amd import _lib
+    try:  # every way of splitting an M-tile's channel blocks over waves (the launcher picks by chunk size): the same rows
+        for split in (1, 2, 4):
+            _lib.set_knob("dkrl_split", split)
+            again = ranking.build_entity_table(model, text, entities, 53, torch.device("cuda"))
+            assert torch.allclose(again, table, rtol=1e-6, atol=1e-7), split
+    finally:
+        _lib.reset_knobs()
+    out = torch.full((4, 128), 7.0, device="cuda")                     # mask None: every token counts
+    with torch.no_grad():
+        model.encode_into(out, text.tok[:4].cuda(), None)
+        assert torch.allclose(out, model.encode(text.tok[:4].cuda(), None), rtol=2e-5, atol=2e-6)
+        n_before = len(calls)                                          # a chunk of three-token descriptions: another pooling window
+        model.encode_into(out, text.tok[:4, :3].cuda(), torch.ones(4, 3, device="cuda"))
+        assert len(calls) == n_before
+        assert torch.allclose(out, model.encode(text.tok[:4, :3].cuda(), torch.ones(4, 3, device="cuda")))
+    with torch.enable_grad():                                          # training keeps the stock modules (autograd)
+        n_before = len(calls)
+        model.encode_into(out, text.tok[:4].cuda(), text.mask[:4].cuda())
+        assert len(calls) == n_before
+    bad = text.tok[:4].clone()
+    bad[2, 0] = V
+    with torch.no_grad():
+        model.encode_into(out, bad.cuda(), text.mask[:4].cuda())
+        with pytest.raises(IndexError):
+            model.check_tokens()
+        model.check_tokens()
+        with pytest.raises(IndexError):
+            ops.dkrl_rows(bad.cuda(), text.mask[:4].cuda(), model.embeddings.weight, model.conv1, model.conv2, out, True)
+
+
+@pytest.mark.default_routing
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,block,D", [(1, 64, 128), (100, 64, 128), (128, 64, 64), (333, 50, 300), (70, 1000, 768)])
 def test_build_queries_equals_the_torch_prelude(n, block, D):
     """blp_build_queries (train.py:132-145 + utils.py:46-83 for a whole set of triples, one kernel) against the same

@@ -8,7 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from blp_amd import models  # noqa: E402
+from blp_amd import _lib, models  # noqa: E402
 
 
 def main():
@@ -23,17 +23,39 @@ def main():
         mask = (torch.arange(L)[None, :] < lens[:, None]).float().to(dev)
         with torch.no_grad():
             for _ in range(3):
-                out = m(tok, mask)
+                out = m.encode(tok, mask)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             reps = 20 if n <= 512 else 3
             for _ in range(reps):
-                out = m(tok, mask)
+                out = m.encode(tok, mask)
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / reps * 1e6
+            out2 = torch.empty(n, 128, device=dev)
+            for _ in range(3):
+                m.encode_into(out2, tok, mask)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                m.encode_into(out2, tok, mask)
+            torch.cuda.synchronize()
+            fused = (time.perf_counter() - t0) / reps * 1e6
+            err = (out2 - out).abs().max().item()
+            by_split = {}
+            for split in (1, 2, 4):  # waves per M-tile, forced (hooks build)
+                _lib.set_knob("dkrl_split", split)
+                m.encode_into(out2, tok, mask)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    m.encode_into(out2, tok, mask)
+                torch.cuda.synchronize()
+                by_split[split] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+            _lib.set_knob("dkrl_split", 0)
         flops = 2.0 * n * L * 2 * E * 128 + 2.0 * n * (L // 4) * 2 * 128 * 128
-        print(f"DKRL E={E} chunk {n} x {L}: {us:9.1f} us per chunk  ({flops / us / 1e6:6.2f} TF/s of conv arithmetic); "
-              f"FB15k-237 table (14 541 entities): {us * 14541 / n / 1e3:7.2f} ms", flush=True)
+        print(f"DKRL E={E} chunk {n} x {L}: stock {us:9.1f} us per chunk ({flops / us / 1e6:6.2f} TF/s of conv arithmetic), fused "
+              f"{fused:9.1f} us ({flops / fused / 1e6:6.2f} TF/s; {us / fused:4.1f}x; max |diff| {err:.1e}); FB15k-237 table "
+              f"(14 541 entities): {us * 14541 / n / 1e3:7.2f} -> {fused * 14541 / n / 1e3:7.2f} ms; waves per M-tile forced: {by_split}", flush=True)
 
 
 if __name__ == "__main__":
