@@ -401,6 +401,8 @@ class Job:
                             "pre-pass + exact refinement.  Every f32 product is three bf16 MFMA products (hi*hi + hi*lo + "
                             "lo*hi), so the roof is the dense bf16 MFMA peak / 3 = 833 TF (5.3x the f32 MFMA peak).",
                     "mfma_busy": None}
+        if self.table.element_size() == 2:
+            roof["arith"] += f"; the candidate table is a {self.cfg['table_dtype']} copy, every element widened to f32 (exactly) before it is used"
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["kernel_ms"] = kernel_ms
         roof["passes_per_launch"] = self.passes_per_launch()  # > 1: kernel_ms, traffic and the algorithmic figures are one pass's share
