@@ -182,3 +182,33 @@ def test_seeded_random_cases(oracle, seed):
     want = _oracle_counts(oracle, model, wide.cpu(), rel_w, ent2idx, triples, index)
     head_pos, tail_pos = _loop_positions(T, batch)
     assert np.array_equal(got[head_pos].cpu().numpy(), want[:T]) and np.array_equal(got[tail_pos].cpu().numpy(), want[T:])
+
+
+def test_integration_md_16_bit_stub_is_runnable(oracle):
+    """The second ctypes stub of INTEGRATION.md section 2 (blp_rank_all_batches_t + blp_gather_triple_vectors_t on a 16-bit copy
+    of the table), executed as printed on top of the first one: counts == the oracle's on the widened table, in the loop's
+    layout, at the reference's Wikidata5M batching (a pass per 2 triples: the ring kernels) and at a batch of 5 (a widened copy)."""
+    import os
+    import re
+    import types
+    from blp_amd import _lib, utils
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    first = re.search(r"```python\n(# blp_hip\.py.*?)```", text, flags=re.S).group(1)
+    second = re.search(r"```python\n(_L\.blp_gather_triple_vectors_t\.argtypes.*?)```", text, flags=re.S).group(1)
+    stub = types.ModuleType("blp_hip_stub16")
+    exec(first.replace('"libblp_hip.so"', repr(_lib.LIB_PATH)) + "\n" + second, stub.__dict__)
+    N, D, R, T = 70000, 128, 5, 9
+    for model, dtype, batch in (("transe", torch.float16, 2), ("complex", torch.bfloat16, 2), ("distmult", torch.float16, 5)):
+        table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=7)
+        ent16 = table.to(dtype).cuda()
+        rows = torch.stack((ent2idx[triples[:, 0]], ent2idx[triples[:, 1]], triples[:, 2]), dim=1).cuda()
+        head_pos, tail_pos = _loop_positions(T, batch)
+        rel_id = torch.empty(2 * T, dtype=torch.int64)
+        rel_id[head_pos] = rel_id[tail_pos] = triples[:, 2]
+        got = stub.rank_all_batches_16(model, ent16, rows, rel_w.cuda(), rel_id.cuda(), T, batch)
+        index = utils.FilterIndex(edges, num_relations=R)
+        want = _oracle_counts(oracle, model, ent16.float().cpu(), rel_w, ent2idx, triples, index)
+        assert np.array_equal(got[head_pos][:, :2].cpu().numpy(), want[:T, :2]), model   # (no filter handed over: raw counts)
+        assert np.array_equal(got[tail_pos][:, :2].cpu().numpy(), want[T:, :2]), model
+        assert torch.equal(got[:, 2:], got[:, :2])
