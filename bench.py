@@ -718,6 +718,13 @@ def inbatch_bench(device, iters=200):
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e6
 
+        def wall_single_thread(fn, n):
+            # the same with the engine's device threads off (torch.autograd.set_multithreading_enabled(False): backward()
+            # then runs its nodes on the calling thread -- no hand-over to the per-device worker and back, which is most of
+            # what an empty node costs; a single-GPU training loop can run that way, nn.DataParallel cannot)
+            with torch.autograd.set_multithreading_enabled(False):
+                return wall(fn, n)
+
         # raw C-ABI, back to back on the current stream
         L = _lib.lib()
         loss = torch.empty((), dtype=torch.float32, device=device)
@@ -749,6 +756,8 @@ def inbatch_bench(device, iters=200):
                                           else "Python autograd.Function + ctypes",
                      "us_per_step_autograd": wall(fused, iters), "us_forward_no_grad": wall(forward_only, iters),
                      "us_autograd_floor_no_kernels": wall(floor, iters) if ops.torch_glue() is not None else None,
+                     "us_per_step_autograd_engine_single_threaded": wall_single_thread(fused, iters),
+                     "us_autograd_floor_engine_single_threaded": wall_single_thread(floor, iters) if ops.torch_glue() is not None else None,
                      "torch_us_per_step": wall(stock, max(20, iters // 4)),
                      "pairs_per_step": B * (K + 1)}
     return out

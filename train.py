@@ -170,13 +170,19 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
     use_amp = amp is not None and device != torch.device('cpu')
     amp_dtype = torch.float16 if amp == 'fp16' else torch.bfloat16
     scaler = torch.amp.GradScaler('cuda', enabled=use_amp and amp == 'fp16')
+    single_device = device == torch.device('cpu') or torch.cuda.device_count() <= 1
     for epoch in range(1, max_epochs + 1):
         train_loss = 0
         for step, data in enumerate(train_loader):
             with torch.autocast('cuda', dtype=amp_dtype, enabled=use_amp):
                 loss = net(*data).mean()
             optimizer.zero_grad()
-            scaler.scale(loss).backward()
+            # one device: backward() runs its nodes on THIS thread (no hand-over to the engine's per-device worker and back:
+            # [measured] compute_loss(...).backward() 82 -> 30 us at the FB15k-237 batch, 62 -> 19 us of it the engine's own
+            # cost; bench.py: inbatch_loss.us_per_step_autograd_engine_single_threaded); nn.DataParallel over several devices
+            # needs the workers
+            with torch.autograd.set_multithreading_enabled(not single_device):
+                scaler.scale(loss).backward()
             scaler.step(optimizer)
             scaler.update()
             if scheduler is not None:
