@@ -414,8 +414,8 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot1
 bool rank_stream16_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
     if (q_head > kStreamQ || q_tail > kStreamQ || N <= 0 || q_head + q_tail <= 0) return false;
     if (!(D == 128 || D == 256) || ld % 8 != 0 || ld >= (1 << 22)) return false;
-    const int64_t n_rounds = ((N + kTileRows - 1) / kTileRows + kWaves - 1) / kWaves;
-    return model == TRANSE || model == DISTMULT || model == COMPLEX || model == SIMPLE ? n_rounds < (int64_t)0x7fffffff : false;
+    if (model != TRANSE && model != DISTMULT && model != COMPLEX && model != SIMPLE) return false;
+    return ((N + kTileRows - 1) / kTileRows + kWaves - 1) / kWaves < (int64_t)0x7fffffff;  // (the kernels' 32-bit round index)
 }
 bool rank_stream16_takes_passes(int model, int D, int64_t N, int64_t ld, int64_t batch, int64_t n) {
     if (!rank_stream16_applicable(model, D, N, ld, batch, batch)) return false;
