@@ -31,8 +31,13 @@ __device__ __forceinline__ void piece_fetch(f32x4 (&b)[8], const void* __restric
     constexpr int kPieceStep = kSubCols * 4;
 #endif
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
+#ifdef BLP_STREAM_PLAIN_LOADS  // experiment (tools/step_ab.py, tools/table16_probe.py): cacheable loads -- does a table that fits the Infinity Cache stay there between passes?
+        b[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff[i] + s * kPieceStep);
+#else
         b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff[i] + s * kPieceStep));
+#endif
+    }
 }
 
 // MANY PASSES IN ONE LAUNCH (StreamPasses, rank_common.h; the reference's Wikidata5M evaluation is a pass per two triples).

@@ -7,7 +7,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from blp_amd import ops  # noqa: E402
+from blp_amd import _lib, ops  # noqa: E402
+if os.environ.get("BLP_PROBE_LIB"):  # a variant build of the library (blp_amd.build.build(variant=...))
+    _lib.LIB_PATH = os.path.abspath(os.environ["BLP_PROBE_LIB"])
 
 
 def main():
