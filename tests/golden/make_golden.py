@@ -10,7 +10,7 @@ suite, smoke() or bench.py reads /root/reference at run time.
 only inside this script so that ``import data`` / ``import train`` succeed.  The functions whose
 outputs we record (models.*_score, LinkPrediction.compute_loss, utils.get_metrics,
 utils.get_triple_filters, utils.make_ent2idx, data.get_negative_sampling_indices,
-train.eval_link_prediction) are the reference's own, unmodified.
+train.eval_link_prediction, models.BOW / models.DKRL `encode`) are the reference's own, unmodified.
 """
 import logging
 import os
@@ -308,6 +308,41 @@ def gen_filters_and_eval():
              eval_batch_size=np.int64(8), emb_batch_size=np.int64(16))
 
 
+def gen_encoders():
+    """The description encoders whose table build is fused on the GPU (models.BOW: models.py:140-155; models.DKRL:
+    models.py:158-204), through the reference's own `encode` (F.normalize for TransE, models.py:38-43): padded descriptions of
+    every length, two chunk lengths (one M-tile of 32 positions; two)."""
+    for L in (9, 37):
+        gen = torch.Generator().manual_seed(_seed("encoders", L))
+        vocab, E, n, dim = 40, 20, 14, 128
+        word_emb = torch.randn(vocab, E, generator=gen) * 0.3
+        emb_file = os.path.join(tempfile.mkdtemp(), "emb.pt")
+        torch.save(word_emb, emb_file)
+        lengths = torch.randint(1, L + 1, (n,), generator=gen)
+        lengths[0] = L
+        tok = torch.randint(1, vocab, (n, L), generator=gen)
+        mask = (torch.arange(L).unsqueeze(0) < lengths.unsqueeze(1)).float()
+        tok = tok * mask.long()
+        out = {}
+        for rel_model in ("transe", "distmult"):
+            torch.manual_seed(_seed("dkrl", rel_model, L))
+            dkrl = models.DKRL(dim, rel_model, "margin", 3, 0.0, embeddings=emb_file)
+            with torch.no_grad():
+                dkrl.conv1.bias.uniform_(-0.2, 0.2)
+                dkrl.conv2.bias.uniform_(-0.2, 0.2)
+                out[f"dkrl_{rel_model}"] = dkrl.encode(tok, mask)
+                if rel_model == "transe":
+                    out.update(conv1_w=dkrl.conv1.weight.detach(), conv1_b=dkrl.conv1.bias.detach(),
+                               conv2_w=dkrl.conv2.weight.detach(), conv2_b=dkrl.conv2.bias.detach())
+                else:  # the same weights: only the normalisation differs
+                    dkrl.load_state_dict({**dkrl.state_dict(), "conv1.weight": out["conv1_w"], "conv1.bias": out["conv1_b"],
+                                          "conv2.weight": out["conv2_w"], "conv2.bias": out["conv2_b"]})
+                    out[f"dkrl_{rel_model}"] = dkrl.encode(tok, mask)
+                bow = models.BOW(rel_model, "margin", 3, 0.0, embeddings=emb_file)
+                out[f"bow_{rel_model}"] = bow.encode(tok, mask)
+        save(f"encoders_L{L}", word_emb=word_emb, tok=tok, mask=mask, **out)
+
+
 def main():
     torch.set_num_threads(1)
     logging.basicConfig(level=logging.WARNING)
@@ -317,6 +352,7 @@ def main():
     gen_loss()
     gen_neg_sampling()
     gen_filters_and_eval()
+    gen_encoders()
 
 
 if __name__ == "__main__":

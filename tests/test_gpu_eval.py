@@ -635,6 +635,36 @@ def test_dkrl_table_build_is_one_kernel(rel_model, E, V, L, monkeypatch):
 
 @pytest.mark.default_routing
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["encoders_L9", "encoders_L37"])
+def test_fused_table_builds_reproduce_the_reference_encoders(name, monkeypatch):
+    """blp_bow_rows / blp_dkrl_rows (the table build of the bag-of-words and DKRL encoders as one kernel each) against the
+    outputs of the REFERENCE's own encoders on the same weights, tokens and masks (tests/golden/encoders_*.npz, generated by
+    importing models.BOW / models.DKRL: models.py:140-204; F.normalize for TransE, models.py:38-43): within 2e-6 absolute of values of
+    magnitude <= 1 (floating point: the reduction orders are the kernels' own)."""
+    from conftest import golden
+    from blp_amd import ops
+    from test_host_golden import _golden_encoders
+    g = golden(name)
+    tok, mask = torch.from_numpy(g["tok"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    used = []
+    real_bow, real_dkrl = ops.bow_rows, ops.dkrl_rows
+    monkeypatch.setattr(ops, "bow_rows", lambda *a, **k: (used.append("bow"), real_bow(*a, **k))[1])
+    monkeypatch.setattr(ops, "dkrl_rows", lambda *a, **k: (used.append("dkrl"), real_dkrl(*a, **k))[1])
+    for rel_model in ("transe", "distmult"):
+        dkrl, bow = _golden_encoders(g, rel_model, "cuda")
+        with torch.no_grad():
+            out = torch.empty(tok.shape[0], 128, device="cuda")
+            dkrl.encode_into(out, tok, mask)
+            assert torch.allclose(out.cpu(), torch.from_numpy(g[f"dkrl_{rel_model}"]), rtol=1e-5, atol=2e-6), rel_model
+            out = torch.empty(tok.shape[0], g["word_emb"].shape[1], device="cuda")
+            bow.encode_into(out, tok, mask)
+            assert torch.allclose(out.cpu(), torch.from_numpy(g[f"bow_{rel_model}"]), rtol=1e-5, atol=2e-6), rel_model
+        dkrl.check_tokens(); bow.check_tokens()
+    assert used == ["dkrl", "bow", "dkrl", "bow"]
+
+
+@pytest.mark.default_routing
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,block,D", [(1, 64, 128), (100, 64, 128), (128, 64, 64), (333, 50, 300), (70, 1000, 768)])
 def test_build_queries_equals_the_torch_prelude(n, block, D):
     """blp_build_queries (train.py:132-145 + utils.py:46-83 for a whole set of triples, one kernel) against the same

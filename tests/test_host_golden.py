@@ -328,3 +328,27 @@ def test_sacred_shim_cli_semantics():
         ex.run_commandline(["train.py", "link_prediction", "with", "nope=1"])
     with pytest.raises(KeyError):
         ex.run_commandline(["train.py", "rerank"])
+
+
+def _golden_encoders(g, rel_model, device="cpu"):
+    word_emb = torch.from_numpy(g["word_emb"]).clone()
+    dkrl = models.DKRL(128, rel_model, "margin", 3, 0.0, embeddings=word_emb.clone())
+    with torch.no_grad():
+        dkrl.conv1.weight.copy_(torch.from_numpy(g["conv1_w"])); dkrl.conv1.bias.copy_(torch.from_numpy(g["conv1_b"]))
+        dkrl.conv2.weight.copy_(torch.from_numpy(g["conv2_w"])); dkrl.conv2.bias.copy_(torch.from_numpy(g["conv2_b"]))
+    bow = models.BOW(rel_model, "margin", 3, 0.0, embeddings=word_emb.clone())
+    return dkrl.to(device), bow.to(device)
+
+
+@pytest.mark.parametrize("name", golden_names("encoders_"))
+def test_description_encoders_reproduce_the_reference(name):
+    """models.BOW / models.DKRL `encode` (the stock-module expressions a CPU model and every training step run; the fused
+    table-build kernels are held against the same fixtures on the GPU) == the reference's encoders on the same weights, tokens
+    and masks (models.py:140-204, normalised for TransE: models.py:38-43)."""
+    g = golden(name)
+    tok, mask = torch.from_numpy(g["tok"]), torch.from_numpy(g["mask"])
+    for rel_model in ("transe", "distmult"):
+        dkrl, bow = _golden_encoders(g, rel_model)
+        with torch.no_grad():
+            assert torch.allclose(dkrl.encode(tok, mask), torch.from_numpy(g[f"dkrl_{rel_model}"]), rtol=1e-6, atol=1e-7)
+            assert torch.allclose(bow.encode(tok, mask), torch.from_numpy(g[f"bow_{rel_model}"]), rtol=1e-6, atol=1e-7)
