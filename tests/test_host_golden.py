@@ -352,3 +352,20 @@ def test_description_encoders_reproduce_the_reference(name):
         with torch.no_grad():
             assert torch.allclose(dkrl.encode(tok, mask), torch.from_numpy(g[f"dkrl_{rel_model}"]), rtol=1e-6, atol=1e-7)
             assert torch.allclose(bow.encode(tok, mask), torch.from_numpy(g[f"bow_{rel_model}"]), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_rank_triples_widens_a_16_bit_table_on_the_dense_routes(dtype):
+    """A 16-bit copy of the table on a CPU tensor (the reference's dense route, no HIP library): ranked as the table widened to
+    float32 -- the rule the 16-bit entry of the library follows on the GPU (blp_rank_all_batches_t; tests/test_gpu_table16.py)."""
+    g = torch.Generator().manual_seed(4)
+    N, D, T, R = 90, 16, 23, 3
+    table = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=-1).to(dtype)
+    model = models.LinkPrediction(D, "transe", "margin", R, 0)
+    triples = torch.stack((torch.randint(0, N, (T,), generator=g), torch.randint(0, N, (T,), generator=g),
+                           torch.randint(0, R, (T,), generator=g)), dim=1)
+    ent2idx = torch.arange(N)
+    index = utils.FilterIndex(torch.cat((triples, triples.flip(0)[:, [1, 0, 2]])), num_relations=R)
+    _, got, _ = ranking.rank_triples(model, table, triples, ent2idx, index, block_size=8)
+    _, want, _ = ranking.rank_triples(model, table.float(), triples, ent2idx, index, block_size=8)
+    assert torch.equal(got, want)
