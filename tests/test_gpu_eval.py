@@ -430,6 +430,34 @@ def test_link_prediction_cli_on_gpu(tmp_path, amp):
 
 
 @pytest.mark.default_routing
+def test_link_prediction_cli_on_gpu_with_the_dkrl_encoder(tmp_path):
+    """python train.py link_prediction with model=glove-dkrl (scripts/glove-dkrl-*.sh: the CNN description encoder, dim 128):
+    training through the stock modules + the fused in-batch loss, every evaluation's entity table through blp_dkrl_rows, the
+    ranking at D = 128; metrics logged, normalised embeddings saved."""
+    import os
+    import subprocess
+    import sys
+    from blp_amd.data import write_synthetic_dataset
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    write_synthetic_dataset(str(tmp_path / "data"), "umls-synth", num_entities=135, num_relations=46,
+                            num_train=1280, num_valid=160, num_test=160, vocab_size=500, emb_dim=300, seed=0)
+    cmd = [sys.executable, os.path.join(root, "train.py"), "link_prediction", "with", "dataset=umls-synth",
+           "inductive=False", "model=glove-dkrl", "dim=128", "rel_model=transe", "loss_fn=margin", "regularizer=1e-3",
+           "max_len=32", "num_negatives=16", "lr=1e-4", "use_scheduler=False", "batch_size=64",
+           "emb_batch_size=512", "eval_batch_size=128", "max_epochs=1", f"data_root={tmp_path / 'data'}", "seed=1"]
+    proc = subprocess.run(cmd, cwd=tmp_path, env=dict(os.environ, PYTHONPATH=root), capture_output=True,
+                          text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    log = proc.stderr + proc.stdout
+    for needle in ("valid mrr:", "test mrr:", "mrr_filt:", "hits@10_filt:"):
+        assert needle in log, needle
+    assert "Training on CPU" not in log
+    ent_emb = torch.load(tmp_path / "output" / "ent_emb-None.pt")
+    assert ent_emb.shape == (1, 135, 128)
+    assert torch.allclose(ent_emb[0].float().norm(dim=-1).cpu(), torch.ones(135), atol=1e-3)
+
+
+@pytest.mark.default_routing
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,E,D", [(1, 32, 64), (63, 768, 128), (200, 768, 128), (130, 100, 256), (517, 1024, 64)])
 @pytest.mark.parametrize("normalize", [False, True])
