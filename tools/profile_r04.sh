@@ -4,7 +4,7 @@
 # kernels, and the small logs (reference-batched passes, shard model, loop layouts).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out/r
-export WORKLOADS="fb15k237-transe fb15k237-distmult fb15k237-complex fb15k237-simple fb15k237-transe-d768 wikidata5m-transe wikidata5m-complex wikidata5m-transe-block wikidata5m-complex-block wikidata5m-protocol"
+export WORKLOADS="fb15k237-transe fb15k237-distmult fb15k237-complex fb15k237-simple fb15k237-transe-d768 wikidata5m-transe wikidata5m-complex wikidata5m-transe-f16 wikidata5m-complex-f16 wikidata5m-transe-block wikidata5m-complex-block wikidata5m-protocol"
 bash tools/profile_all.sh > gpurun_out/r/profile_all.log 2>&1
 python bench.py --steps 20 --warmup 5 2> gpurun_out/r/bench_default.stderr | tail -1 > gpurun_out/r/bench_default.json
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/sad tools/sad_ubench.hip > gpurun_out/r/sad_ubench.log 2>&1 && /tmp/sad >> gpurun_out/r/sad_ubench.log 2>&1
