@@ -75,6 +75,11 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 F32_PEAK_TFLOPS = 157.3         # f32 vector (FMA) peak == f32 MFMA peak; plain add/sub ops reach half
 BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md); the bilinear pre-pass spends 3 bf16
 BF16X3_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3   # products per f32-equivalent product, so its roof is a third of it
+# The TransE pre-pass issues v_sad_u16 (2 elements x (subtract + |.|-accumulate) per lane and instruction).  Measured issue rate
+# with 4 waves per SIMD (tools/sad_ubench.hip -> profiles/r04/sad_ubench.log): 4.23 - 4.48 cycles per instruction and SIMD, not
+# the 4 a quarter-rate instruction would take -> 2 x 2 x 64 lanes x 1024 SIMDs x 2.4 GHz / 4.3 = 146.3 Tops/s.
+SAD_CYCLES_PER_INST = 4.3
+SAD_PEAK_TOPS = 2 * 2 * 64 * 1024 * 2.4e9 / SAD_CYCLES_PER_INST / 1e12
 
 WORKLOADS = {
     "fb15k237-transe": dict(model="transe", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
@@ -355,7 +360,7 @@ class Job:
         alg_bytes = n_local * D * self.table.element_size() + Q * (2 * D * 4 + 24)
         t_k = kernel_ms * 1e-3
         transe = model == "transe"
-        peak_tf = F32_PEAK_TFLOPS if transe else BF16X3_PEAK_TFLOPS
+        peak_tf = SAD_PEAK_TOPS if transe else BF16X3_PEAK_TFLOPS
         if alg_bytes / (HBM_PEAK_GBPS * 1e9) >= alg_flops / (peak_tf * 1e12):
             ppl = self.passes_per_launch()
             ring = ppl > 1 or (not transe and (model == "complex" or n_local < 1_700_000)) or (transe and n_local < 1_700_000)
@@ -371,18 +376,18 @@ class Job:
                               "rank_stream_wg_kernel (exact f32 keys; the table streamed once through workgroup tiles, two tiles in flight per workgroup)"}
         elif transe:
             wide = D not in (64, 128, 256)
-            roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+            roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": SAD_PEAK_TOPS, "unit": "TFLOP/s",
                     "arith": "u16 fixed-point v_sad_u16 pre-pass (decides >= 99.5 % of the pairs within a proven band) + exact f32 "
                              "re-scoring of the rest in the reference's order; NOT the reference's f32 lane-ops",
                     "peak_source": "builder-measured v_sad_u16 issue rate, tools/sad_ubench.hip -> profiles/r04/sad_ubench.log "
-                                   "(4 cycles per instruction and SIMD: 2 elements x 2 ops x 64 lanes x 1024 SIMDs x 2.4 GHz / 4 = "
-                                   "157.3 Tops/s); numerically equal to the guide's f32 vector-FMA peak, not taken from it",
+                                   "(4.23 - 4.48 cycles per instruction and SIMD at 4 waves/SIMD, taken as 4.3: 2 elements x 2 ops x "
+                                   "64 lanes x 1024 SIMDs x 2.4 GHz / 4.3 = 146.3 Tops/s); the guide has no figure for this instruction",
                     "kernel": ("wide_rank_sad_kernel + wide_refine_* (any-width u16 v_sad_u16 pre-pass)" if wide else
                                "rank_sad_kernel<128> + sad_refine_* (u16 fixed-point v_sad_u16 pre-pass + band + exact f32 "
                                "refinement; range / quantise kernels included)"),
-                    "note": "VALU roof (an L1 norm has no matrix-core form): 157.3 Tops/s is the f32 vector-FMA peak and "
-                            "also what v_sad_u16 delivers at 4 cycles/instruction (2 elements x (subtract + |.|-accumulate) "
-                            "x 64 lanes); the exact f32 add/sub kernel tops out at half of it.  achieved = 2 ops x D x Q x N "
+                    "note": "VALU roof (an L1 norm has no matrix-core form): 146.3 Tops/s is what v_sad_u16 delivers at its "
+                            "measured 4.3 cycles/instruction (2 elements x (subtract + |.|-accumulate) x 64 lanes; 157.3 at a "
+                            "nominal 4); the exact f32 add/sub kernel tops out at half of that.  achieved = 2 ops x D x Q x N "
                             "/ time of the whole rank pass.  SURVEY 8(d)'s own accounting for the reference's f32 arithmetic "
                             "-- N x Q x D x c lane-ops, c = 3 on the head side (add r, subtract t, |.|-accumulate) and 2 on the "
                             "tail side, against the 78.6 T/s non-FMA f32 lane-op rate -- is in `survey_8d_lane_ops`: a frac "
@@ -912,6 +917,116 @@ def table_build_bench(device):
     return out
 
 
+LINE_LIMIT = 6000               # bytes of the final stdout line (the driver's reader lost round 4's 26 KB line)
+DETAILS_FILE = "bench_details.json"
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant figures (the compact line); everything else as it is."""
+    if isinstance(x, float) and x == x and x not in (float("inf"), float("-inf")):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _short(text, n):
+    return text if text is None or len(text) <= n else text[:n - 1] + "\u2026"
+
+
+def compact_roofline(roof):
+    """The roofline object of the contract (bound / achieved / peak / unit / frac / traffic) + the kernel's name and time;
+    the prose (`note`, `peak_source`, the long `arith`) stays in the details file."""
+    if not roof:
+        return roof
+    out = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "passes_per_launch",
+                                     "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch")}
+    out["kernel"] = _short(roof.get("kernel"), 72)
+    if roof.get("mfma_busy") is not None:
+        out["mfma_busy"] = roof["mfma_busy"]
+    if "survey_8d_lane_ops" in roof:
+        out["survey_8d_lane_ops_frac"] = roof["survey_8d_lane_ops"]["frac"]
+    out["pmc_source"] = _short(roof.get("pmc_source"), 96)
+    return out
+
+
+def compact_sub(sub, world):
+    roof = sub.get("roofline") or {}
+    out = {"value": sub.get("value"), "ms_per_step": sub.get("ms_per_step"), "frac": roof.get("frac"), "bound": roof.get("bound"),
+           "kernel_ms": roof.get("kernel_ms")}
+    if "decided_frac" in sub:
+        out["decided_frac"] = sub["decided_frac"]
+    if "vs_random_step" in sub:
+        out["vs_random_step"] = sub["vs_random_step"]
+    if world > 1:
+        out["exchange_ms"], out["axis"] = sub.get("exchange_ms"), sub.get("shard_axis")
+    parity = sub.get("parity_check")
+    if parity and not parity.startswith("skipped"):
+        out["parity"] = "ok" if parity.endswith("identical counts") else "MISMATCH"
+    return out
+
+
+def compact_result(result, limit=LINE_LIMIT):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline`, `parity_check` and a few numbers per sub-result,
+    under `limit` bytes for every N.  Everything else (per-rank lists, prose notes, the baselines' legs, table-build and
+    call-overhead figures) is in DETAILS_FILE, which this line names.  If the line would still be too long, optional
+    sections go, least important first; the contract's keys never do."""
+    world = result.get("n_gpus", 1)
+    line = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data") if k in result}
+    line["arith"] = _short(result.get("arith"), 120)
+    cfg = dict(result.get("config", {}))
+    cfg.pop("step", None)
+    line["config"] = cfg
+    for k in ("ms_per_step_raw_only", "mrr", "mrr_filtered", "hits@1,3,10", "hits@1,3,10_filtered", "exchange_ms", "parity_check"):
+        if k in result:
+            line[k] = result[k]
+    line["roofline"] = compact_roofline(result.get("roofline"))
+    cpu = result.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": _short(cpu["kind"], 40),
+                                "sample": _short(cpu["sample"], 110), "cpu_model": cpu.get("cpu_model"),
+                                "logical_cpus": cpu.get("logical_cpus"), "c_oracle_value": (cpu.get("c_oracle") or {}).get("value")}
+    tg = result.get("torch_gpu_baseline")
+    if tg:
+        line["torch_gpu_baseline_value"] = tg["value"]
+    if "sub_results" in result:
+        line["sub_results"] = {name: compact_sub(sub, world) for name, sub in result["sub_results"].items()}
+    if "inbatch_loss" in result:
+        line["inbatch_loss"] = {name: {k: v.get(k) for k in ("us_per_step_kernels", "us_per_step_autograd", "torch_us_per_step")}
+                                for name, v in result["inbatch_loss"].items()}
+    if "hbm_probe" in result:
+        line["hbm_probe"] = {k: result["hbm_probe"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms", "traffic")}
+    if "call_overhead" in result:
+        line["call_overhead"] = {k: result["call_overhead"].get(k) for k in ("library_call_us", "rank_all_128_queries_fb15k237_us")}
+    line["details"] = result.get("details")
+    line = _sig(line)
+    line["value"], line["ms_per_step"] = result["value"], result["ms_per_step"]  # (full precision: value == units / time, to the bit)
+    for drop in ("call_overhead", "torch_gpu_baseline_value", "inbatch_loss", "hbm_probe", "hits@1,3,10", "hits@1,3,10_filtered"):
+        if len(json.dumps(line)) <= limit:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) > limit and "sub_results" in line:  # (many sharded sub-results: two numbers each)
+        line["sub_results"] = {k: {"value": v["value"], "frac": v["frac"]} for k, v in line["sub_results"].items()}
+    if len(json.dumps(line)) > limit:
+        line.pop("sub_results", None)
+    return line
+
+
+def write_details(result, path):
+    """The full object (what round 4 printed as one 26 KB line), indented, next to bench.py -- or where --details says."""
+    try:
+        with open(path, "w") as f:
+            json.dump(result, f, indent=1)
+            f.write("\n")
+        return path
+    except OSError as exc:  # (a read-only tree: the compact line must still be printed)
+        print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -921,6 +1036,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--no-sub-results", action="store_true")
+    ap.add_argument("--details", default=os.path.join(ROOT, DETAILS_FILE),
+                    help="where rank 0 writes the FULL result object (the stdout line is its compact form, < 6 KB)")
     ap.add_argument("--shard-axis", default="auto", choices=["auto", "candidate", "query"],
                     help="N > 1: which axis to shard (default: blp_amd.ranking.choose_shard_axis; the Wikidata5M-scale "
                          "table always along the candidate axis)")
@@ -1013,7 +1130,9 @@ def main():
         if rank == 0:  # one GPU's HBM-bound operating point (the other ranks wait at the barrier below)
             result["hbm_probe"] = hbm_probe(device, events)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        written = write_details(result, args.details)
+        result["details"] = os.path.relpath(written, ROOT) if written else None
+        print(json.dumps(compact_result(result)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

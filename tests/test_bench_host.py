@@ -51,3 +51,81 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=120, cwd=ROOT, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "does not match --gpus" in bad.stderr
+
+
+def _fabricated_result(world):
+    """A full bench result with every section at its longest: all sub-results with their prose, per-rank lists of `world` ranks."""
+    import bench
+    roof = {"bound": "valu", "achieved": 128.5, "peak": bench.SAD_PEAK_TOPS, "unit": "TFLOP/s", "arith": "a" * 200, "peak_source": "p" * 300,
+            "kernel": "k" * 150, "note": "n" * 800, "survey_8d_lane_ops": {"lane_ops_per_launch": 4.9e11, "achieved_Tops": 160.6, "peak_Tops": 78.65, "frac": 2.04},
+            "frac": 0.8785, "kernel_ms": 3.0626399, "passes_per_launch": 1, "traffic": 317288448.0, "pmc_source": "s" * 140,
+            "algorithmic_bytes_per_launch": 118260512, "algorithmic_flops_per_launch": 393616727040.0, "mfma_busy": 0.4971234}
+    sub = {"value": 54206474300.589836, "ms_per_step": 1170.05949599843, "ms_per_step_raw_only": 1166.325209022034, "mrr": 4.377748104640011e-06,
+           "mrr_filtered": 4.377748104640011e-06, "hits@1,3,10": [0.0, 0.0, 0.0], "hits@1,3,10_filtered": [0.0, 0.0, 0.0], "roofline": roof,
+           "steps": 2, "timed_runs": 1, "unit": "scored triples/s", "parity_check": "64 queries vs CPU oracle (raw + filtered): identical counts",
+           "table_passes_per_step": 3447, "ms_per_table_pass": 0.3394428476931912, "kernel_ms_per_rank": [0.123456789] * world,
+           "exchange_ms": 1.23456789, "exchange_ms_per_rank": [1.23456789] * world, "shard_axis": "candidate", "ranks": world,
+           "decided_frac": 0.87654321, "vs_random_step": 2.3456789}
+    names = list(bench.SUB_RESULTS) + ([f"{n}@{a}" for n, a in bench.SUB_RESULTS_EXTRA_SHARDED] if world > 1 else [])
+    result = {"metric": "scored triples/sec, all-entity eval (raw + filtered ranks, MRR + Hits@k)", "value": 489012345678.9012, "unit": "scored triples/s",
+              "n_gpus": world, "steps": 10, "warmup": 2, "ms_per_step": 3.1443210987, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+              "dtype": "f32", "arith": roof["arith"], "data": "d" * 104,
+              "config": {"workload": "fb15k237-transe", "rel_model": "transe", "entities": 14541, "dim": 128, "queries_per_step": 105740,
+                         "triples_per_ranking_call": 52870, "filter_graph_edges": 310116, "step": "s" * 120, "parallelism": f"query-axis shards x{world}",
+                         "shard_axis": "query", "ranks_in_process_group": world, "backend": "nccl"},
+              "ms_per_step_raw_only": 3.0123456, "mrr": 0.000675208123, "mrr_filtered": 0.000675211123, "hits@1,3,10": [1.89143e-05] * 3,
+              "hits@1,3,10_filtered": [1.89143e-05] * 3, "roofline": roof, "kernel_ms_per_rank": [2.9] * world, "exchange_ms": 0.5,
+              "exchange_ms_per_rank": [0.5] * world, "shard_axis": "query", "ranks": world,
+              "parity_check": "64 queries vs CPU oracle (raw + filtered): identical counts",
+              "cpu_baseline": {"value": 3452465.3194224145, "unit": "scored triples/s", "cores": 1, "c_oracle": {"value": 20975265.59, "kind": "c" * 150, "sample": "x" * 50},
+                               "kind": "port, vectorised filter (" + "k" * 90, "value_by_threads": {"1": 3.4e6, "8": 2.5e6, "32": 3.1e6, "128": 1.5e6},
+                               "value_1_thread": 3.4e6, "cpu_model": "AMD EPYC 9575F 64-Core Processor", "logical_cpus": 256, "sample": "s" * 200},
+              "torch_gpu_baseline": {"value": 1.2e10, "unit": "scored triples/s", "kind": "k" * 90, "sample": "s" * 50},
+              "sub_results": {n: dict(sub) for n in names},
+              "inbatch_loss": {n: {"us_per_step_kernels": 22.123456, "us_per_step_autograd": 81.54321, "torch_us_per_step": 2959.36, "other": "o" * 300}
+                               for n in bench.INBATCH_SHAPES},
+              "call_overhead": {"ops_rank_all_us": 15.1, "library_call_us": 10.9519, "python_wrapper_us": 4.2, "rank_all_128_queries_fb15k237_us": 27.6805},
+              "table_build": {"t" * 70: {"stock_us": 1.0, "fused_us": 0.5}},
+              "hbm_probe": {"workload": "w" * 80, "bound": "hbm", "achieved": 6756.49, "peak": 8000.0, "unit": "GB/s", "frac": 0.844562, "kernel_ms": 0.348584,
+                            "whole_call_ms": 0.36, "scored_triples_per_s": 5.1e10, "traffic": 2353090000.0, "pmc_source": "p" * 140},
+              "details": "bench_details.json"}
+    return result
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_stdout_line_stays_under_the_drivers_limit(world):
+    """Round 4's single JSON line was 26 KB and the driver's reader lost it (BENCH_r04.parsed null).  The stdout line is now
+    bench.compact_result(full): under 6 KB for every N, the contract's keys intact, `roofline` with bound / achieved / peak /
+    unit / frac / traffic, `cpu_baseline` with value / unit / cores / kind / sample, each sub-result by value, ms_per_step and
+    roofline fraction; the full object goes to the file the line names."""
+    import json
+    import bench
+    full = _fabricated_result(world)
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_result(full)
+    text = json.dumps(line)
+    assert len(text) < 6144, len(text)
+    assert json.loads(text) == line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "parity_check", "sub_results", "details"):
+        assert key in line, key
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["n_gpus"] == world
+    assert line["config"]["workload"] == "fb15k237-transe" and "step" not in line["config"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"} and "note" not in line["roofline"]
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert set(line["sub_results"]) == set(full["sub_results"])
+    for sub in line["sub_results"].values():
+        assert sub["value"] > 0 and sub["frac"] > 0
+        assert ("exchange_ms" in sub) == (world > 1)
+    # a limit that cannot hold the optional sections: they go, the contract's keys stay
+    small = bench.compact_result(full, limit=2500)
+    assert len(json.dumps(small)) <= 2500 and "roofline" in small and "cpu_baseline" in small and small["value"] == full["value"]
+
+
+def test_details_file_holds_the_full_result(tmp_path):
+    import json
+    import bench
+    full = _fabricated_result(1)
+    path = bench.write_details(full, str(tmp_path / "d.json"))
+    assert json.load(open(path)) == full
+    assert bench.write_details(full, str(tmp_path / "no" / "such" / "dir" / "d.json")) is None  # the line is still printed

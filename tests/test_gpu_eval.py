@@ -151,7 +151,7 @@ def test_rank_all_replays_from_a_captured_graph(rel_model, q, oracle):
 
 @pytest.mark.default_routing
 @pytest.mark.parametrize("axis", ["candidate", "query"])
-def test_bench_two_ranks_share_one_gpu_functional(axis):
+def test_bench_two_ranks_share_one_gpu_functional(axis, tmp_path):
     """bench.py's N > 1 paths run as 2 ranks on this one GPU with the gloo backend.  Candidate shards:
     replicated true-entity vectors, count exchange + sum.  Query shards: each rank ranks its slice of
     the triples against the whole table, metric sums are all-reduced.  Either way the MRR / Hits must
@@ -163,17 +163,18 @@ def test_bench_two_ranks_share_one_gpu_functional(axis):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--steps", "1", "--warmup", "0", "--workload", "fb15k237-transe", "--no-cpu-baseline", "--no-hbm-probe",
               "--no-sub-results"]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True,
-                         timeout=600, cwd=root)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--details", str(tmp_path / "one.json")],
+                         capture_output=True, text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     env = dict(os.environ, BLP_BENCH_BACKEND="gloo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--shard-axis", axis, *common],
+                          "--gpus", "2", "--shard-axis", axis, *common, "--details", str(tmp_path / "two.json")],
                          capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
-    a = json.loads(one.stdout.strip().splitlines()[-1])
-    b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    line = [l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1]
+    assert len(line) < 6144 and json.loads(line)["n_gpus"] == 2 and json.loads(line)["config"]["ranks_in_process_group"] == 2
+    a, b = json.load(open(tmp_path / "one.json")), json.load(open(tmp_path / "two.json"))  # (the full objects behind the two lines)
     assert b["n_gpus"] == 2 and a["n_gpus"] == 1
     assert b["config"]["parallelism"] == f"{axis}-axis shards x2"
     assert b["config"]["ranks_in_process_group"] == 2 and len(b["kernel_ms_per_rank"]) == 2
@@ -184,7 +185,7 @@ def test_bench_two_ranks_share_one_gpu_functional(axis):
 
 
 @pytest.mark.default_routing
-def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
+def test_bench_default_two_rank_line_reports_the_candidate_axis_too(tmp_path):
     """The line the driver gets from `python bench.py --gpus N` with its defaults, started WITHOUT a launcher (round 3's
     bench.py exited asking for torch.distributed.run): here N = 2 over gloo on this one GPU.  bench.py starts its own two
     ranks; ONE JSON line comes back; the FB15k-237 evaluation runs on the query axis and everything at Wikidata5M scale on
@@ -198,12 +199,18 @@ def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
     env = dict(os.environ, BLP_BENCH_BACKEND="gloo")
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(key, None)
-    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=2400, cwd=root, env=env)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--details", str(tmp_path / "two.json")], capture_output=True, text=True, timeout=2400, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    b = json.loads(lines[0])
+    # the line the driver reads: compact (< 6 KB with every sharded sub-result), exchange_ms and the axis per sub-result kept
+    assert len(lines[0]) < 6144, len(lines[0])
+    compact = json.loads(lines[0])
+    assert compact["n_gpus"] == 2 and compact["config"]["ranks_in_process_group"] == 2 and compact["exchange_ms"] > 0
+    assert all(sub["exchange_ms"] > 0 and sub["axis"] in ("candidate", "query") for sub in compact["sub_results"].values())
+    b = json.load(open(tmp_path / "two.json"))  # the full object
+    assert set(compact["sub_results"]) == set(b["sub_results"]) and compact["value"] == b["value"]
     assert b["n_gpus"] == 2 and b["config"]["shard_axis"] == "query" and b["parity_check"].endswith("identical counts")
     assert b["config"]["ranks_in_process_group"] == 2 and b["config"]["backend"] == "gloo"
     assert b["shard_axis"] == "query" and len(b["exchange_ms_per_rank"]) == 2 and b["exchange_ms"] > 0
@@ -222,24 +229,24 @@ def test_bench_default_two_rank_line_reports_the_candidate_axis_too():
     for name in ("wikidata5m-transe-block", "wikidata5m-transe"):
         sub = b["sub_results"][name]
         one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload",
-                              name, "--no-cpu-baseline", "--no-hbm-probe", "--no-sub-results"],
+                              name, "--no-cpu-baseline", "--no-hbm-probe", "--no-sub-results", "--details", str(tmp_path / "one.json")],
                              capture_output=True, text=True, timeout=900, cwd=root, env=env)
         assert one.returncode == 0, one.stderr[-2000:]
-        a = json.loads(one.stdout.strip().splitlines()[-1])
+        a = json.load(open(tmp_path / "one.json"))
         assert abs(a["mrr"] - sub["mrr"]) < 1e-15 and abs(a["mrr_filtered"] - sub["mrr_filtered"]) < 1e-15, name
         assert a["hits@1,3,10"] == pytest.approx(sub["hits@1,3,10"], abs=1e-15), name
     # a rank that dies takes the launcher's status with it: no line, non-zero exit (RCCL ranks on a box with fewer GPUs
     # than ranks: the rank without a device of its own gives up before the rendezvous)
     if torch.cuda.device_count() == 1:
         dead = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-sub-results",
-                               "--no-hbm-probe"], capture_output=True, text=True, timeout=600, cwd=root,
+                               "--no-hbm-probe", "--details", str(tmp_path / "dead.json")], capture_output=True, text=True, timeout=600, cwd=root,
                               env=dict(env, BLP_BENCH_BACKEND="nccl"))
         assert dead.returncode != 0 and not [l for l in dead.stdout.splitlines() if l.startswith("{")]
         assert "has no device 1" in dead.stderr
 
 
 @pytest.mark.default_routing
-def test_bench_line_keeps_the_contract():
+def test_bench_line_keeps_the_contract(tmp_path):
     """`python bench.py` with its defaults: ONE JSON line on stdout with the driver's keys; the step is the whole
     evaluation (raw + filtered), with the raw-only time beside it; the roofline of the dominant kernel; the CPU
     baseline on all threads and on one, with the CPU model; driver-timed sub-results for the bilinear configs and the
@@ -249,16 +256,30 @@ def test_bench_line_keeps_the_contract():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=1500, cwd=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--details",
+                          str(tmp_path / "details.json")], capture_output=True, text=True, timeout=1500, cwd=root)
     assert run.returncode == 0, run.stderr[-2000:]
     lines = [l for l in run.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
-    r = json.loads(lines[0])
+    # the stdout line is the COMPACT form (round 4's 26 KB line was lost by the driver's reader): under 6 KB, the contract's keys,
+    # roofline / cpu_baseline / a few numbers per sub-result; the full object is in the file it names
+    assert len(lines[0]) < 6144, len(lines[0])
+    line = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "ms_per_step_raw_only", "mrr",
-                "mrr_filtered", "sub_results", "hbm_probe"):
-        assert key in r, key
+                "mrr_filtered", "sub_results", "hbm_probe", "parity_check", "details"):
+        assert key in line, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "pmc_source"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"], key
+    r = json.load(open(os.path.join(root, line["details"])))  # (--details: a path relative to the repo root comes back)
+    assert r["value"] == line["value"] and r["ms_per_step"] == line["ms_per_step"] and r["n_gpus"] == line["n_gpus"]
+    assert line["roofline"]["frac"] == pytest.approx(r["roofline"]["frac"], rel=1e-4)
+    assert set(line["sub_results"]) == set(r["sub_results"])
+    for name, sub in line["sub_results"].items():
+        assert sub["value"] == pytest.approx(r["sub_results"][name]["value"], rel=1e-4), name
+        assert sub["frac"] == pytest.approx(r["sub_results"][name]["roofline"]["frac"], rel=1e-4), name
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
     assert r["vs_baseline"] is None and r["config"]["workload"] == "fb15k237-transe"
     assert r["config"]["filter_graph_edges"] == 310116
