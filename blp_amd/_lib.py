@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
                 -4: "BLP_ERR_WORKSPACE"}
 
 # every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
-SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supported",
+SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_selftest", "blp_dim_supported",
            "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex", "blp_rank_all_idx",
            "blp_rank_all_shard", "blp_gather_triple_vectors", "blp_rank_all_batches", "blp_rank_all_batches_workspace_bytes",
            "blp_rank_all_batches_passes_per_launch", "blp_rank_all_batches_t", "blp_rank_all_batches_t_workspace_bytes",
@@ -28,10 +28,10 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_dim_supporte
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows", "blp_dkrl_rows_supported", "blp_dkrl_rows",
            "blp_build_queries")
-HOOK_SYMBOLS = ("blp_debug_set_knob", "blp_debug_gemm_dump")  # libblp_hip.hooks.so only
+HOOK_SYMBOLS = ("blp_debug_set_knob", "blp_debug_gemm_dump", "blp_debug_reset_selftest")  # libblp_hip.hooks.so only
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
          "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
-         "small_kernel", "stream_kernel", "dkrl_split")  # blp_amd/csrc/knobs.h
+         "small_kernel", "stream_kernel", "dkrl_split", "mfma_selftest")  # blp_amd/csrc/knobs.h
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h
@@ -50,7 +50,8 @@ class HipLibraryError(RuntimeError):
 class BlpCaps(ctypes.Structure):
     _fields_ = [("compute_units", ctypes.c_int), ("wavefront_size", ctypes.c_int),
                 ("lds_bytes_per_cu", ctypes.c_int), ("clock_mhz", ctypes.c_int),
-                ("hbm_bytes", ctypes.c_int64), ("arch", ctypes.c_char * 32)]
+                ("hbm_bytes", ctypes.c_int64), ("arch", ctypes.c_char * 32), ("mfma_bf16_accum", ctypes.c_int),
+                ("mfma_bf16_accum_worst", ctypes.c_float)]
 
 
 class BlpFilter(ctypes.Structure):  # blp_filter of include/blp_hip.h
@@ -118,6 +119,8 @@ def _load(path, hooks):
     L.blp_last_error.argtypes = []
     L.blp_device_caps.restype = _i
     L.blp_device_caps.argtypes = [_i, ctypes.POINTER(BlpCaps)]
+    L.blp_selftest.restype = _i
+    L.blp_selftest.argtypes = [_i, _vp]
     L.blp_dim_supported.restype = _i
     L.blp_dim_supported.argtypes = [_i, _i]
     L.blp_rank_all_workspace_bytes.restype = _sz
@@ -197,6 +200,8 @@ def _load(path, hooks):
         L.blp_debug_gemm_dump.argtypes = [_vp, _vp]
         L.blp_debug_set_knob.restype = _i
         L.blp_debug_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+        L.blp_debug_reset_selftest.restype = _i
+        L.blp_debug_reset_selftest.argtypes = [_i]
     return L
 
 
@@ -252,4 +257,18 @@ def device_caps(device=0):
     check(lib().blp_device_caps(device, ctypes.byref(caps)), "blp_device_caps")
     return {"compute_units": caps.compute_units, "wavefront_size": caps.wavefront_size,
             "lds_bytes_per_cu": caps.lds_bytes_per_cu, "clock_mhz": caps.clock_mhz,
-            "hbm_bytes": caps.hbm_bytes, "arch": caps.arch.decode()}
+            "hbm_bytes": caps.hbm_bytes, "arch": caps.arch.decode(),
+            "mfma_bf16_accum": {0: "not tested yet", 1: "passed", 2: "FAILED: bilinear blocks use the f32-chain pre-pass"}[caps.mfma_bf16_accum],
+            "mfma_bf16_accum_worst": caps.mfma_bf16_accum_worst}
+
+
+def selftest(device=0, stream=None):
+    """include/blp_hip.h: blp_selftest -- the matrix-pipe accumulation self-test behind the bilinear pre-pass, once per device
+    (a set-up call: it waits for the stream).  Returns True if the device passed (bf16 x 3 MFMA pre-pass), False if bilinear
+    blocks are served by the f32-chain pre-pass."""
+    import torch
+    raw = torch.cuda.current_stream(device).cuda_stream if stream is None else stream
+    state = lib().blp_selftest(int(device), ctypes.c_void_p(raw))
+    if state < 0:
+        check(state, "blp_selftest")
+    return state == 1

@@ -88,7 +88,7 @@ std::atomic<long long> g_knobs[blp::KNOB_COUNT];  // zero-initialised: every kno
 const char* const kKnobNames[blp::KNOB_COUNT] = {"rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups",
                                                  "sad_min_queries", "gemm_pass_words", "gemm_tiles_per_chunk",
                                                  "exact_query_chunk", "small_kernel",
-                                                 "stream_kernel", "dkrl_split"};
+                                                 "stream_kernel", "dkrl_split", "mfma_selftest"};
 #endif
 
 }  // namespace
@@ -110,6 +110,11 @@ int blp_debug_set_knob(const char* name, long long value) {
             return BLP_OK;
         }
     return fail(BLP_ERR_BAD_ARG, "blp_debug_set_knob: unknown knob '%s'", name);
+}
+
+int blp_debug_reset_selftest(int device) {
+    blp::mfma_accum_reset(device);
+    return BLP_OK;
 }
 
 int blp_debug_gemm_dump(float* scores, float* eps) {
@@ -247,7 +252,23 @@ int blp_device_caps(int device, blp_caps* out) {
     out->hbm_bytes = (int64_t)prop.totalGlobalMem;
     std::memset(out->arch, 0, sizeof(out->arch));
     std::strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    out->mfma_bf16_accum = blp::mfma_accum_state(device);
+    out->mfma_bf16_accum_worst = blp::mfma_accum_worst(device);
     return BLP_OK;
+}
+
+int blp_selftest(int device, void* stream) {
+    if (int state = blp::mfma_accum_state(device)) return state;
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    void* scratch = nullptr;
+    hipError_t err = hipMalloc(&scratch, 4096);
+    if (err != hipSuccess) return hip_fail(err, "blp_selftest: hipMalloc");
+    const int state = blp::mfma_accum_selftest(device, scratch, static_cast<hipStream_t>(stream), &err);
+    (void)hipFree(scratch);
+    if (err != hipSuccess) return hip_fail(err, "blp_selftest");
+    if (state == 0) return fail(BLP_ERR_BAD_ARG, "blp_selftest: the stream is being captured into a graph (or device %d is out of range): no verdict", device);
+    return state;
 }
 
 int blp_dim_supported(int model, int D) {

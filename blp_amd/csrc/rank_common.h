@@ -145,6 +145,16 @@ hipError_t launch_rank_stream16(int model, int D, int dtype, const void* table, 
                                 const float* key_true, int64_t q_head, int64_t q_tail, unsigned long long* acc,
                                 const StreamDot& dot, int n_cu, hipStream_t stream, const StreamPasses& passes);
 
+// rank_gemm.hip: the run-time guard behind the bf16 band's one empirical assumption (how v_mfma_f32_32x32x16_bf16 rounds its
+// accumulation): per device 0 = not tested yet, 1 = holds, 2 = violated (bilinear blocks take the f32-chain pre-pass).
+// mfma_accum_selftest runs it once per device on `stream` (scratch: >= 512 bytes of device memory) and waits for it; 0 = no
+// verdict now (the stream is being captured).
+int mfma_accum_state(int device);
+float mfma_accum_worst(int device);  // the largest |S~ - S3| / (262 u T) the self-test saw (fails at 0.5)
+int mfma_accum_selftest(int device, void* scratch, hipStream_t stream, hipError_t* err_out);
+#ifdef BLP_TEST_HOOKS
+void mfma_accum_reset(int device);
+#endif
 // rank_gemm.hip: bilinear models as an MFMA GEMM + error band + exact refinement.
 void gemm_set_dump(float* s, float* eps);  // blp_debug_gemm_dump (tests)
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail);

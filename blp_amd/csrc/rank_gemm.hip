@@ -32,6 +32,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "dot_band.h"
 #include "exact_coop.h"
 #include "knobs.h"
@@ -1029,6 +1032,173 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Run-time guard behind assumption (A) of the bf16 band: the ISA does not say how
+// v_mfma_f32_32x32x16_bf16 rounds its 16-term accumulation; the band prices it as "no worse than one truncating f32
+// addition per product", which with the kernel's order (all cross terms, then the main products) bounds |S~ - S3| by
+// 262 u T.  Tests measure that on the bench data -- the PRODUCT must not depend on a test having run on this stepping /
+// firmware.  So, once per device, before the first bilinear pre-pass: a self-test kernel pushes adversarial operand
+// sets through the very MFMA sequence of rank_gemm_bf16_kernel (same instruction, same operand layout, cross terms first)
+// and compares every accumulator with the split sum evaluated exactly (f64: products of bf16 pairs have 16-bit
+// significands, 384 of them add exactly enough in 53 bits) against HALF the bound the band uses.  Any violation (or a
+// non-finite accumulator where the exact value is finite) routes every bilinear block of this device to the f32-chain
+// pre-pass (rank_gemm_kernel: an exact fma chain, C = 320, provable without (A)); blp_device_caps reports the verdict.
+// Operand sets, chosen per candidate row (A operand) and per query column (B operand) of a 32 x 32 tile, so that one
+// tile holds all 64 combinations 16 times over, with the per-block seed varying the values:
+//   0 same sign, magnitudes in [1, 2)              4 random signs, exponents spread over 2^-20 .. 2^20
+//   1 one element of 2^20 among same-sign 2^-4s    5 tiny: 2^-60 scale (products at the edge of the f32 denormals)
+//   2 alternating signs, equal magnitudes          6 huge: 2^50 scale
+//   3 geometric decay 2^-(k/4)                     7 all-ones significands (longest carries), same sign
+struct MfmaSelftest { float worst; unsigned bad; };  // per block: max |S~ - S3| / (262 u T + slack), #non-finite accumulators
+
+__device__ __forceinline__ unsigned selftest_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// element k of operand vector `idx` (row of A / column of B) of pattern `idx & 7`, an f32 value
+__device__ __forceinline__ float selftest_value(unsigned seed, unsigned idx, int k) {
+    const unsigned h = selftest_hash(seed * 0x9e3779b9u + idx * 131u + (unsigned)k * 2654435761u);
+    const float frac = 1.0f + (float)(h & 0xffffu) * (1.0f / 65536.0f);  // [1, 2): 16 significant bits -> hi and lo parts both live
+    const float sign = (h >> 31) ? -1.0f : 1.0f;
+    switch (idx & 7u) {
+    case 0: return frac;
+    case 1: return k == (int)((idx * 5u + seed) & 127u) ? 1048576.0f * frac : 0.0625f * frac;
+    case 2: return (k & 1) ? -(1.0f + (float)((idx + seed) & 255u) * (1.0f / 256.0f)) : (1.0f + (float)((idx + seed) & 255u) * (1.0f / 256.0f));
+    case 3: return frac * __builtin_ldexpf(1.0f, -(k >> 2));
+    case 4: return sign * frac * __builtin_ldexpf(1.0f, (int)((h >> 16) & 31u) - 16);
+    case 5: return sign * frac * __builtin_ldexpf(1.0f, -60);
+    case 6: return sign * frac * __builtin_ldexpf(1.0f, 50);
+    default: return 1.9921875f * 1.001953125f;  // hi = 1.1111111b, lo = 1.1111111b x 2^-9: all-ones significands in both parts
+    }
+}
+__device__ __forceinline__ void selftest_split(float x, float& hi, float& lo) {
+    unsigned h, l;
+    split_bf16(x, 0.f, h, l);
+    hi = __uint_as_float(h << 16);
+    lo = __uint_as_float(l << 16);
+}
+
+__global__ __launch_bounds__(64) void mfma_selftest_kernel(MfmaSelftest* __restrict__ out) {
+    constexpr int D = 128, STEPS = D / 16;
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    const unsigned seed = blockIdx.x + 1u;
+    // operands in the pre-pass kernel's layout: lane l holds, for K-step st, elements k = 16 st + 8 (l >> 5) + j, j = 0..7, of
+    // candidate row (l & 31) (A) and of query column (l & 31) (B), as four packed bf16 pairs each, hi and lo parts
+    uint4 a_hi[STEPS], a_lo[STEPS], b_hi[STEPS], b_lo[STEPS];
+    static_for<STEPS>([&](auto kk) {
+        constexpr int st = decltype(kk)::value;
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            av[j] = selftest_value(seed, (unsigned)col, 16 * st + 8 * half + j);
+            bv[j] = selftest_value(seed ^ 0x5bd1e995u, (unsigned)col + 32u * (seed & 1u) + (seed >> 1), 16 * st + 8 * half + j);
+        }
+        split_bf16(av[0], av[1], a_hi[st].x, a_lo[st].x); split_bf16(av[2], av[3], a_hi[st].y, a_lo[st].y);
+        split_bf16(av[4], av[5], a_hi[st].z, a_lo[st].z); split_bf16(av[6], av[7], a_hi[st].w, a_lo[st].w);
+        split_bf16(bv[0], bv[1], b_hi[st].x, b_lo[st].x); split_bf16(bv[2], bv[3], b_hi[st].y, b_lo[st].y);
+        split_bf16(bv[4], bv[5], b_hi[st].z, b_lo[st].z); split_bf16(bv[6], bv[7], b_hi[st].w, b_lo[st].w);
+    });
+    // the pre-pass's sequence for one accumulator: all cross terms (lo x bh, hi x bl per K-step), then the main products
+    f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    static_for<STEPS>([&](auto kk) {
+        constexpr int st = decltype(kk)::value;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo[st]), __builtin_bit_cast(bf16x8, b_hi[st]), s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi[st]), __builtin_bit_cast(bf16x8, b_lo[st]), s, 0, 0, 0);
+    });
+    static_for<STEPS>([&](auto kk) {
+        constexpr int st = decltype(kk)::value;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi[st]), __builtin_bit_cast(bf16x8, b_hi[st]), s, 0, 0, 0);
+    });
+    // the exact split sum of each of this lane's 16 accumulators (column `col`, rows acc_row(r, half)), from the same values
+    float worst = 0.f;
+    unsigned bad = 0;
+    const unsigned bidx = (unsigned)col + 32u * (seed & 1u) + (seed >> 1);
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+        const unsigned row = (unsigned)acc_row(r, half);
+        double s3 = 0.0, t = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < D; ++k) {
+            float ah, al, bh, bl;
+            selftest_split(selftest_value(seed, row, k), ah, al);
+            selftest_split(selftest_value(seed ^ 0x5bd1e995u, bidx, k), bh, bl);
+            const double p = (double)ah * (double)bh, c1 = (double)al * (double)bh, c2 = (double)ah * (double)bl;
+            s3 += p + c1 + c2;
+            t += fabs(p) + fabs(c1) + fabs(c2);
+        }
+        const float got = s[r];
+        if (!(fabsf(got) <= 3.0e38f)) { ++bad; continue; }  // NaN / Inf where every exact value is finite
+        // 262 u T is what the band allows the matrix pipe; 2^-118 covers flushed denormal products (the band's own
+        // guard is 1e-35 = 2^-116); the verdict fails at HALF of the sum (the margin the GPU tests keep, too)
+        const double bound = 262.0 * 5.9604644775390625e-8 * t + 3.009265538105056e-36;
+        const float ratio = (float)(fabs((double)got - s3) / bound);
+        worst = ratio > worst ? ratio : worst;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float w2 = __shfl_xor(worst, off);
+        worst = w2 > worst ? w2 : worst;
+        bad += __shfl_xor(bad, off);
+    }
+    if (lane == 0) out[blockIdx.x] = MfmaSelftest{worst, bad};
+}
+
+constexpr int kSelftestBlocks = 64;
+constexpr int kMaxDevices = 64;
+// The one piece of process-wide state of the product library (SURVEY 8b allows "a per-device lazily-built constant table
+// guarded by a mutex"): per device 0 = not tested yet, 1 = (A) holds, 2 = violated.  Written once per device under the mutex.
+static std::atomic<int> g_mfma_accum_state[kMaxDevices];
+static std::atomic<float> g_mfma_accum_worst[kMaxDevices];
+static std::mutex g_mfma_selftest_mutex;
+
+int mfma_accum_state(int device) {
+    return device >= 0 && device < kMaxDevices ? g_mfma_accum_state[device].load(std::memory_order_acquire) : 0;
+}
+float mfma_accum_worst(int device) {
+    return device >= 0 && device < kMaxDevices ? g_mfma_accum_worst[device].load(std::memory_order_relaxed) : 0.f;
+}
+#ifdef BLP_TEST_HOOKS
+void mfma_accum_reset(int device) {  // blp_debug_reset_selftest: the next bilinear block of this device tests again
+    if (device >= 0 && device < kMaxDevices) g_mfma_accum_state[device].store(0, std::memory_order_release);
+}
+#endif
+
+// Runs the self-test on `stream` with `scratch` (>= kSelftestBlocks * 8 bytes of device memory) and WAITS for it: the one
+// host synchronisation of the library, once per device.  A stream that is being captured into a graph cannot be waited
+// for: the verdict then stays open (returns 0) and the caller takes the provable path for this call.
+int mfma_accum_selftest(int device, void* scratch, hipStream_t stream, hipError_t* err_out) {
+    *err_out = hipSuccess;
+    if (device < 0 || device >= kMaxDevices) return 2;  // (no slot to remember a verdict in: stay on the provable path)
+    int state = g_mfma_accum_state[device].load(std::memory_order_acquire);
+    if (state) return state;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    std::lock_guard<std::mutex> lock(g_mfma_selftest_mutex);
+    state = g_mfma_accum_state[device].load(std::memory_order_acquire);
+    if (state) return state;
+    MfmaSelftest host[kSelftestBlocks];
+    mfma_selftest_kernel<<<dim3(kSelftestBlocks), 64, 0, stream>>>(static_cast<MfmaSelftest*>(scratch));
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);
+    if (err != hipSuccess) { *err_out = err; return 0; }
+    float worst = 0.f;
+    unsigned bad = 0;
+    for (const MfmaSelftest& b : host) {
+        worst = b.worst > worst || b.worst != b.worst ? b.worst : worst;
+        bad += b.bad;
+    }
+    if (knob(KNOB_MFMA_SELFTEST) == 1) worst = __builtin_inff();  // test knob: as if the matrix pipe had broken the bound
+    state = (bad == 0 && worst < 0.5f) ? 1 : 2;
+    g_mfma_accum_worst[device].store(worst, std::memory_order_relaxed);
+    g_mfma_accum_state[device].store(state, std::memory_order_release);
+    return state;
+}
+
 // ------------------------------------------------------------------------------------------------
 struct GemmWorkspace {
     float* key_true; float* eps_q;
@@ -1126,7 +1296,15 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
     GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
     const int64_t pass_tiles = w.pass_ctiles;
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
-    const bool f32_kernel = gemm_use_f32();
+    // The bf16 x 3 pre-pass only on a device whose matrix pipe has passed the accumulation self-test (assumption (A) of the
+    // band; once per device, the candidate-image region of the workspace as its scratch); a violation, or a verdict that
+    // cannot be had now (the stream is being captured), takes the f32-chain pre-pass, whose band is arithmetic alone.
+    int device = 0;
+    (void)hipGetDevice(&device);
+    hipError_t selftest_err = hipSuccess;
+    const int verdict = gemm_use_f32() ? 1 : mfma_accum_selftest(device, w.cimg, stream, &selftest_err);
+    if (selftest_err != hipSuccess) return selftest_err;
+    const bool f32_kernel = gemm_use_f32() || verdict != 1;
     // the bf16 path folds the true keys of a small call into its prelude launch (below)
     const bool keys_in_prelude = !f32_kernel && Q <= kTrueKeyLaneMaxQueries;
     hipError_t err = hipSuccess;

@@ -11,9 +11,10 @@
  *     by the caller (torch: tensor.data_ptr()); nothing is allocated or freed inside a call;
  *   - `device` is the HIP device ordinal the pointers live on, `stream` a hipStream_t (torch:
  *     torch.cuda.current_stream().cuda_stream; NULL = the legacy default stream).  Calls only
- *     enqueue work on `stream`: no host synchronisation, safe to capture in a hipGraph;
- *   - re-entrant: no process-wide mutable state (the test knobs exist only in the -DBLP_TEST_HOOKS build, see the
- *     end of this file); one thread per device (nn.DataParallel replicas) may call concurrently.  ctypes releases
+ *     enqueue work on `stream`: no host synchronisation, safe to capture in a hipGraph (one exception, once per device:
+ *     blp_selftest below);
+ *   - re-entrant: no process-wide mutable state except the per-device verdict of the matrix-pipe self-test (blp_selftest:
+ *     written once, under a mutex; the test knobs exist only in the -DBLP_TEST_HOOKS build, see the end of this file); one thread per device (nn.DataParallel replicas) may call concurrently.  ctypes releases
  *     the GIL for the duration of the call;
  *   - return 0 (BLP_OK) or a negative blp_status; blp_last_error() gives the thread-local message;
  *   - f32 tensors, int64 indices exactly as the reference produces them (neg_idx, true_idx);
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 400 /* major*10000 + minor*100 + patch */
+#define BLP_HIP_VERSION 500 /* major*10000 + minor*100 + patch; 5.0.0: blp_caps grew (mfma_bf16_accum), blp_selftest */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -52,11 +53,31 @@ typedef struct blp_caps {
     int clock_mhz;            /* max engine clock                   */
     int64_t hbm_bytes;        /* total device memory                */
     char arch[32];            /* "gfx950..."                        */
+    int mfma_bf16_accum;      /* verdict of the matrix-pipe self-test on this device (blp_selftest): 0 = not run yet,
+                                 1 = passed (bilinear blocks use the bf16 x 3 MFMA pre-pass), 2 = FAILED (they use the
+                                 f32-chain pre-pass, ~3.5 x slower, same results)                              */
+    float mfma_bf16_accum_worst; /* the largest |S~ - S3| / (262 u T) the self-test measured; it fails at 0.5 */
 } blp_caps;
 
 int blp_version(void);
 const char *blp_last_error(void);
 int blp_device_caps(int device, blp_caps *out);
+
+/* The matrix-pipe self-test behind the bilinear pre-pass (DistMult / ComplEx / SimplE blocks of >= 32 queries).  That
+ * pre-pass decides most (query, candidate) pairs from a bf16 x 3 MFMA product inside an error band; every term of the
+ * band is arithmetic except one: how v_mfma_f32_32x32x16_bf16 rounds its 16-term accumulation, which the ISA does not
+ * document.  Once per device this library therefore pushes adversarial operand sets (same-sign runs, one huge term among
+ * tiny ones, exact cancellation, 2^-60 / 2^50 scales, all-ones significands) through the pre-pass's own MFMA sequence
+ * and compares every accumulator with the exactly evaluated split sum against HALF of what the band allows.  A device
+ * that fails is served by the f32-chain pre-pass (exact fused multiply-adds; its band needs no assumption) -- the results
+ * are the same either way, only the speed differs.
+ *   blp_selftest(device, stream)  runs it now if it has not run on `device` (allocates and frees 512 bytes, enqueues on
+ *        `stream` and WAITS for it -- a set-up call, not to be captured into a graph); returns the verdict (1 / 2) or a
+ *        negative status.  Optional: the first bilinear blp_rank_all* call on a device runs it by itself, with its
+ *        workspace as scratch -- that ONE call synchronises `stream`; if `stream` is being captured the verdict stays
+ *        open and that call takes the f32-chain pre-pass.
+ * This per-device verdict (an int, written once under a mutex) is the library's only process-wide state. */
+int blp_selftest(int device, void *stream);
 /* storage types of the arrays that may come in 16 bits (the in-batch loss' embeddings; the candidate table of
  * blp_rank_all_batches_t) */
 enum { BLP_DTYPE_F32 = 0, BLP_DTYPE_F16 = 1, BLP_DTYPE_BF16 = 2 };
@@ -462,6 +483,10 @@ int blp_debug_set_knob(const char *name, long long value);
  * (query, candidate) pair into two dense (Q, N) f32 matrices; `counts` of that call are meaningless.  One-shot (the
  * pointers are dropped when that call returns); NULL, NULL cancels. */
 int blp_debug_gemm_dump(float *scores, float *eps);
+
+/* Forget `device`'s self-test verdict: the next blp_selftest / bilinear block tests again (with knob "mfma_selftest" = 1 it
+ * then reports a violation whatever it measures -- how tests reach the f32-chain route). */
+int blp_debug_reset_selftest(int device);
 #endif
 
 #ifdef __cplusplus

@@ -49,7 +49,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     L = _lib.lib()
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.blp_version() == 400
+    assert L.blp_version() == 500
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 8)  # coefficients, key, accumulator
