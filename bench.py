@@ -86,6 +86,15 @@ WORKLOADS = {
     "fb15k237-distmult": dict(model="distmult", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
     "fb15k237-complex": dict(model="complex", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
     "fb15k237-simple": dict(model="simple", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116),
+    # Away from the friendly operating point: near-duplicate descriptions -> clustered rows (`clusters`
+    # centres, every row = its centre + `noise` x randn, then normalised / scaled as usual) and a trained model's triples (the
+    # true tail drawn from the `top` best-scoring entities of (h, r, ?)): many candidates tie or nearly tie with the true
+    # entity, the pre-pass decides fewer pairs and the exact refinement gets more (`decided_frac`, `vs_random_step`).
+    # noise = 0: exact duplicates (entities with the same description get the same vector), 29 copies of each row.
+    "fb15k237-transe-clustered": dict(model="transe", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116,
+                                      clusters=500, noise=0.0, top=145, random_twin="fb15k237-transe"),
+    "fb15k237-distmult-clustered": dict(model="distmult", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116,
+                                        clusters=500, noise=0.0, top=145, random_twin="fb15k237-distmult"),
     # the BERT-BOW / BERT-DKRL width (models.py:118-135, 165-172): TransE at the word-embedding width 768
     "fb15k237-transe-d768": dict(model="transe", N=14541, D=768, R=237, triples=52870, block=65536, edges=310116),
     # reference batching: eval_batch_size = 2 triples per table pass, 64 passes per step; the reference's
@@ -107,7 +116,7 @@ WORKLOADS = {
     # the reference's own Wikidata5M protocol: candidates = the entities of the evaluated split only (train.py:312-314)
     "wikidata5m-protocol": dict(model="transe", N=7475, D=128, R=822, triples=6894, block=65536, edges=0, loop_batch=2),
 }
-SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-f16",
+SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "fb15k237-transe-clustered", "fb15k237-distmult-clustered", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-f16",
                "wikidata5m-complex-f16", "wikidata5m-transe-block",
                "wikidata5m-complex-block", "wikidata5m-transe-full", "wikidata5m-complex-full", "wikidata5m-protocol")
 # N > 1: the same names on the axis a sharded evaluation of that shape takes ("auto": ranking.choose_shard_axis -> query for the
@@ -149,15 +158,36 @@ def make_data(cfg, device, seed=1, sort=True, rows=None):
         table = torch.nn.functional.normalize(table, dim=-1) if cfg["model"] == "transe" else table * 0.1
         if rows is not None:
             table = table[lo:hi].contiguous()
+    if cfg.get("clusters"):  # (small tables only: made whole)
+        centres = torch.randn(cfg["clusters"], D, device=device, generator=g)
+        member = torch.randint(0, cfg["clusters"], (N,), device=device, generator=g)
+        table = centres[member] + cfg["noise"] * torch.randn(N, D, device=device, generator=g)
+        table = torch.nn.functional.normalize(table, dim=-1) if cfg["model"] == "transe" else table * 0.1
     bound = (6.0 / (R + D)) ** 0.5
     rel_w = (torch.rand(R, D, device=device, generator=g) * 2 - 1) * bound
     heads = torch.randint(0, N, (T,), device=device, generator=g)
     tails = torch.randint(0, N, (T,), device=device, generator=g)
     rels = torch.randint(0, R, (T,), device=device, generator=g)
+    if cfg.get("top"):
+        tails = trained_tails(cfg, table, rel_w, heads, rels, g)
     if sort:
         order = torch.argsort(rels, stable=True)
         heads, tails, rels = heads[order], tails[order], rels[order]
     return table, rel_w, heads, tails, rels
+
+
+def trained_tails(cfg, table, rel_w, heads, rels, g, chunk=2048):
+    """A true tail per (h, r) the way a trained model ranks it: uniformly one of the cfg['top'] best-scoring entities of the
+    tail query (h, r, ?) -- plain torch, set-up only (not timed): TransE -||h + r - t||_1 (models.py:222-223), DistMult
+    sum(h * r * t) (models.py:226-227)."""
+    out = torch.empty_like(heads)
+    for lo in range(0, heads.shape[0], chunk):
+        h, r = table[heads[lo:lo + chunk]], rel_w[rels[lo:lo + chunk]]
+        scores = -torch.cdist(h + r, table, p=1) if cfg["model"] == "transe" else (h * r) @ table.T
+        best = scores.topk(cfg["top"], dim=1).indices
+        pick = torch.randint(0, cfg["top"], (best.shape[0], 1), device=heads.device, generator=g)
+        out[lo:lo + chunk] = best.gather(1, pick)[:, 0]
+    return out
 
 
 def build_queries(table, rel_w, heads, tails, rels):
@@ -322,6 +352,21 @@ class Job:
             torch.cuda.synchronize()
             total += self.ranking.exchange_ms(timing)
         return total / reps
+
+    def prepass_stats(self):
+        """What the pre-pass leaves to the exact path on this workload's block (one GPU): the whole query block through a bare
+        ops.rank_all on a workspace of our own, then include/blp_hip.h: blp_rank_all_prepass_stats on it.  Not timed."""
+        from blp_amd import ops
+        if self.world > 1 or self.cfg["block"] < self.T or self.table.dtype != torch.float32:
+            return None
+        rel_w = self.model.rel_emb.weight.detach()
+        h, t, r = self.triples[:, 0], self.triples[:, 1], self.triples[:, 2]
+        q_fixed, q_rel, true_row = build_queries(self.table, rel_w, h, t, r)
+        if not ops.rank_all_supported(self.cfg["model"], self.D, self.T, self.T):
+            return None
+        ws = torch.empty(ops.rank_all_workspace_bytes(self.cfg["model"], self.N, self.D, self.T, self.T), dtype=torch.uint8, device=self.device)
+        ops.rank_all(self.cfg["model"], self.table, q_fixed, q_rel, self.T, true_row=true_row, workspace=ws)
+        return ops.prepass_stats(self.cfg["model"], self.N, self.D, self.T, self.T, ws)
 
     def loop_layout(self, reps=5):
         """The same evaluation handed over in the REFERENCE LOOP's layout (train.py:128-157: batch after batch of
@@ -804,6 +849,12 @@ def sub_result(name, axis, device, world, rank, backend, steps, events):
         f["table_passes_per_step"], f["ms_per_table_pass"] = passes, f["ms_per_step"] / passes
     if "loop_batch" in sub.cfg and world == 1:
         f["reference_loop_layout"] = sub.loop_layout()
+    if world == 1 and (sub.cfg.get("clusters") or name in ("fb15k237-distmult", "fb15k237-transe")):
+        stats = sub.prepass_stats()
+        if stats:
+            f["prepass"] = stats
+            if stats["decided_frac"] is not None:
+                f["decided_frac"] = stats["decided_frac"]
     del sub, t, c
     torch.cuda.empty_cache()
     return f
@@ -980,7 +1031,7 @@ def compact_result(result, limit=LINE_LIMIT):
     cfg = dict(result.get("config", {}))
     cfg.pop("step", None)
     line["config"] = cfg
-    for k in ("ms_per_step_raw_only", "mrr", "mrr_filtered", "hits@1,3,10", "hits@1,3,10_filtered", "exchange_ms", "parity_check"):
+    for k in ("ms_per_step_raw_only", "mrr", "mrr_filtered", "hits@1,3,10", "hits@1,3,10_filtered", "exchange_ms", "parity_check", "decided_frac"):
         if k in result:
             line[k] = result[k]
     line["roofline"] = compact_roofline(result.get("roofline"))
@@ -1101,6 +1152,10 @@ def main():
         }
         result.update(fields)
         result["parity_check"] = parity_spot_check(job, triples, counts)
+        if world == 1:
+            result["prepass"] = job.prepass_stats()
+            if result["prepass"] and result["prepass"]["decided_frac"] is not None:
+                result["decided_frac"] = result["prepass"]["decided_frac"]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(job)
             result["torch_gpu_baseline"] = torch_gpu_baseline(job)
@@ -1120,6 +1175,12 @@ def main():
                 for k in ("kernel_ms_per_rank", "exchange_ms", "exchange_ms_per_rank", "shard_axis", "ranks"):
                     f.pop(k)
             subs[key] = f
+        if rank == 0:  # the clustered workloads against the same shapes on i.i.d. random data
+            for key, f in subs.items():
+                twin = WORKLOADS.get(key, {}).get("random_twin")
+                base = result["ms_per_step"] if twin == args.workload else subs.get(twin, {}).get("ms_per_step")
+                if twin and base:
+                    f["vs_random_step"] = f["ms_per_step"] / base
         # the training-side scoring is replicas only: every rank runs the same step, rank 0 reports its own
         inbatch = inbatch_bench(device)
         if rank == 0:

@@ -257,6 +257,21 @@ int blp_device_caps(int device, blp_caps* out) {
     return BLP_OK;
 }
 
+int blp_rank_all_prepass_stats(int model, int64_t N, int D, int64_t q_head, int64_t q_tail, const void* workspace,
+                               size_t workspace_bytes, int64_t out[4], int device, void* stream) {
+    if (!valid_model(model) || !out || N < 0 || q_head < 0 || q_tail < 0 || !blp_rank_all_supported(model, D, q_head, q_tail))
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_prepass_stats: bad arguments");
+    if (!workspace || workspace_bytes < blp_rank_all_workspace_bytes(model, N, D, q_head, q_tail))
+        return fail(BLP_ERR_WORKSPACE, "blp_rank_all_prepass_stats: not the workspace of a blp_rank_all call of this shape");
+    DeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
+    blp::PrepassStats st;
+    hipError_t err = blp::prepass_stats(model, D, N, q_head, q_tail, workspace, &st, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_all_prepass_stats");
+    out[0] = st.pairs; out[1] = st.listed; out[2] = st.flagged_rows; out[3] = st.path;
+    return BLP_OK;
+}
+
 int blp_selftest(int device, void* stream) {
     if (int state = blp::mfma_accum_state(device)) return state;
     DeviceGuard guard(device);

@@ -843,6 +843,64 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// Measurement: how much a pre-pass left to the exact path (blp_rank_all_prepass_stats).  Synchronous, allocates 32 bytes.
+__global__ __launch_bounds__(256) void count_bits_kernel(const unsigned* __restrict__ flags, int64_t n_words,
+                                                         const uint2* __restrict__ pairs, const unsigned* __restrict__ n_pairs,
+                                                         int mask_entries, unsigned long long* __restrict__ out) {
+    unsigned long long f = 0, m = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int64_t i = i0; i < n_words; i += stride) f += __popc(flags[i]);
+    const int64_t n = *n_pairs;
+    if (mask_entries)
+        for (int64_t i = i0; i < n; i += stride) m += __popc(pairs[i].y & 0xffffu);
+    for (int off = 32; off > 0; off >>= 1) {
+        f += __shfl_xor(f, off);
+        m += __shfl_xor(m, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (f) atomicAdd(out, f);
+        if (m) atomicAdd(out + 1, m);
+    }
+    if (i0 == 0) out[2] = (unsigned long long)n;
+}
+
+hipError_t launch_count_bits(const unsigned* flags, int64_t n_words, const uint2* pairs, const unsigned* n_pairs, bool mask_entries,
+                             unsigned long long host_out[3], hipStream_t stream) {
+    unsigned long long* dev = nullptr;
+    hipError_t err = hipMalloc(&dev, 32);
+    if (err != hipSuccess) return err;
+    err = hipMemsetAsync(dev, 0, 32, stream);
+    if (err == hipSuccess) {
+        count_bits_kernel<<<dim3(1024), 256, 0, stream>>>(flags, n_words, pairs, n_pairs, mask_entries ? 1 : 0, dev);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(host_out, dev, 24, hipMemcpyDeviceToHost, stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);
+    (void)hipFree(dev);
+    return err;
+}
+
+hipError_t prepass_stats(int model, int D, int64_t N, int64_t q_head, int64_t q_tail, const void* workspace, PrepassStats* out,
+                         hipStream_t stream) {
+    out->pairs = (long long)(q_head + q_tail) * (long long)N;
+    out->listed = out->flagged_rows = 0;
+    out->path = 0;
+    if (rank_small_applicable(model, D, N, q_head, q_tail)) return hipSuccess;  // (the order of launch_rank_all)
+    if (rank_gemm_applicable(model, D, q_head, q_tail)) {
+        int device = 0;
+        (void)hipGetDevice(&device);
+        return gemm_prepass_stats(D, N, q_head, q_tail, workspace, device, out, stream);
+    }
+    if (rank_sad_wide_applicable(model, D, q_head, q_tail)) {
+        out->path = 4;
+        out->listed = out->flagged_rows = -1;
+        return hipSuccess;
+    }
+    if (rank_sad_applicable(model, D, N, q_head, q_tail)) return sad_prepass_stats(D, N, q_head, q_tail, workspace, out, stream);
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Building blocks the pre-pass paths (rank_gemm.hip, rank_sad.hip) share with the exact path: true-entity keys (+ zeroed
 // accumulators) and the filter / finalize step.  They read the query vectors directly: no coefficient array.
 template <int MODEL, int D>

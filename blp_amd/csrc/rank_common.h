@@ -145,6 +145,18 @@ hipError_t launch_rank_stream16(int model, int D, int dtype, const void* table, 
                                 const float* key_true, int64_t q_head, int64_t q_tail, unsigned long long* acc,
                                 const StreamDot& dot, int n_cu, hipStream_t stream, const StreamPasses& passes);
 
+// Measurement (include/blp_hip.h: blp_rank_all_prepass_stats): what the pre-pass of the last launch_rank_all on `workspace`
+// left to the exact path.  path: 0 = no pre-pass took this block (exact kernels), 1 = TransE v_sad_u16, 2 = bf16 x 3 MFMA,
+// 3 = f32-chain MFMA (not counted: listed = flagged_rows = -1), 4 = any-width TransE (not counted).  Last candidate slab only.
+struct PrepassStats { long long pairs, listed, flagged_rows; int path; };
+hipError_t prepass_stats(int model, int D, int64_t N, int64_t q_head, int64_t q_tail, const void* workspace, PrepassStats* out,
+                         hipStream_t stream);
+hipError_t gemm_prepass_stats(int D, int64_t N, int64_t q_head, int64_t q_tail, const void* workspace, int device, PrepassStats* out, hipStream_t stream);
+hipError_t sad_prepass_stats(int D, int64_t N, int64_t q_head, int64_t q_tail, const void* workspace, PrepassStats* out, hipStream_t stream);
+// one workgroup-strided pass: out[0] += sum popc(flags[i]); out[1] += (mask_entries ? sum popc(pairs[i].y & 0xffff) : 0) over *n_pairs entries
+hipError_t launch_count_bits(const unsigned* flags, int64_t n_words, const uint2* pairs, const unsigned* n_pairs, bool mask_entries,
+                             unsigned long long host_out[3], hipStream_t stream);
+
 // rank_gemm.hip: the run-time guard behind the bf16 band's one empirical assumption (how v_mfma_f32_32x32x16_bf16 rounds its
 // accumulation): per device 0 = not tested yet, 1 = holds, 2 = violated (bilinear blocks take the f32-chain pre-pass).
 // mfma_accum_selftest runs it once per device on `stream` (scratch: >= 512 bytes of device memory) and waits for it; 0 = no

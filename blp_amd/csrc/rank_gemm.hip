@@ -1269,6 +1269,24 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     return w;
 }
 
+hipError_t gemm_prepass_stats(int D, int64_t N, int64_t q_head, int64_t q_tail, const void* workspace, int device, PrepassStats* out,
+                              hipStream_t stream) {
+    const GemmWorkspace w = carve_gemm(const_cast<void*>(workspace), D, N, q_head, q_tail);
+    if (gemm_use_f32() || mfma_accum_state(device) != 1) {  // the f32-chain kernel's fixed pair regions are not counted
+        out->path = 3;
+        out->listed = out->flagged_rows = -1;
+        return hipSuccess;
+    }
+    out->path = 2;
+    const int64_t rows = N < w.pass_ctiles * kGCT ? N : w.pass_ctiles * kGCT;  // (the first slab's bitmap width; one slab as a rule)
+    const int64_t words = ((rows + kGCT - 1) / kGCT + 15) / 16;
+    unsigned long long host[3] = {0, 0, 0};
+    const hipError_t err = launch_count_bits(w.flags, (q_head + q_tail) * words, w.pairs, w.n_pairs, true, host, stream);
+    out->flagged_rows = (long long)host[0] * 16;  // a flag = one (query, 16-candidate half-tile)
+    out->listed = (long long)host[1];
+    return err;
+}
+
 constexpr int64_t kGemmMinQueries = 32;  // (one query tile: the chain's five launches are what a call this small costs)
 bool rank_gemm_applicable(int model, int D, int64_t q_head, int64_t q_tail) {
     if (knob(KNOB_RANK_KERNEL) == 1) return false;  // test knob: the exact f32 kernels

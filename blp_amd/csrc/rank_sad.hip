@@ -574,6 +574,19 @@ bool rank_sad_applicable(int model, int D, int64_t N, int64_t q_head, int64_t q_
     return forced || Q * N >= kSadMinPairs;
 }
 
+hipError_t sad_prepass_stats(int D, int64_t N, int64_t q_head, int64_t q_tail, const void* workspace, PrepassStats* out,
+                             hipStream_t stream) {
+    const SadWorkspace w = carve_sad(const_cast<void*>(workspace), D, N, q_head, q_tail);
+    out->path = 1;
+    const int64_t tiles_per_group = kSW * sad_tiles_per_wave(D);
+    const int64_t words = (w.pass_groups * tiles_per_group + 31) / 32;
+    unsigned long long host[3] = {0, 0, 0};
+    const hipError_t err = launch_count_bits(w.flags, (q_head + q_tail) * words, w.pairs, &w.params->n_pairs, false, host, stream);
+    out->flagged_rows = (long long)host[0] * 64;  // a flag = one (query, 64-candidate tile)
+    out->listed = (long long)host[2];             // one entry per undecided pair
+    return err;
+}
+
 size_t rank_sad_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail) {
     if (!rank_sad_applicable(model, D, N, q_head, q_tail)) return 0;
     return carve_sad(nullptr, D, N, q_head, q_tail).bytes;

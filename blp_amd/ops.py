@@ -53,9 +53,17 @@ def _filter_spec(filter, Q, dev):
 # ~4 us of a 20 us small call).  The sizes come from the library (blp_rank_all*_workspace_bytes), memoised per shape.
 _workspaces = {}
 _ws_bytes_memo = {}
+# Only SMALL workspaces are kept (the point of the cache is the 20 us call): an evaluation block's scratch -- hundreds of MB of
+# operand images and pair lists, GBs at Wikidata5M scale -- is a per-call torch.empty that goes back to the caching allocator
+# when the call returns (stream-ordered: the allocator hands the block to later work on the same stream only), so it is not
+# pinned through the training steps that follow an evaluation (round 4 kept the largest one per stream for the life of the
+# process: a configuration that fitted before could run out of memory).
+WORKSPACE_CACHE_MAX_BYTES = 32 << 20
 
 
 def _workspace(dev, stream, nbytes):
+    if nbytes > WORKSPACE_CACHE_MAX_BYTES:
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
     key = (dev.index, stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -147,7 +155,7 @@ def rank_all_supported(rel_model, dim, q_head, q_tail):
 
 
 def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=None,
-             filt_rowptr=None, filt_col=None, out=None, rel_ids=None, filter=None):
+             filt_rowptr=None, filt_col=None, out=None, rel_ids=None, filter=None, workspace=None):
     """Rank-count every query against every row of ``table`` in one pass over the table.
 
     table (N, D) f32; q_fixed, q_rel (Q, D) f32; queries [0, q_head) replace the head (q_fixed is the
@@ -157,6 +165,8 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     filter: a SegmentFilter (slices of a FilterIndex on the device; no per-batch list).
     rel_ids (Q,) int64, optional: the relation id of each query (equal id => identical q_rel row); accepted for
     compatibility and ignored (include/blp_hip.h: q_rel_id), never changes a result.
+    workspace: optional uint8 device tensor of >= rank_all_workspace_bytes(...) bytes to use as the call's scratch (a caller
+    that wants to look at it afterwards: prepass_stats); default: this module's own.
     Returns counts (Q, 4) int32: gt, ge, gt_filtered, ge_filtered.
     """
     _require_device(table, q_fixed, q_rel, true_row, q_true, filt_rowptr, filt_col, rel_ids)
@@ -206,7 +216,10 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     model = _lib.MODEL_IDS[rel_model]
     ws_bytes = _rank_ws_bytes(L, model, N, D, q_head, Q - q_head)
     stream = torch._C._cuda_getCurrentRawStream(dev.index)
-    workspace = _workspace(dev, stream, ws_bytes)
+    if workspace is None:
+        workspace = _workspace(dev, stream, ws_bytes)
+    elif not workspace.is_cuda or workspace.dtype != torch.uint8 or workspace.numel() < ws_bytes or workspace.data_ptr() % 256:
+        raise ValueError(f"workspace must be a 256-byte aligned uint8 device tensor of >= {ws_bytes} bytes")
     if filter is not None:
         status = L.blp_rank_all_ex(model, table.data_ptr(), N, D, table.stride(0) if N > 0 else D, q_fixed.data_ptr(),
                                    q_rel.data_ptr(), _addr(rel_ids), _addr(true_row), _addr(q_true), q_head, Q - q_head,
@@ -219,6 +232,30 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     if status:
         _lib.check(status, "blp_rank_all")
     return counts
+
+
+def rank_all_workspace_bytes(rel_model, N, D, q_head, q_tail):
+    return int(_lib.lib().blp_rank_all_workspace_bytes(_lib.MODEL_IDS[rel_model], int(N), int(D), int(q_head), int(q_tail)))
+
+
+PREPASS_PATHS = {0: "exact kernels (no pre-pass)", 1: "v_sad_u16 pre-pass", 2: "bf16 x 3 MFMA pre-pass", 3: "f32-chain MFMA pre-pass",
+                 4: "any-width v_sad_u16 pre-pass"}
+
+
+def prepass_stats(rel_model, N, D, q_head, q_tail, workspace):
+    """include/blp_hip.h: blp_rank_all_prepass_stats -- what the pre-pass of the last rank_all(..., workspace=workspace) of this
+    shape left to the exact path.  Waits for the stream.  {"pairs", "listed", "flagged_rows", "path", "decided_frac"};
+    decided_frac is None on the paths that are not counted."""
+    out = (ctypes.c_int64 * 4)()
+    dev = workspace.device
+    L = _lib.lib()
+    _lib.check(L.blp_rank_all_prepass_stats(_lib.MODEL_IDS[rel_model], int(N), int(D), int(q_head), int(q_tail), workspace.data_ptr(),
+                                            workspace.numel(), out, dev.index, torch._C._cuda_getCurrentRawStream(dev.index)),
+               "blp_rank_all_prepass_stats")
+    pairs, listed, flagged, path = (int(x) for x in out)
+    undecided = None if listed < 0 else listed + flagged
+    return {"pairs": pairs, "listed": listed, "flagged_rows": flagged, "path": PREPASS_PATHS[path],
+            "decided_frac": None if undecided is None or pairs == 0 else 1.0 - undecided / pairs}
 
 
 def rank_all_idx(rel_model, table, fixed_row, rel_emb, rel_ids, q_head, true_row, filter=None, out=None):

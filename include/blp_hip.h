@@ -264,6 +264,15 @@ int64_t blp_rank_all_batches_passes_per_launch(int model, int64_t N, int D, int6
 int64_t blp_rank_all_batches_t_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
                                                  int64_t batch, int64_t block_triples);
 
+/* Measurement aid (bench.py's `decided_frac`): what the pre-pass of the LAST blp_rank_all / _ex / _idx call that ran on
+ * `workspace` (same model, N, D, q_head, q_tail) left to the exact path.  out[0] = (query, candidate) pairs of the block,
+ * out[1] = undecided pairs it listed one by one, out[2] = candidates inside the segments it flagged for wholesale exact
+ * re-scoring (a workgroup's list was full), out[3] = the path: 0 = no pre-pass (exact kernels took the block), 1 = TransE
+ * v_sad_u16, 2 = bf16 x 3 MFMA, 3 = f32-chain MFMA and 4 = any-width TransE (these two are not counted: out[1] = out[2] = -1).
+ * Blocks ranked in several candidate slabs report their last slab.  Waits for `stream`, allocates 32 bytes for the call. */
+int blp_rank_all_prepass_stats(int model, int64_t N, int D, int64_t q_head, int64_t q_tail, const void *workspace,
+                               size_t workspace_bytes, int64_t out[4], int device, void *stream);
+
 /* The same counts from a DENSE score matrix already in HBM: scores (Q, N) f32 with row stride ld, the
  * true entity given per query as a column index (true_idx, the reference's `true_ents`,
  * utils.py:102) or as a score (true_score); exactly one of the two.  Replaces utils.py:103-105 and the

@@ -48,7 +48,7 @@ from test_gpu_parity import oracle_counts, random_problem
 orc.build()
 assert _lib.device_caps(0)["mfma_bf16_accum"] == "not tested yet"
 for model in ("transe", "distmult"):
-    table, q_fixed, q_rel, true_row = random_problem(model, 3000, 128, 70, 60, seed=5)
+    table, q_fixed, q_rel, true_row = random_problem(model, 6000, 128, 70, 60, seed=5)
     got = ops.rank_all(model, table.cuda(), q_fixed.cuda(), q_rel.cuda(), 70, true_row=true_row.cuda()).cpu().numpy()
     assert np.array_equal(got, oracle_counts(orc, model, table, q_fixed, q_rel, 70, true_row=true_row)), model
     print(model, _lib.device_caps(0)["mfma_bf16_accum"])
