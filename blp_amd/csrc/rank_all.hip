@@ -846,11 +846,11 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 // Measurement: how much a pre-pass left to the exact path (blp_rank_all_prepass_stats).  Synchronous, allocates 32 bytes.
 __global__ __launch_bounds__(256) void count_bits_kernel(const unsigned* __restrict__ flags, int64_t n_words,
                                                          const uint2* __restrict__ pairs, const unsigned* __restrict__ n_pairs,
-                                                         int mask_entries, unsigned long long* __restrict__ out) {
+                                                         int mask_entries, unsigned max_entries, unsigned long long* __restrict__ out) {
     unsigned long long f = 0, m = 0;
     const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     for (int64_t i = i0; i < n_words; i += stride) f += __popc(flags[i]);
-    const int64_t n = *n_pairs;
+    const int64_t n = *n_pairs < max_entries ? *n_pairs : max_entries;
     if (mask_entries)
         for (int64_t i = i0; i < n; i += stride) m += __popc(pairs[i].y & 0xffffu);
     for (int off = 32; off > 0; off >>= 1) {
@@ -865,13 +865,13 @@ __global__ __launch_bounds__(256) void count_bits_kernel(const unsigned* __restr
 }
 
 hipError_t launch_count_bits(const unsigned* flags, int64_t n_words, const uint2* pairs, const unsigned* n_pairs, bool mask_entries,
-                             unsigned long long host_out[3], hipStream_t stream) {
+                             unsigned long long host_out[3], hipStream_t stream, unsigned max_entries) {
     unsigned long long* dev = nullptr;
     hipError_t err = hipMalloc(&dev, 32);
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(dev, 0, 32, stream);
     if (err == hipSuccess) {
-        count_bits_kernel<<<dim3(1024), 256, 0, stream>>>(flags, n_words, pairs, n_pairs, mask_entries ? 1 : 0, dev);
+        count_bits_kernel<<<dim3(1024), 256, 0, stream>>>(flags, n_words, pairs, n_pairs, mask_entries ? 1 : 0, max_entries, dev);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipMemcpyAsync(host_out, dev, 24, hipMemcpyDeviceToHost, stream);

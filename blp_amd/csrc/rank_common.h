@@ -155,7 +155,7 @@ hipError_t gemm_prepass_stats(int D, int64_t N, int64_t q_head, int64_t q_tail, 
 hipError_t sad_prepass_stats(int D, int64_t N, int64_t q_head, int64_t q_tail, const void* workspace, PrepassStats* out, hipStream_t stream);
 // one workgroup-strided pass: out[0] += sum popc(flags[i]); out[1] += (mask_entries ? sum popc(pairs[i].y & 0xffff) : 0) over *n_pairs entries
 hipError_t launch_count_bits(const unsigned* flags, int64_t n_words, const uint2* pairs, const unsigned* n_pairs, bool mask_entries,
-                             unsigned long long host_out[3], hipStream_t stream);
+                             unsigned long long host_out[3], hipStream_t stream, unsigned max_entries = 0xffffffffu);
 
 // rank_gemm.hip: the run-time guard behind the bf16 band's one empirical assumption (how v_mfma_f32_32x32x16_bf16 rounds its
 // accumulation): per device 0 = not tested yet, 1 = holds, 2 = violated (bilinear blocks take the f32-chain pre-pass).

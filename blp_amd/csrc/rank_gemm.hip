@@ -326,7 +326,8 @@ constexpr int kBfMinTilesPerChunk = 16;          // query tiles per workgroup: 1
 constexpr int kBfMaxTilesPerChunk = 96;          // (rank_gemm_impl); the test knob takes any multiple of 4 up to 96 (from 92 on: one workgroup per CU)
 constexpr int kBfResident = 512;                 // workgroups the chip holds (2 per CU)
 constexpr int kBfSetupTiles = 5;                 // a workgroup's set-up, in query tiles of work
-constexpr int kBfQuotaPerTile = 8 * kBfTPW;      // undecided pairs a workgroup can list, per query tile of its chunk
+constexpr int kBfQuotaPerTile = 16 * kBfTPW;     // entries a workgroup can list, per query tile of its chunk (16 KB of LDS at 64 tiles: two workgroups
+                                                 // per CU use 148 of the 160 KB; round 4: 8 per tile -- duplicate rows ran half the workgroups out of it)
 
 // (x0, x1) -> packed bf16 pairs hi, lo (x0 in the low half)
 __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -908,6 +909,58 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
 #endif
 }
 
+// Between the passes (blocks of >= kFlagsToEntriesMinQueries queries): every flagged (query, 16-candidate) half-segment --
+// a workgroup's slice of the list was full when a lane wanted to list it -- becomes an entry of the SPILL region with all of
+// its existing rows marked, and its flag is cleared; the pair pass then re-scores it like any listed entry, spread over
+// every half-wave of the chip.  Why: flags come in runs (the LAST queries of a chunk whose workgroups ran out of quota), and
+// the sweep below, one wave per query and 64 consecutive queries per workgroup, took 3.7 ms for the 186 000 flags of the
+// clustered FB15k-237 block (duplicate rows: ~29 ties per query) where the same rows cost the pair pass 0.4 ms.  A flag
+// that finds the region full stays a flag (the sweep is still exact, only slower).  One thread per flag word.
+constexpr int64_t kFlagsToEntriesMinQueries = 2048;
+__global__ __launch_bounds__(256) void flags_to_entries_kernel(unsigned* __restrict__ flags, int64_t Q, int words_per_query,
+                                                               int64_t n_rows, unsigned* __restrict__ counter,
+                                                               uint2* __restrict__ spill, unsigned capacity) {
+    const int64_t total = Q * words_per_query, stride = (int64_t)gridDim.x * 256;
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x - lane; i0 < total; i0 += stride) {  // wave-uniform trip count
+        const int64_t i = i0 + lane;
+        const unsigned w = i < total ? flags[i] : 0u;
+        if (__ballot(w != 0) == 0) continue;
+        // room for the wave's flags with one atomic: an exclusive prefix sum of the lanes' bit counts
+        const unsigned mine = __popc(w);
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off);
+            incl += lane >= off ? up : 0u;
+        }
+        const unsigned all = __shfl(incl, 63);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(counter, all);
+        base = __shfl(base, 0);
+        if (base + all > capacity) {  // (the counter overshoots from here on: readers clamp it; reserved slots below the capacity read as empty)
+            for (unsigned k = base + lane; k < capacity && k < base + all; k += 64) spill[k] = make_uint2(0u, 0u);
+            continue;
+        }
+        if (w) {
+            const int64_t q = i / words_per_query;
+            const int word = (int)(i - q * words_per_query);
+            unsigned slot = base + incl - mine, bits = w;
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int hseg = word * 32 + b, half = hseg & 1;
+                const int64_t row0 = (int64_t)(hseg >> 1) * kGCT;
+                unsigned mask = 0;  // bit 15 - r = accumulator register r = row acc_row(r, half) of the tile (the entries' convention)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mask |= (unsigned)(row0 + acc_row(r, half) < n_rows) << (15 - r);
+                spill[slot++] = make_uint2((unsigned)q * 2u + (unsigned)half, ((unsigned)(hseg >> 1) << 16) | mask);
+            }
+            flags[i] = 0;
+        }
+    }
+}
+
 // Pass 2a: the listed entries, one per 32-lane half-wave; every undecided pair of the entry is re-scored exactly
 // (coop_score) and counted.
 template <int MODEL, int D>
@@ -917,14 +970,18 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
                                                            const float* __restrict__ key_true, int64_t q_head,
                                                            const uint2* __restrict__ pairs,
                                                            const unsigned* __restrict__ n_pairs,
+                                                           const uint2* __restrict__ spill, unsigned spill_capacity,
                                                            unsigned long long* __restrict__ acc) {
-    const unsigned n = *n_pairs;
+    // the workgroups' list, then the entries made of flagged half-segments (flags_to_entries_kernel; counter n_pairs[1], clamped:
+    // a wave that found the region full left it overshooting)
+    const unsigned n_final = n_pairs[0], n_spill = n_pairs[1] < spill_capacity ? n_pairs[1] : spill_capacity;
+    const unsigned long long n = (unsigned long long)n_final + n_spill;
     const int lane = threadIdx.x & 63, sub = lane & 31;
     const unsigned wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned e0 = wave_id * 2; e0 < n; e0 += n_waves * 2) {  // wave-uniform trip count
-        const unsigned ei = e0 + (lane >> 5);
+    for (unsigned long long e0 = (unsigned long long)wave_id * 2; e0 < n; e0 += (unsigned long long)n_waves * 2) {  // wave-uniform trip count
+        const unsigned long long ei = e0 + (lane >> 5);
         const bool live = ei < n;
-        const uint2 p = live ? pairs[ei] : make_uint2(0u, 0u);
+        const uint2 p = !live ? make_uint2(0u, 0u) : ei < n_final ? pairs[ei] : spill[ei - n_final];
         const int64_t q = p.x >> 1;
         const int half = p.x & 1;
         const int64_t row0 = (int64_t)(p.y >> 16) * kGCT;
@@ -974,8 +1031,12 @@ __global__ __launch_bounds__(256) void refine_pair_slots_kernel(const float* __r
     if (gt | ge) atomicAdd(acc + q, gt | (ge << 32));
 }
 
-// Pass 2b: one wave per query.  The wave sweeps the query's flag words 64 at a time; every flagged
-// (query, 16-candidate) half-segment is re-scored exactly, four half-segments per iteration.
+// Pass 2b: one wave per query.  The wave sweeps the query's flag words 64 at a time; every flagged (query, 16-candidate)
+// half-segment is re-scored exactly, two half-segments per iteration: each 32-lane half of the wave walks the 16 rows of its
+// half-segment with the cooperative routine of the pair pass (coop_score: lane j is accumulator A[j] of torch.sum's 32, every
+// load one 128-byte line).  Round 4 gave every LANE a row of its own (load_row: 64 lanes gathering 16 bytes each from 64
+// different rows per instruction, 128 registers of row per lane): fine while flags were rare, 3.7 ms for the 186 000 flags of
+// the clustered FB15k-237 block (duplicate rows: ~29 ties per query) against 0.39 ms for as many rows on the pair list.
 template <int MODEL, int D>
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ table, int64_t N, int64_t ld,
                                                      const QRows q_fixed,
@@ -984,7 +1045,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
                                                      int words_per_query, const unsigned* __restrict__ flags,
                                                      unsigned long long* __restrict__ acc) {
     __shared__ int list[kSweepQueries], n_list;
-    const int lane = threadIdx.x & 63, part = lane >> 4;
+    const int lane = threadIdx.x & 63, part = lane >> 5, sub = lane & 31;
     const int64_t q_base = (int64_t)blockIdx.x * kSweepQueries;
     const int n = flagged_queries(flags, q_base, Q, words_per_query, false, list, &n_list);
     for (int i = threadIdx.x >> 6; i < n; i += 4) {
@@ -993,6 +1054,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
     const float kt = key_true[q];
     const float* f = q_fixed.row(q);
     const float* rl = q_rel.row(q);
+    const bool is_head = q < q_head;
     unsigned gt = 0, ge = 0;
     for (int w0 = 0; w0 < words_per_query; w0 += 64) {
         const unsigned mine = w0 + lane < words_per_query ? row[w0 + lane] : 0u;
@@ -1002,36 +1064,33 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
             nonzero &= nonzero - 1;
             unsigned bits = __shfl(mine, src);
             const int hseg_base = (w0 + src) * 32;
-            while (bits) {
-                int b = -1;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {  // k-th set bit -> 16-lane group k
-                    const int bk = bits ? __builtin_ctz(bits) : -1;
-                    bits &= bits - 1;  // 0 stays 0
-                    b = part == k ? bk : b;
-                }
+            while (bits) {  // wave-uniform: the next two set bits, one per 32-lane half
+                const int b0 = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int b1 = bits ? __builtin_ctz(bits) : -1;
+                bits &= bits - 1;  // 0 stays 0
+                const int b = part == 0 ? b0 : b1;
                 const int hseg = hseg_base + (b < 0 ? 0 : b);
-                const int64_t r = (int64_t)(hseg >> 1) * kGCT + acc_row(lane & 15, hseg & 1);
-                const bool ok = b >= 0 && r < N;
-                float e[D];
-                load_row<D>(e, table + (ok ? r : 0) * ld);
-                const float key = q < q_head ? Scorer<MODEL, HEAD, D>::template score<false>(e, LazyCoef<MODEL, HEAD, D>{f, rl})
-                                             : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, rl});
-                gt += ok && key > kt;
-                ge += ok && key >= kt;
+                const int64_t row0 = (int64_t)(hseg >> 1) * kGCT;
+                const int hh = hseg & 1;
+                for (int rr = 0; rr < 16; ++rr) {  // (both halves walk 16 rows; a half without a segment, or past the table, idles)
+                    const int64_t r = row0 + acc_row(rr, hh);
+                    const bool ok = b >= 0 && r < N;
+                    const float* e = table + (ok ? r : 0) * ld;
+                    float key;
+                    if (is_head) key = coop_score<MODEL, HEAD, D>(e, f, rl, sub);
+                    else key = coop_score<MODEL, TAIL, D>(e, f, rl, sub);
+                    gt += ok && key > kt;
+                    ge += ok && key >= kt;
+                }
             }
         }
     }
-    if (__ballot(gt | ge) == 0) continue;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        gt += __shfl_down(gt, off);
-        ge += __shfl_down(ge, off);
-    }
-    if (lane == 0) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
+    // every lane of a half holds that half's counts: lanes 0 and 32 carry them
+    const unsigned gt2 = gt + __shfl(gt, 32), ge2 = ge + __shfl(ge, 32);
+    if (lane == 0 && (gt2 | ge2)) atomicAdd(acc + q, (unsigned long long)gt2 | ((unsigned long long)ge2 << 32));
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Run-time guard behind assumption (A) of the bf16 band: the ISA does not say how
@@ -1205,6 +1264,7 @@ struct GemmWorkspace {
     float4* img_head; float4* img_tail;
     uint4* cimg; float* cnmax;  // bf16 candidate image (whole table) and its per-half-tile band factors
     unsigned long long* acc; unsigned* n_pairs; unsigned* flags; uint2* pairs;
+    uint2* spill; int64_t spill_entries;  // bf16 kernel: entries made of flagged half-segments (flags_to_entries_kernel; counter n_pairs[1])
     int64_t pass_ctiles;  // candidate tiles per GEMM + refine pass
     size_t bytes;
 };
@@ -1212,6 +1272,14 @@ struct GemmWorkspace {
 // Pair-list entries one pass over T candidate tiles can write: every workgroup owns a fixed region of its
 // kernel's quota, so this is (candidate groups) x (query chunks) x quota -- for whichever of the two
 // pass-1 kernels needs more (their groupings of tiles and of query tiles differ).
+// Spill region of the bf16 path for a pass over T candidate tiles (where flagged half-segments become entries): room for one
+// entry per 8 (query, tile) combinations = 1 / 16 of all half-segments (500 clusters of duplicate rows on the FB15k-237 block
+// flag 1 / 500 of them), at most 2^31 entries.
+static int64_t spill_entries(int64_t T, int64_t q_head, int64_t q_tail) {
+    const int64_t e = (q_head + q_tail) * T / 8;
+    return e < ((int64_t)1 << 31) - 64 ? e : ((int64_t)1 << 31) - 64;
+}
+
 static int64_t pair_entries(int64_t T, int64_t q_head, int64_t q_tail) {
     const int64_t th = (q_head + kGQT - 1) / kGQT, tt = (q_tail + kGQT - 1) / kGQT;
     auto chunks = [&](int64_t per) { return (th + per - 1) / per + (tt + per - 1) / per; };
@@ -1233,7 +1301,8 @@ static int64_t tiles_per_pass(int64_t N, int64_t q_head, int64_t q_tail) {
     const int64_t cap = (int64_t)256 << 20;
     int64_t words = ((N + kGCT - 1) / kGCT + 15) / 16;
     const int64_t by_flags = cap / 4 / Q;
-    const int64_t by_pairs = cap / 8 / pair_entries(16, q_head, q_tail);  // entries grow linearly in whole 16-tile words
+    // (entries grow linearly in whole 16-tile words; list + spill region together get three times the bitmap's cap)
+    const int64_t by_pairs = 3 * cap / 8 / (pair_entries(16, q_head, q_tail) + spill_entries(16, q_head, q_tail));
     if (words > by_flags) words = by_flags;
     if (words > by_pairs) words = by_pairs;
     if (words * 16 > kBfMaxSlabTiles) words = kBfMaxSlabTiles / 16;  // an entry holds the slab-local tile in 16 bits
@@ -1265,6 +1334,9 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     off = align_up(off + (size_t)Q * (size_t)(w.pass_ctiles / 16) * 4, 256);
     w.pairs = reinterpret_cast<uint2*>(p + off);
     off = align_up(off + (size_t)pair_entries(w.pass_ctiles, q_head, q_tail) * 8, 256);
+    w.spill = reinterpret_cast<uint2*>(p + off);
+    w.spill_entries = spill_entries(w.pass_ctiles, q_head, q_tail);
+    off = align_up(off + (size_t)w.spill_entries * 8, 256);
     w.bytes = off;
     return w;
 }
@@ -1281,9 +1353,13 @@ hipError_t gemm_prepass_stats(int D, int64_t N, int64_t q_head, int64_t q_tail, 
     const int64_t rows = N < w.pass_ctiles * kGCT ? N : w.pass_ctiles * kGCT;  // (the first slab's bitmap width; one slab as a rule)
     const int64_t words = ((rows + kGCT - 1) / kGCT + 15) / 16;
     unsigned long long host[3] = {0, 0, 0};
-    const hipError_t err = launch_count_bits(w.flags, (q_head + q_tail) * words, w.pairs, w.n_pairs, true, host, stream);
+    hipError_t err = launch_count_bits(w.flags, (q_head + q_tail) * words, w.pairs, w.n_pairs, true, host, stream);
     out->flagged_rows = (long long)host[0] * 16;  // a flag = one (query, 16-candidate half-tile)
     out->listed = (long long)host[1];
+    if (err != hipSuccess) return err;
+    // ... and the entries made of flagged half-segments: all 16 rows each (slots a wave left empty count nothing; the counter may overshoot)
+    err = launch_count_bits(w.flags, 0, w.spill, w.n_pairs + 1, true, host, stream, (unsigned)w.spill_entries);
+    out->listed += (long long)host[1];
     return err;
 }
 
@@ -1417,8 +1493,12 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             rank_gemm_bf16_kernel<MODEL, D, false><<<dim3((unsigned)n_blocks), kBfW * 64, lds_bf16, stream>>>(
                 cimg, cnmax, n_rows, ih, it, w.key_true, w.eps_q, (int)q_head, (int)q_tail, (int)n_groups, (int)chunks_head,
                 tiles_per_chunk, words, w.acc, w.flags, w.pairs, w.n_pairs, nullptr, nullptr);
+            // flagged half-segments of a large block become entries of the balanced pair pass (what stays flagged: the sweep below)
+            if (Q >= kFlagsToEntriesMinQueries)
+                flags_to_entries_kernel<<<dim3(1024), 256, 0, stream>>>(w.flags, Q, words, n_rows, w.n_pairs + 1, w.spill,
+                                                                        (unsigned)w.spill_entries);
             refine_pairs_kernel<MODEL, D><<<dim3(2048), 256, 0, stream>>>(slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs,
-                                                                        w.n_pairs, w.acc);
+                                                                        w.n_pairs, w.spill, (unsigned)w.spill_entries, w.acc);
         }
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
             slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.acc);
