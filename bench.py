@@ -214,6 +214,47 @@ def make_filter_index(cfg, heads, tails, rels, seed=3):
     return utils.FilterIndex(test, num_relations=cfg["R"], device=heads.device)
 
 
+def workload_axis(cfg, world, shard_axis="auto"):
+    """The axis an evaluation of this workload is sharded along on `world` ranks: blp_amd.ranking.choose_shard_axis (query for
+    FB15k-237-sized tables with many triples), the north_star's CANDIDATE axis for everything at Wikidata5M scale, or --shard-axis."""
+    from blp_amd import ranking
+    if world <= 1:
+        return "none"
+    axis = ranking.choose_shard_axis(cfg["N"], cfg["D"], 2 * cfg["triples"], world)
+    if cfg["N"] > 1_000_000:
+        axis = "candidate"
+    return axis if shard_axis == "auto" else shard_axis
+
+
+def run_plan(world, shard_axis="auto"):
+    """What `python bench.py --gpus world` is going to do, computed without a GPU (`--plan`; tests/test_bench_host.py): per
+    sub-result its axis, every rank's shard of the table / of the triples, the collectives of ONE step with their byte counts
+    (blp_amd.ranking.exchange_plan = what rank_triples issues) and the steps it times."""
+    from blp_amd import ranking
+    todo = [("fb15k237-transe", "auto", "fb15k237-transe")] + [(n, "auto", n) for n in SUB_RESULTS]
+    if world > 1:
+        todo += [(n, a, f"{n}@{a}") for n, a in SUB_RESULTS_EXTRA_SHARDED]
+    plan = {}
+    for name, forced, key in todo:
+        cfg = WORKLOADS[name]
+        axis = workload_axis(cfg, world, forced if forced != "auto" else shard_axis)
+        N, T = cfg["N"], cfg["triples"]
+        rows = [ranking.shard_bounds(N, world, r) if axis == "candidate" else (0, N) for r in range(world)]
+        triples = [ranking.shard_bounds(T, world, r) if axis == "query" else (0, T) for r in range(world)]
+        half = bool(cfg.get("table_dtype"))
+        plan[key] = {"axis": axis, "table_rows_per_rank": rows, "triples_per_rank": triples,
+                     "table_bytes_per_rank": [(hi - lo) * cfg["D"] * (2 if half else 4) for lo, hi in rows],
+                     "exchanges_per_step": ranking.exchange_plan(N, cfg["D"], T, world, axis, half_table=half),
+                     "timed_steps": heavy_steps(world) if cfg.get("heavy") else None}
+    return plan
+
+
+def heavy_steps(world):
+    """(timed steps, warm-up steps) of the whole-evaluation workloads (> 1 s per step on one GPU): two timed steps on one GPU,
+    one on several -- `python bench.py --gpus 8` times 12 sub-results with every rank in each, and stays under two minutes."""
+    return (2, 1) if world == 1 else (1, 0)
+
+
 class HipEvents:
     """Raw hipEvent_t pairs on the HIP runtime torch already loaded (for the C-ABI timing hook)."""
 
@@ -245,12 +286,7 @@ class Job:
         self.name, self.cfg, self.device, self.world, self.rank, self.backend = name, WORKLOADS[name], device, world, rank, backend
         cfg = self.cfg
         self.N, self.D, self.T = cfg["N"], cfg["D"], cfg["triples"]
-        axis = ranking.choose_shard_axis(self.N, self.D, 2 * self.T, world)
-        if world > 1 and cfg["N"] > 1_000_000:
-            axis = "candidate"  # north_star: the 4.6 M-entity ranking is sharded along the candidate axis
-        if world > 1 and shard_axis != "auto":
-            axis = shard_axis
-        self.axis = axis if world > 1 else "none"
+        self.axis = workload_axis(cfg, world, shard_axis)  # (north_star: the 4.6 M-entity ranking along the candidate axis)
         self.lo, self.hi = ranking.shard_bounds(self.N, world, rank) if self.axis == "candidate" else (0, self.N)
         # a candidate shard of a Wikidata5M-scale table generates its own rows only; small tables are made whole (rank 0
         # keeps the whole one for the parity spot check) and sliced
@@ -472,8 +508,9 @@ class Job:
 
     def measure(self, steps, warmup, events):
         """The JSON fields of this workload: whole evaluation (raw + filtered) and raw-only, the roofline."""
-        if self.heavy:  # a step takes seconds: two timed steps, one of everything else
-            steps, warmup = min(steps, 2), min(warmup, 1)
+        if self.heavy:  # a step takes seconds: two timed steps (one on several GPUs), one of everything else
+            cap_steps, cap_warmup = heavy_steps(self.world)
+            steps, warmup = min(steps, cap_steps), min(warmup, cap_warmup)
         raw_steps = 1 if self.heavy else max(1, min(steps, 5))
         elapsed, (triples, counts, sums) = self.timed(steps, warmup, filtered=True)
         raw_elapsed, _ = self.timed(raw_steps, 0 if self.heavy else 1, filtered=False)
@@ -813,19 +850,41 @@ def inbatch_bench(device, iters=200):
     return out
 
 
-def relaunch_with_ranks(n_gpus):
+def relaunch_with_ranks(n_gpus, timeout_s=None):
     """`python bench.py --gpus N` started without a launcher: start the N ranks ourselves (one process per GPU through
     torch.distributed.run, rendezvous on 127.0.0.1 and a free port), hand rank 0's single JSON line through on stdout and
-    return the launcher's exit status -- non-zero if any rank died."""
+    return the launcher's exit status -- non-zero if any rank died (the launcher names the failed ranks on stderr, which is
+    passed through).  The run is bounded: after BLP_BENCH_TIMEOUT_S seconds (default 900; a hung collective would otherwise
+    hold the box until the driver's own limit) the launcher's process group is killed, status 124."""
+    import signal
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "8")       # (the launcher would set 1 and say so on stderr; the CPU side is tiny either way)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    # dmabuf IPC.  Not measured by this package (no RCCL run of it has had two GPUs): the build environment's own note -- "the
+    # host driver only supports dmabuf IPC, and without it RCCL / CUDA-tensor sharing across processes fails with
+    # hipIpcGetMemHandle: invalid argument"; it is exported on the GPU boxes already, this only keeps it when the caller's
+    # environment was scrubbed.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    timeout_s = float(os.environ.get("BLP_BENCH_TIMEOUT_S", "900")) if timeout_s is None else timeout_s
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    return subprocess.call(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)  # (its own process group: the launcher AND its ranks can be stopped)
+    try:
+        return proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n_gpus}-rank run did not finish within {timeout_s:.0f} s (BLP_BENCH_TIMEOUT_S): stopping it", file=sys.stderr, flush=True)
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            proc.wait(timeout=20)
+        except (subprocess.TimeoutExpired, ProcessLookupError):
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            proc.wait()
+        return 124
 
 
 def sub_result(name, axis, device, world, rank, backend, steps, events):
@@ -1092,8 +1151,13 @@ def main():
     ap.add_argument("--shard-axis", default="auto", choices=["auto", "candidate", "query"],
                     help="N > 1: which axis to shard (default: blp_amd.ranking.choose_shard_axis; the Wikidata5M-scale "
                          "table always along the candidate axis)")
+    ap.add_argument("--plan", action="store_true", help="print what a run on --gpus N ranks would do (axes, shards, the bytes of "
+                    "every collective, steps of the long workloads) as JSON and exit; needs no GPU")
     args = ap.parse_args()
 
+    if args.plan:
+        print(json.dumps(run_plan(args.gpus, args.shard_axis), indent=1))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(relaunch_with_ranks(args.gpus))  # no launcher around us: be our own
     rank = int(os.environ.get("RANK", "0"))

@@ -156,6 +156,41 @@ def choose_shard_axis(num_rows, dim, num_queries, world_size):
     return "query" if small_table and num_queries // world_size >= QUERY_AXIS_MIN_QUERIES else "candidate"
 
 
+def replicates_whole_table(num_entities, num_triples, half_table=False):
+    """Candidate-axis shards need the vectors the queries are made of on every rank: the whole table by ONE all-gather when it is
+    smaller than the 2T vectors of the triples, else those 2T vectors by ONE all-reduce of an owner-filled array."""
+    return num_entities <= 2 * num_triples and not half_table
+
+
+def exchange_plan(num_entities, dim, num_triples, world, axis, half_table=False):
+    """The collectives ONE evaluation of num_triples triples (2 * num_triples queries) issues on `world` ranks, as
+    rank_triples below issues them (its fused path; same conditions): a list of {"op", "what", "bytes_per_rank",
+    "bytes_total"} -- bytes_per_rank = what one rank contributes, bytes_total = what every rank holds afterwards.  SURVEY
+    8e: the candidate axis ends in ONE all-gather of the int32 counts, G x Q x 16 bytes in all.  No GPU needed (tests, bench's
+    plan of an N-GPU run)."""
+    if world <= 1:
+        return []
+    Q = 2 * num_triples
+    plan = []
+    if axis == "candidate":
+        if replicates_whole_table(num_entities, num_triples, half_table):
+            per = (num_entities + world - 1) // world  # all_gather_rows pads every shard to the longest
+            plan.append({"op": "all_gather", "what": "table rows (the queries' vectors: the table is smaller than they are)",
+                         "bytes_per_rank": per * dim * 4, "bytes_total": world * per * dim * 4})
+        else:
+            plan.append({"op": "all_reduce", "what": "(2T, D) f32 vectors of the triples' entities, each filled by the shard that owns the row",
+                         "bytes_per_rank": Q * dim * 4, "bytes_total": Q * dim * 4})
+        plan.append({"op": "all_gather", "what": "(2T, 4) int32 rank counts of every shard, then a sum",
+                     "bytes_per_rank": Q * 16, "bytes_total": world * Q * 16})
+    elif axis == "query":
+        per = (num_triples + world - 1) // world
+        plan.append({"op": "all_gather", "what": "(T / G, 8) int32 counts of each rank's triples (head and tail query side by side)",
+                     "bytes_per_rank": per * 32, "bytes_total": world * per * 32})
+    else:
+        raise ValueError(f"unknown shard axis {axis!r}")
+    return plan
+
+
 def _via_host(tensor, group):
     """gloo carries host memory only: device tensors go through a host copy there (functional runs of the N > 1
     path on fewer GPUs than ranks, tests); RCCL takes them as they are."""
@@ -333,7 +368,7 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         rel_w = model.rel_emb.weight
         source, by_position = table, False
         half_table = table.dtype != torch.float32  # the 16-bit copy of the table (ops.rank_all_batches): candidates only
-        if by_candidate and num_entities <= 2 * num_triples and not half_table:  # small table: all of it, one all-gather
+        if by_candidate and replicates_whole_table(num_entities, num_triples, half_table):  # small table: all of it, one all-gather
             with _Stopwatch(timing, device):
                 source = all_gather_rows(table, num_entities, world, group)
         elif by_candidate or half_table:                          # big table: the 2T vectors of the triples, one all-reduce

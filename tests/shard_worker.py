@@ -60,6 +60,25 @@ def main():
     torch.cuda.synchronize()
     equal = bool(torch.equal(counts, single))
 
+    # (0) the collectives of one evaluation: op and bytes one rank hands in, in the order issued (== ranking.exchange_plan)
+    issued = []
+    real_reduce, real_gather = ranking._all_reduce, ranking._all_gather_into
+
+    def logged_reduce(tensor, group=None):
+        issued.append(["all_reduce", tensor.numel() * tensor.element_size()])
+        return real_reduce(tensor, group)
+
+    def logged_gather(full, part, group=None):
+        issued.append(["all_gather", part.numel() * part.element_size()])
+        return real_gather(full, part, group)
+
+    ranking._all_reduce, ranking._all_gather_into = logged_reduce, logged_gather
+    try:
+        ranking.rank_triples(model, shard, dev_triples, dev_e2i, index, **kw)
+    finally:
+        ranking._all_reduce, ranking._all_gather_into = real_reduce, real_gather
+    torch.cuda.synchronize()
+
     # (1) which aten ops run while the blocks are issued
     log = BlockLoopOps()
     real = ops.rank_all_batches
@@ -101,7 +120,7 @@ def main():
         names = [f"profiler unavailable: {exc!r}"[:200]]
     source = "table" if N <= 2 * T else "vectors"
     print(json.dumps({"rank": rank, "counts_equal_single_process": equal, "ids_ok": bool(ok), "source": source,
-                      "library_calls_for_all_blocks": len(calls), "torch_compute_ops_in_block_loop": sorted(set(log.seen)),
+                      "library_calls_for_all_blocks": len(calls), "collectives": issued, "torch_compute_ops_in_block_loop": sorted(set(log.seen)),
                       "kernels_per_block": per_block, "kernel_names": names}), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -129,3 +129,61 @@ def test_details_file_holds_the_full_result(tmp_path):
     path = bench.write_details(full, str(tmp_path / "d.json"))
     assert json.load(open(path)) == full
     assert bench.write_details(full, str(tmp_path / "no" / "such" / "dir" / "d.json")) is None  # the line is still printed
+
+
+def test_eight_rank_plan_without_a_gpu():
+    """`python bench.py --gpus 8 --plan`: what the driver's 8-GPU run will do, computed here without a GPU -- the same
+    sub-result names as one rank (+ the headline on the candidate axis), everything at Wikidata5M scale on the north_star's
+    candidate axis with disjoint shards that cover the table, and per step exactly the exchanges of SURVEY 8e: the (2T, D) f32
+    vectors of the queries replicated ONCE (one all-reduce) and ONE all-gather of the (2T, 4) int32 counts = G x Q x 16 bytes
+    (1.76 MB at Q = 13 788, G = 8); the FB15k-237 evaluations on the query axis with one all-gather of per-triple counts."""
+    import bench
+    plan = bench.run_plan(8)
+    assert set(plan) == {"fb15k237-transe", *bench.SUB_RESULTS, "fb15k237-transe@candidate"}
+    for name, p in plan.items():
+        cfg = bench.WORKLOADS[name.split("@")[0]]
+        N, T, D = cfg["N"], cfg["triples"], cfg["D"]
+        big = N > 1_000_000
+        assert p["axis"] == ("candidate" if big or "@candidate" in name else "query"), name
+        ex = p["exchanges_per_step"]
+        if p["axis"] == "candidate":
+            rows = p["table_rows_per_rank"]
+            assert rows[0][0] == 0 and rows[-1][1] == N and all(a[1] == b[0] for a, b in zip(rows, rows[1:])), name
+            assert max(hi - lo for lo, hi in rows) - min(hi - lo for lo, hi in rows) <= 8, name  # balanced shards
+            assert all(t == [0, T] or t == (0, T) for t in p["triples_per_rank"]), name  # every rank ranks every query
+            assert [e["op"] for e in ex] == (["all_reduce", "all_gather"] if big else ["all_gather", "all_gather"]), name
+            assert ex[-1]["bytes_per_rank"] == 2 * T * 16 and ex[-1]["bytes_total"] == 8 * 2 * T * 16, name
+            if big:
+                assert ex[0]["bytes_total"] == 2 * T * D * 4, name  # the replicated vectors never grow with the table
+                assert sum(p["table_bytes_per_rank"]) == N * D * (2 if cfg.get("table_dtype") else 4), name
+        else:
+            assert [e["op"] for e in ex] == ["all_gather"] and ex[0]["bytes_total"] == 8 * -(-T // 8) * 32, name
+            trip = p["triples_per_rank"]
+            assert trip[0][0] == 0 and trip[-1][1] == T and all(a[1] == b[0] for a, b in zip(trip, trip[1:])), name
+    assert plan["wikidata5m-transe-block"]["exchanges_per_step"][-1]["bytes_total"] == 8 * 13788 * 16 == 1764864
+    assert plan["wikidata5m-transe-full"]["timed_steps"] == [1, 0] or plan["wikidata5m-transe-full"]["timed_steps"] == (1, 0)
+    assert bench.run_plan(1)["wikidata5m-transe-full"]["timed_steps"] in ([2, 1], (2, 1))
+    assert all(p["exchanges_per_step"] == [] and p["axis"] == "none" for p in bench.run_plan(1).values())
+
+
+def test_plan_flag_prints_json_without_a_gpu():
+    import json
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plan"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    plan = json.loads(run.stdout)
+    assert plan["wikidata5m-complex"]["axis"] == "candidate" and len(plan["wikidata5m-complex"]["table_rows_per_rank"]) == 4
+
+
+def test_self_launched_run_is_bounded_in_time(tmp_path, monkeypatch):
+    """bench.relaunch_with_ranks gives the launcher BLP_BENCH_TIMEOUT_S seconds: a rank that never finishes (a hung collective)
+    is stopped with its whole process group, status 124, and the reason is on stderr."""
+    import time
+    import bench
+    hang = tmp_path / "hang.py"
+    hang.write_text("import time\ntime.sleep(600)\n")
+    monkeypatch.setattr(bench, "__file__", str(hang))
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    t0 = time.time()
+    status = bench.relaunch_with_ranks(2, timeout_s=8)
+    assert status == 124 and time.time() - t0 < 60

@@ -148,6 +148,12 @@ def test_candidate_axis_two_gloo_ranks_take_the_fused_path(model, N, T, block):
         assert r["source"] == ("table" if N <= 2 * T else "vectors")
         assert r["torch_compute_ops_in_block_loop"] == [], r["torch_compute_ops_in_block_loop"]
         assert r["library_calls_for_all_blocks"] == 1  # blp_rank_all_batches: the blocks are issued by the library
+        # the collectives actually issued == the plan bench.py / the CPU tests compute without a GPU (the vectors of
+        # the queries replicated once, ONE all-gather of the (2T, 4) int32 counts)
+        from blp_amd import ranking
+        plan = ranking.exchange_plan(N, 128, T, 2, "candidate")
+        assert r["collectives"] == [[e["op"], e["bytes_per_rank"]] for e in plan], (r["collectives"], plan)
+        assert plan[-1]["bytes_total"] == 2 * (2 * T) * 16
         limit = 3 if 2 * min(T, block) * (N // 2) < 400000 or min(T, block) <= 4 else (8 if model == "transe" else 6)
         if r["kernels_per_block"] is not None:  # the profiler saw the device activity of this process
             assert 1 <= r["kernels_per_block"] <= limit, (r["kernels_per_block"], r["kernel_names"])
