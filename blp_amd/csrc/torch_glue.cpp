@@ -111,6 +111,46 @@ struct AutogradFloor : public torch::autograd::Function<AutogradFloor> {
     }
 };
 
+// (tools/autograd_floor_probe.py: which part of such a node costs what.  flags: 1 = save nothing, 2 = no scratch tensors in forward,
+//  4 = no gradient for rel_vecs, 8 = none for ent_embs, 16 = gradients are plain at::empty of the saved sizes, not empty_like)
+struct AutogradFloorV : public torch::autograd::Function<AutogradFloorV> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& ent_embs, const at::Tensor& rel_vecs,
+                              const at::Tensor& neg_idx, int64_t flags) {
+        const int64_t B = ent_embs.size(0), K = neg_idx.size(1);
+        const auto f32 = ent_embs.options().dtype(at::kFloat);
+        at::Tensor loss = at::empty({}, f32);
+        if (!(flags & 2)) {
+            at::Tensor pos = at::empty({2 * B + kSavePosExtra}, f32), neg = at::empty({B, K}, f32);
+            if (!(flags & 1)) ctx->save_for_backward({ent_embs, rel_vecs, neg_idx, pos, neg});
+        } else if (!(flags & 1)) {
+            ctx->save_for_backward({ent_embs, rel_vecs, neg_idx});
+        }
+        ctx->saved_data["flags"] = flags;
+        ctx->saved_data["e_shape"] = ent_embs.sizes().vec();
+        ctx->saved_data["r_shape"] = rel_vecs.sizes().vec();
+        ctx->saved_data["dev"] = (int64_t)ent_embs.get_device();
+        return loss;
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const int64_t flags = ctx->saved_data["flags"].toInt();
+        const auto opt = at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, (c10::DeviceIndex)ctx->saved_data["dev"].toInt());
+        at::Tensor ge, gr;
+        if (flags & 16 || flags & 1) {
+            if (!(flags & 8)) ge = at::empty(ctx->saved_data["e_shape"].toIntVector(), opt);
+            if (!(flags & 4)) gr = at::empty(ctx->saved_data["r_shape"].toIntVector(), opt);
+        } else {
+            const auto saved = ctx->get_saved_variables();
+            if (!(flags & 8)) ge = at::empty_like(saved[0]);
+            if (!(flags & 4)) gr = at::empty_like(saved[1]);
+        }
+        return {ge, gr, at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor autograd_floor_variant(const at::Tensor& ent_embs, const at::Tensor& rel_vecs, const at::Tensor& neg_idx, int64_t flags) {
+    return AutogradFloorV::apply(ent_embs, rel_vecs, neg_idx, flags);
+}
+
 at::Tensor autograd_floor(const at::Tensor& ent_embs, const at::Tensor& rel_vecs, const at::Tensor& neg_idx) {
     return AutogradFloor::apply(ent_embs, rel_vecs, neg_idx);
 }
@@ -135,5 +175,6 @@ PYBIND11_MODULE(_torch_glue, m) {
           "compute_loss on in-batch negatives: (ent_embs, rel_vecs, neg_idx, model_id, loss_id, regularizer, raw_stream) -> loss");
     m.def("autograd_floor", &autograd_floor, py::call_guard<py::gil_scoped_release>(),
           "a node of the same shape that launches nothing (bench.py: what autograd itself costs per step)");
+    m.def("autograd_floor_variant", &autograd_floor_variant, py::call_guard<py::gil_scoped_release>(), "autograd_floor with parts switched off (probe)");
     m.attr("save_pos_extra_floats") = kSavePosExtra;
 }

@@ -351,8 +351,16 @@ def test_bench_line_keeps_the_contract(tmp_path):
     # the training-side step: three launches; from Python with the autograd engine's worker threads and on the calling thread
     ib = r["inbatch_loss"]["inbatch-fb15k237"]
     assert ib["launches_per_step"] == 3 and 0 < ib["us_per_step_kernels"] < ib["us_per_step_autograd"]
-    assert 0 < ib["us_per_step_autograd_engine_single_threaded"] < ib["us_per_step_autograd"]
-    assert ib["us_per_step_autograd_engine_single_threaded"] < 60.0  # (measured 30; the review's bar was 45)
+    # default autograd threading, settled state (measured 42 us at B = 64; the review's bar: 45): PyTorch's own floor -- the same
+    # node without kernels, measured beside it (24 - 31 us settled, 50 - 65 us in the first seconds of a process: host behaviour)
+    # -- plus what this package adds (12 us: three launches, two C-ABI calls, five allocations)
+    assert ib["us_per_step_autograd"] == pytest.approx(ib["us_autograd_floor_no_kernels"] + ib["us_node_cost"], rel=1e-9)
+    assert 0 < ib["us_node_cost"] < 25.0 and 0 < ib["us_node_cost_in_graph"] < 25.0
+    assert ib["us_per_step_autograd"] < 70.0 and ib["us_per_step_autograd_engine_single_threaded"] < 60.0
+    # the reference's training wrapper: two nn.DataParallel replicas on this device, fused loss against stock expressions
+    dp = ib["dataparallel_two_replicas"]
+    assert dp["replicas"] == 2 and 0 < dp["fused_us_per_step"] < dp["stock_us_per_step"]
+    assert 0 < dp["fused_one_replica_alone_us"] < dp["stock_one_replica_alone_us"]
 
 
 @pytest.mark.parametrize("rel_model,D", [("transe", 300), ("transe", 768), ("distmult", 96), ("complex", 192),
