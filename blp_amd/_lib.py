@@ -24,7 +24,7 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_selftest", "
            "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex", "blp_rank_all_idx",
            "blp_rank_all_shard", "blp_gather_triple_vectors", "blp_rank_all_batches", "blp_rank_all_batches_workspace_bytes",
            "blp_rank_all_batches_passes_per_launch", "blp_rank_all_batches_t", "blp_rank_all_batches_t_workspace_bytes",
-           "blp_rank_all_batches_t_passes_per_launch", "blp_gather_triple_vectors_t", "blp_profile_next_rank_kernel", "blp_rank_all_prepass_stats", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
+           "blp_rank_all_batches_t_passes_per_launch", "blp_rank_all_batches_t_native", "blp_gather_triple_vectors_t", "blp_profile_next_rank_kernel", "blp_rank_all_prepass_stats", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
            "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows", "blp_dkrl_rows_supported", "blp_dkrl_rows",
            "blp_build_queries")
@@ -121,6 +121,8 @@ def _load(path, hooks):
     L.blp_device_caps.argtypes = [_i, ctypes.POINTER(BlpCaps)]
     L.blp_rank_all_prepass_stats.restype = _i
     L.blp_rank_all_prepass_stats.argtypes = [_i, _i64, _i, _i64, _i64, _vp, _sz, ctypes.POINTER(ctypes.c_int64), _i, _vp]
+    L.blp_rank_all_batches_t_native.restype = _i
+    L.blp_rank_all_batches_t_native.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
     L.blp_selftest.restype = _i
     L.blp_selftest.argtypes = [_i, _vp]
     L.blp_dim_supported.restype = _i

@@ -312,8 +312,8 @@ static int rank_all_checked(int model, const float* table, int64_t N, int D, int
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
     if (!blp_rank_all_supported(model, D, q_head, q_tail))
         return fail(BLP_ERR_UNSUPPORTED_DIM,
-                    "blp_rank_all: D = %d not supported for this block (64 / 128 / 256 always; TransE with >= 256 "
-                    "queries at any D %% 4 == 0 up to 1024): see blp_rank_all_supported", D);
+                    "blp_rank_all: D = %d not supported for this block (64 / 128 / 256 always; TransE at any "
+                    "D %% 4 == 0 up to 1024): see blp_rank_all_supported", D);
     if (N < 0 || q_head < 0 || q_tail < 0 || ld < D)
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all: negative size or ld < D (N=%lld q_head=%lld q_tail=%lld ld=%lld)",
                     (long long)N, (long long)q_head, (long long)q_tail, (long long)ld);
@@ -440,6 +440,14 @@ size_t blp_rank_all_batches_t_workspace_bytes(int model, int table_dtype, int64_
     if (table_dtype == BLP_DTYPE_F32) return blp_rank_all_batches_workspace_bytes(model, N, D, n_triples, batch, block_triples);
     if (!valid_model(model) || !valid_table_dtype(table_dtype) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
     return blp::rank_all_batches16_workspace_bytes(model, D, N, ld, n_triples, batch, block_triples);
+}
+
+int blp_rank_all_batches_t_native(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                  int64_t block_triples) {
+    if (table_dtype == BLP_DTYPE_F32 || !valid_model(model) || !valid_table_dtype(table_dtype) || D <= 0 || N < 0 || n_triples < 0 ||
+        batch <= 0 || block_triples < 0)
+        return 0;
+    return blp::rank_all_batches_native16(model, D, N, ld, n_triples, batch, block_triples) ? 1 : 0;
 }
 
 int64_t blp_rank_all_batches_t_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bow_rows_kernel(const int64_t* __restrict
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
         const float nrm = sqrtf(ss);
-        scale = 1.0f / (nrm > 1e-12f ? nrm : 1e-12f);
+        scale = nrm > 1e-12f ? nrm : 1e-12f;  // (divided by, as F.normalize does: a multiplication by the reciprocal differs in the last bit)
     }
     float* dst = out + i * ldo;
 #pragma unroll
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void bow_rows_kernel(const int64_t* __restrict
         const int c = 4 * lane + 256 * k;
         if (c < E) {
             if (normalize)
-                *reinterpret_cast<float4*>(dst + c) = make_float4(acc[k].x * scale, acc[k].y * scale, acc[k].z * scale, acc[k].w * scale);
+                *reinterpret_cast<float4*>(dst + c) = make_float4(acc[k].x / scale, acc[k].y / scale, acc[k].z / scale, acc[k].w / scale);
             else
                 *reinterpret_cast<float4*>(dst + c) = acc[k];
         }

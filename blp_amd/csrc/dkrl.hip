@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void dkrl_rows_kernel(const int64_t* __restric
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
             const float nrm = sqrtf(ss);
-            scale = 1.0f / (nrm > 1e-12f ? nrm : 1e-12f);
+            scale = nrm > 1e-12f ? nrm : 1e-12f;  // (divided by, as F.normalize does)
         }
         if (ie < n) {
-            out[ie * ldo + lane] = normalize ? v[0] * scale : v[0];
-            out[ie * ldo + lane + 64] = normalize ? v[1] * scale : v[1];
+            out[ie * ldo + lane] = normalize ? v[0] / scale : v[0];
+            out[ie * ldo + lane + 64] = normalize ? v[1] / scale : v[1];
         }
     }
     if (bad && i_real < n) atomicMin(bad_tok, -1);

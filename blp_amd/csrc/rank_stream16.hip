@@ -412,7 +412,9 @@ __global__ __launch_bounds__(kWaves * 64, NQ <= 4 ? 4 : 3) void rank_stream_dot1
 // A pass (or all passes of a reference-batched call) of <= 4 + 4 queries over a 16-bit table: D = 128 or 256 (a 128-byte
 // row-piece is 64 columns, two pieces in the ring), 16-byte aligned rows, 32-bit byte offsets inside a tile.
 bool rank_stream16_applicable(int model, int D, int64_t N, int64_t ld, int64_t q_head, int64_t q_tail) {
-    if (q_head > kStreamQ || q_tail > kStreamQ || N <= 0 || q_head + q_tail <= 0) return false;
+    // (both sides non-empty: with q_head == 0 the TransE kernel's head units would still request coefficient rows past the tail
+    //  rows' -- every caller ranks a batch's head AND tail queries, so the one-sided case goes to the other kernels)
+    if (q_head > kStreamQ || q_tail > kStreamQ || N <= 0 || q_head <= 0 || q_tail <= 0) return false;
     if (!(D == 128 || D == 256) || ld % 8 != 0 || ld >= (1 << 22)) return false;
     if (model != TRANSE && model != DISTMULT && model != COMPLEX && model != SIMPLE) return false;
     return ((N + kTileRows - 1) / kTileRows + kWaves - 1) / kWaves < (int64_t)0x7fffffff;  // (the kernels' 32-bit round index)

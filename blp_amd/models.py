@@ -267,10 +267,12 @@ class BOW(WordEmbeddingsLP):
         embs = torch.sum(text_mask.unsqueeze(dim=-1) * embs, dim=1)
         return embs / lengths
 
-    def encode_into(self, out, text_tok, text_mask=None):
+    def encode_into(self, out, text_tok, text_mask=None, defer_check=False):
         """Table build (train.py:96-121): on a HIP device and outside autograd the lookup, the masked mean, F.normalize and
         the row assignment are one kernel that reads every gathered word vector once (ops.bow_rows -> blp_bow_rows); the
-        stock modules stream the (B, L, E) gather three times."""
+        stock modules stream the (B, L, E) gather three times.  A token id outside the embedding table raises IndexError
+        before this returns (one host read) -- unless ``defer_check``: the caller then calls check_tokens() itself after
+        its last chunk (ranking.build_entity_table: one read per table instead of one per chunk)."""
         weight = self.embeddings.weight
         if out.is_cuda and not torch.is_grad_enabled() and out.dtype == torch.float32 and weight.dtype == torch.float32 \
                 and text_tok.dim() == 2 and out.stride(1) == 1 and ops.bow_rows_supported(weight.shape[1]) \
@@ -278,7 +280,10 @@ class BOW(WordEmbeddingsLP):
             flag = self.__dict__.get("_bow_bad_tok")  # (a plain attribute: not a buffer, not in the state_dict)
             if flag is None or flag.device != out.device:
                 flag = self.__dict__["_bow_bad_tok"] = torch.zeros((), dtype=torch.int32, device=out.device)
-            return ops.bow_rows(text_tok, text_mask, weight, out, self.normalize_embs, bad_flag=flag)
+            rows = ops.bow_rows(text_tok, text_mask, weight, out, self.normalize_embs, bad_flag=flag)
+            if not defer_check:
+                self.check_tokens()
+            return rows
         return super().encode_into(out, text_tok, text_mask)
 
     def check_tokens(self):
@@ -315,8 +320,9 @@ class DKRL(WordEmbeddingsLP):
         lengths = torch.sum(text_mask, dim=-1)
         return torch.tanh(torch.sum(embs * text_mask, dim=-1) / lengths)
 
-    def encode_into(self, out, text_tok, text_mask=None):
-        """Table build (train.py:96-121): on a HIP device and outside autograd the whole encoder, F.normalize and the row
+    def encode_into(self, out, text_tok, text_mask=None, defer_check=False):
+        """(``defer_check``: as BOW.encode_into.)
+        Table build (train.py:96-121): on a HIP device and outside autograd the whole encoder, F.normalize and the row
         assignment are one kernel (ops.dkrl_rows -> blp_dkrl_rows: conv1 on the matrix cores in f32, pooling and tanh in its
         accumulators, conv2 folded into the masked mean); the stock modules run a gather, two transposes, two convolutions, two
         poolings and five elementwise kernels over (B, L, E) / (B, dim, L) temporaries."""
@@ -329,7 +335,10 @@ class DKRL(WordEmbeddingsLP):
             flag = self.__dict__.get("_dkrl_bad_tok")  # (a plain attribute: not a buffer, not in the state_dict)
             if flag is None or flag.device != out.device:
                 flag = self.__dict__["_dkrl_bad_tok"] = torch.zeros((), dtype=torch.int32, device=out.device)
-            return ops.dkrl_rows(text_tok, text_mask, weight, self.conv1, self.conv2, out, self.normalize_embs, bad_flag=flag)
+            rows = ops.dkrl_rows(text_tok, text_mask, weight, self.conv1, self.conv2, out, self.normalize_embs, bad_flag=flag)
+            if not defer_check:
+                self.check_tokens()
+            return rows
         return super().encode_into(out, text_tok, text_mask)
 
     def check_tokens(self):

@@ -234,6 +234,16 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     return counts
 
 
+def table16_is_read_directly(rel_model, dtype, N, D, n_triples, batch, block_triples=None):
+    """include/blp_hip.h: blp_rank_all_batches_t_native -- True if rank_all_batches over a float16 / bfloat16 table of these sizes
+    streams the 16-bit rows themselves (half the bytes per pass); False if the library would widen the table to f32 first."""
+    if dtype not in TABLE_DTYPES or dtype == torch.float32:
+        return False
+    ld = (D + 7) // 8 * 8
+    return bool(_lib.lib().blp_rank_all_batches_t_native(_lib.MODEL_IDS[rel_model], TABLE_DTYPES[dtype], int(N), int(D), ld, int(n_triples),
+                                                         int(batch), int(batch if block_triples is None else block_triples)))
+
+
 def rank_all_workspace_bytes(rel_model, N, D, q_head, q_tail):
     return int(_lib.lib().blp_rank_all_workspace_bytes(_lib.MODEL_IDS[rel_model], int(N), int(D), int(q_head), int(q_tail)))
 
@@ -745,9 +755,14 @@ def torch_glue():
             from . import _torch_glue as g
             L = _lib.lib()
             g.bind(*(ctypes.cast(fn, ctypes.c_void_p).value for fn in (L.blp_inbatch_loss_fwd_t, L.blp_inbatch_loss_bwd_t, L.blp_last_error)))
-            assert g.save_pos_extra_floats + 2 == _lib.inbatch_save_pos_floats(1)
+            if g.save_pos_extra_floats + 2 != _lib.inbatch_save_pos_floats(1):  # a stale build against an older header
+                raise ImportError(f"blp_amd/_torch_glue.so was built for another include/blp_hip.h (save_pos: {g.save_pos_extra_floats} + 2 "
+                                  f"floats, the library wants {_lib.inbatch_save_pos_floats(1)}); rebuild with python -m blp_amd.build")
             _glue_module = g
-        except ImportError:
+        except Exception as exc:  # not built, another torch, a stale build, a failed bind: the Python autograd.Function serves
+            import warnings
+            if not isinstance(exc, ModuleNotFoundError):
+                warnings.warn(f"blp_amd: C++ autograd glue not used ({exc}); falling back to the Python autograd.Function")
             _glue_module = None
     return _glue_module
 

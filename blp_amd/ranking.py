@@ -423,9 +423,7 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
         q_rel = model.rel_emb(rel_ids)
         q_true = source[true_src] if by_candidate else None
         seg = None
-        tail_block = n % block_size or min(block_size, n)  # rank_block decides per block: both shapes must take segments
-        if index is not None and n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n)) \
-                and fused_ranking_takes(model, table, 2 * tail_block):  # slices of the sorted index: nothing is listed per batch
+        if index is not None and n > 0 and fused_ranking_takes(model, table, 2 * min(block_size, n)):  # slices of the sorted index: nothing is listed per batch
             seg = index.segments(triples[mine], ent2idx, device)
             seg = seg._replace(seg_lo=seg.seg_lo[order_src], seg_hi=seg.seg_hi[order_src], exclude=seg.exclude[order_src])
         counts = torch.empty((2 * n, 4), dtype=torch.int32, device=device)
@@ -504,7 +502,11 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
             text_tok, text_mask, _ = text_dataset.get_entity_description(batch_ents)
             # the model writes its rows itself: the BERT encoders fuse enc_linear + normalise + this assignment
             # (models.BertEmbeddingsLP.encode_into -> blp_project_rows); same values as model(tok, mask), train.py:109
-            model.encode_into(table[idx: idx + batch_ents.shape[0]], text_tok.to(device), text_mask.to(device))
+            rows, tok, mask = table[idx: idx + batch_ents.shape[0]], text_tok.to(device), text_mask.to(device)
+            if hasattr(model, "check_tokens"):  # (the fused bag-of-words / DKRL builds: their token-id check once per table, below)
+                model.encode_into(rows, tok, mask, defer_check=True)
+            else:
+                model.encode_into(rows, tok, mask)
         else:
             table[idx: idx + batch_ents.shape[0]] = model(batch_ents.to(device))
         if log is not None and (it + 1) % report == 0:
@@ -531,8 +533,12 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
 
     ``rank_table_dtype`` (torch.float16 / torch.bfloat16; default None = the reference's float32): rank against a 16-bit COPY of
     the table ("emit fp16 copy").  A deliberate change of the INPUT, not of the arithmetic: the candidates are
-    the rounded rows, scored in f32 in the reference's order (counts = the reference's on the rounded table, bit for bit); at
-    the reference's Wikidata5M batching the passes over the table read half the bytes.  The returned embeddings stay float32."""
+    the rounded rows, scored in f32 in the reference's order (counts = the reference's on the rounded table, bit for bit).
+    Honoured ONLY where it pays: at the reference's Wikidata5M batching (``block_size`` <= 4 triples per table pass, dim 128 /
+    256, a table long enough for the streaming kernels) the passes read the 16-bit rows themselves, half the bytes; for any
+    other shape the library would widen the copy back to float32 before ranking -- more memory and time than the float32
+    table and different metrics for nothing -- so the float32 table is ranked and a log line says so (train.py:
+    ``rank_table_dtype=float16``).  The returned embeddings stay float32."""
     model = _module(model)
     if device is None:
         device = next(model.parameters()).device
@@ -569,7 +575,15 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     axis = shard_axis if shard_axis != "auto" else choose_shard_axis(num_entities, table.shape[1], 2 * num_triples, world)
     if sharded and world > 1 and axis == "query":  # full table everywhere, each rank takes a slice of the triples
         table = all_gather_rows(table, num_entities, world, group)
-    rank_table = table if rank_table_dtype in (None, torch.float32) or not table.is_cuda else table.to(rank_table_dtype)
+    rank_table = table
+    if rank_table_dtype not in (None, torch.float32) and table.is_cuda:
+        local_triples = shard_bounds(num_triples, world, rank) if (sharded and world > 1 and axis == "query") else (0, num_triples)
+        if ops.table16_is_read_directly(model.rel_model, rank_table_dtype, table.shape[0], table.shape[1],
+                                        local_triples[1] - local_triples[0], block_size):
+            rank_table = table.to(rank_table_dtype)
+        else:
+            _log.info(f"rank_table_dtype={rank_table_dtype}: not used for this evaluation ({block_size} triples per ranking pass, dim "
+                      f"{table.shape[1]}, {table.shape[0]:,} rows: the library would widen a 16-bit copy back to float32); ranking the float32 table")
     triples, counts, ids_ok = rank_triples(model, rank_table, triples, ent2idx.to(device), index, num_entities=num_entities,
                                            group=group, world=world, rank=rank, axis=axis, block_size=block_size)
     del rank_table

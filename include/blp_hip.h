@@ -261,6 +261,12 @@ int blp_profile_next_rank_kernel(void *start_event, void *stop_event);
  * blp_profile_next_rank_kernel bracket divides by it. */
 int64_t blp_rank_all_batches_passes_per_launch(int model, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
                                                int64_t block_triples);
+/* 1 if a blp_rank_all_batches_t call of these sizes READS the 16-bit table directly (the ring kernels of the reference-batched
+ * passes: batch <= 4 triples, D = 128 / 256, a table long enough to stream) -- then a pass moves half the bytes of the f32
+ * table; 0 if it would first widen the table to f32 inside its workspace (N * D * 4 more bytes and a pass over the table per
+ * call: every other shape -- a caller that has the f32 table should rank that one instead; blp_amd.ranking does). */
+int blp_rank_all_batches_t_native(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                  int64_t block_triples);
 int64_t blp_rank_all_batches_t_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
                                                  int64_t batch, int64_t block_triples);
 

@@ -600,10 +600,13 @@ def test_bow_table_build_is_one_kernel(rel_model, E, V, L, monkeypatch):
     bad = text.tok[:4].clone()
     bad[2, 0] = V
     with torch.no_grad():
-        model.encode_into(out, bad.cuda(), text.mask[:4].cuda())   # (no host sync per chunk: the flag waits on the device)
+        with pytest.raises(IndexError):                             # a direct caller hears about it before the call returns
+            model.encode_into(out, bad.cuda(), text.mask[:4].cuda())
+        model.check_tokens()                                        # the flag was reset
+        model.encode_into(out, bad.cuda(), text.mask[:4].cuda(), defer_check=True)  # (a table build: no host read per chunk, the flag waits on the device)
         with pytest.raises(IndexError):
             model.check_tokens()
-        model.check_tokens()                                        # the flag was reset
+        model.check_tokens()
         with pytest.raises(IndexError):                             # the bare op checks on the spot
             ops.bow_rows(bad.cuda(), text.mask[:4].cuda(), model.embeddings.weight, out, True)
     text.tok[7, 0] = V
@@ -682,7 +685,10 @@ def test_dkrl_table_build_is_one_kernel(rel_model, E, V, L, monkeypatch):
     bad = text.tok[:4].clone()
     bad[2, 0] = V
     with torch.no_grad():
-        model.encode_into(out, bad.cuda(), text.mask[:4].cuda())
+        with pytest.raises(IndexError):
+            model.encode_into(out, bad.cuda(), text.mask[:4].cuda())
+        model.check_tokens()
+        model.encode_into(out, bad.cuda(), text.mask[:4].cuda(), defer_check=True)
         with pytest.raises(IndexError):
             model.check_tokens()
         model.check_tokens()

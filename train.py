@@ -62,6 +62,10 @@ def config():
     seed = None
     amp = None  # None | 'fp16' | 'bf16': autocast the training step (BASELINE config 5; not in the reference)
     device_sampler = False  # draw the in-batch negative indices on the GPU (same law as data.py:35-81, other RNG stream)
+    rank_table_dtype = None  # None | 'float16' | 'bfloat16': rank the evaluations against a 16-bit copy of the entity table, one
+    #                          table pass per eval batch as the reference does (only where the passes then read the 16-bit rows
+    #                          themselves: eval_batch_size <= 4, dim 128 / 256 -- the Wikidata5M scripts; elsewhere a log line says
+    #                          it is not used).  Changes the INPUT (rounded rows), not the arithmetic; not in the reference
     eval_dropout = True  # the reference builds its entity tables in train mode (train.py:57-121 never calls model.eval()):
     #                      True reproduces that; False puts the encoder in eval mode for the table build (deterministic metrics)
 
@@ -95,9 +99,14 @@ def _get_model(model, dim, rel_model, loss_fn, num_entities, num_relations, enco
 @ex.command
 def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_name, regularizer, max_len,
                     num_negatives, lr, use_scheduler, batch_size, emb_batch_size, eval_batch_size, max_epochs,
-                    checkpoint, use_cached_text, data_root, seed, amp, device_sampler, eval_dropout, _run, _log):
+                    checkpoint, use_cached_text, data_root, seed, amp, device_sampler, eval_dropout, rank_table_dtype, _run, _log):
     if amp not in (None, 'fp16', 'bf16'):
         raise ValueError(f'Unknown amp mode {amp}')
+    if rank_table_dtype not in (None, 'float16', 'bfloat16'):
+        raise ValueError(f'Unknown rank_table_dtype {rank_table_dtype}')
+    # a 16-bit ranking table goes with the reference's pass structure (a table pass per eval batch); everything else is ranked in
+    # blocks of 65 536 triples
+    table16 = dict(rank_table_dtype=getattr(torch, rank_table_dtype), block_size=eval_batch_size) if rank_table_dtype else {}
     if seed is not None:
         torch.manual_seed(seed)
         np.random.seed(seed)
@@ -196,10 +205,10 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
         if dataset != 'Wikidata5M':
             _log.info('Evaluating on sample of training set')
             eval_link_prediction(net, train_eval_loader, train_data, train_ent, epoch, emb_batch_size, _run, _log,
-                                 prefix='train', max_num_batches=len(valid_loader), device=device, eval_mode=not eval_dropout)
+                                 prefix='train', max_num_batches=len(valid_loader), device=device, eval_mode=not eval_dropout, **table16)
         _log.info('Evaluating on validation set')
         val_mrr, _ = eval_link_prediction(net, valid_loader, train_data, train_val_ent, epoch, emb_batch_size,
-                                          _run, _log, prefix='valid', device=device, eval_mode=not eval_dropout)
+                                          _run, _log, prefix='valid', device=device, eval_mode=not eval_dropout, **table16)
         if val_mrr > best_valid_mrr:  # best checkpoint by raw validation MRR
             best_valid_mrr = val_mrr
             torch.save(net.state_dict(), checkpoint_file)
@@ -216,14 +225,14 @@ def link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder_
     _log.info('Evaluating on validation set (with filtering)')
     eval_link_prediction(net, valid_loader, train_data, train_val_ent, max_epochs + 1, emb_batch_size, _run, _log,
                          prefix='valid', filtering_graph=graph, new_entities=val_new_ents, device=device,
-                         eval_mode=not eval_dropout)
+                         eval_mode=not eval_dropout, **table16)
     if dataset == 'Wikidata5M':
         graph = utils.FilterIndex(test_data.triples, num_relations=train_data.rel_categories.shape[0], device=device)
     _log.info('Evaluating on test set')
     _, ent_emb = eval_link_prediction(net, test_loader, train_data, train_val_test_ent, max_epochs + 1,
                                       emb_batch_size, _run, _log, prefix='test', filtering_graph=graph,
                                       new_entities=test_new_ents, return_embeddings=True, device=device,
-                                      eval_mode=not eval_dropout)
+                                      eval_mode=not eval_dropout, **table16)
 
     torch.save(ent_emb, osp.join(OUT_PATH, f'ent_emb-{_run._id}.pt'))
     torch.save(train_val_test_ent, osp.join(OUT_PATH, f'ents-{_run._id}.pt'))
