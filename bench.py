@@ -1248,6 +1248,13 @@ def main():
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(relaunch_with_ranks(args.gpus))  # no launcher around us: be our own
+    # stdout carries ONE line, the JSON result, and nothing else: from here on file descriptor 1 is stderr -- RCCL prints a version
+    # banner through C stdio when its first communicator comes up (nn.DataParallel's replicate on one GPU is enough; every rank
+    # of an N > 1 run), which a pipe delivers at process exit, i.e. AFTER a line printed from Python -- and the result goes to
+    # the saved descriptor at the very end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1345,7 +1352,8 @@ def main():
     if rank == 0:
         written = write_details(result, args.details)
         result["details"] = os.path.relpath(written, ROOT) if written else None
-        print(json.dumps(compact_result(result)), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(compact_result(result)) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -225,6 +225,7 @@ def test_rank_table_dtype_is_honoured_only_where_the_passes_read_16_bits(rel_mod
     from test_host_golden import _Run, _Triples
     N, D, R, T = 20000, 128, 5, 40
     table, rel_w, ent2idx, triples, _ = _problem(rel_model, N, D, T, R, seed=3)
+    triples = torch.stack((ent2idx[triples[:, 0]], ent2idx[triples[:, 1]], triples[:, 2]), dim=1)  # (transductive: entity id = table row)
     model = models.TransductiveLinkPrediction(D, rel_model, "margin", N, R, 0)
     model.rel_emb.weight.data = rel_w.clone()
     model = model.cuda()
