@@ -308,7 +308,8 @@ def test_bench_line_keeps_the_contract(tmp_path):
     subs = r["sub_results"]
     import bench
     assert set(subs) == set(bench.SUB_RESULTS) == {
-        "fb15k237-distmult", "fb15k237-complex", "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-f16",
+        "fb15k237-distmult", "fb15k237-complex", "fb15k237-transe-clustered", "fb15k237-distmult-clustered",
+        "wikidata5m-transe", "wikidata5m-complex", "wikidata5m-transe-f16",
         "wikidata5m-complex-f16", "wikidata5m-transe-block", "wikidata5m-complex-block", "wikidata5m-transe-full",
         "wikidata5m-complex-full", "wikidata5m-protocol"}
     assert "arith" in r and r["arith"] == roof["arith"] and "v_sad_u16" in roof["arith"] and "sad_ubench" in roof["peak_source"]
@@ -332,6 +333,14 @@ def test_bench_line_keeps_the_contract(tmp_path):
                 assert "rank_stream" in sub["roofline"]["kernel"] and "16" in sub["roofline"]["kernel"], name
         else:
             assert sub["roofline"]["passes_per_launch"] == 1, name
+    # away from i.i.d. random tables: 500 clusters of duplicate rows + a trained model's triples -- what the pre-pass leaves
+    # undecided and what the step costs against the same shape on random data (measured 1.07 x / 1.3 x; the bar: 3 x)
+    assert 0.99 < r["decided_frac"] < 1.0 and 0.99 < subs["fb15k237-distmult"]["decided_frac"] < 1.0
+    for name in ("fb15k237-transe-clustered", "fb15k237-distmult-clustered"):
+        twin = subs.get(bench.WORKLOADS[name]["random_twin"], r)  # (the TransE twin is the headline workload itself)
+        assert 0.98 < subs[name]["decided_frac"] < twin["decided_frac"], name
+        assert 0.8 < subs[name]["vs_random_step"] < 3.0 and subs[name]["parity_check"].endswith("identical counts"), name
+        assert line["sub_results"][name]["vs_random_step"] == pytest.approx(subs[name]["vs_random_step"], rel=1e-4)
     # sustained (3 447 passes, > 1 s) against the 64-pass burst: within a few per cent of each other
     for m in ("transe", "complex"):
         burst, full = subs[f"wikidata5m-{m}"]["roofline"]["frac"], subs[f"wikidata5m-{m}-full"]["roofline"]["frac"]

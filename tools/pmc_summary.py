@@ -12,6 +12,7 @@ import subprocess
 
 DOMINANT = {"fb15k237-transe": "rank_sad_kernel", "fb15k237-distmult": "rank_gemm_bf16", "fb15k237-complex": "rank_gemm_bf16",
             "fb15k237-simple": "rank_gemm_bf16", "fb15k237-transe-d768": "wide_rank_sad_kernel",
+            "fb15k237-transe-clustered": "rank_sad_kernel", "fb15k237-distmult-clustered": "rank_gemm_bf16",
             "wikidata5m-transe": "rank_stream_kernel", "wikidata5m-complex": "rank_stream_dot_kernel",  # (the ring kernels: all passes of a step in one launch)
             "wikidata5m-transe-block": "rank_sad_kernel", "wikidata5m-complex-block": "rank_gemm_bf16",
             "wikidata5m-protocol": "rank_sad_kernel",
