@@ -1003,6 +1003,8 @@ def sub_result(name, axis, device, world, rank, backend, steps, events):
             if stats["decided_frac"] is not None:
                 f["decided_frac"] = stats["decided_frac"]
     del sub, t, c
+    from blp_amd import ops
+    ops.release_workspaces()
     torch.cuda.empty_cache()
     return f
 

@@ -53,12 +53,15 @@ def _filter_spec(filter, Q, dev):
 # ~4 us of a 20 us small call).  The sizes come from the library (blp_rank_all*_workspace_bytes), memoised per shape.
 _workspaces = {}
 _ws_bytes_memo = {}
-# Only SMALL workspaces are kept (the point of the cache is the 20 us call): an evaluation block's scratch -- hundreds of MB of
-# operand images and pair lists, GBs at Wikidata5M scale -- is a per-call torch.empty that goes back to the caching allocator
-# when the call returns (stream-ordered: the allocator hands the block to later work on the same stream only), so it is not
-# pinned through the training steps that follow an evaluation (round 4 kept the largest one per stream for the life of the
-# process: a configuration that fitted before could run out of memory).
-WORKSPACE_CACHE_MAX_BYTES = 32 << 20
+# The cache is bounded two ways (round 4 kept the largest workspace per stream for the life of the process, so an evaluation's
+# scratch -- hundreds of MB of operand images and pair lists -- stayed pinned through the training steps that followed it and a
+# configuration that fitted before could run out of memory): (a) ranking.eval_link_prediction calls release_workspaces() when
+# it is done, so nothing of an evaluation outlives it; (b) a workspace above WORKSPACE_CACHE_MAX_BYTES (the Wikidata5M-scale
+# blocks: GBs) is never kept at all -- a per-call torch.empty that goes back to the caching allocator when the call returns
+# (stream-ordered: the allocator hands the block to later work on the same stream only).  Everything below the cap is kept
+# WITHIN an evaluation: allocating the FB15k-237 block's 250 MB per call cost the evaluation step 40 us and, when the allocator
+# had split the block in between, a hipMalloc of ~9 ms now and then (profiles/r05/clustered_sweep.log, first version).
+WORKSPACE_CACHE_MAX_BYTES = 1 << 30
 
 
 def _workspace(dev, stream, nbytes):

@@ -587,6 +587,8 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     triples, counts, ids_ok = rank_triples(model, rank_table, triples, ent2idx.to(device), index, num_entities=num_entities,
                                            group=group, world=world, rank=rank, axis=axis, block_size=block_size)
     del rank_table
+    if table.is_cuda:
+        ops.release_workspaces()  # the evaluation's scratch does not stay pinned through the training steps that follow
     rr, hits = metrics_from_counts(counts)
     num_predictions = 2 * num_triples
     _log.info(f"The total number of predictions is {num_predictions:,}")

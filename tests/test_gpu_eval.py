@@ -36,6 +36,8 @@ def test_eval_link_prediction_on_gpu_matches_reference(rel_model):
                                                 new_entities=new_ents, return_embeddings=True, block_size=16)
     want = dict(zip(g["scalar_names"].tolist(), g["scalar_values"].tolist()))
     assert set(run.scalars) == set(want)
+    from blp_amd import ops
+    assert not ops._workspaces  # the evaluation's ranking scratch is released when it is done (not pinned through training)
     # The entity table is built by the (stock PyTorch) BOW encoder on the GPU, whose mean can differ
     # from the CPU's in the last bit; ranks are then computed exactly on THAT table.  Hits@k / MRR of
     # this toy problem are insensitive to it (tolerance 1e-6 as in the task statement's 1e-5).
