@@ -978,71 +978,31 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
     const unsigned long long n = (unsigned long long)n_final + n_spill;
     const int lane = threadIdx.x & 63, sub = lane & 31;
     const unsigned wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    // Two entries per half-wave at a time (A and B: independent load -> score chains the compiler interleaves): an entry is a
-    // chain of dependent loads -- the entry, its query's key and rows, the candidate row -- and one entry at a time left the
-    // pass latency-bound (0.5 M entries of the random FB15k-237 block: 73 us; the 3 - 6 M of the clustered ones: 0.4 - 0.8 ms).
-    struct Entry {
-        unsigned und; int half; int64_t q, row0; bool is_head; const float* f; const float* r; float kt; unsigned gt, ge;
-    };
-    auto fetch = [&](unsigned long long ei) {
-        Entry t;
+    for (unsigned long long e0 = (unsigned long long)wave_id * 2; e0 < n; e0 += (unsigned long long)n_waves * 2) {  // wave-uniform trip count
+        const unsigned long long ei = e0 + (lane >> 5);
         const bool live = ei < n;
         const uint2 p = !live ? make_uint2(0u, 0u) : ei < n_final ? pairs[ei] : spill[ei - n_final];
-        t.q = p.x >> 1;
-        t.half = p.x & 1;
-        t.row0 = (int64_t)(p.y >> 16) * kGCT;
-        t.und = live ? p.y & 0xffffu : 0u;
-        t.is_head = t.q < q_head;
-        t.f = q_fixed.row(t.q);
-        t.r = q_rel.row(t.q);
-        t.kt = key_true[t.q];
-        t.gt = t.ge = 0;
-        return t;
-    };
-    // the entry's next undecided row (an exhausted entry idles on row 0 of the table)
-    auto next_row = [&](Entry& t, bool& work) {
-        const int bit = t.und ? 31 - __builtin_clz(t.und) : 0;
-        work = t.und != 0;
-        t.und &= ~(1u << bit);
-        return work ? table + (t.row0 + acc_row(15 - bit, t.half)) * ld : table;
-    };
-    auto count = [&](Entry& t, bool work, float key) {
-        t.gt += work && key > t.kt;
-        t.ge += work && key >= t.kt;
-    };
-    auto step_pair = [&](Entry& a, Entry& b, auto side) {  // both entries on one side: no branch between the two score chains
-        constexpr int SIDE = decltype(side)::value;
-        bool wa, wb;
-        const float* ea = next_row(a, wa);
-        const float* eb = next_row(b, wb);
-        const float ka = coop_score<MODEL, SIDE, D>(ea, a.f, a.r, sub);
-        const float kb = coop_score<MODEL, SIDE, D>(eb, b.f, b.r, sub);
-        count(a, wa, ka);
-        count(b, wb, kb);
-    };
-    auto step_one = [&](Entry& t) {
-        bool w;
-        const float* e = next_row(t, w);
-        float key;
-        if (t.is_head) key = coop_score<MODEL, HEAD, D>(e, t.f, t.r, sub);
-        else key = coop_score<MODEL, TAIL, D>(e, t.f, t.r, sub);
-        count(t, w, key);
-    };
-    for (unsigned long long e0 = (unsigned long long)wave_id * 4; e0 < n; e0 += (unsigned long long)n_waves * 4) {  // wave-uniform trip count
-        Entry a = fetch(e0 + (lane >> 5)), b = fetch(e0 + 2 + (lane >> 5));
-        const unsigned long long heads = __ballot(a.is_head) & __ballot(b.is_head), tails = __ballot(!a.is_head) & __ballot(!b.is_head);
-        if (heads == ~0ull) {  // (wave-uniform: entries are listed query chunk by query chunk, a chunk is all head or all tail)
-            while (__ballot((a.und | b.und) != 0)) step_pair(a, b, ic<HEAD>{});  // the halves walk their own masks
-        } else if (tails == ~0ull) {
-            while (__ballot((a.und | b.und) != 0)) step_pair(a, b, ic<TAIL>{});
-        } else {
-            while (__ballot((a.und | b.und) != 0)) {
-                step_one(a);
-                step_one(b);
-            }
+        const int64_t q = p.x >> 1;
+        const int half = p.x & 1;
+        const int64_t row0 = (int64_t)(p.y >> 16) * kGCT;
+        unsigned und = live ? p.y & 0xffffu : 0u;
+        const bool is_head = q < q_head;
+        const float* f = q_fixed.row(q);
+        const float* r = q_rel.row(q);
+        const float kt = key_true[q];
+        unsigned gt = 0, ge = 0;
+        while (__ballot(und != 0)) {  // the halves walk their own masks; an exhausted half idles
+            const int bit = und ? 31 - __builtin_clz(und) : 0;
+            const bool work = und != 0;
+            und &= ~(1u << bit);
+            const float* e = table + (row0 + acc_row(15 - bit, half)) * ld;
+            float key;
+            if (is_head) key = coop_score<MODEL, HEAD, D>(work ? e : table, f, r, sub);
+            else key = coop_score<MODEL, TAIL, D>(work ? e : table, f, r, sub);
+            gt += work && key > kt;
+            ge += work && key >= kt;
         }
-        if (sub == 0 && (a.gt | a.ge)) atomicAdd(acc + a.q, (unsigned long long)a.gt | ((unsigned long long)a.ge << 32));
-        if (sub == 0 && (b.gt | b.ge)) atomicAdd(acc + b.q, (unsigned long long)b.gt | ((unsigned long long)b.ge << 32));
+        if (sub == 0 && (gt | ge)) atomicAdd(acc + q, (unsigned long long)gt | ((unsigned long long)ge << 32));
     }
 }
 
