@@ -133,6 +133,29 @@ def test_clustered_block_equals_exact_kernels_and_oracle(bench, oracle, model):
         assert st["path"].startswith("bf16") and st["flagged_rows"] == 0
 
 
+@pytest.mark.parametrize("model", ["distmult", "transe"])
+def test_heavy_ties_overflow_every_list_and_stay_exact(bench, model):
+    """100 clusters of exact duplicates: 145 rows tie with every query's true entity (1 % of the table) -- more than the
+    workgroups' lists AND the spill region of the bilinear path hold, so flags survive the conversion and the one-wave-per-query
+    sweeps run in earnest (TransE: the pair lists overflow into flagged tiles).  Slow (the cliff DESIGN 4.3 documents), exact:
+    every one of the 105 740 queries against the exact f32 kernels."""
+    name = f"test-heavy-ties-{model}"
+    bench.WORKLOADS[name] = dict(bench.WORKLOADS[f"fb15k237-{model}"], clusters=100, noise=0.0, top=145)
+    try:
+        job = bench.Job(name, torch.device("cuda", 0))
+        triples, counts, _ = job.step(filtered=True)
+        torch.cuda.synchronize()
+        exact = _direct(job, triples, rank_kernel=1)
+        assert torch.equal(counts, exact), f"{int((counts != exact).any(dim=1).sum())} queries differ from the exact kernels"
+        c = counts.cpu().numpy()
+        assert np.median(c[:, 1] - c[:, 0]) >= 100  # ge - gt = the true entity's cluster
+        st = job.prepass_stats()
+        print(f"{model}, 100 clusters: decided {st['decided_frac']:.4f}, listed {st['listed']:,}, flagged rows {st['flagged_rows']:,}")
+        assert st["flagged_rows"] > 0 and st["decided_frac"] < 0.995
+    finally:
+        del bench.WORKLOADS[name]
+
+
 def test_wikidata5m_block_prepass_equals_exact_kernel():
     """The Wikidata5M-scale block workload (13 788 queries x 4.6 M candidates, 30 candidate slabs of the fixed-point
     pre-pass, the split's own triples as the filtering graph): every count equals the exact f32 kernel's."""

@@ -62,6 +62,13 @@ def make_case(rng, shipped=False):
         q_head, q_tail = int(rng.integers(0, 40)), int(rng.integers(0, 40))
         if rng.random() < 0.4:
             q_head, q_tail = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+    heavy_ties = False
+    if rng.random() < 0.04:  # blocks of >= 2 048 queries against a table of few distinct rows: the pair lists overflow, flags become
+        heavy_ties = True     # entries of the spill region (rank_gemm.hip: flags_to_entries_kernel) or stay flags when that is full too
+        q_head, q_tail = int(rng.integers(900, 3200)), int(rng.integers(1200, 3200))
+        N = int(rng.integers(1500, 9000))
+        if model == "transe":
+            D = int(rng.choice([64, 128]))
     if shipped:
         N, q_head, q_tail = shipped_shape(rng, model)
         if N * D > 6_000_000 and D not in (64, 128):  # keep the host-side table generation of a case short
@@ -72,11 +79,14 @@ def make_case(rng, shipped=False):
     kind = rng.choice(["normal", "normalized", "dyadic", "ties", "outlier", "tiny", "mixed_scale", "nan", "inf", "zero_rows",
                        "constant"])
     table = torch.randn(N, D, generator=g)
-    if kind == "normalized":
+    if heavy_ties and not shipped:
+        kind = "ties"
+        table = table[torch.randint(0, max(1, N // int(rng.choice([20, 60, 200]))), (N,), generator=g)]
+    elif kind == "normalized":
         table = torch.nn.functional.normalize(table, dim=-1)
     elif kind == "dyadic":
         table = torch.randint(-8, 9, (N, D), generator=g).float() / 8
-    elif kind == "ties":
+    elif kind == "ties" and not heavy_ties:
         table = table[torch.randint(0, max(1, N // 5), (N,), generator=g)]
     elif kind == "outlier":
         table[int(rng.integers(0, N)), int(rng.integers(0, D))] = float(rng.choice([1e4, -1e6, 1e30]))
