@@ -542,6 +542,21 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));  // (HIP's uint4 is a struct: not an asm operand)
 __device__ __forceinline__ u32x4_t as_quad(const uint4& x) { return __builtin_bit_cast(u32x4_t, x); }
 #define BLP_KSTEP_CLOBBERS "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"
+// -DBLP_GEMM_PRIO=1: the wave raises its issue priority for the K-steps of a stage (s_setprio 3 with its first MFMA, back to 0
+// behind its last); =2: the other way round.  An experiment (tools/step_ab.py), not the shipped build.
+#ifndef BLP_GEMM_PRIO
+#define BLP_GEMM_PRIO 0
+#endif
+#if BLP_GEMM_PRIO == 1
+#define BLP_PRIO_ENTER "s_setprio 3\n\t"
+#define BLP_PRIO_LEAVE "\n\ts_setprio 0"
+#elif BLP_GEMM_PRIO == 2
+#define BLP_PRIO_ENTER "s_setprio 0\n\t"
+#define BLP_PRIO_LEAVE "\n\ts_setprio 3"
+#else
+#define BLP_PRIO_ENTER ""
+#define BLP_PRIO_LEAVE ""
+#endif
 #define BLP_KCROSS_BODY(C0, C1)                                                                             \
     asm("v_mfma_f32_32x32x16_bf16 %0, %4, %8, " C0 "\n\t"                                                    \
         "v_cmp_gt_f32_e64 s[84:85], %10, %12\n\t"                                                           \
@@ -561,6 +576,9 @@ __device__ __forceinline__ void kstep_cross(f32x16_t& n0, f32x16_t& n1, u32x4_t 
                                             u32x4_t bh, u32x4_t bl, float c0, float c1, float th, float tl, unsigned& gm,
                                             unsigned& lm) {
     if constexpr (FIRST) {
+#if BLP_GEMM_PRIO
+        asm volatile(BLP_PRIO_ENTER "s_nop 0");
+#endif
         BLP_KCROSS_BODY("0", "0")
             : "=&v"(n0), "=&v"(n1), "+v"(gm), "+v"(lm)
             : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(bh), "v"(bl), "v"(c0), "v"(c1), "v"(th), "v"(tl)
@@ -834,6 +852,9 @@ __global__ __launch_bounds__(kBfW * 64, kBfWavesPerSimd) void rank_gemm_bf16_ker
                     kstep_main(nxt[0], nxt[1], as_quad(c[0].hi[st]), as_quad(c[1].hi[st]), bh[st & 1], cur[1][2 * st],
                                cur[1][2 * st + 1], thr_hi[1], thr_lo[1], gm[1], lm[1]);
                 });
+#if BLP_GEMM_PRIO
+                asm volatile("s_nop 0" BLP_PRIO_LEAVE : "+v"(gm[1]));  // (behind the last K-step: it produces gm[1])
+#endif
             } else {
                 zero_acc(nxt);
                 mfma_tile(nxt, nbuf);
