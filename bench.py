@@ -95,6 +95,13 @@ WORKLOADS = {
                                       clusters=500, noise=0.0, top=145, random_twin="fb15k237-transe"),
     "fb15k237-distmult-clustered": dict(model="distmult", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116,
                                         clusters=500, noise=0.0, top=145, random_twin="fb15k237-distmult"),
+    # ... and far away from it: 20 clusters of duplicates = 5 % of the table ties with every query's true entity.  The pre-pass's
+    # lists run full and the exact kernel re-ranks the block (csrc/rank_common.h: Gate): the bounded worst case.  Not sub-results
+    # (tools/clustered_sweep.py, tools/step_ab.py, tests/test_gpu_fullsize.py use them).
+    "fb15k237-transe-ties5pct": dict(model="transe", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116,
+                                     clusters=20, noise=0.0, top=145, random_twin="fb15k237-transe"),
+    "fb15k237-distmult-ties5pct": dict(model="distmult", N=14541, D=128, R=237, triples=52870, block=65536, edges=310116,
+                                       clusters=20, noise=0.0, top=145, random_twin="fb15k237-distmult"),
     # the BERT-BOW / BERT-DKRL width (models.py:118-135, 165-172): TransE at the word-embedding width 768
     "fb15k237-transe-d768": dict(model="transe", N=14541, D=768, R=237, triples=52870, block=65536, edges=310116),
     # reference batching: eval_batch_size = 2 triples per table pass, 64 passes per step; the reference's

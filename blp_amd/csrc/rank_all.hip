@@ -396,7 +396,8 @@ __global__ __launch_bounds__(kWaves * 64, (D == 256 ? 1 : (MODEL == TRANSE ? 3 :
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
     int n_tiles, int n_quad_groups, int q_chunk, const int64_t* __restrict__ q_rel_id,
-    unsigned long long* __restrict__ acc) {
+    unsigned long long* __restrict__ acc, const Gate gate) {
+    if (gate.counter != nullptr && !gate_heavy(gate)) return;  // (the pre-pass paths' exact fallback: only when the lists ran full)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -712,7 +713,7 @@ static hipError_t launch_static_pass(const float* table, int64_t N, int64_t ld, 
     const int64_t resident = (int64_t)n_cu * 3, groups = n_quads < resident ? n_quads : resident;
     const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)2 * kQB * kMaxCoef(D) * 4 + (size_t)kWaves * 2 * kQueryChunk * 4;
     rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)groups), kWaves * 64, lds, stream>>>(
-        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, (int)n_tiles, (int)groups, kQueryChunk, nullptr, acc);
+        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, (int)n_tiles, (int)groups, kQueryChunk, nullptr, acc, Gate{nullptr, 0u});
     return hipGetLastError();
 }
 
@@ -789,7 +790,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         } else
             rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-                (int)groups, q_chunk, q_rel_id, w.acc);
+                (int)groups, q_chunk, q_rel_id, w.acc, Gate{nullptr, 0u});
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
 
@@ -840,6 +841,73 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
     case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     default:       return hipErrorInvalidValue;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The pre-pass paths' bounded worst case (rank_common.h: Gate): when the lists ran full, the exact kernel re-ranks the block.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void fallback_prep_kernel(const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
+                                                            float* __restrict__ coef_head, float* __restrict__ coef_tail,
+                                                            unsigned long long* __restrict__ acc, const Gate gate) {
+    if (!gate_heavy(gate)) return;
+    using SH = Scorer<MODEL, HEAD, D>;
+    using ST = Scorer<MODEL, TAIL, D>;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t q = i0; q < q_head + q_tail; q += stride) acc[q] = 0;  // what the pre-pass counted is recounted
+    const int64_t n_head = q_head * SH::C, total = n_head + q_tail * ST::C;
+    for (int64_t i = i0; i < total; i += stride) {
+        if (i < n_head) {
+            const int64_t q = i / SH::C;
+            coef_head[i] = SH::coef(q_fixed.row(q), q_rel.row(q), (int)(i % SH::C));
+        } else {
+            const int64_t k = i - n_head, q = k / ST::C;
+            coef_tail[k] = ST::coef(q_fixed.row(q_head + q), q_rel.row(q_head + q), (int)(k % ST::C));
+        }
+    }
+}
+
+size_t exact_fallback_coef_floats(int D, int64_t q_head, int64_t q_tail) {
+    return (size_t)(q_head + q_tail) * max_coef(D) + 64;
+}
+
+template <int MODEL, int D>
+static hipError_t exact_fallback_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel, int64_t q_head,
+                                      int64_t q_tail, float* coef, const float* key_true, unsigned long long* acc, Gate gate, int n_cu,
+                                      hipStream_t stream) {
+    const int64_t Q = q_head + q_tail;
+    if (Q == 0 || N == 0) return hipSuccess;
+    float* coef_head = coef;
+    float* coef_tail = coef + (((size_t)q_head * max_coef(D) + 63) / 64) * 64;
+    fallback_prep_kernel<MODEL, D><<<dim3(1024), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, coef_head, coef_tail, acc, gate);
+    // one workgroup per query chunk (or a few), grid-striding over the tile quads: as many workgroups as the chip holds a few
+    // times over, not one per (quad, chunk) -- tens of thousands of workgroups that return at once would cost the common
+    // case ~20 us
+    const int64_t n_tiles = (N + kTileRows - 1) / kTileRows, n_quads = (n_tiles + kWaves - 1) / kWaves;
+    const int64_t n_chunks = (Q + kQueryChunk - 1) / kQueryChunk, resident = (int64_t)n_cu * 3;
+#ifndef BLP_FALLBACK_GRID
+#define BLP_FALLBACK_GRID 16  // x the resident workgroups ([measured] FB15k-237 TransE block at 5 % ties, 4 / 16 / one workgroup per tile quad: 17.5 / 15.6 / 13.2 ms; what the gated launch costs the random-data DistMult step: 0 / +0.2 / +0.9 %)
+#endif
+    int64_t groups = (BLP_FALLBACK_GRID * resident + n_chunks - 1) / n_chunks;
+    groups = groups < 1 ? 1 : (groups > n_quads ? n_quads : groups);
+    const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)2 * kQB * kMaxCoef(D) * 4 + (size_t)kWaves * 2 * kQueryChunk * 4;
+    if (groups * n_chunks > 0x7fffffff) return hipErrorInvalidValue;
+    rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)(groups * n_chunks)), kWaves * 64, lds, stream>>>(
+        table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)groups, kQueryChunk, nullptr, acc, gate);
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_fallback(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
+                                 int64_t q_head, int64_t q_tail, float* coef, const float* key_true, unsigned long long* acc, Gate gate,
+                                 int n_cu, hipStream_t stream) {
+#define BLP_FALLBACK_CASE(M, DD)                                                                                        \
+    if (model == M && D == DD)                                                                                          \
+        return exact_fallback_impl<M, DD>(table, N, ld, q_fixed, q_rel, q_head, q_tail, coef, key_true, acc, gate, n_cu, stream);
+    BLP_FALLBACK_CASE(TRANSE, 64) BLP_FALLBACK_CASE(TRANSE, 128) BLP_FALLBACK_CASE(TRANSE, 256)
+    BLP_FALLBACK_CASE(DISTMULT, 64) BLP_FALLBACK_CASE(DISTMULT, 128)
+    BLP_FALLBACK_CASE(COMPLEX, 64) BLP_FALLBACK_CASE(COMPLEX, 128)
+    BLP_FALLBACK_CASE(SIMPLE, 64) BLP_FALLBACK_CASE(SIMPLE, 128)
+#undef BLP_FALLBACK_CASE
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------

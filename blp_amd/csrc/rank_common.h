@@ -80,6 +80,25 @@ hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t 
                                   const FilterSpec& filter, const unsigned long long* acc, int32_t* counts,
                                   hipStream_t stream, int n_partials = 1);
 
+// ---- the bounded worst case of the pre-pass paths (round 5) --------------------------------------------------------------
+// A pre-pass pays off while it leaves little to the exact path.  When a device-side counter says it has not -- the pair lists
+// ran (nearly) full: exact ties with the true entity on whole percents of the table -- the refinement kernels stand down and
+// the EXACT kernel of rank_all.hip re-ranks the block from scratch, so that a block never costs more than pre-pass + exact
+// kernel (TransE 3 + 8 ms, bilinear 1 + 15 ms for the FB15k-237 block; the refinement alone took 130 / 70 ms on tables with 5 %
+// duplicates of the true entity).  Everything is decided ON THE DEVICE: every kernel involved reads the counter and returns
+// at once when it is not its turn (`gate`: the counter; heavy <=> *gate >= gate_min).  gate == nullptr: no gating.
+struct Gate { const unsigned* counter; unsigned heavy_from; };
+__device__ __forceinline__ bool gate_heavy(const Gate& g) { return g.counter != nullptr && *g.counter >= g.heavy_from; }
+// floats of coefficient rows the exact re-ranking needs for (q_head + q_tail) queries; blocks below kFallbackMinPairs (or ranked
+// in several candidate slabs) have no fallback: 0
+constexpr int64_t kFallbackMinPairs = (int64_t)1 << 27;
+size_t exact_fallback_coef_floats(int D, int64_t q_head, int64_t q_tail);
+// if heavy: zero acc, materialise the coefficient rows, rank every query against every row with rank_tiles_kernel (counts into
+// acc; key_true as computed by the pre-pass path); else: two launches that return at once
+hipError_t launch_exact_fallback(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
+                                 int64_t q_head, int64_t q_tail, float* coef, const float* key_true, unsigned long long* acc, Gate gate,
+                                 int n_cu, hipStream_t stream);
+
 constexpr int64_t kTrueKeyLaneMaxQueries = 2048;  // up to here true keys are one lane per query (exact_coop.h: true_key_lane)
 
 // rank_all.hip: true-entity keys by the exact routine (and the Q rank-count accumulators `acc` zeroed on the way)

@@ -992,7 +992,8 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const float* __restri
                                                            const uint2* __restrict__ pairs,
                                                            const unsigned* __restrict__ n_pairs,
                                                            const uint2* __restrict__ spill, unsigned spill_capacity,
-                                                           unsigned long long* __restrict__ acc) {
+                                                           unsigned long long* __restrict__ acc, const Gate gate) {
+    if (gate_heavy(gate)) return;  // more flags than the spill region holds: the exact kernel re-ranks the block (rank_common.h: Gate)
     // the workgroups' list, then the entries made of flagged half-segments (flags_to_entries_kernel; counter n_pairs[1], clamped:
     // a wave that found the region full left it overshooting)
     const unsigned n_final = n_pairs[0], n_spill = n_pairs[1] < spill_capacity ? n_pairs[1] : spill_capacity;
@@ -1064,7 +1065,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
                                                      const QRows q_rel,
                                                      const float* __restrict__ key_true, int64_t q_head, int64_t Q,
                                                      int words_per_query, const unsigned* __restrict__ flags,
-                                                     unsigned long long* __restrict__ acc) {
+                                                     unsigned long long* __restrict__ acc, const Gate gate) {
+    if (gate_heavy(gate)) return;
     __shared__ int list[kSweepQueries], n_list;
     const int lane = threadIdx.x & 63, part = lane >> 5, sub = lane & 31;
     const int64_t q_base = (int64_t)blockIdx.x * kSweepQueries;
@@ -1286,6 +1288,7 @@ struct GemmWorkspace {
     uint4* cimg; float* cnmax;  // bf16 candidate image (whole table) and its per-half-tile band factors
     unsigned long long* acc; unsigned* n_pairs; unsigned* flags; uint2* pairs;
     uint2* spill; int64_t spill_entries;  // bf16 kernel: entries made of flagged half-segments (flags_to_entries_kernel; counter n_pairs[1])
+    float* fallback_coef;  // coefficient rows of the exact re-ranking (rank_common.h: Gate), or nullptr: this block has no fallback
     int64_t pass_ctiles;  // candidate tiles per GEMM + refine pass
     size_t bytes;
 };
@@ -1358,6 +1361,12 @@ static GemmWorkspace carve_gemm(void* base, int D, int64_t N, int64_t q_head, in
     w.spill = reinterpret_cast<uint2*>(p + off);
     w.spill_entries = spill_entries(w.pass_ctiles, q_head, q_tail);
     off = align_up(off + (size_t)w.spill_entries * 8, 256);
+    // the exact fallback: blocks of one candidate slab, of the size flags are turned into entries at, and >= kFallbackMinPairs pairs
+    w.fallback_coef = nullptr;
+    if (w.pass_ctiles * kGCT >= N && Q >= kFlagsToEntriesMinQueries && Q * N >= kFallbackMinPairs) {
+        w.fallback_coef = reinterpret_cast<float*>(p + off);
+        off = align_up(off + exact_fallback_coef_floats(D, q_head, q_tail) * 4, 256);
+    }
     w.bytes = off;
     return w;
 }
@@ -1405,7 +1414,7 @@ void gemm_set_dump(float* s, float* eps) { g_dump_s = s; g_dump_eps = eps; }
 template <int MODEL, int D>
 static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
                                  const QRows q_true, int64_t q_head, int64_t q_tail,
-                                 const FilterSpec& filter, int32_t* counts, void* workspace,
+                                 const FilterSpec& filter, int32_t* counts, void* workspace, int n_cu,
                                  hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
     GemmWorkspace w = carve_gemm(workspace, D, N, q_head, q_tail);
@@ -1491,6 +1500,7 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             if (err != hipSuccess) return err;
         }
         const float* slab = table + slab0 * ld;
+        Gate gate{nullptr, 0u};
         if (f32_kernel) {
             const int64_t n_entries = n_blocks * kPairQuota;
             rank_gemm_kernel<MODEL, D><<<dim3((unsigned)n_blocks), kGW * 64, lds_f32, stream>>>(
@@ -1518,11 +1528,19 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
             if (Q >= kFlagsToEntriesMinQueries)
                 flags_to_entries_kernel<<<dim3(1024), 256, 0, stream>>>(w.flags, Q, words, n_rows, w.n_pairs + 1, w.spill,
                                                                         (unsigned)w.spill_entries);
+            // heavy <=> the flags outnumber the spill region (n_pairs[1] counts every flag, also those that found it full): exact
+            // ties on whole percents of the table -- every flag costs 16 exact scores where the exact kernel re-ranks everything
+            gate = Gate{w.fallback_coef ? w.n_pairs + 1 : nullptr, (unsigned)w.spill_entries};
             refine_pairs_kernel<MODEL, D><<<dim3(2048), 256, 0, stream>>>(slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs,
-                                                                        w.n_pairs, w.spill, (unsigned)w.spill_entries, w.acc);
+                                                                        w.n_pairs, w.spill, (unsigned)w.spill_entries, w.acc, gate);
         }
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
-            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.acc);
+            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.acc, gate);
+        if (gate.counter) {
+            err = launch_exact_fallback(MODEL, D, table, N, ld, q_fixed, q_rel, q_head, q_tail, w.fallback_coef, w.key_true, w.acc, gate,
+                                        n_cu, stream);
+            if (err != hipSuccess) return err;
+        }
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     err = launch_filter_finalize(MODEL, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter,
@@ -1535,11 +1553,10 @@ hipError_t launch_rank_all_gemm(int model, int D, const float* table, int64_t N,
                                 const FilterSpec& filter, int32_t* counts,
                                 void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop) {
-    (void)n_cu;
 #define BLP_GEMM_CASE(M, DD)                                                                                    \
     if (model == M && D == DD)                                                                                  \
         return rank_gemm_impl<M, DD>(table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter, \
-                                     counts, workspace, stream, ev_start, ev_stop);
+                                     counts, workspace, n_cu, stream, ev_start, ev_stop);
     BLP_GEMM_CASE(DISTMULT, 128) BLP_GEMM_CASE(DISTMULT, 64)
     BLP_GEMM_CASE(COMPLEX, 128) BLP_GEMM_CASE(COMPLEX, 64)
     BLP_GEMM_CASE(SIMPLE, 128) BLP_GEMM_CASE(SIMPLE, 64)

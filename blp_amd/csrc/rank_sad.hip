@@ -408,7 +408,8 @@ __global__ __launch_bounds__(64) void sad_refine_pairs_kernel(const float* __res
                                                               const float* __restrict__ key_true, int64_t q_head,
                                                               const uint2* __restrict__ pairs,
                                                               const SadParams* __restrict__ params,
-                                                              unsigned long long* __restrict__ acc) {
+                                                              unsigned long long* __restrict__ acc, const Gate gate) {
+    if (gate_heavy(gate)) return;  // the lists ran full: the exact kernel re-ranks the block (rank_common.h: Gate)
     __shared__ __attribute__((aligned(16))) float slab[64 * kRefStride];
     const int lane = threadIdx.x;
     const int64_t n = params->n_pairs;
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
                                                                int64_t Q, int words_per_query,
                                                                const unsigned* __restrict__ flags,
                                                                const SadParams* __restrict__ params,
-                                                               unsigned long long* __restrict__ acc) {
+                                                               unsigned long long* __restrict__ acc, const Gate gate) {
+    if (gate_heavy(gate)) return;  // the lists ran full: the exact kernel re-ranks the block (rank_common.h: Gate)
     __shared__ int list[kSweepQueries], n_list;
     const bool all = !sad_scale(params).ok;
     const int lane = threadIdx.x & 63;
@@ -489,6 +491,7 @@ struct SadWorkspace {
     unsigned long long* acc;
     SadParams* params; SadParams* partial; int2* thr; unsigned* qimg; uint4* cimg; unsigned* resid; unsigned* flags;
     uint2* pairs;
+    float* fallback_coef;  // coefficient rows of the exact re-ranking (rank_common.h: Gate), or nullptr: this block has no fallback
     int64_t pass_groups;  // candidate groups (kSW * TPW tiles) per pre-pass + refine pass
     size_t bytes;
 };
@@ -556,6 +559,13 @@ static SadWorkspace carve_sad(void* base, int D, int64_t N, int64_t q_head, int6
     w.pairs = reinterpret_cast<uint2*>(p + off);
     const int64_t per_group = sad_queries_per_group(D, N, Q);
     off = align_up(off + (size_t)w.pass_groups * ((Q + per_group - 1) / per_group) * kSQuota * 8, 256);
+    // the exact fallback: blocks of one candidate slab and at least kFallbackMinPairs pairs
+    w.fallback_coef = nullptr;
+    const int64_t n_groups_all = ((N + 63) / 64 + tiles_per_group - 1) / tiles_per_group;
+    if (w.pass_groups >= n_groups_all && Q * N >= kFallbackMinPairs && Q <= 0x7fffffff / 2) {
+        w.fallback_coef = reinterpret_cast<float*>(p + off);
+        off = align_up(off + exact_fallback_coef_floats(D, q_head, q_tail) * 4, 256);
+    }
     w.bytes = off;
     return w;
 }
@@ -648,10 +658,19 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
             w.cimg + (slab0 / 64) * (D / 8) * 64, w.resid + slab0, n_rows, (int)n_groups, per_group, w.qimg, w.thr, Q, words, w.acc,
             w.flags, w.pairs, w.params);
         const int64_t pair_blocks = (n_blocks * kSQuota + 63) / 64;  // 64 pairs per single-wave workgroup and iteration
+        // heavy <=> the workgroups' lists are >= 90 % full (capacity: kSQuota entries each): exact ties on whole percents of the
+        // table -- the flagged tiles would then cost 64 exact scores per flag (132 ms for the FB15k-237 block at 5 % ties) where
+        // the exact kernel re-ranks everything in 8
+        const Gate gate{w.fallback_coef ? &w.params->n_pairs : nullptr, (unsigned)((n_blocks * kSQuota / 10 * 9) < 0xffffffffll ? n_blocks * kSQuota / 10 * 9 : 0xffffffffll)};
         sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 40 ? pair_blocks : (int64_t)n_cu * 40)), 64, 0, stream>>>(
-            slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc);
+            slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc, gate);
         sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
-            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc);
+            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc, gate);
+        if (gate.counter) {
+            err = launch_exact_fallback(TRANSE, D, table, N, ld, q_fixed, q_rel, q_head, q_tail, w.fallback_coef, w.key_true, w.acc, gate,
+                                        n_cu, stream);
+            if (err != hipSuccess) return err;
+        }
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     err = launch_filter_finalize(TRANSE, D, table, N, ld, q_fixed, q_rel, w.key_true, q_head, q_tail, filter,
