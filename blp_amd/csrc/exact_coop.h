@@ -335,4 +335,26 @@ __device__ __forceinline__ void true_key_lane_side(const QRows& q_true, const QR
                        : Scorer<MODEL, TAIL, D>::template score<false>(e, LazyCoef<MODEL, TAIL, D>{f, r});
 }
 
+// rank_common.h: FallbackPrep -- called by ALL threads of a refinement kernel's grid when the gate says heavy
+template <int MODEL, int D>
+__device__ __forceinline__ void fallback_prep(const FallbackPrep& fp, const QRows& q_fixed, const QRows& q_rel, int64_t q_head,
+                                              int64_t q_tail) {
+    using SH = Scorer<MODEL, HEAD, D>;
+    using ST = Scorer<MODEL, TAIL, D>;
+    float* coef_head = fp.coef;
+    float* coef_tail = fp.coef + fallback_coef_tail_offset(D, q_head);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t q = i0; q < q_head + q_tail; q += stride) fp.acc[q] = 0;  // what the pre-pass counted is recounted
+    const int64_t n_head = q_head * SH::C, total = n_head + q_tail * ST::C;
+    for (int64_t i = i0; i < total; i += stride) {
+        if (i < n_head) {
+            const int64_t q = i / SH::C;
+            coef_head[i] = SH::coef(q_fixed.row(q), q_rel.row(q), (int)(i % SH::C));
+        } else {
+            const int64_t k = i - n_head, q = k / ST::C;
+            coef_tail[k] = ST::coef(q_fixed.row(q_head + q), q_rel.row(q_head + q), (int)(k % ST::C));
+        }
+    }
+}
+
 }  // namespace blp

@@ -845,27 +845,6 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
 
 // ------------------------------------------------------------------------------------------------
 // The pre-pass paths' bounded worst case (rank_common.h: Gate): when the lists ran full, the exact kernel re-ranks the block.
-template <int MODEL, int D>
-__global__ __launch_bounds__(256) void fallback_prep_kernel(const QRows q_fixed, const QRows q_rel, int64_t q_head, int64_t q_tail,
-                                                            float* __restrict__ coef_head, float* __restrict__ coef_tail,
-                                                            unsigned long long* __restrict__ acc, const Gate gate) {
-    if (!gate_heavy(gate)) return;
-    using SH = Scorer<MODEL, HEAD, D>;
-    using ST = Scorer<MODEL, TAIL, D>;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    for (int64_t q = i0; q < q_head + q_tail; q += stride) acc[q] = 0;  // what the pre-pass counted is recounted
-    const int64_t n_head = q_head * SH::C, total = n_head + q_tail * ST::C;
-    for (int64_t i = i0; i < total; i += stride) {
-        if (i < n_head) {
-            const int64_t q = i / SH::C;
-            coef_head[i] = SH::coef(q_fixed.row(q), q_rel.row(q), (int)(i % SH::C));
-        } else {
-            const int64_t k = i - n_head, q = k / ST::C;
-            coef_tail[k] = ST::coef(q_fixed.row(q_head + q), q_rel.row(q_head + q), (int)(k % ST::C));
-        }
-    }
-}
-
 size_t exact_fallback_coef_floats(int D, int64_t q_head, int64_t q_tail) {
     return (size_t)(q_head + q_tail) * max_coef(D) + 64;
 }
@@ -876,9 +855,8 @@ static hipError_t exact_fallback_impl(const float* table, int64_t N, int64_t ld,
                                       hipStream_t stream) {
     const int64_t Q = q_head + q_tail;
     if (Q == 0 || N == 0) return hipSuccess;
-    float* coef_head = coef;
-    float* coef_tail = coef + (((size_t)q_head * max_coef(D) + 63) / 64) * 64;
-    fallback_prep_kernel<MODEL, D><<<dim3(1024), 256, 0, stream>>>(q_fixed, q_rel, q_head, q_tail, coef_head, coef_tail, acc, gate);
+    float* coef_head = coef;  // (written, with the zeroed counts, by the path's last refinement kernel: exact_coop.h: fallback_prep)
+    float* coef_tail = coef + fallback_coef_tail_offset(D, q_head);
     // one workgroup per query chunk (or a few), grid-striding over the tile quads: as many workgroups as the chip holds a few
     // times over, not one per (quad, chunk) -- tens of thousands of workgroups that return at once would cost the common
     // case ~20 us

@@ -89,15 +89,22 @@ hipError_t launch_filter_finalize(int model, int D, const float* table, int64_t 
 // at once when it is not its turn (`gate`: the counter; heavy <=> *gate >= gate_min).  gate == nullptr: no gating.
 struct Gate { const unsigned* counter; unsigned heavy_from; };
 __device__ __forceinline__ bool gate_heavy(const Gate& g) { return g.counter != nullptr && *g.counter >= g.heavy_from; }
+// What a refinement kernel does INSTEAD of refining when the gate says heavy (one launch fewer than a kernel of its own would
+// be: ~5 us of every common-case block): zero the counts the pre-pass took and materialise the coefficient rows of the exact
+// kernel, grid-strided over whatever grid the caller has.  coef: exact_fallback_coef_floats(...) floats.
+struct FallbackPrep { float* coef; unsigned long long* acc; };
 // floats of coefficient rows the exact re-ranking needs for (q_head + q_tail) queries; blocks below kFallbackMinPairs (or ranked
 // in several candidate slabs) have no fallback: 0
 constexpr int64_t kFallbackMinPairs = (int64_t)1 << 27;
 size_t exact_fallback_coef_floats(int D, int64_t q_head, int64_t q_tail);
-// if heavy: zero acc, materialise the coefficient rows, rank every query against every row with rank_tiles_kernel (counts into
-// acc; key_true as computed by the pre-pass path); else: two launches that return at once
+// if heavy: rank every query against every row with rank_tiles_kernel (counts into acc, which the last refinement kernel of the
+// path zeroed together with writing the coefficient rows: fallback_prep below; key_true as computed by the pre-pass path);
+// else: one launch that returns at once
 hipError_t launch_exact_fallback(int model, int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed, const QRows q_rel,
                                  int64_t q_head, int64_t q_tail, float* coef, const float* key_true, unsigned long long* acc, Gate gate,
                                  int n_cu, hipStream_t stream);
+// where the tail-side coefficient rows start inside `coef`
+__host__ __device__ inline size_t fallback_coef_tail_offset(int D, int64_t q_head) { return (((size_t)q_head * 2 * D + 63) / 64) * 64; }
 
 constexpr int64_t kTrueKeyLaneMaxQueries = 2048;  // up to here true keys are one lane per query (exact_coop.h: true_key_lane)
 

@@ -1065,8 +1065,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ t
                                                      const QRows q_rel,
                                                      const float* __restrict__ key_true, int64_t q_head, int64_t Q,
                                                      int words_per_query, const unsigned* __restrict__ flags,
-                                                     unsigned long long* __restrict__ acc, const Gate gate) {
-    if (gate_heavy(gate)) return;
+                                                     unsigned long long* __restrict__ acc, const Gate gate, const FallbackPrep prep) {
+    if (gate_heavy(gate)) {  // (rank_common.h: Gate) the exact kernel re-ranks the block; this grid prepares it
+        fallback_prep<MODEL, D>(prep, q_fixed, q_rel, q_head, Q - q_head);
+        return;
+    }
     __shared__ int list[kSweepQueries], n_list;
     const int lane = threadIdx.x & 63, part = lane >> 5, sub = lane & 31;
     const int64_t q_base = (int64_t)blockIdx.x * kSweepQueries;
@@ -1530,12 +1533,14 @@ static hipError_t rank_gemm_impl(const float* table, int64_t N, int64_t ld, cons
                                                                         (unsigned)w.spill_entries);
             // heavy <=> the flags outnumber the spill region (n_pairs[1] counts every flag, also those that found it full): exact
             // ties on whole percents of the table -- every flag costs 16 exact scores where the exact kernel re-ranks everything
-            gate = Gate{w.fallback_coef ? w.n_pairs + 1 : nullptr, (unsigned)w.spill_entries};
+            // (ComplEx switches at twice that: its exact kernel takes 27 ms for the FB15k-237 block, the others' 15)
+            const int64_t heavy_from = w.spill_entries * (MODEL == COMPLEX ? 2 : 1);
+            gate = Gate{w.fallback_coef ? w.n_pairs + 1 : nullptr, (unsigned)(heavy_from < 0xffffffffll ? heavy_from : 0xffffffffll)};
             refine_pairs_kernel<MODEL, D><<<dim3(2048), 256, 0, stream>>>(slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs,
                                                                         w.n_pairs, w.spill, (unsigned)w.spill_entries, w.acc, gate);
         }
         refine_kernel<MODEL, D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
-            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.acc, gate);
+            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.acc, gate, FallbackPrep{w.fallback_coef, w.acc});
         if (gate.counter) {
             err = launch_exact_fallback(MODEL, D, table, N, ld, q_fixed, q_rel, q_head, q_tail, w.fallback_coef, w.key_true, w.acc, gate,
                                         n_cu, stream);

@@ -436,8 +436,12 @@ __global__ __launch_bounds__(256) void sad_refine_tiles_kernel(const float* __re
                                                                int64_t Q, int words_per_query,
                                                                const unsigned* __restrict__ flags,
                                                                const SadParams* __restrict__ params,
-                                                               unsigned long long* __restrict__ acc, const Gate gate) {
-    if (gate_heavy(gate)) return;  // the lists ran full: the exact kernel re-ranks the block (rank_common.h: Gate)
+                                                               unsigned long long* __restrict__ acc, const Gate gate,
+                                                               const FallbackPrep prep, int64_t q_tail) {
+    if (gate_heavy(gate)) {  // the lists ran full: the exact kernel re-ranks the block (rank_common.h: Gate); this grid prepares it
+        fallback_prep<TRANSE, D>(prep, q_fixed, q_rel, q_head, q_tail);
+        return;
+    }
     __shared__ int list[kSweepQueries], n_list;
     const bool all = !sad_scale(params).ok;
     const int lane = threadIdx.x & 63;
@@ -665,7 +669,8 @@ static hipError_t rank_sad_impl(const float* table, int64_t N, int64_t ld, const
         sad_refine_pairs_kernel<D><<<dim3((unsigned)(pair_blocks < (int64_t)n_cu * 40 ? pair_blocks : (int64_t)n_cu * 40)), 64, 0, stream>>>(
             slab, ld, q_fixed, q_rel, w.key_true, q_head, w.pairs, w.params, w.acc, gate);
         sad_refine_tiles_kernel<D><<<dim3((unsigned)((Q + kSweepQueries - 1) / kSweepQueries)), 256, 0, stream>>>(
-            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc, gate);
+            slab, n_rows, ld, q_fixed, q_rel, w.key_true, q_head, Q, words, w.flags, w.params, w.acc, gate,
+            FallbackPrep{w.fallback_coef, w.acc}, q_tail);
         if (gate.counter) {
             err = launch_exact_fallback(TRANSE, D, table, N, ld, q_fixed, q_rel, q_head, q_tail, w.fallback_coef, w.key_true, w.acc, gate,
                                         n_cu, stream);
