@@ -1167,7 +1167,8 @@ def compact_sub(sub, world):
         out["decided_frac"] = sub["decided_frac"]
     if "vs_random_step" in sub:
         out["vs_random_step"] = sub["vs_random_step"]
-    if world > 1:
+    if world > 1:  # (13 sub-results on several ranks: the per-rank kernel time stays in the details file)
+        out.pop("kernel_ms")
         out["exchange_ms"], out["axis"] = sub.get("exchange_ms"), sub.get("shard_axis")
     parity = sub.get("parity_check")
     if parity and not parity.startswith("skipped"):

@@ -101,7 +101,9 @@ int blp_dim_supported(int model, int D);
  * The (Q, N) score matrix is never materialised.  Results are the reference's, bit for bit, whichever
  * kernel serves the block: exact f32 kernels for small blocks; for blocks of many
  * queries a cheap pre-pass (16-bit fixed-point v_sad_u16 for TransE, bf16 x 3 MFMA GEMM for the
- * bilinear models) with a rigorous error band, then exact re-scoring of the undecided pairs.
+ * bilinear models) with a rigorous error band, then exact re-scoring of the undecided pairs -- and when a pre-pass leaves
+ * more undecided than its lists hold (exact ties with the true entity on whole percents of the table), a device-side counter
+ * makes the exact kernels re-rank the block instead: a block never costs more than pre-pass + exact kernel.
  *
  *   table      (N, D) f32, row stride ld floats (ld % 4 == 0, 16-byte aligned base)
  *   q_fixed    (Q, D) f32  the entity kept fixed (tail_embs for head queries, head_embs for tail)
