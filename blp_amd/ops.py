@@ -237,12 +237,15 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     return counts
 
 
-def table16_is_read_directly(rel_model, dtype, N, D, n_triples, batch, block_triples=None):
+def table16_is_read_directly(rel_model, dtype, N, D, n_triples, batch, block_triples=None, ld=None):
     """include/blp_hip.h: blp_rank_all_batches_t_native -- True if rank_all_batches over a float16 / bfloat16 table of these sizes
-    streams the 16-bit rows themselves (half the bytes per pass); False if the library would widen the table to f32 first."""
+    streams the 16-bit rows themselves (half the bytes per pass); False if the library would widen the table to f32 first.
+    ``ld``: the row stride (elements) the call will be made with; default = what rank_all_batches passes for a contiguous
+    ``table.to(dtype)`` copy (D, or D padded to a multiple of 8 by _table_rows when D % 8 != 0)."""
     if dtype not in TABLE_DTYPES or dtype == torch.float32:
         return False
-    ld = (D + 7) // 8 * 8
+    if ld is None:
+        ld = (D + 7) // 8 * 8
     return bool(_lib.lib().blp_rank_all_batches_t_native(_lib.MODEL_IDS[rel_model], TABLE_DTYPES[dtype], int(N), int(D), ld, int(n_triples),
                                                          int(batch), int(batch if block_triples is None else block_triples)))
 

@@ -20,12 +20,13 @@ What changes relative to the reference, and what does not:
 CPU tensors (the reference's CPU-runnable smoke configuration) take the reference's own dense route
 through score_fn + get_metrics.
 """
+import copy
 import math
 
 import torch
 import torch.distributed as dist
 
-from . import models, ops, utils
+from . import models, multidevice, ops, utils
 
 HIT_POSITIONS = (1, 3, 10)
 
@@ -197,8 +198,16 @@ def _via_host(tensor, group):
     return tensor.is_cuda and dist.get_backend(group) == "gloo"
 
 
+def _threads(group):
+    """True if ``group`` is a member of a one-process / one-thread-per-device group (multidevice.DeviceGroup) rather than
+    a torch.distributed process group: the same two collectives, issued for all devices from one thread."""
+    return isinstance(group, multidevice.Member)
+
+
 def _all_reduce(tensor, group=None):
-    if _via_host(tensor, group):
+    if _threads(group):
+        group.all_reduce(tensor)
+    elif _via_host(tensor, group):
         host = tensor.cpu()
         dist.all_reduce(host, group=group)
         tensor.copy_(host)
@@ -207,7 +216,9 @@ def _all_reduce(tensor, group=None):
 
 
 def _all_gather_into(full, part, group=None):
-    if _via_host(part, group):
+    if _threads(group):
+        group.all_gather_into(full, part)
+    elif _via_host(part, group):
         host = torch.empty(full.shape, dtype=full.dtype)
         dist.all_gather_into_tensor(host, part.cpu(), group=group)
         full.copy_(host)
@@ -237,8 +248,11 @@ class ShardedRanker:
         self.table = local_table
         self.num_rows = int(num_rows)
         self.group = group
-        self.world = dist.get_world_size(group) if self._distributed() else 1
-        self.rank = dist.get_rank(group) if self._distributed() else 0
+        if _threads(group):
+            self.world, self.rank = group.world, group.rank
+        else:
+            self.world = dist.get_world_size(group) if self._distributed() else 1
+            self.rank = dist.get_rank(group) if self._distributed() else 0
         self.lo, self.hi = shard_bounds(self.num_rows, self.world, self.rank)
         if local_table.shape[0] != self.hi - self.lo:
             raise ValueError(f"rank {self.rank} must hold rows [{self.lo}, {self.hi}) of the table, "
@@ -457,7 +471,8 @@ def rank_triples(model, table, triples, ent2idx, index=None, *, num_entities=Non
 
 # ----------------------------------------------------------------------------------- evaluation
 def _module(model):
-    return model.module if isinstance(model, torch.nn.DataParallel) else model
+    wrappers = (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)
+    return model.module if isinstance(model, wrappers) else model
 
 
 def _loader_triples(loader, max_num_batches):
@@ -516,14 +531,66 @@ def build_entity_table(model, text_dataset, entities, emb_batch_size, device, lo
     return table
 
 
+def table16_everywhere(rel_model, dtype, num_entities, dim, num_triples, block_size, world, axis):
+    """Whether EVERY rank's shard of an evaluation would stream a 16-bit copy of the table itself (ops.table16_is_read_directly),
+    evaluated for all ranks' (rows, triples) from the shard layout alone -- so that every rank takes the same decision
+    without an exchange.  A per-rank decision can differ between ranks (the last candidate shard is shorter and the
+    library's routing has a row threshold): some ranks would then rank the rounded copy and others the float32 table,
+    the summed counts would mix two inputs, and -- the copy deciding which collective replicates the queries' vectors
+    (replicates_whole_table) -- the ranks could issue mismatched collectives and hang."""
+    by_query = world > 1 and axis == "query"
+    for r in range(max(world, 1)):
+        lo, hi = (0, num_entities) if (world <= 1 or by_query) else shard_bounds(num_entities, world, r)
+        t_lo, t_hi = shard_bounds(num_triples, world, r) if by_query else (0, num_triples)
+        if not ops.table16_is_read_directly(rel_model, dtype, hi - lo, dim, t_hi - t_lo, block_size):
+            return False
+    return True
+
+
+def _shard_of_evaluation(model, text_dataset, entities, emb_batch_size, device, _log, triples, ent2idx, index, *, group, world, rank,
+                         shard_axis, block_size, rank_table_dtype):
+    """What ONE rank (a process of a torch.distributed group, or a device thread of a multidevice.DeviceGroup) does of an
+    evaluation: encode its rows of the entity table (train.py:96-121), rank the triples against them (rank_triples; the
+    collectives of SURVEY.md 8e inside).  Returns (table -- this rank's rows, or all rows on the query axis --, axis,
+    triples, counts (2T, 4) int32 of the WHOLE evaluation, ids_ok)."""
+    num_entities, num_triples = entities.shape[0], triples.shape[0]
+    lo, hi = shard_bounds(num_entities, world, rank)
+    table = build_entity_table(model, text_dataset, entities, emb_batch_size, device, _log if rank == 0 else None, rows=(lo, hi))
+    triples = triples.to(device)  # in loader order (train.py:128-131)
+    axis = shard_axis if shard_axis != "auto" else choose_shard_axis(num_entities, table.shape[1], 2 * num_triples, world)
+    if world > 1 and axis == "query":  # full table everywhere, each rank takes a slice of the triples
+        table = all_gather_rows(table, num_entities, world, group)
+    rank_table = table
+    if rank_table_dtype not in (None, torch.float32) and table.is_cuda:
+        if table16_everywhere(model.rel_model, rank_table_dtype, num_entities, table.shape[1], num_triples, block_size, world, axis):
+            rank_table = table.to(rank_table_dtype)
+        else:
+            # (the library would widen a 16-bit copy back to float32: more memory and time than the float32 table and other
+            #  metrics for nothing; and the reference's pass structure -- a table pass per eval batch -- only pays with it)
+            block_size = max(block_size, 65536)
+            if rank == 0:
+                _log.info(f"rank_table_dtype={rank_table_dtype}: not used for this evaluation (dim {table.shape[1]}, {num_entities:,} rows "
+                          f"on {world} rank(s): the library would widen a 16-bit copy back to float32); ranking the float32 table "
+                          f"in blocks of {block_size:,} triples")
+    triples, counts, ids_ok = rank_triples(model, rank_table, triples, ent2idx.to(device), index, num_entities=num_entities,
+                                           group=group, world=world, rank=rank, axis=axis, block_size=block_size)
+    return table, axis, triples, counts, ids_ok
+
+
 @torch.no_grad()
 def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, emb_batch_size, _run, _log,
                          prefix="", max_num_batches=None, filtering_graph=None, new_entities=None,
                          return_embeddings=False, device=None, group=None, block_size=65536, shard_axis="auto",
-                         eval_mode=False, rank_table_dtype=None):
+                         eval_mode=False, rank_table_dtype=None, devices=None):
     """Drop-in for train.eval_link_prediction (same positional arguments, metric names and return
-    value).  ``device`` defaults to the model's device; ``group`` (or an initialised default process
-    group) shards the evaluation, along ``shard_axis`` = "candidate" | "query" | "auto".
+    value).  ``device`` defaults to the model's device.  Several GPUs, two ways (both: SURVEY.md 8e -- every shard encodes
+    and keeps its own rows, ONE all-gather of the int32 counts; ``shard_axis`` = "candidate" | "query" | "auto"):
+
+      * ``devices`` = [device, ...]: THIS process, one Python thread per device -- the reference's own process model
+        (nn.DataParallel, train.py:329-330,344).  Every thread gets a replica of the model, builds its row shard, ranks on its
+        own stream; the counts are combined by RCCL calls issued for all devices from one thread (multidevice.DeviceGroup).
+        A device may repeat (two shards on one GPU).  The metrics, and the returned table, live on devices[0].
+      * ``group`` (or an initialised default process group): one PROCESS per device under torch.distributed.run.
 
     ``eval_mode``: the reference never leaves train mode (train.py:57-121 has no model.eval()), so its entity table is
     built with BERT's dropout active and its metrics differ run to run.  The default (False) keeps whatever mode the
@@ -535,15 +602,21 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     the table ("emit fp16 copy").  A deliberate change of the INPUT, not of the arithmetic: the candidates are
     the rounded rows, scored in f32 in the reference's order (counts = the reference's on the rounded table, bit for bit).
     Honoured ONLY where it pays: at the reference's Wikidata5M batching (``block_size`` <= 4 triples per table pass, dim 128 /
-    256, a table long enough for the streaming kernels) the passes read the 16-bit rows themselves, half the bytes; for any
-    other shape the library would widen the copy back to float32 before ranking -- more memory and time than the float32
-    table and different metrics for nothing -- so the float32 table is ranked and a log line says so (train.py:
-    ``rank_table_dtype=float16``).  The returned embeddings stay float32."""
+    256, a table long enough for the streaming kernels ON EVERY RANK) the passes read the 16-bit rows themselves, half the
+    bytes; for any other shape the float32 table is ranked in the default 65 536-triple blocks and a log line says so
+    (train.py: ``rank_table_dtype=float16``).  The returned embeddings stay float32."""
     model = _module(model)
     if device is None:
         device = next(model.parameters()).device
     compute_filtered = filtering_graph is not None
     dataset = triples_loader.dataset
+    if devices is not None and group is not None:
+        raise ValueError("give `devices` (threads of this process) or `group` (a process group), not both")
+    if devices is not None:
+        threads = multidevice.DeviceGroup(devices)
+        device = threads.devices[0]
+    else:
+        threads = None
 
     if isinstance(model, models.InductiveLinkPrediction):
         if compute_filtered:
@@ -560,33 +633,42 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
             index = filtering_graph if isinstance(filtering_graph, utils.FilterIndex) else utils.FilterIndex(filtering_graph, device=device)
     num_entities = entities.shape[0]
 
-    sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-    world = dist.get_world_size(group) if sharded else 1
-    rank = dist.get_rank(group) if sharded else 0
-    lo, hi = shard_bounds(num_entities, world, rank)
     was_training = model.training
     if eval_mode:
         model.eval()
-    table = build_entity_table(model, text_dataset, entities, emb_batch_size, device, _log, rows=(lo, hi))
-
-    triples = _loader_triples(triples_loader, max_num_batches).to(device)  # in loader order (train.py:128-131)
+    triples = _loader_triples(triples_loader, max_num_batches)
     num_triples = triples.shape[0]
+    common = dict(shard_axis=shard_axis, block_size=block_size, rank_table_dtype=rank_table_dtype)
+    if threads is not None:
+        # one replica per device thread, made here on the calling thread (a module is not copied while another thread runs it);
+        # the model itself serves the first thread on its own device
+        home = next(model.parameters()).device
+        replicas, used_home = [], False
+        for d in threads.devices:
+            if d == home and not used_home:
+                replicas.append(model)
+                used_home = True
+            else:
+                replicas.append(copy.deepcopy(model).to(d))
+        if index is not None:
+            for d in set(threads.devices):
+                if d.type == "cuda":
+                    index.device_arrays(d)  # moved once, here, not by whichever thread asks first
+        world = threads.world
+        _log.info(f"Evaluating on {world} device thread(s): {', '.join(str(d) for d in threads.devices)} ({threads.exchange} exchange)")
+        shards = threads.run(lambda m: _shard_of_evaluation(replicas[m.rank], text_dataset, entities, emb_batch_size, m.device, _log, triples,
+                                                            ent2idx, index, group=m, world=world, rank=m.rank, **common))
+        del replicas
+        table, axis, triples, counts, ids_ok = shards[0]
+        sharded = world > 1
+    else:
+        sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        world = dist.get_world_size(group) if sharded else 1
+        rank = dist.get_rank(group) if sharded else 0
+        shards = None
+        table, axis, triples, counts, ids_ok = _shard_of_evaluation(model, text_dataset, entities, emb_batch_size, device, _log, triples,
+                                                                    ent2idx, index, group=group, world=world, rank=rank, **common)
     _log.info("Computing metrics on set of triples")
-    axis = shard_axis if shard_axis != "auto" else choose_shard_axis(num_entities, table.shape[1], 2 * num_triples, world)
-    if sharded and world > 1 and axis == "query":  # full table everywhere, each rank takes a slice of the triples
-        table = all_gather_rows(table, num_entities, world, group)
-    rank_table = table
-    if rank_table_dtype not in (None, torch.float32) and table.is_cuda:
-        local_triples = shard_bounds(num_triples, world, rank) if (sharded and world > 1 and axis == "query") else (0, num_triples)
-        if ops.table16_is_read_directly(model.rel_model, rank_table_dtype, table.shape[0], table.shape[1],
-                                        local_triples[1] - local_triples[0], block_size):
-            rank_table = table.to(rank_table_dtype)
-        else:
-            _log.info(f"rank_table_dtype={rank_table_dtype}: not used for this evaluation ({block_size} triples per ranking pass, dim "
-                      f"{table.shape[1]}, {table.shape[0]:,} rows: the library would widen a 16-bit copy back to float32); ranking the float32 table")
-    triples, counts, ids_ok = rank_triples(model, rank_table, triples, ent2idx.to(device), index, num_entities=num_entities,
-                                           group=group, world=world, rank=rank, axis=axis, block_size=block_size)
-    del rank_table
     if table.is_cuda:
         ops.release_workspaces()  # the evaluation's scratch does not stay pinned through the training steps that follow
     rr, hits = metrics_from_counts(counts)
@@ -639,7 +721,10 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
     if was_training and eval_mode:
         model.train()
     if return_embeddings:
-        if sharded and world > 1 and axis != "query":  # the full table only on request: all-gather of the shards
-            table = all_gather_rows(table, num_entities, world, group)
+        if sharded and world > 1 and axis != "query":  # the full table only on request
+            if shards is not None:  # device threads: the shards come to devices[0] by peer copies
+                table = torch.cat([s[0].to(device) for s in shards])
+            else:                   # processes: all-gather of the shards
+                table = all_gather_rows(table, num_entities, world, group)
         return mrr, table.unsqueeze(0)
     return mrr, None

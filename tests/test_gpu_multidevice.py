@@ -118,3 +118,137 @@ def test_compute_loss_on_two_gloo_ranks_equals_the_reference(name, tmp_path):
     assert got["full_loss"].item() == pytest.approx(float(g["loss"]), rel=1e-6, abs=1e-7)
     np.testing.assert_allclose(got["full_grad_ent"].numpy(), g["grad_ent"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(got["full_grad_rel_w"].numpy(), g["grad_rel_w"], rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The EVALUATION on several devices from one process: one thread per device (blp_amd.multidevice), each with its replica, its
+# rows of the entity table, its stream; counts combined by one all-gather + sum.  One GPU here: two (three)
+# shards on device 0 -- the threads, the per-call device / stream arguments, the shard form of the kernels and the exchange
+# are all exercised; with >= 2 GPUs the devices are distinct and the exchange is RCCL's group launch.
+def _device_list(n):
+    have = torch.cuda.device_count()
+    return list(range(n)) if have >= n else [0] * n
+
+
+@pytest.mark.parametrize("rel_model", REL_MODELS)
+@pytest.mark.parametrize("n_dev,axis", [(2, "auto"), (3, "candidate"), (2, "query")])
+def test_eval_link_prediction_on_device_threads_matches_reference(rel_model, n_dev, axis):
+    """eval_link_prediction(devices=[...]) through the HIP path: the reference's own scalar dict (golden, generated by the
+    imported reference) and its returned embeddings."""
+    import logging
+    from blp_amd import ops, ranking
+    from test_host_golden import _Run, toy_eval_setup
+    g = golden(f"eval_toy_{rel_model}")
+    model, text, loader, index, entities, new_ents = toy_eval_setup(g, rel_model, device="cuda")
+    run = _Run()
+    mrr, ent_emb = ranking.eval_link_prediction(model, loader, text, entities, 3, int(g["emb_batch_size"]), run, logging.getLogger("t"),
+                                                prefix="test", filtering_graph=index, new_entities=new_ents, return_embeddings=True,
+                                                block_size=16, devices=_device_list(n_dev), shard_axis=axis)
+    want = dict(zip(g["scalar_names"].tolist(), g["scalar_values"].tolist()))
+    assert set(run.scalars) == set(want)
+    for name, value in want.items():
+        assert run.scalars[name] == pytest.approx(value, abs=1e-6), name   # (the tolerance: the GPU-built table, test_gpu_eval.py)
+    assert ent_emb.device == torch.device("cuda", 0)
+    np.testing.assert_allclose(ent_emb[0].cpu().numpy(), g["ent_emb"], rtol=1e-6, atol=1e-7)
+    assert not ops._workspaces
+
+
+@pytest.mark.parametrize("model,N,T,block", [("transe", 3000, 900, 65536), ("complex", 40000, 24, 2), ("distmult", 3000, 2600, 1024),
+                                             ("simple", 50000, 7, 2)])
+def test_device_threads_counts_equal_the_oracle(oracle, model, N, T, block):
+    """ranking.rank_triples on the candidate axis from device threads (big blocks: the pre-pass kernels on a shard; the
+    reference's Wikidata5M batching, 2 triples per pass: the streaming ring kernels on a shard): every thread ends with the
+    ORACLE's counts, raw and filtered; the exchanges issued are the plan's."""
+    from blp_amd import models, multidevice, ranking, utils
+    from test_gpu_shard import _oracle_counts, _problem
+    D, R, world = 128, 5, 3
+    table, rel_w, ent2idx, triples, edges = _problem(model, N, D, T, R, seed=N + T)
+    index = utils.FilterIndex(edges, num_relations=R)
+    want = _oracle_counts(oracle, model, table, rel_w, ent2idx, triples, index)
+    net = models.LinkPrediction(D, model, "margin", R, 0)
+    net.rel_emb.weight.data = rel_w.clone()
+    group = multidevice.DeviceGroup(_device_list(world))
+    replicas = [net.cuda() if d == group.devices[0] else None for d in group.devices]
+    import copy
+    replicas = [r if r is not None else copy.deepcopy(net).to(d) for r, d in zip(replicas, group.devices)]
+
+    def shard(m):
+        lo, hi = ranking.shard_bounds(N, world, m.rank)
+        _, counts, ok = ranking.rank_triples(replicas[m.rank], table[lo:hi].to(m.device), triples.to(m.device), ent2idx.to(m.device), index,
+                                             num_entities=N, group=m, world=world, rank=m.rank, axis="candidate", block_size=block)
+        return counts.cpu().numpy(), bool(ok)
+
+    for counts, ok in group.run(shard):
+        assert ok and np.array_equal(counts, want)
+    plan = ranking.exchange_plan(N, D, T, world, "candidate")
+    assert [(op, nbytes) for op, nbytes in group.issued] == [(p["op"], p["bytes_per_rank"]) for p in plan]
+
+
+@pytest.mark.default_routing
+def test_link_prediction_cli_evaluates_on_device_threads(tmp_path):
+    """python train.py link_prediction ... eval_devices=[0,0]: the reference's launch (one process), every evaluation sharded
+    over the listed devices by threads -- and the same numbers as the run that evaluates on one device."""
+    import json
+    from blp_amd.data import write_synthetic_dataset
+    write_synthetic_dataset(str(tmp_path / "data"), "umls-synth", num_entities=135, num_relations=46,
+                            num_train=1280, num_valid=160, num_test=160, vocab_size=500, emb_dim=128, seed=0)
+    base = [sys.executable, os.path.join(ROOT, "train.py"), "link_prediction", "with", "dataset=umls-synth", "inductive=False",
+            "model=glove-bow", "rel_model=transe", "loss_fn=margin", "regularizer=1e-2", "max_len=32", "num_negatives=16", "lr=1e-3",
+            "use_scheduler=False", "batch_size=64", "emb_batch_size=512", "eval_batch_size=64", "max_epochs=1",
+            f"data_root={tmp_path / 'data'}", "seed=1"]
+    scalars = {}
+    for name, extra in (("threads", ["eval_devices=[0,0]"] if torch.cuda.device_count() < 2 else []), ("single", ["eval_devices=[0]"])):
+        cwd = tmp_path / name
+        cwd.mkdir()
+        # (on a multi-GPU box both runs train alike -- DataParallel over all devices --; "threads" then evaluates on all of them
+        #  by default, "single" on one)
+        proc = subprocess.run(base + extra, cwd=cwd, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        log = proc.stderr + proc.stdout
+        n_threads = max(torch.cuda.device_count(), 2) if name == "threads" else 1
+        assert f"Evaluating on {n_threads} device thread(s)" in log, log[-2000:]
+        scalars[name] = json.load(open(cwd / "output" / "scalars-None.json"))
+    for key, value in scalars["single"].items():
+        if key.startswith(("valid_", "test_", "train_mrr", "train_hits")):
+            assert scalars["threads"][key] == pytest.approx(value, abs=1e-6), key
+
+
+@pytest.mark.default_routing
+def test_link_prediction_cli_under_torchrun_on_the_gpu(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 train.py ... on this box: with two GPUs the ranks take cuda:0 / cuda:1
+    and exchange through RCCL; with one they share it and exchange through gloo (RCCL refuses two ranks on a device) --
+    either way every rank trains on its slice of the batch (fused in-batch loss), evaluates its candidate shard through the
+    HIP ranking, and rank 0's scalars equal a single process's on the checkpoint the job saved."""
+    import json
+    import socket
+    from blp_amd.data import write_synthetic_dataset
+    write_synthetic_dataset(str(tmp_path / "data"), "umls-synth", num_entities=135, num_relations=46,
+                            num_train=1280, num_valid=160, num_test=160, vocab_size=500, emb_dim=128, seed=0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    args = ["link_prediction", "with", "dataset=umls-synth", "inductive=False", "model=glove-bow", "rel_model=transe", "loss_fn=margin",
+            "regularizer=1e-2", "max_len=32", "num_negatives=16", "lr=1e-3", "use_scheduler=False", "batch_size=64", "emb_batch_size=512",
+            "eval_batch_size=64", f"data_root={tmp_path / 'data'}", "seed=1"]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = tmp_path / "two"
+    two.mkdir()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "train.py"), *args, "max_epochs=1"]
+    proc = subprocess.run(cmd, cwd=two, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    log = proc.stderr + proc.stdout
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    assert f"2 processes, backend {backend}" in log, log[-2000:]
+    sharded = json.load(open(two / "output" / "scalars-None.json"))
+    one = tmp_path / "one"
+    one.mkdir()
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), *args, "max_epochs=0", f"checkpoint={two / 'output' / 'model-None.pt'}",
+           "eval_devices=[0]"]
+    proc = subprocess.run(cmd, cwd=one, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    single = json.load(open(one / "output" / "scalars-None.json"))
+    compared = [k for k in single if k.startswith(("valid_", "test_"))]
+    assert len(compared) == 22
+    for key in compared:
+        assert sharded[key] == pytest.approx(single[key], abs=1e-6), key
