@@ -75,10 +75,14 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 F32_PEAK_TFLOPS = 157.3         # f32 vector (FMA) peak == f32 MFMA peak; plain add/sub ops reach half
 BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md); the bilinear pre-pass spends 3 bf16
 BF16X3_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3   # products per f32-equivalent product, so its roof is a third of it
-# The TransE pre-pass issues v_sad_u16 (2 elements x (subtract + |.|-accumulate) per lane and instruction).  Measured issue rate
-# with 4 waves per SIMD (tools/sad_ubench.hip -> profiles/r04/sad_ubench.log): 4.23 - 4.48 cycles per instruction and SIMD, not
-# the 4 a quarter-rate instruction would take -> 2 x 2 x 64 lanes x 1024 SIMDs x 2.4 GHz / 4.3 = 146.3 Tops/s.
+HBM_MEASURED_GBPS = 6290.0      # the guide's measured float4-copy rate (79 % of spec): `peak_measured` beside the spec `peak`
+# The TransE pre-pass issues v_sad_u16 (2 elements x (subtract + |.|-accumulate) per lane and instruction).  `peak` is the
+# PUBLISHED rate (MI355X_MICROARCH.md: one VALU wave-instruction per 4 clocks and SIMD, 1 024 SIMDs, 2.4 GHz): 2 elements x 2 ops
+# x 64 lanes x 1 024 SIMDs x 2.4 GHz / 4 = 157.3 Tops/s -- numerically the guide's f32 vector peak.  The issue rate measured with 4
+# waves per SIMD (tools/sad_ubench.hip -> profiles/r04/sad_ubench.log) is 4.23 - 4.48 cycles per instruction and SIMD, taken as
+# 4.3 -> 146.3 Tops/s: reported BESIDE the published figure as `peak_measured` / `frac_measured`, not instead of it.
 SAD_CYCLES_PER_INST = 4.3
+SAD_PUBLISHED_TOPS = 2 * 2 * 64 * 1024 * 2.4e9 / 4.0 / 1e12
 SAD_PEAK_TOPS = 2 * 2 * 64 * 1024 * 2.4e9 / SAD_CYCLES_PER_INST / 1e12
 
 WORKLOADS = {
@@ -130,6 +134,26 @@ SUB_RESULTS = ("fb15k237-distmult", "fb15k237-complex", "fb15k237-transe-cluster
 # FB15k-237-sized tables; the Wikidata5M-scale table always along the north_star's candidate axis), plus the headline
 # workload on the candidate axis
 SUB_RESULTS_EXTRA_SHARDED = (("fb15k237-transe", "candidate"),)
+N1_REFERENCE_FILE = os.path.join("profiles", "n1_reference.json")  # committed one-GPU figures per workload: `vs_1gpu` of an N > 1 line
+
+
+def headline_workload(world):
+    """The workload on the TOP LEVEL of the line.  One GPU: BASELINE.json's metric configuration (FB15k-237 BLP-TransE).  Several:
+    the quantity the north_star's scaling target is defined on -- the Wikidata5M-scale TransE ranking in the reference's batching
+    (2 triples = 4 queries per table pass) sharded along the CANDIDATE axis, ONE all-gather of the int32 counts per evaluation;
+    the FB15k-237 evaluations (query axis, and the candidate axis) are then sub-results."""
+    return "fb15k237-transe" if world <= 1 else "wikidata5m-transe"
+
+
+def n1_reference(workload):
+    """{"value", "ms_per_step", "source"} of the committed one-GPU run of `workload` (profiles/n1_reference.json), or None."""
+    try:
+        with open(os.path.join(ROOT, N1_REFERENCE_FILE)) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
 TABLE_CHUNK_ROWS = 1 << 16      # a Wikidata5M-scale table is generated in chunks of this many rows, each from its own seed
 
 
@@ -241,6 +265,7 @@ def run_plan(world, shard_axis="auto"):
     todo = [("fb15k237-transe", "auto", "fb15k237-transe")] + [(n, "auto", n) for n in SUB_RESULTS]
     if world > 1:
         todo += [(n, a, f"{n}@{a}") for n, a in SUB_RESULTS_EXTRA_SHARDED]
+    # (the top level of the line is headline_workload(world); every other entry is a sub-result)
     plan = {}
     for name, forced, key in todo:
         cfg = WORKLOADS[name]
@@ -304,7 +329,13 @@ class Job:
         self.model = self.model.to(device)
         self.triples = torch.stack((heads, tails, rels), dim=1).contiguous()   # (T, 3) entity / relation ids
         self.ent2idx = torch.arange(self.N, device=device)                    # ids are table rows in the synthetic sets
+        # one-off cost outside the timed step, reported (the reference builds its networkx graph once as well, train.py:298-302):
+        # the sort + unique of the filtering graph's edges on the device (includes generating the synthetic edges' tensor copy)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
         self.index = make_filter_index(cfg, heads, tails, rels)
+        torch.cuda.synchronize(device)
+        self.filter_index_build_ms = (time.perf_counter() - t0) * 1e3
         self.index.segments(self.triples[:1], self.ent2idx, device)           # sorted arrays resident before the clock starts
         self.table_dtype = getattr(torch, cfg["table_dtype"]) if cfg.get("table_dtype") else torch.float32
         if self.table_dtype != torch.float32:  # the 16-bit copy IS the table of this workload; checks see it widened (exact)
@@ -454,6 +485,7 @@ class Job:
             ring = ppl > 1 or (not transe and (model == "complex" or n_local < 1_700_000)) or (transe and n_local < 1_700_000)
             dot = "approximate keys (a chain of fused multiply-adds) decided within a band, undecided rows re-scored in the reference's order; "
             roof = {"bound": "hbm", "achieved": alg_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "peak_measured": HBM_MEASURED_GBPS,  # (MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy)
                     "arith": ("f32, the reference's operations in its order (2-3 VALU operations per element and query)" if transe or not ring else
                               "f32 fused multiply-add chain per (row, query) decided within a proven band against the exact true key; "
                               "undecided rows re-scored in the reference's f32 order"),
@@ -464,18 +496,20 @@ class Job:
                               "rank_stream_wg_kernel (exact f32 keys; the table streamed once through workgroup tiles, two tiles in flight per workgroup)"}
         elif transe:
             wide = D not in (64, 128, 256)
-            roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": SAD_PEAK_TOPS, "unit": "TFLOP/s",
+            roof = {"bound": "valu", "achieved": alg_flops / t_k / 1e12, "peak": SAD_PUBLISHED_TOPS, "unit": "TFLOP/s",
+                    "peak_measured": SAD_PEAK_TOPS,
                     "arith": "u16 fixed-point v_sad_u16 pre-pass (decides >= 99.5 % of the pairs within a proven band) + exact f32 "
                              "re-scoring of the rest in the reference's order; NOT the reference's f32 lane-ops",
-                    "peak_source": "builder-measured v_sad_u16 issue rate, tools/sad_ubench.hip -> profiles/r04/sad_ubench.log "
-                                   "(4.23 - 4.48 cycles per instruction and SIMD at 4 waves/SIMD, taken as 4.3: 2 elements x 2 ops x "
-                                   "64 lanes x 1024 SIMDs x 2.4 GHz / 4.3 = 146.3 Tops/s); the guide has no figure for this instruction",
+                    "peak_source": "peak: MI355X_MICROARCH.md's VALU issue rate (one wave-instruction per 4 clocks and SIMD) -> 2 elements "
+                                   "x 2 ops x 64 lanes x 1024 SIMDs x 2.4 GHz / 4 = 157.3 Tops/s.  peak_measured: the v_sad_u16 issue rate "
+                                   "measured by tools/sad_ubench.hip -> profiles/r04/sad_ubench.log (4.23 - 4.48 cycles per instruction "
+                                   "and SIMD at 4 waves/SIMD, taken as 4.3) -> 146.3 Tops/s",
                     "kernel": ("wide_rank_sad_kernel + wide_refine_* (any-width u16 v_sad_u16 pre-pass)" if wide else
                                "rank_sad_kernel<128> + sad_refine_* (u16 fixed-point v_sad_u16 pre-pass + band + exact f32 "
                                "refinement; range / quantise kernels included)"),
-                    "note": "VALU roof (an L1 norm has no matrix-core form): 146.3 Tops/s is what v_sad_u16 delivers at its "
-                            "measured 4.3 cycles/instruction (2 elements x (subtract + |.|-accumulate) x 64 lanes; 157.3 at a "
-                            "nominal 4); the exact f32 add/sub kernel tops out at half of that.  achieved = 2 ops x D x Q x N "
+                    "note": "VALU roof (an L1 norm has no matrix-core form): 157.3 Tops/s is v_sad_u16 at the published 4 cycles per "
+                            "instruction (2 elements x (subtract + |.|-accumulate) x 64 lanes); 146.3 at its measured 4.3 "
+                            "(peak_measured); the exact f32 add/sub kernel tops out at half of that.  achieved = 2 ops x D x Q x N "
                             "/ time of the whole rank pass.  SURVEY 8(d)'s own accounting for the reference's f32 arithmetic "
                             "-- N x Q x D x c lane-ops, c = 3 on the head side (add r, subtract t, |.|-accumulate) and 2 on the "
                             "tail side, against the 78.6 T/s non-FMA f32 lane-op rate -- is in `survey_8d_lane_ops`: a frac "
@@ -497,6 +531,8 @@ class Job:
         if self.table.element_size() == 2:
             roof["arith"] += f"; the candidate table is a {self.cfg['table_dtype']} copy, every element widened to f32 (exactly) before it is used"
         roof["frac"] = roof["achieved"] / roof["peak"]
+        if "peak_measured" in roof:
+            roof["frac_measured"] = roof["achieved"] / roof["peak_measured"]
         roof["kernel_ms"] = kernel_ms
         roof["passes_per_launch"] = self.passes_per_launch()  # > 1: kernel_ms, traffic and the algorithmic figures are one pass's share
         # HBM bytes / matrix-pipe busy fraction of the dominant kernel come from the committed rocprofv3 PMC passes (a
@@ -541,6 +577,8 @@ class Job:
             "kernel_ms_per_rank": per_rank,
             "exchange_ms": max(exchange_per_rank), "exchange_ms_per_rank": exchange_per_rank,
             "shard_axis": self.axis, "ranks": self.world,
+            "filter_index_build_ms": self.filter_index_build_ms,  # once per evaluation set-up, NOT inside ms_per_step
+            "filter_index_edges": self.index.num_edges,
         }
         return out, triples, counts
 
@@ -1150,6 +1188,8 @@ def compact_roofline(roof):
         return roof
     out = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "passes_per_launch",
                                      "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch")}
+    if "peak_measured" in roof:  # the published peak is `peak`; a measured derate sits beside it, never instead of it
+        out["peak_measured"], out["frac_measured"] = roof["peak_measured"], roof.get("frac_measured")
     out["kernel"] = _short(roof.get("kernel"), 72)
     if roof.get("mfma_busy") is not None:
         out["mfma_busy"] = roof["mfma_busy"]
@@ -1188,7 +1228,8 @@ def compact_result(result, limit=LINE_LIMIT):
     cfg = dict(result.get("config", {}))
     cfg.pop("step", None)
     line["config"] = cfg
-    for k in ("ms_per_step_raw_only", "mrr", "mrr_filtered", "hits@1,3,10", "hits@1,3,10_filtered", "exchange_ms", "parity_check", "decided_frac"):
+    for k in ("ms_per_step_raw_only", "mrr", "mrr_filtered", "hits@1,3,10", "hits@1,3,10_filtered", "exchange_ms", "parity_check", "decided_frac",
+              "filter_index_build_ms", "vs_1gpu", "kernel_ms_per_rank", "exchange_ms_per_rank"):
         if k in result:
             line[k] = result[k]
     line["roofline"] = compact_roofline(result.get("roofline"))
@@ -1235,12 +1276,68 @@ def write_details(result, path):
         return None
 
 
+def dry_run_collectives(device, world, rank, backend, result_fd, nbytes=1024, timeout_s=120):
+    """`--dry-nccl`: the process group of an N > 1 run and the three collectives ONE evaluation issues (ranking.exchange_plan: the
+    all-gather of table rows, the all-reduce of the queries' vectors, the all-gather of the int32 counts), 1 KB each, values
+    checked.  Every rank reports on stderr; rank 0 prints one JSON line {"dry_nccl": "ok", "ranks": N, ...} on stdout.  A rank
+    that fails names itself and the step ("rank 3: all_reduce: <error>") and the process exits with status 3 -- before the
+    driver spends a scaling run on a box whose RCCL cannot come up."""
+    import datetime
+    from blp_amd import ranking
+    step = "init_process_group"
+    try:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = dict(timeout=datetime.timedelta(seconds=timeout_s))
+            if backend == "gloo":
+                dist.init_process_group("gloo", **kw)
+            else:
+                dist.init_process_group("nccl", device_id=device, **kw)
+        group_size = dist.get_world_size() if world > 1 else 1
+        n = nbytes // 4
+        step = "all_gather (table rows)"
+        rows = torch.full((n // 8, 8), float(rank), device=device)
+        full = ranking.all_gather_rows(rows, world * (n // 8), world)
+        assert full[:, 0].reshape(world, -1).mean(dim=1).tolist() == [float(r) for r in range(world)], "wrong values"
+        step = "all_reduce (query vectors)"
+        vec = torch.full((n,), float(rank + 1), device=device)
+        if world > 1:
+            ranking._all_reduce(vec)
+        assert vec[0].item() == (world * (world + 1) / 2 if world > 1 else 1.0), "wrong sum"
+        step = "all_gather (int32 counts)"
+        part = torch.full((n,), rank, dtype=torch.int32, device=device)
+        gathered = torch.empty(world * n, dtype=torch.int32, device=device)
+        if world > 1:
+            ranking._all_gather_into(gathered, part)
+        else:
+            gathered.copy_(part)
+        assert gathered.reshape(world, n)[:, 0].tolist() == list(range(world)), "wrong values"
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        print(f"bench.py --dry-nccl: rank {rank} of {group_size} on {device}: ok", file=sys.stderr, flush=True)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"dry_nccl": "ok", "ranks": group_size, "backend": backend if world > 1 else None,
+                                             "collectives": ["all_gather", "all_reduce", "all_gather"], "bytes_each": nbytes}) + "\n").encode())
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    except BaseException as exc:  # noqa: BLE001 -- named, then a status the launcher reports
+        print(f"bench.py --dry-nccl: rank {rank}: {step}: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+        return 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="fb15k237-transe", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="the top-level workload (default: headline_workload(--gpus): fb15k237-transe on one GPU, wikidata5m-transe -- "
+                         "candidate axis -- on several)")
+    ap.add_argument("--dry-nccl", action="store_true", help="pre-flight of an N > 1 run: bring the process group up, run the three "
+                    "collectives of an evaluation on 1 KB each, print one JSON line and exit (a failing rank is named, status 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--no-sub-results", action="store_true")
@@ -1252,6 +1349,9 @@ def main():
     ap.add_argument("--plan", action="store_true", help="print what a run on --gpus N ranks would do (axes, shards, the bytes of "
                     "every collective, steps of the long workloads) as JSON and exit; needs no GPU")
     args = ap.parse_args()
+    default_line = args.workload is None
+    if default_line:
+        args.workload = headline_workload(args.gpus)
 
     if args.plan:
         print(json.dumps(run_plan(args.gpus, args.shard_axis), indent=1))
@@ -1270,6 +1370,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if args.dry_nccl and not torch.cuda.is_available() and os.environ.get("BLP_BENCH_BACKEND") == "gloo":
+        # (the pre-flight's own plumbing can be exercised without a GPU: gloo, host tensors -- tests/test_bench_host.py)
+        raise SystemExit(dry_run_collectives(torch.device("cpu"), world, rank, "gloo", result_fd))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the measured path)")
     # BLP_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks
@@ -1282,6 +1385,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     ranks_seen = 1
+    if args.dry_nccl:
+        raise SystemExit(dry_run_collectives(device, world, rank, backend, result_fd))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "gloo":
@@ -1320,6 +1425,10 @@ def main():
                        "shard_axis": job.axis, "ranks_in_process_group": ranks_seen, "backend": backend if world > 1 else None},
         }
         result.update(fields)
+        if world > 1:  # against the committed one-GPU run of the SAME workload (the driver computes its own efficiency from its N = 1 line)
+            ref = n1_reference(args.workload)
+            result["vs_1gpu"] = result["value"] / ref["value"] if ref else None
+            result["one_gpu_reference"] = ref
         result["parity_check"] = parity_spot_check(job, triples, counts)
         if world == 1:
             result["prepass"] = job.prepass_stats()
@@ -1330,13 +1439,13 @@ def main():
             result["torch_gpu_baseline"] = torch_gpu_baseline(job)
     del triples, counts, job
     torch.cuda.empty_cache()
-    default_line = args.workload == "fb15k237-transe"
     if not args.no_sub_results and default_line:
         # The same names for every N (SCALE's N = 1 line against BENCH, field by field).  N > 1: every rank takes part in
         # every sub-result -- each step has its exchanges (replicated query vectors, one all-gather of counts).
         subs = {}
         todo = [(name, "auto", name) for name in SUB_RESULTS]
-        if world > 1:
+        if world > 1:  # (the one-GPU headline becomes a sub-result: on the axis a sharded evaluation of its shape takes, and on the candidate axis)
+            todo = [("fb15k237-transe", "auto", "fb15k237-transe")] + todo
             todo += [(name, axis, f"{name}@{axis}") for name, axis in SUB_RESULTS_EXTRA_SHARDED]
         for name, axis, key in todo:
             f = sub_result(name, axis, device, world, rank, backend, args.steps, events)
