@@ -25,19 +25,23 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_selftest", "
            "blp_rank_all_shard", "blp_gather_triple_vectors", "blp_rank_all_batches", "blp_rank_all_batches_workspace_bytes",
            "blp_rank_all_batches_passes_per_launch", "blp_rank_all_batches_t", "blp_rank_all_batches_t_workspace_bytes",
            "blp_rank_all_batches_t_passes_per_launch", "blp_rank_all_batches_t_native", "blp_gather_triple_vectors_t", "blp_profile_next_rank_kernel", "blp_rank_all_prepass_stats", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
-           "blp_score_bwd", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_inbatch_loss_fwd_t",
+           "blp_score_bwd", "blp_inbatch_loss_save_floats", "blp_inbatch_loss_fwd_launches", "blp_inbatch_loss_fwd_t",
            "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows", "blp_dkrl_rows_supported", "blp_dkrl_rows",
            "blp_build_queries")
 HOOK_SYMBOLS = ("blp_debug_set_knob", "blp_debug_gemm_dump", "blp_debug_reset_selftest")  # libblp_hip.hooks.so only
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
          "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
-         "small_kernel", "stream_kernel", "dkrl_split", "mfma_selftest")  # blp_amd/csrc/knobs.h
+         "small_kernel", "stream_kernel", "dkrl_split", "mfma_selftest", "inbatch_probe")  # blp_amd/csrc/knobs.h
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h
-def inbatch_save_pos_floats(B):
-    """BLP_INBATCH_SAVE_POS_FLOATS(B) of include/blp_hip.h: floats the `save_pos` argument of blp_inbatch_loss_fwd needs."""
-    return 2 * B + 6 * 64 + 2
+INBATCH_TICKET_INTS = 4  # BLP_INBATCH_TICKET_INTS of include/blp_hip.h
+
+
+def inbatch_save_floats(model_id, B, K, D):
+    """blp_inbatch_loss_save_floats: floats the `save_pos` argument of blp_inbatch_loss_fwd_t needs (positives' scores, partial
+    loss sums, the index of neg_idx the backward walks)."""
+    return int(lib().blp_inbatch_loss_save_floats(int(model_id), int(B), int(K), int(D)))
 
 
 METRIC_SUMS_DOUBLES = 520  # BLP_METRIC_SUMS_DOUBLES: room the `sums` argument of blp_rank_metric_sums needs
@@ -175,13 +179,12 @@ def _load(path, hooks):
     L.blp_score_bwd.restype = _i
     L.blp_score_bwd.argtypes = [_i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
                                 _vp, _vp, _vp, _vp, _i, _vp]
-    L.blp_inbatch_loss_fwd.restype = _i
-    L.blp_inbatch_loss_fwd.argtypes = [_i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]
-    L.blp_inbatch_loss_bwd.restype = _i
-    L.blp_inbatch_loss_bwd.argtypes = [_i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
-                                       _i, _vp]
+    L.blp_inbatch_loss_save_floats.restype = ctypes.c_size_t
+    L.blp_inbatch_loss_save_floats.argtypes = [_i, _i, _i, _i]
+    L.blp_inbatch_loss_fwd_launches.restype = _i
+    L.blp_inbatch_loss_fwd_launches.argtypes = [_i, _i, _i, _i, _f]
     L.blp_inbatch_loss_fwd_t.restype = _i
-    L.blp_inbatch_loss_fwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]
+    L.blp_inbatch_loss_fwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp]
     L.blp_inbatch_loss_bwd_t.restype = _i
     L.blp_inbatch_loss_bwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                          _i, _vp]

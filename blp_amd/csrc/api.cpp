@@ -88,7 +88,7 @@ std::atomic<long long> g_knobs[blp::KNOB_COUNT];  // zero-initialised: every kno
 const char* const kKnobNames[blp::KNOB_COUNT] = {"rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups",
                                                  "sad_min_queries", "gemm_pass_words", "gemm_tiles_per_chunk",
                                                  "exact_query_chunk", "small_kernel",
-                                                 "stream_kernel", "dkrl_split", "mfma_selftest"};
+                                                 "stream_kernel", "dkrl_split", "mfma_selftest", "inbatch_probe"};
 #endif
 
 }  // namespace
@@ -644,14 +644,15 @@ static int check_dtypes(const char* who, int ent_dtype, int rel_dtype) {
 
 int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void* ent_embs,
                            const void* rel_vecs, const int64_t* neg_idx, int B, int K, int D, float regularizer,
-                           float* out_loss, float* save_pos, float* save_neg, int device, void* stream) {
+                           float* out_loss, float* save_pos, float* save_neg, int32_t* ticket, int device, void* stream) {
     if (int rc = check_inbatch("blp_inbatch_loss_fwd", model, loss, ent_embs, rel_vecs, neg_idx, B, K, D)) return rc;
     if (int rc = check_dtypes("blp_inbatch_loss_fwd", ent_dtype, rel_dtype)) return rc;
-    if (!out_loss || !save_pos || !save_neg) return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_fwd: NULL output");
+    if (!out_loss || !save_pos || !save_neg || !ticket) return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_fwd: NULL output / ticket");
+    if (reinterpret_cast<uintptr_t>(save_pos) & 7) return fail(BLP_ERR_BAD_ARG, "blp_inbatch_loss_fwd: save_pos must be 8-byte aligned");
     DeviceGuard guard(device);
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
     hipError_t err = blp::launch_inbatch_loss_fwd(model, loss, ent_dtype, rel_dtype, ent_embs, rel_vecs, neg_idx, B, K, D,
-                                                  regularizer, out_loss, save_pos, save_neg,
+                                                  regularizer, out_loss, save_pos, save_neg, reinterpret_cast<unsigned*>(ticket),
                                                   static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_inbatch_loss_fwd launch");
     return BLP_OK;
@@ -674,18 +675,14 @@ int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, co
     return BLP_OK;
 }
 
-int blp_inbatch_loss_fwd(int model, int loss, const float* ent_embs, const float* rel_vecs, const int64_t* neg_idx,
-                         int B, int K, int D, float regularizer, float* out_loss, float* save_pos, float* save_neg,
-                         int device, void* stream) {
-    return blp_inbatch_loss_fwd_t(model, loss, BLP_DTYPE_F32, BLP_DTYPE_F32, ent_embs, rel_vecs, neg_idx, B, K, D,
-                                  regularizer, out_loss, save_pos, save_neg, device, stream);
+int blp_inbatch_loss_fwd_launches(int model, int B, int K, int D, float regularizer) {
+    if (!valid_model(model) || B <= 0 || K <= 0 || D <= 0) return 0;
+    return blp::inbatch_loss_fwd_launches(model, B, K, D, regularizer > 0.0f);
 }
 
-int blp_inbatch_loss_bwd(int model, int loss, const float* ent_embs, const float* rel_vecs, const int64_t* neg_idx,
-                         int B, int K, int D, float regularizer, const float* grad_loss, const float* save_pos,
-                         const float* save_neg, float* grad_ent, float* grad_rel, int device, void* stream) {
-    return blp_inbatch_loss_bwd_t(model, loss, BLP_DTYPE_F32, BLP_DTYPE_F32, ent_embs, rel_vecs, neg_idx, B, K, D,
-                                  regularizer, grad_loss, save_pos, save_neg, grad_ent, grad_rel, device, stream);
+size_t blp_inbatch_loss_save_floats(int model, int B, int K, int D) {
+    if (!valid_model(model) || B <= 0 || K <= 0 || D <= 0) return 0;
+    return blp::inbatch_loss_save_floats(model, B, K, D);
 }
 
 }  // extern "C"

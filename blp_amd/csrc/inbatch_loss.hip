@@ -2,19 +2,22 @@
 // (models.py:251-258) and L2 regularisation (models.py:261-266), forward and backward, for
 // in-batch negatives.  The reference materialises ent_embs.view(2B, D)[neg_idx] as a (B, K, 2, D)
 // temporary and runs ~40 small torch kernels per step; here the gather is implicit (rows are read
-// from the 2B x D matrix, which is 64 KB at B = 64 and lives in L2) and a step is THREE launches:
-//   fwd 1  inbatch_scores_kernel   the B (K + 1) pair scores with coalesced row reads: the bilinear models 32 lanes per
+// from the 2B x D matrix, which is 64 KB at B = 64 and lives in L2) and a step is TWO launches (three when the forward has
+// more than 96 scoring workgroups):
+//   fwd    inbatch_forward_kernel  the B (K + 1) pair scores with coalesced row reads: the bilinear models 32 lanes per
 //                                  pair (lane i = running sum i of torch.sum, then its fold by wavefront shuffles), TransE
-//                                  one lane per pair (its L1 sum is one sequential chain) with the wave's 64 pairs' rows
-//                                  fetched cooperatively through LDS -- scores bit-identical to the reference at the
-//                                  scripts' widths; extra workgroups leave the rows' shares of the L2 regulariser;
-//   fwd 2  inbatch_reduce_kernel   one block: the loss from the B + B K saved scores (f64 accumulation, fixed order);
-//   bwd    inbatch_grad_kernel     entity rows and relation rows in one grid.  A workgroup owns R consecutive rows of
-//                                  ent_embs.view(2B, D) and finds the negative pairs that reference them with ONE
-//                                  stable compaction of neg_idx into LDS (entry order), so the work is
-//                                  O(B K) per step -- not the O(B^2 K) of one full scan per row -- and every row's
-//                                  contributions are added in entry order: no float atomics, gradients are
-//                                  bit-reproducible run to run.
+//                                  four lanes per pair (its L1 sum is one sequential chain walking through them) --
+//                                  scores bit-identical to the reference at the scripts' widths; every workgroup also
+//                                  forms its slots' loss terms (it re-scores the positives of its one or two rows) and
+//                                  leaves their f64 sum; the last workgroup (a ticket) adds the sums in workgroup order --
+//                                  or, with many workgroups, a second launch (inbatch_reduce_kernel) forms the loss from the scores; extra workgroups leave the
+//                                  rows' shares of the L2 regulariser, and others an INDEX of neg_idx (per chunk: the
+//                                  entries grouped by the row they name, stably) for the backward;
+//   bwd    inbatch_grad_kernel     entity rows and relation rows in one grid.  A wave (or S waves) owns a row of
+//                                  ent_embs.view(2B, D) and walks the negative pairs that reference it straight from the
+//                                  forward's index, in entry order: O(B K) work per step whatever the grid (round 5: every
+//                                  workgroup scanned all of neg_idx for its rows -- 92 us at B = 1 024, now 43), no float
+//                                  atomics, gradients bit-reproducible run to run.
 // Storage types: ent_embs / grad_ent in TE, rel_vecs / grad_rel in TR, each f32, f16 or bf16 (TR = TE or
 // f32: under autocast the encoder output is half while nn.Embedding rows stay f32).  Half operands are
 // widened exactly and every operation is the f32 one of the reference; gradients are rounded once on store.
@@ -26,6 +29,7 @@
 
 #include <type_traits>
 
+#include "knobs.h"
 #include "launch.h"
 #include "score_core.h"
 
@@ -46,11 +50,49 @@ __device__ __forceinline__ void wave_lds_fence() {  // LDS accesses of one wave 
 
 __device__ __forceinline__ float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
-constexpr int kReduceBlocks = 64, kReduceSlice = 8192;
-// save_pos layout in floats: [0, B) positive scores | [B, 2B) regulariser shares | 6 kReduceBlocks: three f64 partial sums
-// per block | 1: the ticket counter (zeroed by the scores kernel) -- include/blp_hip.h: BLP_INBATCH_SAVE_POS_FLOATS
-__host__ __device__ inline int save_pos_partials_at(int B) { return 2 * B + (2 * B) % 2; }
-__host__ __device__ inline int save_pos_ticket_at(int B) { return save_pos_partials_at(B) + 6 * kReduceBlocks; }
+// ---------------------------------------------------------------- what the forward leaves for the backward
+// save_pos, in 4-byte units (include/blp_hip.h: blp_inbatch_loss_save_floats):
+//   [0, B)                          the positives' scores
+//   partials  2 doubles per pair / regulariser workgroup of the forward: its slots' loss terms (f64, slot order)
+//   off       n_chunks x (2B + 1) int32: chunk c's exclusive offsets of row j's entries in ITS part of `sorted`
+//   sorted    2BK int32: the entries e of neg_idx.view(-1) (pair e >> 1, slot e & 1), chunk by chunk of `chunk` consecutive
+//             entries, inside a chunk grouped by the row they name (neg_idx[e]) and in entry order within a row
+// The index is what makes the backward O(BK): the negatives that reference row j are off[c][j] .. off[c][j + 1] of every
+// chunk c, and walking the chunks in order visits them in ENTRY order -- a fixed summation order, so gradients are
+// bit-reproducible without float atomics (round 5 had every one of ~128 workgroups scan all of neg_idx for its rows).
+struct SaveLayout {
+    int64_t partials_at, regsh_at, red_at, off_at, sorted_at, total;  // in floats
+    int pair_blocks, reg_blocks, chunk, n_chunks;
+    bool fused;  // the scoring workgroups are few enough for the last one to add their partial sums itself (one launch)
+};
+// Up to this many scoring workgroups finish the loss themselves (a ticket each: same-address device-scope atomics and the
+// uncached round trips behind them, ~3 us in all -- what a second launch costs); more take the second launch, which
+// then costs less than the tickets would ([measured] 1 072 workgroups: 14 us of tickets against a 3 us kernel).
+constexpr int kFusedForwardWgs = 96;
+constexpr int kReduceBlocks = 64, kReduceSlice = 8192;  // inbatch_reduce_kernel: workgroups at most, scores per workgroup
+constexpr int kIdxBins = 1024;      // rows an index workgroup sorts per pass (its LDS histograms); more rows: more passes
+constexpr int kIdxChunk = 1024;     // entries per chunk: 4 waves x 4 slices of 64 (the slices' values live in registers -- the index
+                                    // workgroups share the forward kernel, hence its register budget, with the scoring ones)
+constexpr int kIdxMaxSlices = kIdxChunk / 256;
+__host__ __device__ inline int lanes_per_pair(int model, int D);
+__host__ __device__ inline SaveLayout save_layout(int model, int B, int K, int D, bool regularised) {
+    SaveLayout L;
+    const int per_block = 256 / lanes_per_pair(model, D);
+    L.pair_blocks = (int)(((int64_t)B * (K + 1) + per_block - 1) / per_block);
+    L.reg_blocks = regularised ? (B + 3) / 4 : 0;
+    const int64_t entries = 2ll * B * K;
+    L.chunk = kIdxChunk;
+    L.n_chunks = (int)((entries + L.chunk - 1) / L.chunk);
+    L.fused = L.pair_blocks + L.reg_blocks <= kFusedForwardWgs;
+    L.partials_at = (B + 1) / 2 * 2;  // (doubles: 8-byte aligned)
+    // (sized for a regularised call either way: the size must not depend on a float argument)
+    L.regsh_at = L.partials_at + 4ll * (L.pair_blocks + (B + 3) / 4);  // (many workgroups) the rows' shares of the regulariser
+    L.red_at = (L.regsh_at + B + 1) / 2 * 2;                           // (many workgroups) inbatch_reduce_kernel's partial sums
+    L.off_at = L.red_at + 6 * kReduceBlocks;
+    L.sorted_at = L.off_at + (int64_t)L.n_chunks * (2 * B + 1);
+    L.total = L.sorted_at + entries;
+    return L;
+}
 
 // ---------------------------------------------------------------- forward: scores
 // Three ways to a pair's score, all with the reference's per-element arithmetic (models.py:222-248: each product / sum
@@ -170,77 +212,327 @@ __host__ __device__ inline int lanes_per_pair(int model, int D) {
     return torch_sum_in_registers(model, D) ? 32 : kTreeLanes;
 }
 
-// save_pos: (2 B) floats -- pos[b], then (regularizer > 0) the sum of squares of the head, tail and relation row of pair b.
-// Workgroups [0, pair_blocks): the scores; workgroups after them (regularizer > 0 only): one wave per positive triple,
-// its three rows' squares (models.py:261-266).
+__device__ __forceinline__ float softplus_torch(float x) {  // F.softplus, beta = 1, threshold = 20
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+
+// A value one workgroup hands to another through memory: device-scope atomic store / load (past the caches of this XCD's L2
+// to where the other XCDs see it), the store waited for before the ticket that announces it.
+__device__ __forceinline__ void publish(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double observe(const double* p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned take_ticket(unsigned* counter) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's published stores have completed (s_waitcnt), no cache flush
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return t;
+}
+
+__device__ __forceinline__ void write_loss(int loss, const double (&t)[3], int B, int K, int D, float regularizer, float* out) {
+    const double BK = (double)B * K;  // t: negatives' terms | positives' softplus terms | squares
+    const double model_loss = loss == LOSS_MARGIN ? t[0] / BK : (t[1] / B + t[0] / BK) / 2.0;
+    const double reg = regularizer > 0.0f ? (double)regularizer * t[2] / ((double)B * D) / 3.0 : 0.0;
+    out[0] = (float)(model_loss + reg);
+}
+
+// by ONE wave: the workgroups' partial sums (published with device-scope stores) added in a fixed order
+__device__ __forceinline__ void finish_loss(int loss, const double* partials, int pair_blocks, int n_blocks, int B, int K, int D,
+                                            float regularizer, float* out, int lane, int stride) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int i = lane; i < n_blocks; i += stride) {
+        const double a = observe(&partials[2 * i]), p = observe(&partials[2 * i + 1]);
+        if (i < pair_blocks) {
+            acc[0] += a;
+            acc[1] += p;
+        } else {
+            acc[2] += a;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off);
+    if (lane == 0) write_loss(loss, acc, B, K, D, regularizer, out);
+}
+
+// One pair's score by its lane group (every lane of the wave takes part: the routines shuffle); result in the group's lane 0.
 template <int MODEL, class TE, class TR>
-__global__ __launch_bounds__(256) void inbatch_scores_kernel(const TE* __restrict__ ent, const TR* __restrict__ rel,
-                                                            const int64_t* __restrict__ neg_idx, int B, int K, int D,
-                                                            float* __restrict__ pos, float* __restrict__ neg,
-                                                            unsigned pair_blocks) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0)  // the reduce kernel's ticket counter (behind the scores in save_pos)
-        *reinterpret_cast<unsigned*>(pos + save_pos_ticket_at(B)) = 0u;
-    if (blockIdx.x >= pair_blocks) {  // the regulariser's shares
-        const int b = (int)(blockIdx.x - pair_blocks) * 4 + wave;
-        if (b >= B) return;
-        const TE* h = ent + (size_t)(2 * b) * D;
-        const TR* r = rel + (size_t)b * D;
-        float sq = 0.0f;
-        for (int d = lane; d < 2 * D; d += 64) sq = sq + widen(h[d]) * widen(h[d]);  // head and tail rows are adjacent
-        for (int d = lane; d < D; d += 64) sq = sq + widen(r[d]) * widen(r[d]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sq = sq + __shfl_xor(sq, off);
-        if (lane == 0) pos[B + b] = sq;
-        return;
-    }
-    const int64_t n_pairs = (int64_t)B * (K + 1);
-    const int per_pair = lanes_per_pair(MODEL, D), sub = threadIdx.x & (per_pair - 1);
-    const int64_t slot = (int64_t)blockIdx.x * (256 / per_pair) + threadIdx.x / per_pair;  // over B * (K + 1); k == K: positive
-    const bool live = slot < n_pairs;
-    const int64_t pair = live ? slot : n_pairs - 1;  // (idle lanes redo the last pair: every lane has readable rows)
-    const int b = (int)(pair / (K + 1)), k = (int)(pair % (K + 1));
-    const TR* r = rel + (size_t)b * D;
-    const TE* h;
-    const TE* t;
-    if (k == K) {  // positive pair: models.py:56-57
-        h = ent + (size_t)(2 * b) * D;
-        t = h + D;
-    } else {       // negative pair: models.py:65-67
-        const int64_t* idx = neg_idx + ((size_t)b * K + k) * 2;
-        h = ent + idx[0] * D;
-        t = ent + idx[1] * D;
-    }
-    float s;
+__device__ __forceinline__ float pair_score(const TE* __restrict__ h, const TE* __restrict__ t, const TR* __restrict__ r, int D,
+                                            int per_pair, int sub, int lane) {
     if constexpr (MODEL == TRANSE) {
-        s = per_pair == 4 ? transe_quad(h, t, r, D, lane) : transe_lane(h, t, r, D);
-    } else if (per_pair == 32) {  // torch.sum's order: lane i = running sum i, then its fold
+        return per_pair == 4 ? transe_quad(h, t, r, D, lane) : transe_lane(h, t, r, D);
+    } else {
         const int H = MODEL == DISTMULT ? D : D / 2;
-        float a = 0.0f + bilinear_term<MODEL>(h, t, r, sub, H);
-        for (int c = 1; c < H / 32; ++c) a = a + bilinear_term<MODEL>(h, t, r, 32 * c + sub, H);
-        float v = a + __shfl_down(a, 8, 32);
-        v = v + __shfl_down(a, 16, 32);
-        v = v + __shfl_down(a, 24, 32);
-        s = 0.0f;
+        if (per_pair == 32) {  // torch.sum's order: lane i = running sum i, then its fold
+            float a = 0.0f + bilinear_term<MODEL>(h, t, r, sub, H);
+            for (int c = 1; c < H / 32; ++c) a = a + bilinear_term<MODEL>(h, t, r, 32 * c + sub, H);
+            float v = a + __shfl_down(a, 8, 32);
+            v = v + __shfl_down(a, 16, 32);
+            v = v + __shfl_down(a, 24, 32);
+            float s = 0.0f;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) s = s + __shfl(v, l, 32);
-        if constexpr (MODEL == SIMPLE) s = s / 2.0f;
-    } else {                      // any other width: a shuffle tree over 16 lanes
-        const int H = MODEL == DISTMULT ? D : D / 2;
-        float a = 0.0f;
+            for (int l = 0; l < 8; ++l) s = s + __shfl(v, l, 32);
+            return MODEL == SIMPLE ? s / 2.0f : s;
+        }
+        float a = 0.0f;        // any other width: a shuffle tree over 16 lanes
         for (int j = sub; j < H; j += kTreeLanes) a = a + bilinear_term<MODEL>(h, t, r, j, H);
 #pragma unroll
         for (int off = kTreeLanes / 2; off > 0; off >>= 1) a = a + __shfl_xor(a, off);
-        s = MODEL == SIMPLE ? a / 2.0f : a;
-    }
-    if (live && sub == 0) {
-        if (k == K) pos[b] = s;
-        else neg[(size_t)b * K + k] = s;
+        return MODEL == SIMPLE ? a / 2.0f : a;
     }
 }
 
-__device__ __forceinline__ float softplus_torch(float x) {  // F.softplus, beta = 1, threshold = 20
-    return x > 20.0f ? x : log1pf(expf(x));
+// ---- the index of neg_idx (see SaveLayout): one workgroup sorts one chunk of `chunk` consecutive entries by the row they
+// name, STABLY (entry order within a row).  Wave w owns the w-th quarter of the chunk and walks it 64 entries at a time, in
+// order, against its own LDS histogram: an entry's rank among the wave's earlier entries of the same row is the histogram's
+// value, plus -- when several lanes of one slice name the same row, which the lanes detect with two tagged LDS writes --
+// its rank among those lanes (ballots).  The waves' histograms are then prefixed across waves and across rows (one block
+// scan) and every entry is written to its place.  Rows beyond kIdxBins: further passes over the same chunk.
+__device__ __forceinline__ void index_chunk(const int64_t* __restrict__ neg_idx, int64_t entries, int n_rows, int chunk, int c,
+                                            int* __restrict__ off, int* __restrict__ sorted) {
+    __shared__ unsigned short hist[4][kIdxBins];
+    __shared__ unsigned char tag[4][kIdxBins];
+    __shared__ int start[kIdxBins];
+    __shared__ int wave_tot[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int per_wave = chunk / 4, n_slices = per_wave / 64;  // (chunk == kIdxChunk: n_slices == kIdxMaxSlices)
+    const int64_t e0 = (int64_t)c * chunk + (int64_t)wave * per_wave;
+    const int64_t e_end = ((int64_t)c + 1) * chunk < entries ? ((int64_t)c + 1) * chunk : entries;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int* off_c = off + (size_t)c * (n_rows + 1);
+    int* sorted_c = sorted + (size_t)c * chunk;
+    int placed = 0;  // entries of the rows of earlier passes (block-uniform)
+    int raw[kIdxMaxSlices];  // the wave's entries: every slice's load in flight before the first LDS round trip
+#pragma unroll
+    for (int i = 0; i < kIdxMaxSlices; ++i) {
+        const int64_t e = e0 + 64 * i + lane;
+        raw[i] = (i < n_slices && e < e_end) ? (int)neg_idx[e] : -1;
+    }
+    for (int w0 = 0; w0 < n_rows; w0 += kIdxBins) {
+        for (int i = tid; i < 4 * kIdxBins; i += 256) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        int val[kIdxMaxSlices], rank[kIdxMaxSlices];
+#pragma unroll
+        for (int i = 0; i < kIdxMaxSlices; ++i) {
+            val[i] = -1;
+            rank[i] = 0;
+            if (i < n_slices) {  // (block-uniform)
+                const int v = raw[i];
+                const bool in = v >= w0 && v < w0 + kIdxBins;
+                const int lv = in ? v - w0 : 0;
+                // which lanes share their row with another lane of this slice
+                if (in) tag[wave][lv] = (unsigned char)lane;
+                wave_lds_fence();
+                const bool lost = in && tag[wave][lv] != (unsigned char)lane;
+                wave_lds_fence();
+                if (lost) tag[wave][lv] = (unsigned char)(0x80 | lane);
+                wave_lds_fence();
+                const bool dup = in && (tag[wave][lv] & 0x80);
+                wave_lds_fence();
+                int among = 0, cnt = 1;
+                unsigned long long dm = __ballot(dup);
+                while (dm) {  // (rare: one trip per row named twice in 64 consecutive entries)
+                    const int v0 = __builtin_amdgcn_readlane(lv, __builtin_ctzll(dm));
+                    const unsigned long long m = __ballot(dup && lv == v0);
+                    if (dup && lv == v0) {
+                        among = __popcll(m & below);
+                        cnt = __popcll(m);
+                    }
+                    dm &= ~m;
+                }
+                const int base = in ? hist[wave][lv] : 0;
+                wave_lds_fence();
+                if (in && among == cnt - 1) hist[wave][lv] = (unsigned short)(base + cnt);
+                wave_lds_fence();
+                val[i] = in ? lv : -1;
+                rank[i] = base + among;
+            }
+        }
+        __syncthreads();
+        // the waves' counts of a row -> exclusive prefix across the waves (in place); the rows' totals -> exclusive scan
+        constexpr int kPer = kIdxBins / 256;
+        int tot[kPer], mine = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int bin = tid * kPer + i;
+            int run = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int h = hist[w][bin];
+                hist[w][bin] = (unsigned short)run;
+                run += h;
+            }
+            tot[i] = run;
+            mine += run;
+        }
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = placed, pass_total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before += wave_tot[w];
+            pass_total += wave_tot[w];
+        }
+        int at = before + incl - mine;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int bin = tid * kPer + i;
+            start[bin] = at;
+            if (w0 + bin < n_rows) off_c[w0 + bin] = at;
+            at += tot[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kIdxMaxSlices; ++i)
+            if (i < n_slices && val[i] >= 0)
+                sorted_c[start[val[i]] + hist[wave][val[i]] + rank[i]] = (int)(e0 + 64 * i + lane);
+        placed += pass_total;
+        __syncthreads();
+    }
+    if (tid == 0) off_c[n_rows] = placed;
+}
+
+// The forward in ONE launch.  Workgroups [0, n_chunks): the index of neg_idx for the backward (the longest: dispatched
+// first).  Then pair_blocks workgroups: the scores -- every workgroup first scores the positive pairs of the rows its slots
+// belong to (one or two rows at the scripts' sizes; the reference's bits, recomputed rather than waited for), so that it
+// can form ITS slots' loss terms (models.py:251-258) right away and leave their f64 sum, slot order, in `partials`.  Then
+// (regularizer > 0) one workgroup per four positive triples: the squares of their rows (models.py:261-266).  The workgroup
+// that takes the LAST ticket adds the partials in workgroup order and writes the loss: a fixed summation order whoever comes
+// last, no float atomics, no second launch.  `ticket`: one counter, zero when the kernel starts, left zero.
+template <int MODEL, class TE, class TR>
+__global__ __launch_bounds__(256) void inbatch_forward_kernel(int loss, const TE* __restrict__ ent, const TR* __restrict__ rel,
+                                                             const int64_t* __restrict__ neg_idx, int B, int K, int D,
+                                                             float regularizer, float* __restrict__ pos, float* __restrict__ neg,
+                                                             float* __restrict__ out, unsigned* __restrict__ ticket, SaveLayout L,
+                                                             int probe) {
+    __shared__ float pos_sh[256];
+    __shared__ float term_neg[256], term_pos[256];
+    __shared__ unsigned ticket_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* partials = reinterpret_cast<double*>(pos + L.partials_at);
+    if ((int)blockIdx.x < L.n_chunks) {
+        index_chunk(neg_idx, 2ll * B * K, 2 * B, L.chunk, (int)blockIdx.x, reinterpret_cast<int*>(pos + L.off_at),
+                    reinterpret_cast<int*>(pos + L.sorted_at));
+        return;
+    }
+    const int blk = (int)blockIdx.x - L.n_chunks, n_blocks = L.pair_blocks + L.reg_blocks;
+    double part0 = 0.0, part1 = 0.0;
+    if (blk >= L.pair_blocks) {  // the regulariser: four positive triples, a wave each
+        const int b = (blk - L.pair_blocks) * 4 + wave;
+        float sq = 0.0f;
+        if (b < B) {
+            const TE* h = ent + (size_t)(2 * b) * D;
+            const TR* r = rel + (size_t)b * D;
+            for (int d = lane; d < 2 * D; d += 64) sq = sq + widen(h[d]) * widen(h[d]);  // head and tail rows are adjacent
+            for (int d = lane; d < D; d += 64) sq = sq + widen(r[d]) * widen(r[d]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq = sq + __shfl_xor(sq, off);
+        }
+        if (!L.fused) {  // many workgroups: inbatch_reduce_kernel adds the rows' shares
+            if (lane == 0 && b < B) pos[L.regsh_at + b] = sq;
+            return;
+        }
+        if (lane == 0) term_neg[wave] = sq;
+        __syncthreads();
+        if (tid == 0)
+            for (int i = 0; i < 4; ++i) part0 += (double)term_neg[i];
+    } else {
+        const int64_t n_pairs = (int64_t)B * (K + 1);
+        const int per_pair = lanes_per_pair(MODEL, D), sub = tid & (per_pair - 1), groups = 256 / per_pair, gid = tid / per_pair;
+        const int64_t slot0 = (int64_t)blk * groups, slot = slot0 + gid;  // over B * (K + 1); k == K: positive
+        const int64_t slot_last = slot0 + groups < n_pairs ? slot0 + groups - 1 : n_pairs - 1;
+        const int b_first = (int)(slot0 / (K + 1)), b_last = (int)(slot_last / (K + 1));
+        const bool live = slot < n_pairs;
+        const int64_t pair = live ? slot : n_pairs - 1;  // (idle lanes redo the last pair: every lane has readable rows)
+        const int b = (int)(pair / (K + 1)), k = (int)(pair % (K + 1));
+        const TE* h;
+        const TE* t;
+        if (k == K) {  // positive pair: models.py:56-57
+            h = ent + (size_t)(2 * b) * D;
+            t = h + D;
+        } else {       // negative pair: models.py:65-67
+            const int64_t* idx = neg_idx + ((size_t)b * K + k) * 2;
+            h = ent + idx[0] * D;
+            t = ent + idx[1] * D;
+        }
+        // group gid also scores the positive of row b_first + gid (at most `groups` rows: a row holds at least one slot; idle
+        // groups redo the last row: the routines shuffle) -- independent of its slot's pair, so the two sets of row loads
+        // are in flight together
+        const int bp = b_first + gid <= b_last ? b_first + gid : b_last;
+        const TE* hp = ent + (size_t)(2 * bp) * D;
+        // (the positive first: its rows' loads do not wait for neg_idx, so they are in flight while the slot's indices arrive)
+        const float sp = (probe & 4) || !L.fused ? 0.0f : pair_score<MODEL>(hp, hp + D, rel + (size_t)bp * D, D, per_pair, sub, lane);
+        const float s = pair_score<MODEL>(h, t, rel + (size_t)b * D, D, per_pair, sub, lane);
+        if (!L.fused) {  // many workgroups: the scores only; inbatch_reduce_kernel forms the loss from them
+            if (live && sub == 0) {
+                if (k == K) pos[b] = s;
+                else neg[(size_t)b * K + k] = s;
+            }
+            return;
+        }
+        if (sub == 0) pos_sh[gid] = sp;
+        __syncthreads();
+        if (sub == 0) {
+            float tn = 0.0f, tp = 0.0f;
+            if (live) {
+                if (k == K) {
+                    pos[b] = s;
+                    if (loss == LOSS_NLL) tp = softplus_torch(-s);
+                } else {
+                    neg[(size_t)b * K + k] = s;
+                    if (loss == LOSS_MARGIN) {  // models.py:251-254
+                        float l = 1.0f - pos_sh[b - b_first];
+                        l = l + s;
+                        tn = l < 0.0f ? 0.0f : l;
+                    } else {                    // models.py:257-258
+                        tn = softplus_torch(s);
+                    }
+                }
+            }
+            term_neg[gid] = tn;
+            term_pos[gid] = tp;
+        }
+        __syncthreads();
+        if (wave == 0) {  // the block's terms, slot order within a lane, then a fixed shuffle tree
+            double a = 0.0, p = 0.0;
+            for (int i = lane; i < groups; i += 64) {
+                a += (double)term_neg[i];
+                p += (double)term_pos[i];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                a += __shfl_down(a, off);
+                p += __shfl_down(p, off);
+            }
+            part0 = a;
+            part1 = p;
+        }
+    }
+    // Few workgroups: the one that takes the last ticket adds everybody's partials in block order and writes the loss.  What
+    // crosses workgroups (partials, the counter) is written and read with device-scope atomics that go to memory; nothing
+    // else needs to be visible, so no cache-wide release / acquire (an L2 write-back + invalidate per workgroup) is paid:
+    // take_ticket() waits for this thread's published stores first.
+    if (probe & 2) return;
+    if (tid == 0) {
+        publish(&partials[2 * blk], part0);
+        publish(&partials[2 * blk + 1], part1);
+        ticket_sh = take_ticket(ticket);
+    }
+    __syncthreads();
+    if (ticket_sh != (unsigned)(n_blocks - 1) || wave != 0) return;  // not the last workgroup to finish
+    finish_loss(loss, partials, L.pair_blocks, n_blocks, B, K, D, regularizer, out, lane, 64);
+    if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // as found
 }
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -255,12 +547,14 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return total;
 }
 
-// The loss from the saved scores.  Up to kReduceBlocks workgroups each add a slice of the B K negatives (block 0 also the
+// The second launch of a forward with many scoring workgroups (more than kFusedForwardWgs): the loss from the saved scores.
+// Up to kReduceBlocks workgroups each add a slice of the B K negatives (block 0 also the
 // B positives' and the regulariser's terms) in f64 and leave three partial sums behind the scores in save_pos; the
 // workgroup that takes the last ticket adds the partials in block order -- one launch, a fixed summation order, no float
 // atomics.  (One block for 65 536 negatives -- B = 1 024 -- was a 17 us latency-bound loop.)
 
-__global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, float* __restrict__ pos,
+__global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, const float* __restrict__ pos, const float* __restrict__ regsh,
+                                                             double* __restrict__ partials, unsigned* __restrict__ ticket,
                                                              const float* __restrict__ neg, int B, int K, int D,
                                                              float regularizer, float* __restrict__ out) {
     __shared__ double sh[16];
@@ -305,15 +599,14 @@ __global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, float* _
     }
     if (regularizer > 0.0f && g == 0) {  // models.py:59-60, 261-266: the rows' squares, summed per positive by the scores kernel
         double s = 0.0;
-        for (int i = tid; i < B; i += nt) s += (double)pos[B + i];
+        for (int i = tid; i < B; i += nt) s += (double)regsh[i];
         part[2] = block_sum(s, sh);
     }
-    double* partials = reinterpret_cast<double*>(pos + save_pos_partials_at(B));
     if (G > 1) {
         if (tid == 0) {
             for (int j = 0; j < 3; ++j) partials[3 * g + j] = part[j];
             __threadfence();
-            ticket_sh = atomicAdd(reinterpret_cast<unsigned*>(pos + save_pos_ticket_at(B)), 1u);
+            ticket_sh = atomicAdd(ticket, 1u);
         }
         __syncthreads();
         if (ticket_sh != (unsigned)(G - 1)) return;  // not the last workgroup to finish
@@ -328,8 +621,10 @@ __global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, float* _
         const double model_loss = loss == LOSS_MARGIN ? part[0] / (double)BK : (part[1] / B + part[0] / (double)BK) / 2.0;
         const double reg = regularizer > 0.0f ? (double)regularizer * part[2] / ((double)B * D) / 3.0 : 0.0;
         out[0] = (float)(model_loss + reg);
+        if (G > 1) *ticket = 0u;  // as found
     }
 }
+
 
 // ---------------------------------------------------------------- backward
 // d loss / d neg[b, k] and d loss / d pos[b], recomputed from the saved scores.
@@ -391,11 +686,6 @@ __device__ __forceinline__ float dscore(int operand, const TE* __restrict__ h, c
     }
 }
 
-constexpr int kHitCap = 4096;                 // hits a workgroup holds in LDS per round (more: further rounds)
-constexpr int kScanSlices = 8;                // 64-entry slices of neg_idx per wave and scan step (all in flight together)
-constexpr int kMaxRowsPerBlock = 16;          // R: entity rows a workgroup owns
-constexpr int kMaxTasks = 16;                 // (row, share) tasks of a workgroup
-
 // Two shapes of the backward kernel: rows of up to 128 elements (the scripts' dim) keep 2 elements per lane, which leaves
 // room for 16 waves per workgroup (4 per SIMD hide the dependent loads of the walk); wider rows (up to 512 elements per
 // sweep, more: the scan repeats) take 4 waves.
@@ -403,19 +693,9 @@ template <int SWEEP> struct GradShape;
 template <> struct GradShape<2> { static constexpr int kWaves = 16; };
 template <> struct GradShape<8> { static constexpr int kWaves = 4; };
 // pairs whose row loads are in flight together: every pair in flight holds five wave-uniform values and three row
-// addresses in scalar registers -- eight pairs of a model that reads both halves of its rows spill them
-__host__ __device__ constexpr int grad_batch(int model, int sweep) { return sweep == 2 && (model == TRANSE || model == DISTMULT) ? 8 : 4; }
-
-// Rows per workgroup of the entity part: about 128 workgroups on big batches (every workgroup scans all of neg_idx: the
-// fewer there are, the less is read twice), never more hits expected than a quarter of what the LDS list holds (2 K per
-// row on average).
-static int grad_rows_per_block(int B, int K) {
-    int R = (2 * B + 127) / 128;
-    const int cap = kHitCap / (4 * (K > 0 ? K : 1));  // K hits per row on average
-    if (R > cap) R = cap;
-    if (R > kMaxRowsPerBlock) R = kMaxRowsPerBlock;
-    return R < 1 ? 1 : R;
-}
+// addresses in scalar registers -- eight pairs of a model that reads both halves of its rows spill them (and eight of
+// DistMult's in f32 make the compiler reserve a -- never touched -- stack slot for the spilled scalars: six)
+__host__ __device__ constexpr int grad_batch(int model, int sweep) { return sweep == 2 ? (model == TRANSE ? 8 : (model == DISTMULT ? 6 : 4)) : 4; }
 
 // Element i of a lane's share of a sweep.  SWEEP == 2 (rows of up to 128 elements, D % 4 == 0): the lane owns the two
 // CONSECUTIVE elements 2 lane, 2 lane + 1, so that every operand of a contribution is one 2-element load per half of the row
@@ -541,32 +821,28 @@ __device__ __forceinline__ void consume(float (&g)[SWEEP], unsigned long long ma
     }
 }
 
-// One grid: workgroups [0, ent_blocks) own R rows of ent_embs.view(2B, D) each; workgroups after them own kWaves /
-// rel_shares relation rows, each row's K negatives split over rel_shares waves.
+// One grid: workgroups [0, ent_blocks) own R = kWaves / S rows of ent_embs.view(2B, D) each, S waves ("shares") per row;
+// workgroups after them own kWaves / rel_shares relation rows, each row's K negatives split over rel_shares waves.
 //
-// Entity rows.  The negative pairs that reference row j are the entries e of neg_idx.view(-1) with neg_idx[e] == j
-// (pair e >> 1, slot e & 1).  The workgroup compacts the entries whose value lies in its row range into `hits` IN ENTRY
-// ORDER: wave w owns the w-th contiguous part of neg_idx, counts its hits, and -- after ONE exchange of the waves' totals
-// through LDS -- lists them behind those of the waves before it (ballots and popcounts inside a wave; no barrier inside
-// either loop, eight coalesced loads in flight).  Then every (row, share) task -- a wave takes tasks w, w + kWaves, ...; a row is cut into `shares` tasks by
-// pair index when the workgroup owns fewer rows than it has waves -- walks the list: 64 entries at a time the lanes fetch
-// their pair's rows and loss gradient, the wave then adds gn(pair) * d score / d row for the entries of its task in list
-// order, kBatch pairs' row loads in flight together.  A task's partial sum is parked in LDS; at the end a row's shares are
-// added in share order.  More than kHitCap hits in the range (every negative pointing at a few rows): the scan repeats
-// for the next kHitCap, the parked sums carry over.  Fixed orders everywhere: the gradients are bit-reproducible.
+// Entity rows.  The negative pairs that reference row j are the entries e of neg_idx.view(-1) with neg_idx[e] == j (pair
+// e >> 1, slot e & 1); the forward left them indexed (SaveLayout): chunk c of neg_idx holds off[c][j + 1] - off[c][j] of
+// them, in entry order, at sorted[c * chunk + off[c][j]].  A wave reads its row's two offsets of up to 64 chunks with one
+// load per lane, prefixes the counts (the row's list = the chunks' runs, concatenated: entry order), takes share s of S of
+// it by position, and walks it 64 entries at a time: a lane finds the chunk its entry lies in by a binary search over the
+// prefix (LDS), fetches the entry, its pair's rows and loss gradient; the wave then adds gn(pair) * d score / d row in list
+// order, kBatch pairs' row loads in flight together.  A row's shares are added in share order.  Work per row: its own
+// entries only -- O(BK) for the batch, whatever the number of workgroups.  Fixed orders everywhere: the gradients are
+// bit-reproducible.
 template <int MODEL, class TE, class TR, int SWEEP>
 __global__ __launch_bounds__(GradShape<SWEEP>::kWaves * 64) void inbatch_grad_kernel(
     int loss, const TE* __restrict__ ent, const TR* __restrict__ rel, const int64_t* __restrict__ neg_idx, int B, int K,
     int D, float regularizer, const float* __restrict__ grad_loss, const float* __restrict__ pos,
-    const float* __restrict__ neg, TE* __restrict__ grad_ent, TR* __restrict__ grad_rel, int ent_blocks, int R,
-    int rel_shares) {
+    const float* __restrict__ neg, TE* __restrict__ grad_ent, TR* __restrict__ grad_rel, int ent_blocks, int S,
+    int rel_shares, const int* __restrict__ off, const int* __restrict__ sorted, int chunk, int C) {
     constexpr int WAVES = GradShape<SWEEP>::kWaves, BATCH = grad_batch(MODEL, SWEEP);
-    constexpr int kTasks = WAVES > kMaxTasks ? WAVES : kMaxTasks;
-    __shared__ int hits[kHitCap];
-    __shared__ unsigned short hit_row[kHitCap];
-    __shared__ int wave_count[WAVES];
-    __shared__ int mine[WAVES][64];
-    __shared__ float park[kTasks][64 * SWEEP];
+    __shared__ int run_at[WAVES][64];    // exclusive prefix of the chunks' counts (INT_MAX past the last chunk)
+    __shared__ int run_from[WAVES][64];  // where the row's run starts in the chunk's part of `sorted`
+    __shared__ float park[WAVES][64 * SWEEP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float gl = grad_loss[0];
     const float reg_scale = regularizer > 0.0f ? regularizer * 2.0f / (3.0f * B * D) : 0.0f;
@@ -620,142 +896,87 @@ __global__ __launch_bounds__(GradShape<SWEEP>::kWaves * 64) void inbatch_grad_ke
         return;
     }
 
-    // ---- entity rows [row0, row1)
-    const int row0 = (int)blockIdx.x * R, row1 = row0 + R < 2 * B ? row0 + R : 2 * B;
-    const int n_rows = row1 - row0;
-    const int64_t total = 2ll * B * K;
-    int shares = WAVES / n_rows;  // tasks per row: every wave gets one when the workgroup owns fewer rows than it has waves
-    shares = shares < 1 ? 1 : (n_rows * shares > kTasks ? kTasks / n_rows : shares);
-    const int n_tasks = n_rows * shares;
-    for (int d0 = 0; d0 < D; d0 += 64 * SWEEP) {  // one sweep up to D = 64 SWEEP; wider rows repeat the scan
-        for (int64_t skip = 0;; skip += kHitCap) {  // rounds of at most kHitCap hits (normally one)
-            // -- scan: the entries that name a row of the range, in entry order.  Wave w owns the w-th contiguous part of
-            // neg_idx: it counts its hits (pass 1: 8 coalesced loads in flight, no barrier in the loop), the waves
-            // exchange their totals once, and it lists its hits behind those of the waves before it (pass 2).
-            const int64_t per_wave = ((total + WAVES - 1) / WAVES + 63) / 64 * 64;
-            const int64_t w0 = (int64_t)wave * per_wave, w1 = w0 + per_wave < total ? w0 + per_wave : total;
-            int n_mine = 0;  // (wave-uniform)
-            for (int64_t base = w0; base < w1; base += 64 * kScanSlices) {
-                int x[kScanSlices];  // (row indices: below 2 B < 2^31)
+    // ---- entity rows: wave = (row_local, share)
+    const int R = WAVES / S, row_local = wave / S, my_share = wave % S;
+    const int my_row = (int)blockIdx.x * R + row_local;
+    const bool active = my_row < 2 * B;
+    const int j = active ? my_row : 2 * B - 1;
+    const int stride = 2 * B + 1;
+    // how many entries name row j, and this share's part of the list (by position)
+    int n_list = 0;
+    for (int cb = 0; cb < C; cb += 64) {
+        const int c = cb + lane;
+        int cnt = c < C ? off[(size_t)c * stride + j + 1] - off[(size_t)c * stride + j] : 0;
 #pragma unroll
-                for (int i = 0; i < kScanSlices; ++i) {
-                    const int64_t e = base + 64 * i + lane;
-                    x[i] = e < w1 ? (int)neg_idx[e] : -1;
-                }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        n_list += cnt;
+    }
+    const int my_lo = active ? (int)((int64_t)n_list * my_share / S) : 0, my_hi = active ? (int)((int64_t)n_list * (my_share + 1) / S) : 0;
+    for (int d0 = 0; d0 < D; d0 += 64 * SWEEP) {  // one sweep up to D = 64 SWEEP; wider rows walk the list again
+        float g[SWEEP];
 #pragma unroll
-                for (int i = 0; i < kScanSlices; ++i) n_mine += __popcll(__ballot(x[i] >= row0 && x[i] < row1));
-            }
-            __syncthreads();  // (the previous round's readers of wave_count and hits are done)
-            if (lane == 0) wave_count[wave] = n_mine;
-            __syncthreads();
-            int64_t seen = 0, ord = 0;  // hits of the range in all of neg_idx / before this wave's part
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const int c = wave_count[w];
-                if (w < wave) ord += c;
-                seen += c;
-            }
-            for (int64_t base = w0; base < w1 && n_mine > 0; base += 64 * kScanSlices) {
-                int x[kScanSlices];
-#pragma unroll
-                for (int i = 0; i < kScanSlices; ++i) {
-                    const int64_t e = base + 64 * i + lane;
-                    x[i] = e < w1 ? (int)neg_idx[e] : -1;
-                }
-#pragma unroll
-                for (int i = 0; i < kScanSlices; ++i) {
-                    const bool hit = x[i] >= row0 && x[i] < row1;
-                    const unsigned long long m = __ballot(hit);
-                    const int64_t at = ord + __popcll(m & ((1ull << lane) - 1ull)) - skip;
-                    if (hit && at >= 0 && at < kHitCap) {
-                        hits[at] = (int)(base + 64 * i + lane);
-                        hit_row[at] = (unsigned short)(x[i] - row0);
-                    }
-                    ord += __popcll(m);
-                }
-            }
-            __syncthreads();
-            const int n_hits = (int)(seen - skip < kHitCap ? (seen > skip ? seen - skip : 0) : kHitCap);
-            const bool last_round = seen <= skip + kHitCap;
-            // -- walk: every task adds the contributions of its entries, in list order
-            for (int task = wave; task < n_tasks; task += WAVES) {
-                const int row_local = task / shares, my_share = task % shares, my_row = row0 + row_local;
-                float g[SWEEP];
-                if (skip == 0) {
-#pragma unroll
-                    for (int i = 0; i < SWEEP; ++i) g[i] = 0.0f;
-                    if (my_share == 0) {  // positive pair (2b, 2b + 1, rel b): the row is its head or its tail
-                        const int b = my_row >> 1, slot = my_row & 1;
-                        const float gp = dloss_dpos_wave(loss, pos[b], neg + (size_t)b * K, B, K, lane);
-#pragma unroll
-                        for (int i = 0; i < SWEEP; ++i) {
-                            const int d = elem_at<SWEEP>(d0, lane, i);
-                            if (d < D)
-                                g[i] = gp * dscore<MODEL>(slot, ent + (size_t)(2 * b) * D, ent + (size_t)(2 * b + 1) * D,
-                                                          rel + (size_t)b * D, d, D);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < SWEEP; ++i) g[i] = park[task][lane + 64 * i];
-                }
-                // the task's entries, gathered from the list into the wave's own 64-slot buffer (LDS only: no memory round
-                // trip per 64 list entries, most of which belong to other tasks); a full buffer -- or the last, partial
-                // one -- is then consumed: its lanes fetch their pairs' rows and loss gradients together
-                int filled = 0;  // (wave-uniform)
-                for (int base = 0;; base += 64) {
-                    const bool tail = base >= n_hits;  // one extra trip flushes what is left
-                    if (!tail) {
-                        const bool in = base + lane < n_hits;
-                        const int e = in ? hits[base + lane] : 0;
-                        const bool ours = in && hit_row[base + lane] == row_local && (e >> 1) % shares == my_share;
-                        const unsigned long long mask = __ballot(ours);
-                        const int at = filled + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (ours && at < 64) mine[wave][at] = e;
-                        const int n_new = __popcll(mask);
-                        if (filled + n_new < 64) { filled += n_new; continue; }
-                        // buffer full: consume 64, then park the overflow of this trip at the front
-                        wave_lds_fence();
-                        const int e_full = mine[wave][lane];
-                        wave_lds_fence();
-                        if (ours && at >= 64) mine[wave][at - 64] = e;
-                        filled = filled + n_new - 64;
-                        const int pair = e_full >> 1, pb = pair / K;
-                        const float gn = dloss_dneg(loss, pos[pb], neg[pair], B, K);
-                        const int hv = (int)neg_idx[2 * (size_t)pair], tv = (int)neg_idx[2 * (size_t)pair + 1];
-                        consume<MODEL, SWEEP, BATCH>(g, __ballot(gn != 0.0f), hv, tv, pb, gn, e_full & 1, ent, rel, D, d0, lane);
-                    } else if (filled > 0) {
-                        wave_lds_fence();
-                        const bool in = lane < filled;
-                        const int e_last = in ? mine[wave][lane] : 0;
-                        const int pair = e_last >> 1, pb = pair / K;
-                        const float gn = in ? dloss_dneg(loss, pos[pb], neg[pair], B, K) : 0.0f;
-                        const int hv = (int)neg_idx[2 * (size_t)pair], tv = (int)neg_idx[2 * (size_t)pair + 1];
-                        consume<MODEL, SWEEP, BATCH>(g, __ballot(in && gn != 0.0f), hv, tv, pb, gn, e_last & 1, ent, rel, D, d0, lane);
-                        wave_lds_fence();
-                    }
-                    if (tail) break;
-                }
-#pragma unroll
-                for (int i = 0; i < SWEEP; ++i) park[task][lane + 64 * i] = g[i];
-            }
-            if (last_round) break;
-        }
-        __syncthreads();
-        // -- a row's shares in share order, the regulariser's term, the store
-        for (int row_local = wave; row_local < n_rows; row_local += WAVES) {
-            const int my_row = row0 + row_local;
+        for (int i = 0; i < SWEEP; ++i) g[i] = 0.0f;
+        if (my_share == 0 && active) {  // positive pair (2b, 2b + 1, rel b): the row is its head or its tail
+            const int b = j >> 1, slot = j & 1;
+            const float gp = dloss_dpos_wave(loss, pos[b], neg + (size_t)b * K, B, K, lane);
 #pragma unroll
             for (int i = 0; i < SWEEP; ++i) {
                 const int d = elem_at<SWEEP>(d0, lane, i);
-                if (d < D) {
-                    float g = park[row_local * shares][lane + 64 * i];
-                    for (int s = 1; s < shares; ++s) g += park[row_local * shares + s][lane + 64 * i];
-                    grad_ent[(size_t)my_row * D + d] = (TE)(gl * (g + reg_scale * widen(ent[(size_t)my_row * D + d])));
-                }
+                if (d < D)
+                    g[i] = gp * dscore<MODEL>(slot, ent + (size_t)(2 * b) * D, ent + (size_t)(2 * b + 1) * D, rel + (size_t)b * D, d, D);
             }
         }
-        __syncthreads();
+        int at0 = 0;  // list position of the first entry of this block of 64 chunks
+        for (int cb = 0; cb < C && at0 < my_hi; cb += 64) {
+            const int c = cb + lane;
+            const int from = c < C ? off[(size_t)c * stride + j] : 0;
+            const int cnt = c < C ? off[(size_t)c * stride + j + 1] - from : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            const int blk_n = __shfl(incl, 63);
+            wave_lds_fence();
+            run_at[wave][lane] = c < C ? incl - cnt : 0x7fffffff;
+            run_from[wave][lane] = from;
+            wave_lds_fence();
+            const int a = my_lo > at0 ? my_lo : at0, z = my_hi < at0 + blk_n ? my_hi : at0 + blk_n;
+            for (int w = a; w < z; w += 64) {
+                const bool in = w + lane < z;
+                const int q = (in ? w + lane : a) - at0;  // position inside this block of chunks
+                int l = 0;  // the last chunk whose run starts at or before q: the run that holds q (empty runs share their start with the next)
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (run_at[wave][l + step] <= q) l += step;
+                const int e = sorted[(size_t)(cb + l) * chunk + run_from[wave][l] + (q - run_at[wave][l])];
+                const int pair = e >> 1, pb = pair / K;
+                const float gn = in ? dloss_dneg(loss, pos[pb], neg[pair], B, K) : 0.0f;
+                const int hv = (int)neg_idx[2 * (size_t)pair], tv = (int)neg_idx[2 * (size_t)pair + 1];
+                consume<MODEL, SWEEP, BATCH>(g, __ballot(in && gn != 0.0f), hv, tv, pb, gn, e & 1, ent, rel, D, d0, lane);
+            }
+            at0 += blk_n;
+        }
+        // -- a row's shares in share order, the regulariser's term, the store
+        if (S > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SWEEP; ++i) park[wave][lane + 64 * i] = g[i];
+            __syncthreads();
+            if (my_share == 0) {
+#pragma unroll
+                for (int i = 0; i < SWEEP; ++i)
+                    for (int s = 1; s < S; ++s) g[i] += park[wave + s][lane + 64 * i];
+            }
+        }
+        if (active && my_share == 0) {
+#pragma unroll
+            for (int i = 0; i < SWEEP; ++i) {
+                const int d = elem_at<SWEEP>(d0, lane, i);
+                if (d < D) grad_ent[(size_t)my_row * D + d] = (TE)(gl * (g[i] + reg_scale * widen(ent[(size_t)my_row * D + d])));
+            }
+        }
     }
 }
 
@@ -763,14 +984,20 @@ template <int MODEL, class TE, class TR, int SWEEP>
 static void launch_grad(int loss, const TE* ent, const TR* rel, const int64_t* neg_idx, int B, int K, int D, float regularizer,
                         const float* grad_loss, const float* pos, const float* neg, TE* grad_ent, TR* grad_rel, hipStream_t stream) {
     constexpr int WAVES = GradShape<SWEEP>::kWaves;
-    const int R = grad_rows_per_block(B, K);
+    // entity rows: S waves share a row's list (a wave adds its entries one batch of row loads after the other: a latency chain)
+    // while that keeps the number of waves near what the chip holds at once; a power of two
+    int S = WAVES;
+    while (S > 1 && (int64_t)2 * B * S > 8192) S >>= 1;
+    const int R = WAVES / S;
     // relation rows: a workgroup per row (its K negatives over all the waves) while that does not flood the chip
-    int rel_shares = B <= 128 ? WAVES : (B <= 512 ? 4 : 1);
-    rel_shares = rel_shares > WAVES ? WAVES : rel_shares;
+    int rel_shares = WAVES;
+    while (rel_shares > 1 && (int64_t)B * rel_shares > 4096) rel_shares >>= 1;
     const int ent_blocks = (2 * B + R - 1) / R, rows_per_rel_block = WAVES / rel_shares;
     const int rel_blocks = (B + rows_per_rel_block - 1) / rows_per_rel_block;
+    const SaveLayout L = save_layout(MODEL, B, K, D, regularizer > 0.0f);
     inbatch_grad_kernel<MODEL, TE, TR, SWEEP><<<dim3((unsigned)(ent_blocks + rel_blocks)), WAVES * 64, 0, stream>>>(
-        loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, pos, neg, grad_ent, grad_rel, ent_blocks, R, rel_shares);
+        loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, pos, neg, grad_ent, grad_rel, ent_blocks, S, rel_shares,
+        reinterpret_cast<const int*>(pos + L.off_at), reinterpret_cast<const int*>(pos + L.sorted_at), L.chunk, L.n_chunks);
 }
 
 // ---------------------------------------------------------------- launchers
@@ -798,23 +1025,32 @@ static hipError_t dispatch_types(int ent_dtype, int rel_dtype, F f) {
     return hipErrorInvalidValue;
 }
 
+size_t inbatch_loss_save_floats(int model, int B, int K, int D) { return (size_t)save_layout(model, B, K, D, true).total; }
+int inbatch_loss_fwd_launches(int model, int B, int K, int D, bool regularised) { return save_layout(model, B, K, D, regularised).fused ? 1 : 2; }
+
 hipError_t launch_inbatch_loss_fwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent, const void* rel,
                                    const int64_t* neg_idx, int B, int K, int D, float regularizer,
-                                   float* out_loss, float* save_pos, float* save_neg, hipStream_t stream) {
+                                   float* out_loss, float* save_pos, float* save_neg, unsigned* ticket, hipStream_t stream) {
     if ((int64_t)B * K >= (1ll << 30)) return hipErrorInvalidValue;  // entries of neg_idx are numbered in 32 bits
     return dispatch_model(model, [&](auto m) {
         return dispatch_types(ent_dtype, rel_dtype, [&](auto te, auto tr) {
             using TE = typename decltype(te)::type;
             using TR = typename decltype(tr)::type;
-            const int per_block = 256 / lanes_per_pair(decltype(m)::value, D);
-            const int64_t pairs = (int64_t)B * (K + 1), pair_blocks = (pairs + per_block - 1) / per_block;
-            const int64_t reg_blocks = regularizer > 0.0f ? (B + 3) / 4 : 0;
-            if (pair_blocks + reg_blocks > 0x7fffffff) return hipErrorInvalidValue;
-            inbatch_scores_kernel<decltype(m)::value, TE, TR><<<dim3((unsigned)(pair_blocks + reg_blocks)), 256, 0, stream>>>(
-                static_cast<const TE*>(ent), static_cast<const TR*>(rel), neg_idx, B, K, D, save_pos, save_neg, (unsigned)pair_blocks);
-            int reduce_blocks = (int)(((int64_t)B * K + kReduceSlice - 1) / kReduceSlice);
-            reduce_blocks = reduce_blocks < 1 ? 1 : (reduce_blocks > kReduceBlocks ? kReduceBlocks : reduce_blocks);
-            inbatch_reduce_kernel<<<reduce_blocks, 1024, 0, stream>>>(loss, save_pos, save_neg, B, K, D, regularizer, out_loss);
+            SaveLayout L = save_layout(decltype(m)::value, B, K, D, regularizer > 0.0f);
+            const int probe = (int)knob(KNOB_INBATCH_PROBE);  // (0 in the product library)
+            if (probe & 1) L.n_chunks = 0;
+            const int64_t blocks = (int64_t)L.n_chunks + L.pair_blocks + L.reg_blocks;
+            if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+            inbatch_forward_kernel<decltype(m)::value, TE, TR><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+                loss, static_cast<const TE*>(ent), static_cast<const TR*>(rel), neg_idx, B, K, D, regularizer, save_pos, save_neg,
+                out_loss, ticket, L, probe);
+            if (!L.fused) {
+                int reduce_blocks = (int)(((int64_t)B * K + kReduceSlice - 1) / kReduceSlice);
+                reduce_blocks = reduce_blocks < 1 ? 1 : (reduce_blocks > kReduceBlocks ? kReduceBlocks : reduce_blocks);
+                inbatch_reduce_kernel<<<reduce_blocks, 1024, 0, stream>>>(loss, save_pos, save_pos + L.regsh_at,
+                                                                          reinterpret_cast<double*>(save_pos + L.red_at), ticket + 1, save_neg,
+                                                                          B, K, D, regularizer, out_loss);
+            }
             return hipGetLastError();
         });
     });

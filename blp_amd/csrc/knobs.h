@@ -20,6 +20,7 @@ enum Knob : int {
     KNOB_STREAM_KERNEL,          // 2: <= 4 + 4 queries stay on rank_tiles<STATIC> (else: rank_stream.hip); 3 / 4: the workgroup-tile (order-exact keys) / the ring kernel (bilinear models: approximate keys first) whatever the table length; 5 = 3
     KNOB_DKRL_SPLIT,             // 1 / 2 / 4: waves per M-tile of the DKRL table-build kernel (dkrl.hip)
     KNOB_MFMA_SELFTEST,          // 1: the matrix-pipe accumulation self-test (rank_gemm.hip) reports a violation whatever it measured
+    KNOB_INBATCH_PROBE,          // timing probe of the in-batch loss forward (wrong results!): bit 0: no index workgroups; bit 1: no tickets / final sum; bit 2: no redundant positives
     KNOB_COUNT
 };
 

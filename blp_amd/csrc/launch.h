@@ -139,7 +139,9 @@ hipError_t launch_score_bwd(int model, int D, int64_t M0, int64_t M1, StridedRow
 
 hipError_t launch_inbatch_loss_fwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent, const void* rel,
                                    const int64_t* neg_idx, int B, int K, int D, float regularizer,
-                                   float* out_loss, float* save_pos, float* save_neg, hipStream_t stream);
+                                   float* out_loss, float* save_pos, float* save_neg, unsigned* ticket, hipStream_t stream);
+size_t inbatch_loss_save_floats(int model, int B, int K, int D);
+int inbatch_loss_fwd_launches(int model, int B, int K, int D, bool regularised);
 hipError_t launch_inbatch_loss_bwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent, const void* rel,
                                    const int64_t* neg_idx, int B, int K, int D, float regularizer,
                                    const float* grad_loss, const float* save_pos, const float* save_neg,

@@ -3,8 +3,8 @@
 // No kernel, no HIP call, no arithmetic: this file only moves what blp_amd/ops.py's Python autograd.Function moved -- tensor
 // pointers, sizes and the caller's stream -- into blp_inbatch_loss_fwd_t / _bwd_t of the C-ABI (include/blp_hip.h), which it
 // reaches through function pointers handed over by blp_amd._lib (the library ctypes already loaded: one instance, no link
-// dependency).  Why it exists: LinkPrediction.compute_loss (models.py:51-70) is called once per training step, its three
-// kernels take 22 us, and a Python autograd.Function cost the caller 140 us per step around them (round 3: apply() +
+// dependency).  Why it exists: LinkPrediction.compute_loss (models.py:51-70) is called once per training step, its
+// kernels take ~20 us, and a Python autograd.Function cost the caller 140 us per step around them (round 3: apply() +
 // engine -> Python backward() + five torch.empty + two ctypes calls).  A torch::autograd::Function costs a few us.
 //
 // Built by blp_amd/build.py with the host compiler against the installed torch; if it is missing (another torch build),
@@ -12,11 +12,15 @@
 #include <torch/extension.h>
 
 #include <cstdint>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
 using fwd_fn = int (*)(int, int, int, int, const void*, const void*, const int64_t*, int, int, int, float, float*, float*, float*,
-                       int, void*);
+                       int32_t*, int, void*);
+using size_fn = size_t (*)(int, int, int, int);
 using bwd_fn = int (*)(int, int, int, int, const void*, const void*, const int64_t*, int, int, int, float, const float*,
                        const float*, const float*, void*, void*, int, void*);
 using err_fn = const char* (*)();
@@ -24,6 +28,20 @@ using err_fn = const char* (*)();
 fwd_fn g_fwd = nullptr;
 bwd_fn g_bwd = nullptr;
 err_fn g_err = nullptr;
+size_fn g_save_floats = nullptr;
+
+// The forward's ticket counter (include/blp_hip.h: BLP_INBATCH_TICKET_INTS = 4 int32, zero on entry, left zero by the kernel): one
+// tensor per (device, stream), zeroed when first asked for; calls on one stream are ordered and share it.
+std::mutex g_ticket_mutex;
+std::map<std::pair<int, int64_t>, at::Tensor> g_tickets;
+
+int32_t* ticket_for(const at::Tensor& like, int64_t stream) {
+    const std::pair<int, int64_t> key(like.get_device(), stream);
+    std::lock_guard<std::mutex> lock(g_ticket_mutex);
+    auto it = g_tickets.find(key);
+    if (it == g_tickets.end()) it = g_tickets.emplace(key, at::zeros({4}, like.options().dtype(at::kInt))).first;
+    return it->second.data_ptr<int32_t>();
+}
 
 int dtype_id(at::ScalarType t) {  // BLP_DTYPE_* of include/blp_hip.h
     switch (t) {
@@ -34,7 +52,7 @@ int dtype_id(at::ScalarType t) {  // BLP_DTYPE_* of include/blp_hip.h
     }
 }
 
-constexpr int64_t kSavePosExtra = 6 * 64 + 2;  // BLP_INBATCH_SAVE_POS_FLOATS(B) = 2 B + this (checked against the header by tests)
+constexpr int64_t kAbiVersion = 60000;  // the include/blp_hip.h this file was written against (major checked at bind time by blp_amd.ops)
 
 struct InBatchLoss : public torch::autograd::Function<InBatchLoss> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& ent_embs, const at::Tensor& rel_vecs,
@@ -55,12 +73,13 @@ struct InBatchLoss : public torch::autograd::Function<InBatchLoss> {
         const at::Tensor idx = (neg_idx.scalar_type() == at::kLong ? neg_idx : neg_idx.to(at::kLong)).contiguous();
         const auto f32 = ent.options().dtype(at::kFloat);
         at::Tensor loss = at::empty({}, f32);
-        at::Tensor pos = at::empty({2 * B + kSavePosExtra}, f32);  // positives' scores, regulariser shares, reduction scratch
+        // positives' scores, the workgroups' partial loss sums, the index of neg_idx the backward walks
+        at::Tensor pos = at::empty({(int64_t)g_save_floats((int)model, (int)B, (int)K, (int)D)}, f32);
         at::Tensor neg = at::empty({B, K}, f32);
         const int device = ent.get_device();
         const int rc = g_fwd((int)model, (int)loss_id, ent_t, rel_t, ent.data_ptr(), rel.data_ptr(), idx.data_ptr<int64_t>(), (int)B,
                              (int)K, (int)D, (float)regularizer, loss.data_ptr<float>(), pos.data_ptr<float>(),
-                             neg.data_ptr<float>(), device, reinterpret_cast<void*>(stream));
+                             neg.data_ptr<float>(), ticket_for(ent, stream), device, reinterpret_cast<void*>(stream));
         TORCH_CHECK(rc == 0, "blp_inbatch_loss_fwd failed with status ", rc, ": ", g_err ? g_err() : "");
         ctx->save_for_backward({ent, rel, idx, pos, neg});
         ctx->saved_data["model"] = model;
@@ -101,7 +120,8 @@ struct AutogradFloor : public torch::autograd::Function<AutogradFloor> {
                               const at::Tensor& neg_idx) {
         const int64_t B = ent_embs.size(0), K = neg_idx.size(1);
         const auto f32 = ent_embs.options().dtype(at::kFloat);
-        at::Tensor loss = at::empty({}, f32), pos = at::empty({2 * B + kSavePosExtra}, f32), neg = at::empty({B, K}, f32);
+        at::Tensor loss = at::empty({}, f32), pos = at::empty({(int64_t)g_save_floats(0, (int)B, (int)K, (int)ent_embs.size(2))}, f32),
+                   neg = at::empty({B, K}, f32);
         ctx->save_for_backward({ent_embs, rel_vecs, neg_idx, pos, neg});
         return loss;
     }
@@ -120,7 +140,7 @@ struct AutogradFloorV : public torch::autograd::Function<AutogradFloorV> {
         const auto f32 = ent_embs.options().dtype(at::kFloat);
         at::Tensor loss = at::empty({}, f32);
         if (!(flags & 2)) {
-            at::Tensor pos = at::empty({2 * B + kSavePosExtra}, f32), neg = at::empty({B, K}, f32);
+            at::Tensor pos = at::empty({(int64_t)g_save_floats(0, (int)B, (int)K, (int)ent_embs.size(2))}, f32), neg = at::empty({B, K}, f32);
             if (!(flags & 1)) ctx->save_for_backward({ent_embs, rel_vecs, neg_idx, pos, neg});
         } else if (!(flags & 1)) {
             ctx->save_for_backward({ent_embs, rel_vecs, neg_idx});
@@ -155,10 +175,11 @@ at::Tensor autograd_floor(const at::Tensor& ent_embs, const at::Tensor& rel_vecs
     return AutogradFloor::apply(ent_embs, rel_vecs, neg_idx);
 }
 
-void bind(uintptr_t fwd, uintptr_t bwd, uintptr_t err) {
+void bind(uintptr_t fwd, uintptr_t bwd, uintptr_t err, uintptr_t save_floats) {
     g_fwd = reinterpret_cast<fwd_fn>(fwd);
     g_bwd = reinterpret_cast<bwd_fn>(bwd);
     g_err = reinterpret_cast<err_fn>(err);
+    g_save_floats = reinterpret_cast<size_fn>(save_floats);
 }
 
 at::Tensor inbatch_loss(const at::Tensor& ent_embs, const at::Tensor& rel_vecs, const at::Tensor& neg_idx, int64_t model,
@@ -170,11 +191,11 @@ at::Tensor inbatch_loss(const at::Tensor& ent_embs, const at::Tensor& rel_vecs, 
 
 PYBIND11_MODULE(_torch_glue, m) {
     m.doc() = "blp_amd: C++ autograd plumbing around the C-ABI's in-batch loss (no kernels here)";
-    m.def("bind", &bind, "hand over the addresses of blp_inbatch_loss_fwd_t, blp_inbatch_loss_bwd_t, blp_last_error");
+    m.def("bind", &bind, "hand over the addresses of blp_inbatch_loss_fwd_t, blp_inbatch_loss_bwd_t, blp_last_error, blp_inbatch_loss_save_floats");
     m.def("inbatch_loss", &inbatch_loss, py::call_guard<py::gil_scoped_release>(),
           "compute_loss on in-batch negatives: (ent_embs, rel_vecs, neg_idx, model_id, loss_id, regularizer, raw_stream) -> loss");
     m.def("autograd_floor", &autograd_floor, py::call_guard<py::gil_scoped_release>(),
           "a node of the same shape that launches nothing (bench.py: what autograd itself costs per step)");
     m.def("autograd_floor_variant", &autograd_floor_variant, py::call_guard<py::gil_scoped_release>(), "autograd_floor with parts switched off (probe)");
-    m.attr("save_pos_extra_floats") = kSavePosExtra;
+    m.attr("abi_version") = kAbiVersion;
 }

@@ -701,6 +701,19 @@ def score(rel_model, heads, tails, rels):
 
 
 # --------------------------------------------------------------------------------- in-batch loss
+_tickets = {}
+
+
+def inbatch_ticket(dev, stream):
+    """The forward's ticket counter (include/blp_hip.h: BLP_INBATCH_TICKET_INTS int32, zero on entry, left zero by the kernel):
+    one per (device, stream), zeroed once -- calls on one stream are ordered and share it."""
+    key = (dev.index, stream)
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(_lib.INBATCH_TICKET_INTS, dtype=torch.int32, device=dev)
+    return t
+
+
 class _InBatchLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rel_model, loss_fn, regularizer, ent_embs, rel_vecs, neg_idx):
@@ -721,12 +734,13 @@ class _InBatchLoss(torch.autograd.Function):
         idx = neg_idx.to(torch.int64).contiguous()
         dev = ent.device
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        # BLP_INBATCH_SAVE_POS_FLOATS(B): positives' scores, the rows' regulariser shares, scratch of the loss reduction
-        pos = torch.empty(_lib.inbatch_save_pos_floats(B), dtype=torch.float32, device=dev)
+        # blp_inbatch_loss_save_floats: positives' scores, the workgroups' partial loss sums, the index of neg_idx for the backward
+        pos = torch.empty(_lib.inbatch_save_floats(_lib.MODEL_IDS[rel_model], B, K, D), dtype=torch.float32, device=dev)
         neg = torch.empty((B, K), dtype=torch.float32, device=dev)
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)
         status = _lib.lib().blp_inbatch_loss_fwd_t(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
                                                    _ptr(ent), _ptr(rel), _ptr(idx), B, K, D, float(regularizer),
-                                                   _ptr(loss), _ptr(pos), _ptr(neg), dev.index, _stream(dev))
+                                                   _ptr(loss), _ptr(pos), _ptr(neg), _ptr(inbatch_ticket(dev, stream)), dev.index, stream)
         _lib.check(status, "blp_inbatch_loss_fwd")
         ctx.meta = (rel_model, loss_fn, float(regularizer), B, K, D, rel_vecs.shape, dtypes)
         ctx.save_for_backward(ent, rel, idx, pos, neg)
@@ -760,10 +774,11 @@ def torch_glue():
         try:
             from . import _torch_glue as g
             L = _lib.lib()
-            g.bind(*(ctypes.cast(fn, ctypes.c_void_p).value for fn in (L.blp_inbatch_loss_fwd_t, L.blp_inbatch_loss_bwd_t, L.blp_last_error)))
-            if g.save_pos_extra_floats + 2 != _lib.inbatch_save_pos_floats(1):  # a stale build against an older header
-                raise ImportError(f"blp_amd/_torch_glue.so was built for another include/blp_hip.h (save_pos: {g.save_pos_extra_floats} + 2 "
-                                  f"floats, the library wants {_lib.inbatch_save_pos_floats(1)}); rebuild with python -m blp_amd.build")
+            if getattr(g, "abi_version", 0) // 10000 != L.blp_version() // 10000:  # a stale build against an older header
+                raise ImportError(f"blp_amd/_torch_glue.so was built for include/blp_hip.h {getattr(g, 'abi_version', '< 6.0.0')}, the library is "
+                                  f"{L.blp_version()}; rebuild with python -m blp_amd.build")
+            g.bind(*(ctypes.cast(fn, ctypes.c_void_p).value for fn in (L.blp_inbatch_loss_fwd_t, L.blp_inbatch_loss_bwd_t, L.blp_last_error,
+                                                                       L.blp_inbatch_loss_save_floats)))
             _glue_module = g
         except Exception as exc:  # not built, another torch, a stale build, a failed bind: the Python autograd.Function serves
             import warnings

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define BLP_HIP_VERSION 500 /* major*10000 + minor*100 + patch; 5.0.0: blp_caps grew (mfma_bf16_accum), blp_selftest */
+#define BLP_HIP_VERSION 60000 /* major*10000 + minor*100 + patch; 6.0.0: the in-batch loss in two launches (fwd takes a ticket
+                                 counter, save_pos sized by blp_inbatch_loss_save_floats), entry points pruned */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -331,43 +332,39 @@ int blp_score_bwd(int model, int D, int64_t M0, int64_t M1,
 /* --------------------------------------------------------------------------------------------
  * In-batch negatives loss   LinkPrediction.compute_loss, models.py:51-70 (+ :251-266)
  *
- *   ent_embs  (B, 2, D) f32 contiguous == (2B, D): row 2b = head of b, 2b+1 = tail of b
- *   rel_vecs  (B, D)    f32: rel_emb(rels) already gathered (its backward stays in torch)
+ *   ent_embs  (B, 2, D) contiguous == (2B, D): row 2b = head of b, 2b+1 = tail of b
+ *   rel_vecs  (B, D)    rel_emb(rels) already gathered (its backward stays in torch)
  *   neg_idx   (B, K, 2) int64, values in [0, 2B): rows of ent_embs.view(2B, D)  (data.py:35-81)
  *   regularizer: models.py:59-60, applied iff > 0
- * fwd: loss (1) f32; save_pos (BLP_INBATCH_SAVE_POS_FLOATS(B)) f32 -- the B positive scores, B per-row shares of the
- *      regulariser, then scratch of the loss reduction -- and save_neg (B, K) f32 scores are kept for bwd.  Two launches:
- *      scores (bilinear models: 32 lanes per pair = torch.sum's 32 running sums, folded by wavefront shuffles; TransE:
- *      four lanes per pair, the running L1 sum walking through them -- scores bit-identical to the reference at the
- *      scripts' widths), then the loss (f64 accumulation in a fixed order; the last of up to 64 workgroups adds theirs).
- * bwd: grad_ent (2B, D), grad_rel (B, D), both overwritten, scaled by *grad_loss (device scalar).  One launch,
- *      O(B K) work (a workgroup finds the negatives of its rows with one stable compaction of neg_idx into LDS).
- *      Deterministic (no float atomics: contributions are added in neg_idx order).  margin_loss passes gradient
- *      where the hinge is exactly 0 (models.py:252-253 masks in place).
+ * Storage types: ent_embs and grad_ent are ent_dtype, rel_vecs and grad_rel are rel_dtype (= ent_dtype, or f32: nn.Embedding
+ *      rows stay f32 under autocast -- BASELINE config 5: half-precision embeddings).  Half operands are widened exactly and
+ *      every operation is the f32 one of the reference (f32 accumulate); the loss and the saved scores stay f32; gradients
+ *      are rounded once on store.  The reference has no half path: parity there is a tolerance against the f32 oracle on the
+ *      widened inputs (tests/test_gpu_parity.py::test_inbatch_loss_half_*).
+ * fwd: loss (1) f32; save_pos (blp_inbatch_loss_save_floats(model, B, K, D) floats) -- the B positive scores, the
+ *      workgroups' partial loss sums, and an INDEX of neg_idx (per chunk of consecutive entries: the entries grouped by
+ *      the row they name, in entry order) -- and save_neg (B, K) f32 scores are kept for bwd.  Scores: the bilinear models
+ *      32 lanes per pair = torch.sum's 32 running sums, folded by wavefront shuffles; TransE four lanes per pair, the
+ *      running L1 sum walking through them -- bit-identical to the reference at the scripts' widths.  Loss: every
+ *      workgroup adds its slots' terms in f64 (slot order); the partial sums are then added in workgroup order -- by the
+ *      workgroup that takes the last ticket when there are at most 96 of them (ONE launch: the TransE step at the scripts'
+ *      batch sizes), else by a second, one-workgroup launch (cheaper than that many tickets).  A fixed order either way.
+ *      ticket: BLP_INBATCH_TICKET_INTS int32 the caller keeps PER STREAM, ZERO on entry; the kernel leaves them zero when it
+ *      completes (calls on one stream are ordered and may share them; concurrent streams need their own).
+ * bwd: ONE launch.  grad_ent (2B, D), grad_rel (B, D), both overwritten, scaled by *grad_loss (device scalar).  O(B K) work:
+ *      a row's negatives come from the forward's index, in entry order.  Deterministic (no float atomics).  margin_loss
+ *      passes gradient where the hinge is exactly 0 (models.py:252-253 masks in place).
  * Floating point: the scores are the reference's elementwise terms summed in tree order, so the loss agrees with the
  * reference to ~1e-6 relative and the gradients to ~1e-5 (the bit-exact score_fn is blp_score_fwd).
  * -------------------------------------------------------------------------------------------- */
-#define BLP_INBATCH_SAVE_POS_FLOATS(B) (2 * (B) + 6 * 64 + 2)
-int blp_inbatch_loss_fwd(int model, int loss, const float *ent_embs, const float *rel_vecs,
-                         const int64_t *neg_idx, int B, int K, int D, float regularizer,
-                         float *out_loss, float *save_pos, float *save_neg, int device,
-                         void *stream);
-int blp_inbatch_loss_bwd(int model, int loss, const float *ent_embs, const float *rel_vecs,
-                         const int64_t *neg_idx, int B, int K, int D, float regularizer,
-                         const float *grad_loss, const float *save_pos, const float *save_neg,
-                         float *grad_ent, float *grad_rel, int device, void *stream);
-
-
-/* Storage-typed variants (BASELINE config 5: half-precision embeddings under autocast).  ent_embs and
- * grad_ent are ent_dtype, rel_vecs and grad_rel are rel_dtype (= ent_dtype, or f32: nn.Embedding rows
- * stay f32 under autocast).  Half operands are widened exactly and every operation is the f32 one of
- * the reference (f32 accumulate); loss and the saved scores stay f32; gradients are rounded once on
- * store.  The reference has no half path: parity is a tolerance against the f32 oracle on the
- * widened inputs (tests/test_gpu_parity.py::test_inbatch_loss_half_*). */
+#define BLP_INBATCH_TICKET_INTS 4
+size_t blp_inbatch_loss_save_floats(int model, int B, int K, int D);
+/* kernel launches of blp_inbatch_loss_fwd_t at these sizes: 1 (at most 96 scoring workgroups: the last one finishes the loss) or 2 */
+int blp_inbatch_loss_fwd_launches(int model, int B, int K, int D, float regularizer);
 int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
                            const void *rel_vecs, const int64_t *neg_idx, int B, int K, int D,
                            float regularizer, float *out_loss, float *save_pos, float *save_neg,
-                           int device, void *stream);
+                           int32_t *ticket, int device, void *stream);
 int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
                            const void *rel_vecs, const int64_t *neg_idx, int B, int K, int D,
                            float regularizer, const float *grad_loss, const float *save_pos,

@@ -49,7 +49,7 @@ def test_library_loads_and_exports_every_symbol(built_lib):
     L = _lib.lib()
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.blp_version() == 500
+    assert L.blp_version() == 60000
     assert L.blp_dim_supported(0, 128) == 1
     assert L.blp_dim_supported(0, 100) == 0
     assert L.blp_rank_all_workspace_bytes(0, 14541, 128, 64, 64) >= 128 * (256 * 4 + 4 + 8)  # coefficients, key, accumulator
@@ -76,10 +76,12 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     rc = L.blp_score_fwd(2, 101, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
     assert rc == -2 and b"halves" in L.blp_last_error()  # ComplEx / SimplE split the vector
     one = ctypes.c_void_p(16)  # non-NULL placeholders: validation fails before anything is dereferenced
-    rc = L.blp_inbatch_loss_fwd_t(0, 0, 5, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, 0, None)
+    rc = L.blp_inbatch_loss_fwd_t(0, 0, 5, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, one, 0, None)
     assert rc == -1 and b"dtype" in L.blp_last_error()
-    rc = L.blp_inbatch_loss_fwd_t(0, 0, 0, 1, one, one, one, 4, 4, 128, 0.0, one, one, one, 0, None)
+    rc = L.blp_inbatch_loss_fwd_t(0, 0, 0, 1, one, one, one, 4, 4, 128, 0.0, one, one, one, one, 0, None)
     assert rc == -1  # relation rows narrower than the embeddings
+    rc = L.blp_inbatch_loss_fwd_t(0, 0, 0, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, None, 0, None)
+    assert rc == -1 and b"ticket" in L.blp_last_error()  # the forward's last-workgroup ticket is the caller's (zeroed, per stream)
     rc = L.blp_rank_metric_sums(None, 5, None, None, 0, None)
     assert rc == -1
     # int32 counts: N >= 2^31 is refused; q_fixed / q_rel feed 16-byte vector loads
@@ -260,35 +262,62 @@ def test_metric_sums_buffer_size_matches_the_header():
 
 def test_torch_glue_builds_loads_and_agrees_with_the_header(built_lib):
     """blp_amd/_torch_glue.so (csrc/torch_glue.cpp: the in-batch loss's autograd plumbing as a C++ torch extension -- host
-    code only) builds against the installed torch, imports, binds the product library's entry points and sizes `save_pos`
-    as include/blp_hip.h's BLP_INBATCH_SAVE_POS_FLOATS does; it refuses CPU tensors like the Python plumbing."""
+    code only) builds against the installed torch, imports, binds the product library's entry points (it asks the library's
+    blp_inbatch_loss_save_floats for the size of `save_pos`) and was written against this header's major version; it refuses
+    CPU tensors like the Python plumbing."""
     import torch
     from blp_amd import _lib, build, ops
     assert os.path.exists(build.build_glue())
     glue = ops.torch_glue()
     assert glue is not None and glue.__file__.endswith("_torch_glue.so")
     header = open(os.path.join(ROOT, "include", "blp_hip.h")).read()
-    macro = re.search(r"#define BLP_INBATCH_SAVE_POS_FLOATS\(B\)\s+\((.*)\)", header).group(1)
-    for B in (1, 64, 1024):
-        assert eval(macro, {"B": B}) == 2 * B + glue.save_pos_extra_floats == _lib.inbatch_save_pos_floats(B)
+    assert glue.abi_version // 10000 == int(re.search(r"#define BLP_HIP_VERSION (\d+)", header).group(1)) // 10000 == _lib.lib().blp_version() // 10000
+    assert int(re.search(r"#define BLP_INBATCH_TICKET_INTS (\d+)", header).group(1)) == _lib.INBATCH_TICKET_INTS
+    # save_pos: the B positives' scores + two f64 partial sums per forward workgroup + the index of neg_idx (offsets per chunk
+    # and row + one int per entry) -- grows with B K, never with a float argument
+    for model in range(4):
+        for B, K, D in ((1, 1, 128), (64, 64, 128), (1024, 64, 128), (64, 64, 300), (4096, 64, 128)):
+            n = _lib.inbatch_save_floats(model, B, K, D)
+            chunk = 1024
+            chunks = -(-2 * B * K // chunk)
+            assert n >= B + 2 * B * K + chunks * (2 * B + 1), (model, B, K, D, n)
+            assert n <= B + 2 + 2 * B * K + chunks * (2 * B + 1) + 4 * (-(-B * (K + 1) // 8) + (B + 3) // 4) + 8 + B + 2 + 6 * 64  # (+ the many-workgroup forward's regulariser shares and reduction scratch)
+    assert _lib.inbatch_save_floats(7, 64, 64, 128) == 0 and _lib.inbatch_save_floats(0, 0, 64, 128) == 0
     with pytest.raises(RuntimeError, match="HIP device tensors only"):
         glue.inbatch_loss(torch.zeros(4, 2, 8), torch.zeros(4, 1, 8), torch.zeros(4, 3, 2, dtype=torch.long), 0, 0, 0.0, 0)
 
 
 def test_no_kernel_of_the_in_batch_loss_uses_scratch(built_lib):
-    """Every inbatch_* kernel keeps its working set in registers / LDS: .private_segment_fixed_size == 0 and no spills
-    in the gfx950 code object's notes (tools/kernel_resources.py)."""
+    """Every inbatch_* kernel keeps its working set in registers / LDS: no VGPR spills, and .private_segment_fixed_size == 0
+    in the gfx950 code object's notes (tools/kernel_resources.py) for the forward and for the backward at the scripts' widths
+    (rows of up to 128 elements).  The backward's WIDE-row shape (<.., 8>: D > 128 or D % 4 != 0) of the bilinear models
+    declares 20 bytes -- the slot the compiler reserves for the VGPR its spilled SCALAR registers are parked in -- and never
+    touches them: its disassembly holds no scratch_* / buffer_* instruction (checked here)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
     from blp_amd import build
-    kernels = kernel_resources.kernels_of(os.path.join(build.OBJ, "inbatch_loss.hip.o"))
+    obj = os.path.join(build.OBJ, "inbatch_loss.hip.o")
+    kernels = kernel_resources.kernels_of(obj)
     names = [k for k in kernels if "inbatch" in k]
-    assert len(names) >= 3 * 4 * 5 // 2  # scores + grad per (model, storage types), one reduce
+    assert len(names) >= 2 * 4 * 5  # forward + grad (two row shapes) per (model, storage types)
+    declared = []
     for name in names:
         f = kernels[name]
         # (scalar registers parked in VGPR lanes -- sgpr_spill_count -- touch no memory and are not scratch)
-        assert f["private_segment_fixed_size"] == 0 and f.get("vgpr_spill_count", 0) == 0, (name, f)
+        assert f.get("vgpr_spill_count", 0) == 0, (name, f)
+        if f["private_segment_fixed_size"] != 0:
+            assert f["private_segment_fixed_size"] <= 32 and "inbatch_grad_kernel" in name and "Li8EEEv" in name, (name, f)
+            declared.append(name)
+    if declared:
+        lines = kernel_resources.disassembly(obj)
+        starts = {i: l for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <", l)}
+        order = sorted(starts)
+        for name in declared:
+            begin = next(i for i in order if f"<{name}>" in starts[i])
+            end = next((i for i in order if i > begin), len(lines))
+            body = lines[begin:end]
+            assert len(body) > 500 and not [l for l in body if "scratch_" in l or "buffer_" in l], name
 
 
 def test_no_ranking_kernel_uses_scratch_memory(built_lib):
@@ -305,8 +334,10 @@ def test_no_ranking_kernel_uses_scratch_memory(built_lib):
     kernels = kernel_resources.kernels_of(build.OBJ)
     assert len(kernels) > 150
     nice = dict(zip(kernels, kernel_resources.demangle(list(kernels))))
+    # (+ the in-batch loss backward's wide-row shape: a reserved, never touched 20-byte slot -- the test above reads its disassembly)
     offenders = {nice[k]: f["private_segment_fixed_size"] for k, f in kernels.items()
-                 if f["private_segment_fixed_size"] != 0 and "score_fwd_kernel" not in nice[k]}
+                 if f["private_segment_fixed_size"] != 0 and "score_fwd_kernel" not in nice[k]
+                 and not ("inbatch_grad_kernel" in k and "Li8EEEv" in k)}
     assert not offenders, offenders
-    exempt = [nice[k] for k, f in kernels.items() if f["private_segment_fixed_size"] != 0]
+    exempt = [nice[k] for k, f in kernels.items() if f["private_segment_fixed_size"] != 0 and "inbatch_grad_kernel" not in k]
     assert all("score_fwd_kernel<" in n and "score_fwd_kernel<0>" not in n for n in exempt), exempt

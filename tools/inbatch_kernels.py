@@ -21,13 +21,14 @@ for name in (sys.argv[1:] or list(bench.INBATCH_SHAPES)):
     rel = (torch.randn(B, D, device=dev, generator=g) * 0.3).contiguous()
     neg_idx = torch.randint(0, 2 * B, (B, K, 2), device=dev, generator=g)
     loss = torch.empty((), device=dev)
-    pos, neg = torch.empty(_lib.inbatch_save_pos_floats(B), device=dev), torch.empty(B, K, device=dev)
+    pos, neg = torch.empty(_lib.inbatch_save_floats(_lib.MODEL_IDS[c["model"]], B, K, D), device=dev), torch.empty(B, K, device=dev)
+    ticket = torch.zeros(_lib.INBATCH_TICKET_INTS, dtype=torch.int32, device=dev)
     g_ent, g_rel, one = torch.empty_like(ent), torch.empty(B, D, device=dev), torch.ones((), device=dev)
     args = (_lib.MODEL_IDS[c["model"]], _lib.LOSS_IDS[c["loss"]], _lib.DTYPE_NAMES.index(c["dtype"]), 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for _ in range(300):
         _lib.check(L.blp_inbatch_loss_fwd_t(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
-                                            loss.data_ptr(), pos.data_ptr(), neg.data_ptr(), 0, stream), "fwd")
+                                            loss.data_ptr(), pos.data_ptr(), neg.data_ptr(), ticket.data_ptr(), 0, stream), "fwd")
         _lib.check(L.blp_inbatch_loss_bwd_t(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
                                             one.data_ptr(), pos.data_ptr(), neg.data_ptr(), g_ent.data_ptr(), g_rel.data_ptr(),
                                             0, stream), "bwd")
