@@ -72,21 +72,46 @@ def get_negative_sampling_indices(batch_size, num_negatives, repeats=1):
     return neg_idx.transpose_(0, 1)
 
 
-def get_negative_sampling_indices_on_device(batch_size, num_negatives, device, generator=None):
-    """Same distribution as get_negative_sampling_indices (repeats = 1), drawn directly on ``device``
-    with two randint calls -- no (B, 2B) weight matrix, no host-to-device copy per step (SURVEY.md 8f,
-    next-row 4).  The torch CUDA/HIP generator is a different stream than the CPU one, so the values
-    differ from the reference's for a given seed; the law is identical: for row b one of the two slots
-    is kept and the other is replaced by a slot drawn uniformly from the 2B - 2 slots of the other rows."""
-    b, k = batch_size, num_negatives
-    own = torch.arange(b, device=device).view(b, 1)
-    # uniform over the 2B - 2 slots not in row b: draw in [0, 2B - 2), skip the own pair {2b, 2b + 1}
-    draw = torch.randint(0, 2 * b - 2, (b, k), device=device, generator=generator)
-    replacement = draw + 2 * (draw >= 2 * own).long()
-    which = torch.randint(0, 2, (b, k), device=device, generator=generator)
-    pairs = torch.stack((2 * own, 2 * own + 1), dim=-1).expand(b, k, 2).clone()
+def negative_indices_from_draws(draw, which):
+    """The index construction of the in-batch sampler as a deterministic function of INTEGER draws, on whatever device they
+    live -- the checkable half of the device sampler (the other half is two torch.randint calls):
+
+        draw  (B, K) int64 in [0, 2B - 2): which of the 2B - 2 slots of the OTHER rows replaces a slot of row b -- counted in
+              slot order with row b's own pair {2b, 2b + 1} skipped (what the reference's multinomial over its (B, 2B) weight
+              matrix with the pair zeroed draws, data.py:57-61);
+        which (B, K) int64 in {0, 1}: the column of the pair that is replaced (the reference's randint, data.py:63);
+        ->    (B, K, 2) int64: row b's pair (2b, 2b + 1) with column which[b, k] replaced by the drawn slot (data.py:64-67).
+
+    oracle/ref_port.py restates it with Python loops; tests hold the two bit-for-bit on the GPU box, and invert the
+    reference's own golden indices (tests/golden/neg_sampling.npz) into draws that this function maps back onto them."""
+    b = draw.shape[0]
+    own = torch.arange(b, device=draw.device).view(b, 1)
+    replacement = draw + 2 * (draw >= 2 * own).long()   # skip the own pair
+    pairs = torch.stack((2 * own, 2 * own + 1), dim=-1).expand(b, draw.shape[1], 2).clone()
     pairs.scatter_(2, which.unsqueeze(-1), replacement.unsqueeze(-1))
     return pairs
+
+
+def draws_from_negative_indices(neg_idx):
+    """Inverse of negative_indices_from_draws on valid indices: (draw, which) of a (B, K, 2) index tensor."""
+    b = neg_idx.shape[0]
+    own = torch.arange(b, device=neg_idx.device).view(b, 1)
+    which = (neg_idx[..., 0] == 2 * own).long()  # column 0 intact -> column 1 is the replaced one (a drawn slot is never the row's own)
+    replaced = torch.where(which == 0, neg_idx[..., 0], neg_idx[..., 1])
+    return replaced - 2 * (replaced > 2 * own + 1).long(), which
+
+
+def get_negative_sampling_indices_on_device(batch_size, num_negatives, device, generator=None):
+    """Same distribution as get_negative_sampling_indices (repeats = 1), drawn directly on ``device``: two torch.randint calls
+    (the draws) + negative_indices_from_draws (the indices) -- no (B, 2B) weight matrix, no host-to-device copy per step
+    (SURVEY.md 8f, next-row 4).  The torch CUDA/HIP generator is a different stream than the CPU one, so the values
+    differ from the reference's for a given seed (why train.py keeps the reference's CPU sampler by default: a seeded run
+    reproduces the reference's indices); the law is identical: for row b one of the two slots is kept and the other is
+    replaced by a slot drawn uniformly from the 2B - 2 slots of the other rows."""
+    b, k = batch_size, num_negatives
+    draw = torch.randint(0, 2 * b - 2, (b, k), device=device, generator=generator)
+    which = torch.randint(0, 2, (b, k), device=device, generator=generator)
+    return negative_indices_from_draws(draw, which)
 
 
 class GraphDataset(Dataset):

@@ -115,3 +115,21 @@ def eval_batch(rel_model, table, heads, tails, rel_vecs, filter_mask=None):
         pred[filter_mask] = pred.min() - 1.0
         out["gt_filt"], out["ge_filt"], out["rr_filt"], out["hits_filt"] = rank_metrics(pred, true_idx)
     return out
+
+
+def neg_idx_from_draws(draw, which):
+    """The reference sampler's index construction (data.py:35-81) as plain loops over integer draws -- the checker of
+    blp_amd.data.negative_indices_from_draws.  Slots are numbered row-wise ([[0, 1], [2, 3], ...], data.py:52-53); the candidates
+    of row b are every slot except its own two (the (B, 2B) weight matrix with the pair zeroed, data.py:57-60), so draw d
+    names the d-th slot of [0 .. 2b - 1, 2b + 2 .. 2B - 1]; column `which` of the pair is replaced by it (data.py:63-67)."""
+    b, k = len(draw), len(draw[0])
+    out = []
+    for row in range(b):
+        candidates = [s for s in range(2 * b) if s // 2 != row]
+        rows = []
+        for j in range(k):
+            pair = [2 * row, 2 * row + 1]
+            pair[int(which[row][j])] = candidates[int(draw[row][j])]
+            rows.append(pair)
+        out.append(rows)
+    return torch.tensor(out, dtype=torch.long).reshape(b, k, 2)

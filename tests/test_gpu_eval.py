@@ -412,6 +412,26 @@ def test_generic_width_route_matches_oracle(rel_model, D, oracle):
 
 
 @pytest.mark.default_routing
+def test_device_sampler_indices_equal_the_restatement_bit_for_bit():
+    """train.py `device_sampler=True`: the draws are two torch.randint calls ON the GPU, the indices a deterministic function of
+    them (data.negative_indices_from_draws, torch ops on the device) -- held here against the plain-loop restatement of the
+    reference's construction (oracle/ref_port.py: neg_idx_from_draws, pinned on the CPU against the reference's own golden
+    indices) on the same integer draws, bit for bit; and the sampler itself is exactly randint + randint + that function."""
+    from blp_amd import data
+    from oracle import ref_port
+    for b, k, seed in ((2, 3, 0), (7, 64, 1), (64, 64, 2), (128, 16, 3)):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        draw = torch.randint(0, 2 * b - 2, (b, k), device="cuda", generator=g)
+        which = torch.randint(0, 2, (b, k), device="cuda", generator=g)
+        got = data.negative_indices_from_draws(draw, which)
+        assert got.is_cuda and got.dtype == torch.int64
+        want = ref_port.neg_idx_from_draws(draw.cpu().tolist(), which.cpu().tolist())
+        assert torch.equal(got.cpu(), want), (b, k)
+        g2 = torch.Generator(device="cuda").manual_seed(seed)
+        assert torch.equal(data.get_negative_sampling_indices_on_device(b, k, "cuda", generator=g2), got)
+
+
+@pytest.mark.default_routing
 def test_device_sampler_law_on_the_gpu():
     """data.get_negative_sampling_indices_on_device drawn on the GPU (what train.py `device_sampler=True` puts into
     collate_fn): the law of the reference's sampler (data.py:35-81) -- one slot of the pair kept, the other replaced

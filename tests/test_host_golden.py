@@ -43,6 +43,37 @@ def test_negative_sampling_properties(b, k, rep):
     assert torch.all(replaced // 2 != (torch.arange(b * rep) % b).unsqueeze(1))  # never the own row
 
 
+def test_sampler_index_construction_equals_the_reference_on_its_own_goldens():
+    """The device sampler = integer draws + a deterministic index construction (data.negative_indices_from_draws).  The
+    construction is held against the REFERENCE's sampler: every golden index tensor of the imported reference
+    (neg_sampling.npz, repeats = 1 cases: device-local indices) is inverted into (draw, which), and the construction maps the
+    draws back onto exactly those indices; the plain-loop restatement (oracle/ref_port.py: the checker used on the GPU box)
+    agrees with both."""
+    from oracle import ref_port
+    g = golden("neg_sampling")
+    checked = 0
+    for i in range(4):
+        b, k, rep, _ = (int(x) for x in g[f"case{i}_args"])
+        want = torch.from_numpy(g[f"case{i}_neg_idx"])
+        for r in range(rep):  # (a slice per device: indices local to the slice, data.py:289-298)
+            part = want[r * b:(r + 1) * b]
+            draw, which = data.draws_from_negative_indices(part)
+            assert int(draw.min()) >= 0 and int(draw.max()) < 2 * b - 2 and set(which.unique().tolist()) <= {0, 1}
+            assert torch.equal(data.negative_indices_from_draws(draw, which), part)
+            assert torch.equal(ref_port.neg_idx_from_draws(draw.tolist(), which.tolist()), part)
+            checked += part.numel()
+    assert checked > 8000
+    # and every possible draw of a small batch: the construction is a bijection onto the valid index pairs
+    b = 4
+    draw = torch.arange(2 * b - 2).repeat(b, 2)
+    which = torch.cat((torch.zeros(b, 2 * b - 2, dtype=torch.long), torch.ones(b, 2 * b - 2, dtype=torch.long)), dim=1)
+    idx = data.negative_indices_from_draws(draw, which)
+    assert torch.equal(idx, ref_port.neg_idx_from_draws(draw.tolist(), which.tolist()))
+    assert len({tuple(x) for x in idx[1].tolist()}) == 2 * (2 * b - 2)
+    d2, w2 = data.draws_from_negative_indices(idx)
+    assert torch.equal(d2, draw) and torch.equal(w2, which)
+
+
 def test_device_sampler_has_the_reference_law():
     """The on-device sampler keeps one slot, replaces the other from another row, uniformly."""
     g = torch.Generator().manual_seed(3)
