@@ -146,6 +146,23 @@ def _table_rows(t, name):
 SegmentFilter = collections.namedtuple("SegmentFilter", "seg_lo seg_hi values exclude ent2idx row_base")
 
 
+_selftested = set()
+
+
+def ensure_selftest(device, rel_model=None):
+    """The matrix-pipe self-test of ``device`` (include/blp_hip.h: blp_selftest), once per process and device, from HERE -- a
+    set-up step that waits for the stream -- so that no ranking call ever synchronises inside the C-ABI (which it would, under a
+    process-wide mutex, if the first bilinear block of a device found the verdict open).  TransE never needs it."""
+    if rel_model == "transe":
+        return
+    index = device.index if isinstance(device, torch.device) else int(device)
+    if index not in _selftested:
+        if torch.cuda.is_current_stream_capturing():  # (the test has to be waited for: the library then takes its provable pre-pass)
+            return
+        _lib.selftest(index, torch._C._cuda_getCurrentRawStream(index))
+        _selftested.add(index)
+
+
 def dim_supported(rel_model, dim):
     """True if the fused ranking kernels are compiled for this embedding width."""
     return bool(_lib.lib().blp_dim_supported(_lib.MODEL_IDS[rel_model], int(dim)))
@@ -215,6 +232,7 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
         raise ValueError("out must be a contiguous (Q, 4) int32 tensor")
     if Q == 0:
         return counts
+    ensure_selftest(dev, rel_model)
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
     ws_bytes = _rank_ws_bytes(L, model, N, D, q_head, Q - q_head)
@@ -308,6 +326,7 @@ def rank_all_shard(rel_model, table, source, fixed_row, rel_emb, rel_ids, q_head
         raise ValueError("out must be a contiguous (Q, 4) int32 tensor")
     if Q == 0:
         return counts
+    ensure_selftest(dev, rel_model)
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
     ws_bytes = _rank_ws_bytes(L, model, N, D, q_head, Q - q_head)
@@ -352,6 +371,7 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
         raise ValueError("out must be a contiguous (2 * num_triples, 4) int32 tensor")
     if Q == 0:
         return counts
+    ensure_selftest(dev, rel_model)
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
     ws_bytes = L.blp_rank_all_batches_t_workspace_bytes(model, tdt, N, D, ld, n, int(batch), int(block_triples))

@@ -650,9 +650,10 @@ def eval_link_prediction(model, triples_loader, text_dataset, entities, epoch, e
                 used_home = True
             else:
                 replicas.append(copy.deepcopy(model).to(d))
-        if index is not None:
-            for d in set(threads.devices):
-                if d.type == "cuda":
+        for d in set(threads.devices):
+            if d.type == "cuda":
+                ops.ensure_selftest(d, model.rel_model)  # (a set-up step that waits: here, not in whichever thread ranks first)
+                if index is not None:
                     index.device_arrays(d)  # moved once, here, not by whichever thread asks first
         world = threads.world
         _log.info(f"Evaluating on {world} device thread(s): {', '.join(str(d) for d in threads.devices)} ({threads.exchange} exchange)")

@@ -72,11 +72,13 @@ int blp_device_caps(int device, blp_caps *out);
  * and compares every accumulator with the exactly evaluated split sum against HALF of what the band allows.  A device
  * that fails is served by the f32-chain pre-pass (exact fused multiply-adds; its band needs no assumption) -- the results
  * are the same either way, only the speed differs.
- *   blp_selftest(device, stream)  runs it now if it has not run on `device` (allocates and frees 512 bytes, enqueues on
+ *   blp_selftest(device, stream)  runs it now if it has not run on `device` (allocates and frees 4 096 bytes, enqueues on
  *        `stream` and WAITS for it -- a set-up call, not to be captured into a graph); returns the verdict (1 / 2) or a
- *        negative status.  Optional: the first bilinear blp_rank_all* call on a device runs it by itself, with its
- *        workspace as scratch -- that ONE call synchronises `stream`; if `stream` is being captured the verdict stays
- *        open and that call takes the f32-chain pre-pass.
+ *        negative status.  CALL IT AT SET-UP (blp_amd.ops does, before the first bilinear ranking call of a device): a
+ *        caller that does not leaves it to the first bilinear blp_rank_all* call on the device, which then runs it by
+ *        itself with its workspace as scratch -- that ONE call holds a process-wide mutex and synchronises `stream`
+ *        (several threads making their first calls together are serialised by it); if `stream` is being captured the
+ *        verdict stays open and that call takes the f32-chain pre-pass.
  * This per-device verdict (an int, written once under a mutex) is the library's only process-wide state. */
 int blp_selftest(int device, void *stream);
 /* storage types of the arrays that may come in 16 bits (the in-batch loss' embeddings; the candidate table of
