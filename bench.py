@@ -112,7 +112,7 @@ WORKLOADS = {
     # Wikidata5M filtering graph is the evaluated split's own triples (train.py:381-393)
     "wikidata5m-transe": dict(model="transe", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0),
     "wikidata5m-complex": dict(model="complex", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0),
-    # the same batching against the 16-bit COPY of the table (include/blp_hip.h: blp_rank_all_batches_t; SURVEY 8f row 2: "emit
+    # the same batching against the 16-bit COPY of the table (include/blp_hip.h: blp_rank_all_batches; SURVEY 8f row 2: "emit
     # fp16 copy"): the candidates are the table's rows rounded to IEEE half, scored in f32 in the reference's order -- a
     # different INPUT, the same arithmetic; the pass reads half the bytes
     "wikidata5m-transe-f16": dict(model="transe", N=4_600_000, D=128, R=822, triples=128, block=2, edges=0, table_dtype="float16"),
@@ -411,7 +411,7 @@ class Job:
         n_local = self.hi - self.lo
         model_id = {"transe": 0, "distmult": 1, "complex": 2, "simple": 3}[self.cfg["model"]]
         from blp_amd import ops
-        return max(1, int(_lib.lib().blp_rank_all_batches_t_passes_per_launch(model_id, ops.TABLE_DTYPES[self.table_dtype], n_local, self.D,
+        return max(1, int(_lib.lib().blp_rank_all_batches_passes_per_launch(model_id, ops.TABLE_DTYPES[self.table_dtype], n_local, self.D,
                                                                                self.D, self.T, block, block)))
 
     def exchange_ms(self, reps):
@@ -919,9 +919,9 @@ def inbatch_bench(device, iters=200):
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
         def raw():
-            _lib.check(L.blp_inbatch_loss_fwd_t(*args, ent.data_ptr(), rel2.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+            _lib.check(L.blp_inbatch_loss_fwd(*args, ent.data_ptr(), rel2.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
                                                 loss.data_ptr(), pos.data_ptr(), neg.data_ptr(), ticket.data_ptr(), device.index, stream), "fwd")
-            _lib.check(L.blp_inbatch_loss_bwd_t(*args, ent.data_ptr(), rel2.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+            _lib.check(L.blp_inbatch_loss_bwd(*args, ent.data_ptr(), rel2.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
                                                 one.data_ptr(), pos.data_ptr(), neg.data_ptr(), g_ent.data_ptr(), g_rel.data_ptr(),
                                                 device.index, stream), "bwd")
 
@@ -1105,7 +1105,7 @@ def call_overhead(device, iters=3000):
     ws_bytes = L.blp_rank_all_workspace_bytes(0, 640, 128, 4, 4)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     stream = torch._C._cuda_getCurrentRawStream(device.index)
-    args = (0, table.data_ptr(), 640, 128, 128, qf.data_ptr(), qr.data_ptr(), None, true.data_ptr(), None, 4, 4, None, None,
+    args = (0, table.data_ptr(), 640, 128, 128, qf.data_ptr(), qr.data_ptr(), true.data_ptr(), None, 4, 4, None,
             out.data_ptr(), ws.data_ptr(), ws_bytes, device.index, stream)
     raw, _ = host_us(lambda: L.blp_rank_all(*args), iters)
     cfg = WORKLOADS["fb15k237-transe"]
@@ -1480,7 +1480,7 @@ def main():
             result["sub_results"], result["inbatch_loss"] = subs, inbatch
             result["call_overhead"] = call_overhead(device)
             result["table_build"] = table_build_bench(device)
-    if not args.no_hbm_probe and not args.workload.startswith("wikidata5m"):
+    if not args.no_hbm_probe and (default_line or not args.workload.startswith("wikidata5m")):
         if rank == 0:  # one GPU's HBM-bound operating point (the other ranks wait at the barrier below)
             result["hbm_probe"] = hbm_probe(device, events)
     if rank == 0:

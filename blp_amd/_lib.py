@@ -21,12 +21,11 @@ STATUS_NAMES = {0: "BLP_OK", -1: "BLP_ERR_BAD_ARG", -2: "BLP_ERR_UNSUPPORTED_DIM
 
 # every symbol include/blp_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_selftest", "blp_dim_supported",
-           "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_ex", "blp_rank_all_idx",
-           "blp_rank_all_shard", "blp_gather_triple_vectors", "blp_rank_all_batches", "blp_rank_all_batches_workspace_bytes",
-           "blp_rank_all_batches_passes_per_launch", "blp_rank_all_batches_t", "blp_rank_all_batches_t_workspace_bytes",
-           "blp_rank_all_batches_t_passes_per_launch", "blp_rank_all_batches_t_native", "blp_gather_triple_vectors_t", "blp_profile_next_rank_kernel", "blp_rank_all_prepass_stats", "blp_rank_from_scores", "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd",
-           "blp_score_bwd", "blp_inbatch_loss_save_floats", "blp_inbatch_loss_fwd_launches", "blp_inbatch_loss_fwd_t",
-           "blp_inbatch_loss_bwd_t", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows", "blp_dkrl_rows_supported", "blp_dkrl_rows",
+           "blp_rank_all_workspace_bytes", "blp_rank_all_supported", "blp_rank_all", "blp_rank_all_shard", "blp_gather_triple_vectors",
+           "blp_rank_all_batches", "blp_rank_all_batches_workspace_bytes", "blp_rank_all_batches_passes_per_launch",
+           "blp_rank_all_batches_native16", "blp_profile_next_rank_kernel", "blp_rank_all_prepass_stats", "blp_rank_from_scores",
+           "blp_rank_metrics", "blp_rank_metric_sums", "blp_score_fwd", "blp_score_bwd", "blp_inbatch_loss_save_floats",
+           "blp_inbatch_loss_fwd_launches", "blp_inbatch_loss_fwd", "blp_inbatch_loss_bwd", "blp_project_rows_supported", "blp_project_rows", "blp_bow_rows_supported", "blp_bow_rows", "blp_dkrl_rows_supported", "blp_dkrl_rows",
            "blp_build_queries")
 HOOK_SYMBOLS = ("blp_debug_set_knob", "blp_debug_gemm_dump", "blp_debug_reset_selftest")  # libblp_hip.hooks.so only
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
@@ -39,7 +38,7 @@ INBATCH_TICKET_INTS = 4  # BLP_INBATCH_TICKET_INTS of include/blp_hip.h
 
 
 def inbatch_save_floats(model_id, B, K, D):
-    """blp_inbatch_loss_save_floats: floats the `save_pos` argument of blp_inbatch_loss_fwd_t needs (positives' scores, partial
+    """blp_inbatch_loss_save_floats: floats the `save_pos` argument of blp_inbatch_loss_fwd needs (positives' scores, partial
     loss sums, the index of neg_idx the backward walks)."""
     return int(lib().blp_inbatch_loss_save_floats(int(model_id), int(B), int(K), int(D)))
 
@@ -125,8 +124,8 @@ def _load(path, hooks):
     L.blp_device_caps.argtypes = [_i, ctypes.POINTER(BlpCaps)]
     L.blp_rank_all_prepass_stats.restype = _i
     L.blp_rank_all_prepass_stats.argtypes = [_i, _i64, _i, _i64, _i64, _vp, _sz, ctypes.POINTER(ctypes.c_int64), _i, _vp]
-    L.blp_rank_all_batches_t_native.restype = _i
-    L.blp_rank_all_batches_t_native.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
+    L.blp_rank_all_batches_native16.restype = _i
+    L.blp_rank_all_batches_native16.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
     L.blp_selftest.restype = _i
     L.blp_selftest.argtypes = [_i, _vp]
     L.blp_dim_supported.restype = _i
@@ -136,35 +135,20 @@ def _load(path, hooks):
     L.blp_rank_all_supported.restype = _i
     L.blp_rank_all_supported.argtypes = [_i, _i, _i64, _i64]
     L.blp_rank_all.restype = _i
-    L.blp_rank_all.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
-                               _vp, _sz, _i, _vp]
-    L.blp_rank_all_ex.restype = _i
-    L.blp_rank_all_ex.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.POINTER(BlpFilter),
-                                  _vp, _vp, _sz, _i, _vp]
-    L.blp_rank_all_idx.restype = _i
-    L.blp_rank_all_idx.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, ctypes.POINTER(BlpFilter),
-                                   _vp, _vp, _sz, _i, _vp]
+    L.blp_rank_all.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.POINTER(BlpFilter),
+                               _vp, _vp, _sz, _i, _vp]
     L.blp_rank_all_shard.restype = _i
     L.blp_rank_all_shard.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
                                      ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
-    L.blp_rank_all_batches_workspace_bytes.restype = _sz
-    L.blp_rank_all_batches_workspace_bytes.argtypes = [_i, _i64, _i, _i64, _i64, _i64]
-    L.blp_rank_all_batches_passes_per_launch.restype = _i64
-    L.blp_rank_all_batches_passes_per_launch.argtypes = [_i, _i64, _i, _i64, _i64, _i64, _i64]
-    L.blp_rank_all_batches.restype = _i
-    L.blp_rank_all_batches.argtypes = [_i, _vp, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64,
-                                       ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
     L.blp_gather_triple_vectors.restype = _i
-    L.blp_gather_triple_vectors.argtypes = [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _i, _vp]
-    L.blp_gather_triple_vectors_t.restype = _i
-    L.blp_gather_triple_vectors_t.argtypes = [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _vp, _i, _vp]
-    L.blp_rank_all_batches_t_workspace_bytes.restype = _sz
-    L.blp_rank_all_batches_t_workspace_bytes.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
-    L.blp_rank_all_batches_t_passes_per_launch.restype = _i64
-    L.blp_rank_all_batches_t_passes_per_launch.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
-    L.blp_rank_all_batches_t.restype = _i
-    L.blp_rank_all_batches_t.argtypes = [_i, _vp, _i, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64,
-                                         ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
+    L.blp_gather_triple_vectors.argtypes = [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _vp, _i, _vp]
+    L.blp_rank_all_batches_workspace_bytes.restype = _sz
+    L.blp_rank_all_batches_workspace_bytes.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
+    L.blp_rank_all_batches_passes_per_launch.restype = _i64
+    L.blp_rank_all_batches_passes_per_launch.argtypes = [_i, _i, _i64, _i, _i64, _i64, _i64, _i64]
+    L.blp_rank_all_batches.restype = _i
+    L.blp_rank_all_batches.argtypes = [_i, _vp, _i, _i64, _i, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64,
+                                       ctypes.POINTER(BlpFilter), _vp, _vp, _sz, _i, _vp]
     L.blp_profile_next_rank_kernel.restype = _i
     L.blp_profile_next_rank_kernel.argtypes = [_vp, _vp]
     L.blp_rank_from_scores.restype = _i
@@ -183,10 +167,10 @@ def _load(path, hooks):
     L.blp_inbatch_loss_save_floats.argtypes = [_i, _i, _i, _i]
     L.blp_inbatch_loss_fwd_launches.restype = _i
     L.blp_inbatch_loss_fwd_launches.argtypes = [_i, _i, _i, _i, _f]
-    L.blp_inbatch_loss_fwd_t.restype = _i
-    L.blp_inbatch_loss_fwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp]
-    L.blp_inbatch_loss_bwd_t.restype = _i
-    L.blp_inbatch_loss_bwd_t.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
+    L.blp_inbatch_loss_fwd.restype = _i
+    L.blp_inbatch_loss_fwd.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp]
+    L.blp_inbatch_loss_bwd.restype = _i
+    L.blp_inbatch_loss_bwd.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                          _i, _vp]
     L.blp_build_queries.restype = _i
     L.blp_build_queries.argtypes = [ctypes.POINTER(BlpQueries), _i, _vp]

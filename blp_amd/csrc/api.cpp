@@ -156,7 +156,7 @@ static bool table_rows_aligned(const void* table, int dtype, int64_t ld) {
     return aligned16(table) && (ld & (dtype == BLP_DTYPE_F32 ? 3 : 7)) == 0;
 }
 
-int blp_gather_triple_vectors_t(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len, const void* table,
+int blp_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len, const void* table,
                                 int table_dtype, int64_t N, int D, int64_t ld, int64_t row_base, float* out, int device, void* stream) {
     if (!valid_table_dtype(table_dtype)) return fail(BLP_ERR_BAD_ARG, "blp_gather_triple_vectors: unknown table dtype %d", table_dtype);
     if (n < 0 || N < 0 || D <= 0 || (D & 3) || ld < D || n > (1ll << 40) || (ent2idx && ent2idx_len < 0))
@@ -171,11 +171,6 @@ int blp_gather_triple_vectors_t(const int64_t* triples, int64_t n, const int64_t
                                                        static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return hip_fail(err, "blp_gather_triple_vectors launch");
     return BLP_OK;
-}
-
-int blp_gather_triple_vectors(const int64_t* triples, int64_t n, const int64_t* ent2idx, int64_t ent2idx_len, const float* table,
-                              int64_t N, int D, int64_t ld, int64_t row_base, float* out, int device, void* stream) {
-    return blp_gather_triple_vectors_t(triples, n, ent2idx, ent2idx_len, table, BLP_DTYPE_F32, N, D, ld, row_base, out, device, stream);
 }
 
 int blp_project_rows_supported(int E, int D) { return blp::project_rows_supported(E, D) ? 1 : 0; }
@@ -358,14 +353,14 @@ static int rank_all_checked(int model, const float* table, int64_t N, int D, int
 
 extern "C" {
 
-int blp_rank_all_ex(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
-                    const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true,
-                    int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
-                    size_t workspace_bytes, int device, void* stream) {
+int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
+                 const float* q_rel, const int64_t* true_row, const float* q_true,
+                 int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
+                 size_t workspace_bytes, int device, void* stream) {
     blp::QRows truth;  // stays empty (-> BAD_ARG below, after the model / size checks) unless exactly one form is given
     if ((true_row == nullptr) != (q_true == nullptr))
         truth = true_row ? blp::QRows::rows_of(table, true_row, ld) : blp::QRows::dense(q_true, D);
-    return rank_all_checked(model, table, N, D, ld, blp::QRows::dense(q_fixed, D), blp::QRows::dense(q_rel, D), q_rel_id, truth,
+    return rank_all_checked(model, table, N, D, ld, blp::QRows::dense(q_fixed, D), blp::QRows::dense(q_rel, D), nullptr, truth,
                             q_head, q_tail, filter, counts, workspace, workspace_bytes, device, stream);
 }
 
@@ -383,12 +378,18 @@ int blp_rank_all_shard(int model, const float* table, int64_t N, int D, int64_t 
                             workspace_bytes, device, stream);
 }
 
-size_t blp_rank_all_batches_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch, int64_t block_triples) {
+static int64_t batches_f32_passes_per_launch(int model, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                             int64_t block_triples) {
+    if (!valid_model(model) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
+    return blp::rank_all_batches_passes_per_launch(model, D, N, ld, n_triples, batch, block_triples);
+}
+
+static size_t batches_f32_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch, int64_t block_triples) {
     if (!valid_model(model) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
     return blp::rank_all_batches_workspace_bytes(model, D, N, n_triples, batch, block_triples);
 }
 
-int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_t ld, const float* source, int64_t S,
+static int rank_all_batches_f32(int model, const float* table, int64_t N, int D, int64_t ld, const float* source, int64_t S,
                          int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, int64_t R, const int64_t* rel_id,
                          const int64_t* true_row, int64_t n_triples, int64_t batch, int64_t block_triples, const blp_filter* filter,
                          int32_t* counts, void* workspace, size_t workspace_bytes, int device, void* stream) {
@@ -435,14 +436,14 @@ int blp_rank_all_batches(int model, const float* table, int64_t N, int D, int64_
     return BLP_OK;
 }
 
-size_t blp_rank_all_batches_t_workspace_bytes(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+size_t blp_rank_all_batches_workspace_bytes(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
                                               int64_t block_triples) {
-    if (table_dtype == BLP_DTYPE_F32) return blp_rank_all_batches_workspace_bytes(model, N, D, n_triples, batch, block_triples);
+    if (table_dtype == BLP_DTYPE_F32) return batches_f32_workspace_bytes(model, N, D, n_triples, batch, block_triples);
     if (!valid_model(model) || !valid_table_dtype(table_dtype) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
     return blp::rank_all_batches16_workspace_bytes(model, D, N, ld, n_triples, batch, block_triples);
 }
 
-int blp_rank_all_batches_t_native(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+int blp_rank_all_batches_native16(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
                                   int64_t block_triples) {
     if (table_dtype == BLP_DTYPE_F32 || !valid_model(model) || !valid_table_dtype(table_dtype) || D <= 0 || N < 0 || n_triples < 0 ||
         batch <= 0 || block_triples < 0)
@@ -450,50 +451,50 @@ int blp_rank_all_batches_t_native(int model, int table_dtype, int64_t N, int D, 
     return blp::rank_all_batches_native16(model, D, N, ld, n_triples, batch, block_triples) ? 1 : 0;
 }
 
-int64_t blp_rank_all_batches_t_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+int64_t blp_rank_all_batches_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
                                                  int64_t block_triples) {
-    if (table_dtype == BLP_DTYPE_F32) return blp_rank_all_batches_passes_per_launch(model, N, D, ld, n_triples, batch, block_triples);
+    if (table_dtype == BLP_DTYPE_F32) return batches_f32_passes_per_launch(model, N, D, ld, n_triples, batch, block_triples);
     if (!valid_model(model) || !valid_table_dtype(table_dtype) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
     if (blp::rank_all_batches_native16(model, D, N, ld, n_triples, batch, block_triples)) return (n_triples + batch - 1) / batch;
     return n_triples <= batch ? 1 : blp::rank_all_batches_passes_per_launch(model, D, N, D, n_triples, batch, block_triples);
 }
 
-int blp_rank_all_batches_t(int model, const void* table, int table_dtype, int64_t N, int D, int64_t ld, const float* source, int64_t S,
+int blp_rank_all_batches(int model, const void* table, int table_dtype, int64_t N, int D, int64_t ld, const float* source, int64_t S,
                            int64_t ld_src, const int64_t* fixed_row, const float* rel_emb, int64_t R, const int64_t* rel_id,
                            const int64_t* true_row, int64_t n_triples, int64_t batch, int64_t block_triples, const blp_filter* filter,
                            int32_t* counts, void* workspace, size_t workspace_bytes, int device, void* stream) {
     if (table_dtype == BLP_DTYPE_F32)
-        return blp_rank_all_batches(model, static_cast<const float*>(table), N, D, ld, source, S, ld_src, fixed_row, rel_emb, R, rel_id,
+        return rank_all_batches_f32(model, static_cast<const float*>(table), N, D, ld, source, S, ld_src, fixed_row, rel_emb, R, rel_id,
                                     true_row, n_triples, batch, block_triples, filter, counts, workspace, workspace_bytes, device, stream);
-    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: unknown model %d", model);
-    if (!valid_table_dtype(table_dtype)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: unknown table dtype %d", table_dtype);
+    if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: unknown model %d", model);
+    if (!valid_table_dtype(table_dtype)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: unknown table dtype %d", table_dtype);
     if (n_triples < 0 || batch <= 0 || block_triples < 0 || N < 0 || ld < D)
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: bad sizes (n_triples=%lld batch=%lld N=%lld)", (long long)n_triples,
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: bad sizes (n_triples=%lld batch=%lld N=%lld)", (long long)n_triples,
                     (long long)batch, (long long)N);
     if (n_triples == 0) return BLP_OK;
     const int64_t per_block = n_triples <= batch ? n_triples : 1;
     if (!blp_rank_all_supported(model, D, per_block, per_block))
-        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_rank_all_batches_t: D = %d not supported (see blp_rank_all_supported)", D);
-    if (n_triples > (1ll << 40) || N >= (1ll << 31)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: n_triples > 2^40 or N >= 2^31");
+        return fail(BLP_ERR_UNSUPPORTED_DIM, "blp_rank_all_batches: D = %d not supported (see blp_rank_all_supported)", D);
+    if (n_triples > (1ll << 40) || N >= (1ll << 31)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: n_triples > 2^40 or N >= 2^31");
     if (block_triples > (1ll << 29) || (block_triples == 0 && batch > (1ll << 29)) || (n_triples <= batch && n_triples > (1ll << 29)))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: block_triples / batch > 2^29 (a pass ranks 2 x block_triples <= 2^30 queries)");
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: block_triples / batch > 2^29 (a pass ranks 2 x block_triples <= 2^30 queries)");
     if (!source || !fixed_row || !rel_id || !rel_emb || !true_row || !counts || R <= 0 || S <= 0 || (N > 0 && !table))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: NULL pointer, or R <= 0 / S <= 0");
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: NULL pointer, or R <= 0 / S <= 0");
     if (!table_rows_aligned(table, table_dtype, ld) || !aligned16(source) || !aligned16(rel_emb) || !aligned16(counts) || (ld_src & 3) ||
         ld_src < D || (D & 3))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: table rows (a 16-bit table: ld %% 8 == 0) / source / rel_emb / counts must be "
+        return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: table rows (a 16-bit table: ld %% 8 == 0) / source / rel_emb / counts must be "
                                      "16-byte aligned, D %% 4 == 0");
     blp::FilterSpec spec;
     if (filter) {
         if (!filter->seg_lo || !filter->seg_hi || !filter->values || (filter->ent2idx && filter->ent2idx_len < 0))
-            return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches_t: filter needs seg_lo, seg_hi and values");
+            return fail(BLP_ERR_BAD_ARG, "blp_rank_all_batches: filter needs seg_lo, seg_hi and values");
         spec.lo = filter->seg_lo; spec.hi = filter->seg_hi; spec.val = filter->values; spec.exclude = filter->exclude;
         spec.ent2idx = filter->ent2idx; spec.ent2idx_len = filter->ent2idx ? filter->ent2idx_len : 0;
         spec.row_base = filter->row_base;
     }
     const size_t need = blp::rank_all_batches16_workspace_bytes(model, D, N, ld, n_triples, batch, block_triples);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
-        return fail(BLP_ERR_WORKSPACE, "blp_rank_all_batches_t: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", need,
+        return fail(BLP_ERR_WORKSPACE, "blp_rank_all_batches: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", need,
                     workspace_bytes);
     DeviceGuard guard(device);
     if (guard.error() != hipSuccess) return hip_fail(guard.error(), "hipSetDevice");
@@ -504,39 +505,8 @@ int blp_rank_all_batches_t(int model, const void* table, int table_dtype, int64_
     hipError_t err = blp::launch_rank_all_batches16(model, D, table, table_dtype, N, ld, source, ld_src, fixed_row, rel_emb, rel_id, true_row,
                                                     n_triples, batch, block_triples, spec, counts, workspace, cu,
                                                     static_cast<hipStream_t>(stream), ev0, ev1);
-    if (err != hipSuccess) return hip_fail(err, "blp_rank_all_batches_t launch");
+    if (err != hipSuccess) return hip_fail(err, "blp_rank_all_batches launch");
     return BLP_OK;
-}
-
-int blp_rank_all_idx(int model, const float* table, int64_t N, int D, int64_t ld, const int64_t* fixed_row,
-                     const float* rel_emb, int64_t R, const int64_t* rel_id, const int64_t* true_row, int64_t q_head,
-                     int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace, size_t workspace_bytes,
-                     int device, void* stream) {
-    // the unsharded case: the queries' vectors are rows of the candidate table itself
-    return blp_rank_all_shard(model, table, N, D, ld, table, N, ld, fixed_row, rel_emb, R, rel_id, true_row, q_head, q_tail, filter,
-                              counts, workspace, workspace_bytes, device, stream);
-}
-
-int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, const float* q_fixed,
-                 const float* q_rel, const int64_t* q_rel_id, const int64_t* true_row, const float* q_true, int64_t q_head,
-                 int64_t q_tail, const int64_t* filt_rowptr, const int64_t* filt_col, int32_t* counts,
-                 void* workspace, size_t workspace_bytes, int device, void* stream) {
-    if ((filt_rowptr == nullptr) != (filt_col == nullptr))
-        return fail(BLP_ERR_BAD_ARG, "blp_rank_all: filt_rowptr and filt_col must both be given or both NULL");
-    blp_filter csr = {};
-    if (filt_rowptr) {  // CSR = segments [rowptr[q], rowptr[q + 1]) of a list of table rows
-        csr.seg_lo = filt_rowptr;
-        csr.seg_hi = filt_rowptr + 1;
-        csr.values = filt_col;
-    }
-    return blp_rank_all_ex(model, table, N, D, ld, q_fixed, q_rel, q_rel_id, true_row, q_true, q_head, q_tail,
-                           filt_rowptr ? &csr : nullptr, counts, workspace, workspace_bytes, device, stream);
-}
-
-int64_t blp_rank_all_batches_passes_per_launch(int model, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
-                                               int64_t block_triples) {
-    if (!valid_model(model) || D <= 0 || N < 0 || n_triples < 0 || batch <= 0 || block_triples < 0) return 0;
-    return blp::rank_all_batches_passes_per_launch(model, D, N, ld, n_triples, batch, block_triples);
 }
 
 int blp_profile_next_rank_kernel(void* start_event, void* stop_event) {
@@ -642,7 +612,7 @@ static int check_dtypes(const char* who, int ent_dtype, int rel_dtype) {
     return BLP_OK;
 }
 
-int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void* ent_embs,
+int blp_inbatch_loss_fwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent_embs,
                            const void* rel_vecs, const int64_t* neg_idx, int B, int K, int D, float regularizer,
                            float* out_loss, float* save_pos, float* save_neg, int32_t* ticket, int device, void* stream) {
     if (int rc = check_inbatch("blp_inbatch_loss_fwd", model, loss, ent_embs, rel_vecs, neg_idx, B, K, D)) return rc;
@@ -658,7 +628,7 @@ int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, co
     return BLP_OK;
 }
 
-int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void* ent_embs,
+int blp_inbatch_loss_bwd(int model, int loss, int ent_dtype, int rel_dtype, const void* ent_embs,
                            const void* rel_vecs, const int64_t* neg_idx, int B, int K, int D, float regularizer,
                            const float* grad_loss, const float* save_pos, const float* save_neg, void* grad_ent,
                            void* grad_rel, int device, void* stream) {

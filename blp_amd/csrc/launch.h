@@ -75,7 +75,7 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
                                    void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
                                    hipEvent_t ev_stop = nullptr);
 
-// ... with the candidate table in a 16-bit storage type (include/blp_hip.h: blp_rank_all_batches_t)
+// ... with the candidate table in a 16-bit storage type (include/blp_hip.h: blp_rank_all_batches)
 bool rank_all_batches_native16(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples);
 size_t rank_all_batches16_workspace_bytes(int model, int D, int64_t N, int64_t ld, int64_t n, int64_t batch, int64_t block_triples);
 hipError_t launch_rank_all_batches16(int model, int D, const void* table, int dtype, int64_t N, int64_t ld, const float* source,

@@ -1,7 +1,7 @@
 // torch_glue.cpp -- the autograd plumbing of the in-batch loss as a C++ torch extension (blp_amd/_torch_glue*.so).
 //
 // No kernel, no HIP call, no arithmetic: this file only moves what blp_amd/ops.py's Python autograd.Function moved -- tensor
-// pointers, sizes and the caller's stream -- into blp_inbatch_loss_fwd_t / _bwd_t of the C-ABI (include/blp_hip.h), which it
+// pointers, sizes and the caller's stream -- into blp_inbatch_loss_fwd / _bwd_t of the C-ABI (include/blp_hip.h), which it
 // reaches through function pointers handed over by blp_amd._lib (the library ctypes already loaded: one instance, no link
 // dependency).  Why it exists: LinkPrediction.compute_loss (models.py:51-70) is called once per training step, its
 // kernels take ~20 us, and a Python autograd.Function cost the caller 140 us per step around them (round 3: apply() +
@@ -191,7 +191,7 @@ at::Tensor inbatch_loss(const at::Tensor& ent_embs, const at::Tensor& rel_vecs, 
 
 PYBIND11_MODULE(_torch_glue, m) {
     m.doc() = "blp_amd: C++ autograd plumbing around the C-ABI's in-batch loss (no kernels here)";
-    m.def("bind", &bind, "hand over the addresses of blp_inbatch_loss_fwd_t, blp_inbatch_loss_bwd_t, blp_last_error, blp_inbatch_loss_save_floats");
+    m.def("bind", &bind, "hand over the addresses of blp_inbatch_loss_fwd, blp_inbatch_loss_bwd, blp_last_error, blp_inbatch_loss_save_floats");
     m.def("inbatch_loss", &inbatch_loss, py::call_guard<py::gil_scoped_release>(),
           "compute_loss on in-batch negatives: (ent_embs, rel_vecs, neg_idx, model_id, loss_id, regularizer, raw_stream) -> loss");
     m.def("autograd_floor", &autograd_floor, py::call_guard<py::gil_scoped_release>(),

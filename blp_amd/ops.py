@@ -183,8 +183,7 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     true_row (Q,) int64 rows of the true entities in ``table``  -- or -- q_true (Q, D) their vectors
     (sharded ranking).  filt_rowptr (Q+1,), filt_col (nnz,) int64: CSR of filtered rows per query -- or --
     filter: a SegmentFilter (slices of a FilterIndex on the device; no per-batch list).
-    rel_ids (Q,) int64, optional: the relation id of each query (equal id => identical q_rel row); accepted for
-    compatibility and ignored (include/blp_hip.h: q_rel_id), never changes a result.
+    rel_ids: accepted for compatibility and ignored (it was an optimisation hint of the C-ABI before 6.0.0).
     workspace: optional uint8 device tensor of >= rank_all_workspace_bytes(...) bytes to use as the call's scratch (a caller
     that wants to look at it afterwards: prepass_stats); default: this module's own.
     Returns counts (Q, 4) int32: gt, ge, gt_filtered, ge_filtered.
@@ -242,21 +241,22 @@ def rank_all(rel_model, table, q_fixed, q_rel, q_head, true_row=None, q_true=Non
     elif not workspace.is_cuda or workspace.dtype != torch.uint8 or workspace.numel() < ws_bytes or workspace.data_ptr() % 256:
         raise ValueError(f"workspace must be a 256-byte aligned uint8 device tensor of >= {ws_bytes} bytes")
     if filter is not None:
-        status = L.blp_rank_all_ex(model, table.data_ptr(), N, D, table.stride(0) if N > 0 else D, q_fixed.data_ptr(),
-                                   q_rel.data_ptr(), _addr(rel_ids), _addr(true_row), _addr(q_true), q_head, Q - q_head,
-                                   _filter_spec(filter, Q, dev), counts.data_ptr(), workspace.data_ptr(), ws_bytes, dev.index, stream)
+        spec = _filter_spec(filter, Q, dev)
+    elif filt_rowptr is not None:  # a CSR is the segment form with seg_lo = rowptr, seg_hi = rowptr + 1, values = col
+        csr = _lib.BlpFilter(filt_rowptr.data_ptr(), filt_rowptr.data_ptr() + 8, filt_col.data_ptr(), None, None, 0, 0)
+        spec = ctypes.byref(csr)
     else:
-        status = L.blp_rank_all(model, table.data_ptr(), N, D, table.stride(0) if N > 0 else D, q_fixed.data_ptr(),
-                                q_rel.data_ptr(), _addr(rel_ids), _addr(true_row), _addr(q_true), q_head, Q - q_head,
-                                _addr(filt_rowptr), _addr(filt_col), counts.data_ptr(), workspace.data_ptr(), ws_bytes,
-                                dev.index, stream)
+        spec = None
+    status = L.blp_rank_all(model, table.data_ptr(), N, D, table.stride(0) if N > 0 else D, q_fixed.data_ptr(), q_rel.data_ptr(),
+                            _addr(true_row), _addr(q_true), q_head, Q - q_head, spec, counts.data_ptr(), workspace.data_ptr(),
+                            ws_bytes, dev.index, stream)
     if status:
         _lib.check(status, "blp_rank_all")
     return counts
 
 
 def table16_is_read_directly(rel_model, dtype, N, D, n_triples, batch, block_triples=None, ld=None):
-    """include/blp_hip.h: blp_rank_all_batches_t_native -- True if rank_all_batches over a float16 / bfloat16 table of these sizes
+    """include/blp_hip.h: blp_rank_all_batches_native16 -- True if rank_all_batches over a float16 / bfloat16 table of these sizes
     streams the 16-bit rows themselves (half the bytes per pass); False if the library would widen the table to f32 first.
     ``ld``: the row stride (elements) the call will be made with; default = what rank_all_batches passes for a contiguous
     ``table.to(dtype)`` copy (D, or D padded to a multiple of 8 by _table_rows when D % 8 != 0)."""
@@ -264,7 +264,7 @@ def table16_is_read_directly(rel_model, dtype, N, D, n_triples, batch, block_tri
         return False
     if ld is None:
         ld = (D + 7) // 8 * 8
-    return bool(_lib.lib().blp_rank_all_batches_t_native(_lib.MODEL_IDS[rel_model], TABLE_DTYPES[dtype], int(N), int(D), ld, int(n_triples),
+    return bool(_lib.lib().blp_rank_all_batches_native16(_lib.MODEL_IDS[rel_model], TABLE_DTYPES[dtype], int(N), int(D), ld, int(n_triples),
                                                          int(batch), int(batch if block_triples is None else block_triples)))
 
 
@@ -293,7 +293,7 @@ def prepass_stats(rel_model, N, D, q_head, q_tail, workspace):
 
 
 def rank_all_idx(rel_model, table, fixed_row, rel_emb, rel_ids, q_head, true_row, filter=None, out=None):
-    """rank_all with the queries left as INDICES (blp_rank_all_idx): query q's fixed-entity vector is row
+    """rank_all with the queries left as INDICES (blp_rank_all_shard with source == table): query q's fixed-entity vector is row
     ``fixed_row[q]`` of ``table``, its relation vector row ``rel_ids[q]`` of ``rel_emb`` (R, D) -- what the reference
     gathers into ``ent_emb[tails]`` / ``rel_emb(rels)`` (train.py:141-145), un-gathered: no (Q, D) arrays are built or
     streamed.  All indices must be in range (build_queries clamps and flags bad ids).  Same counts as rank_all."""
@@ -352,7 +352,7 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
     batch, the reference's own pass structure, issued back to back by the library)."""
     source = table if source is None else source
     _require_device(table, source, fixed_row, rel_emb, rel_ids, true_row)
-    # (a 16-bit table -- float16 / bfloat16, blp_rank_all_batches_t --: the candidates only; `source`, the queries' own
+    # (a 16-bit table -- float16 / bfloat16 --: the candidates only; `source`, the queries' own
     #  vectors, is float32: gather_triple_vectors widens them)
     table, rel_emb = _table_rows(table, "table"), _f32_rows(rel_emb, "rel_emb").contiguous()
     if source is table and table.dtype != torch.float32:
@@ -374,16 +374,16 @@ def rank_all_batches(rel_model, table, fixed_row, rel_emb, rel_ids, true_row, nu
     ensure_selftest(dev, rel_model)
     L = _lib.lib()
     model = _lib.MODEL_IDS[rel_model]
-    ws_bytes = L.blp_rank_all_batches_t_workspace_bytes(model, tdt, N, D, ld, n, int(batch), int(block_triples))
+    ws_bytes = L.blp_rank_all_batches_workspace_bytes(model, tdt, N, D, ld, n, int(batch), int(block_triples))
     stream = torch._C._cuda_getCurrentRawStream(dev.index)
     workspace = _workspace(dev, stream, ws_bytes)
     spec = None if filter is None else _filter_spec(filter, Q, dev)
-    status = L.blp_rank_all_batches_t(model, table.data_ptr(), tdt, N, D, ld, source.data_ptr(), source.shape[0],
+    status = L.blp_rank_all_batches(model, table.data_ptr(), tdt, N, D, ld, source.data_ptr(), source.shape[0],
                                       source.stride(0) if source.shape[0] > 1 else D, fixed_row.data_ptr(), rel_emb.data_ptr(), rel_emb.shape[0],
                                       rel_ids.data_ptr(), true_row.data_ptr(), n, int(batch), int(block_triples), spec, counts.data_ptr(),
                                       workspace.data_ptr(), ws_bytes, dev.index, stream)
     if status:
-        _lib.check(status, "blp_rank_all_batches_t")
+        _lib.check(status, "blp_rank_all_batches")
     return counts
 
 
@@ -400,7 +400,7 @@ def gather_triple_vectors(triples, ent2idx, table, row_base=0):
     if ent2idx is not None:
         ent2idx = ent2idx.to(torch.int64).contiguous()
     ld = table.stride(0) if tdt or N > 1 else D
-    status = _lib.lib().blp_gather_triple_vectors_t(_ptr(triples), n, _ptr(ent2idx), 0 if ent2idx is None else ent2idx.shape[0],
+    status = _lib.lib().blp_gather_triple_vectors(_ptr(triples), n, _ptr(ent2idx), 0 if ent2idx is None else ent2idx.shape[0],
                                                     _ptr(table), tdt, N, D, ld, int(row_base), _ptr(out),
                                                     table.device.index, _stream(table.device))
     _lib.check(status, "blp_gather_triple_vectors")
@@ -758,7 +758,7 @@ class _InBatchLoss(torch.autograd.Function):
         pos = torch.empty(_lib.inbatch_save_floats(_lib.MODEL_IDS[rel_model], B, K, D), dtype=torch.float32, device=dev)
         neg = torch.empty((B, K), dtype=torch.float32, device=dev)
         stream = torch._C._cuda_getCurrentRawStream(dev.index)
-        status = _lib.lib().blp_inbatch_loss_fwd_t(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
+        status = _lib.lib().blp_inbatch_loss_fwd(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
                                                    _ptr(ent), _ptr(rel), _ptr(idx), B, K, D, float(regularizer),
                                                    _ptr(loss), _ptr(pos), _ptr(neg), _ptr(inbatch_ticket(dev, stream)), dev.index, stream)
         _lib.check(status, "blp_inbatch_loss_fwd")
@@ -774,7 +774,7 @@ class _InBatchLoss(torch.autograd.Function):
         grad_loss = grad_loss.to(torch.float32).contiguous()
         grad_ent = torch.empty((B, 2, D), dtype=ent.dtype, device=dev)
         grad_rel = torch.empty((B, D), dtype=rel.dtype, device=dev)
-        status = _lib.lib().blp_inbatch_loss_bwd_t(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
+        status = _lib.lib().blp_inbatch_loss_bwd(_lib.MODEL_IDS[rel_model], _lib.LOSS_IDS[loss_fn], *dtypes,
                                                    _ptr(ent), _ptr(rel), _ptr(idx), B, K, D, regularizer,
                                                    _ptr(grad_loss), _ptr(pos), _ptr(neg), _ptr(grad_ent),
                                                    _ptr(grad_rel), dev.index, _stream(dev))
@@ -797,7 +797,7 @@ def torch_glue():
             if getattr(g, "abi_version", 0) // 10000 != L.blp_version() // 10000:  # a stale build against an older header
                 raise ImportError(f"blp_amd/_torch_glue.so was built for include/blp_hip.h {getattr(g, 'abi_version', '< 6.0.0')}, the library is "
                                   f"{L.blp_version()}; rebuild with python -m blp_amd.build")
-            g.bind(*(ctypes.cast(fn, ctypes.c_void_p).value for fn in (L.blp_inbatch_loss_fwd_t, L.blp_inbatch_loss_bwd_t, L.blp_last_error,
+            g.bind(*(ctypes.cast(fn, ctypes.c_void_p).value for fn in (L.blp_inbatch_loss_fwd, L.blp_inbatch_loss_bwd, L.blp_last_error,
                                                                        L.blp_inbatch_loss_save_floats)))
             _glue_module = g
         except Exception as exc:  # not built, another torch, a stale build, a failed bind: the Python autograd.Function serves

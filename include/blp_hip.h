@@ -32,7 +32,8 @@ extern "C" {
 #endif
 
 #define BLP_HIP_VERSION 60000 /* major*10000 + minor*100 + patch; 6.0.0: the in-batch loss in two launches (fwd takes a ticket
-                                 counter, save_pos sized by blp_inbatch_loss_save_floats), entry points pruned */
+                                 counter, save_pos sized by blp_inbatch_loss_save_floats); entry points pruned: ONE form per
+                                 operation (storage-typed, filter as blp_filter), q_rel_id gone */
 
 typedef enum blp_status {
     BLP_OK = 0,
@@ -82,7 +83,7 @@ int blp_device_caps(int device, blp_caps *out);
  * This per-device verdict (an int, written once under a mutex) is the library's only process-wide state. */
 int blp_selftest(int device, void *stream);
 /* storage types of the arrays that may come in 16 bits (the in-batch loss' embeddings; the candidate table of
- * blp_rank_all_batches_t) */
+ * blp_rank_all_batches) */
 enum { BLP_DTYPE_F32 = 0, BLP_DTYPE_F16 = 1, BLP_DTYPE_BF16 = 2 };
 
 /* 1 if kernels are compiled for embedding width D of `model` (D % 32 == 0, D <= 256; the
@@ -111,23 +112,18 @@ int blp_dim_supported(int model, int D);
  *   table      (N, D) f32, row stride ld floats (ld % 4 == 0, 16-byte aligned base)
  *   q_fixed    (Q, D) f32  the entity kept fixed (tail_embs for head queries, head_embs for tail)
  *   q_rel      (Q, D) f32  rel_emb(rels)
- *   q_rel_id   (Q) int64   OPTIONAL (may be NULL) relation id of each query (`rels`, train.py:132).
- *                          Contract: queries with equal ids have identical q_rel rows.  Accepted and ignored since
- *                          version 3.0.0 (rounds 1-2 let head-replacing TransE queries of one relation share e + r in
- *                          the exact f32 kernel; the second tile copy cost that kernel its registers).  Never changed a
- *                          result.
  *   true_row   (Q) int64   row of the true entity in `table` (true_ents, train.py:150), or NULL
  *   q_true     (Q, D) f32  the true entity's vector, used when true_row == NULL (candidate-axis
  *                          sharding: the true row may live in another shard).  Exactly one of
  *                          true_row / q_true is non-NULL.
- *   filt_rowptr (Q+1) int64, filt_col (nnz) int64: CSR of table rows that the filtered setting
- *                          removes for each query (the True entries of utils.get_triple_filters'
- *                          mask, utils.py:46-83); NULL/NULL = no filtering (filtered == raw).
- *                          Each row at most once per query (a mask bit is set once however many
- *                          parallel edges the graph has), never the true entity (utils.py:71,78);
- *                          blp_amd.utils.FilterIndex produces exactly that.  Entries outside [0, N)
- *                          are ignored, so a candidate shard holding global rows [lo, lo + N) takes
- *                          the global CSR with lo subtracted from every entry.
+ *   filter     a blp_filter (below): the table rows the filtered setting removes for each query (the True entries of
+ *                          utils.get_triple_filters' mask, utils.py:46-83) as segments of a sorted index of the filtering
+ *                          graph -- or as a plain CSR (seg_lo = rowptr, seg_hi = rowptr + 1, values = col, the rest
+ *                          NULL / 0); NULL = no filtering (filtered == raw).  Each row at most once per query (a mask
+ *                          bit is set once however many parallel edges the graph has), never the true entity
+ *                          (utils.py:71,78); blp_amd.utils.FilterIndex produces exactly that.  Rows outside [0, N) are
+ *                          ignored, so a candidate shard holding global rows [lo, lo + N) takes the global filter
+ *                          with row_base = lo.
  *   counts     (Q, 4) int32 OUT: {#(pred > true), #(pred >= true), same two over the
  *                          non-filtered candidates}.  Overwritten.  With the candidate axis
  *                          sharded, per-shard counts add up to the unsharded ones.
@@ -141,13 +137,7 @@ size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head,
  * TransE at any D % 4 == 0, D <= 1024 (the 300 / 768-wide bag-of-words and DKRL encoders, models.py:118-135,
  * 165-172).  Otherwise callers use blp_score_fwd + blp_rank_from_scores. */
 int blp_rank_all_supported(int model, int D, int64_t q_head, int64_t q_tail);
-int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
-                 const float *q_fixed, const float *q_rel, const int64_t *q_rel_id, const int64_t *true_row,
-                 const float *q_true, int64_t q_head, int64_t q_tail,
-                 const int64_t *filt_rowptr, const int64_t *filt_col, int32_t *counts,
-                 void *workspace, size_t workspace_bytes, int device, void *stream);
-
-/* The same call with the filter given as SEGMENTS of a sorted index of the filtering graph, so that
+/* The filter of a ranking call: SEGMENTS of a sorted index of the filtering graph, so that
  * utils.get_triple_filters (utils.py:46-83: a Python walk over a networkx graph per batch, then a dense
  * (2B, N) mask copied to the device) needs no per-batch list at all:
  *   the graph's edges are sorted once by key (head, rel) with value tail -- and by (tail, rel) with value
@@ -158,7 +148,8 @@ int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
  *   ent2idx_len) = not a candidate (utils.py:72,79); NULL = the values are table rows already;
  *   row_base is subtracted from every row and rows outside [0, N) are skipped (a candidate shard).
  * A value may occur once per segment (parallel edges collapsed when the index is built).
- * The CSR of blp_rank_all is the special case seg_lo = rowptr, seg_hi = rowptr + 1, values = col.
+ * A CSR (rowptr (Q + 1), col (nnz) of table rows) is the special case seg_lo = rowptr, seg_hi = rowptr + 1, values = col,
+ * exclude = ent2idx = NULL, row_base = 0.
  * filter == NULL: no filtering. */
 typedef struct blp_filter {
     const int64_t *seg_lo;   /* (Q) */
@@ -169,25 +160,16 @@ typedef struct blp_filter {
     int64_t ent2idx_len;
     int64_t row_base;
 } blp_filter;
-int blp_rank_all_ex(int model, const float *table, int64_t N, int D, int64_t ld,
-                    const float *q_fixed, const float *q_rel, const int64_t *q_rel_id, const int64_t *true_row,
-                    const float *q_true, int64_t q_head, int64_t q_tail, const blp_filter *filter,
-                    int32_t *counts, void *workspace, size_t workspace_bytes, int device, void *stream);
+int blp_rank_all(int model, const float *table, int64_t N, int D, int64_t ld,
+                 const float *q_fixed, const float *q_rel, const int64_t *true_row, const float *q_true,
+                 int64_t q_head, int64_t q_tail, const blp_filter *filter, int32_t *counts,
+                 void *workspace, size_t workspace_bytes, int device, void *stream);
 
-/* The same with the queries given as INDICES instead of vectors: query q's fixed-entity vector is row fixed_row[q] of
- * `table` itself, its relation vector row rel_id[q] of rel_emb (R, D) f32 contiguous -- exactly what the reference
- * gathers, `ent_emb[tails]` / `ent_emb[heads]` / `rel_emb(rels)` (train.py:141-145), left un-gathered.  No (Q, D) query
- * arrays exist: the prep, true-key, refinement and filter kernels read the rows out of the cache-resident tables
- * instead of streaming 2 x Q x D x 4 bytes each.  Same arithmetic, same counts.  The true entity is a row
- * (true_row).  fixed_row / rel_id / true_row (Q,) int64 on the device, every entry in range -- the library cannot
- * check device data (blp_build_queries clamps and flags bad ids). */
-int blp_rank_all_idx(int model, const float *table, int64_t N, int D, int64_t ld, const int64_t *fixed_row,
-                     const float *rel_emb, int64_t R, const int64_t *rel_id, const int64_t *true_row,
-                     int64_t q_head, int64_t q_tail, const blp_filter *filter, int32_t *counts,
-                     void *workspace, size_t workspace_bytes, int device, void *stream);
-
-/* The same for ONE SHARD OF THE CANDIDATE AXIS (the north_star's multi-GPU layout: the entity table partitioned by rows over
- * the ranks, every rank ranking every query against its own rows).  `table` is this rank's shard -- global rows
+/* The same with the queries given as INDICES instead of vectors, for ONE SHARD OF THE CANDIDATE AXIS (the north_star's
+ * multi-GPU layout: the entity table partitioned by rows over the ranks, every rank ranking every query against its own
+ * rows) -- or, with source == table, for the whole table: query q's fixed-entity vector is row fixed_row[q] of `source`, its
+ * relation vector row rel_id[q] of rel_emb (R, D) f32 contiguous -- exactly what the reference gathers into ent_emb[tails] /
+ * rel_emb(rels) (train.py:141-145), un-gathered: no (Q, D) arrays are built or streamed.  `table` is this rank's shard -- global rows
  * [row_base, row_base + N), the CANDIDATES -- while the queries' own vectors, the fixed entity and the true entity of every
  * triple, are rows of a second array `source` (S, D), row stride ld_src, that every rank holds in full: either the whole
  * table (small tables: one all-gather per evaluation) or the vectors of the entities that occur in the triples
@@ -195,7 +177,7 @@ int blp_rank_all_idx(int model, const float *table, int64_t N, int D, int64_t ld
  * reference's `ent_emb[tails]`, `ent_emb[heads]`, `rel_emb(rels)` (train.py:141-145) stay un-gathered, `true_ents`
  * (train.py:150) becomes the true entity's score from its vector, and the filter's row_base keeps the rows of other shards
  * out (blp_filter).  Per-shard counts add up exactly to the unsharded counts: one all-gather of (Q, 4) int32 + a sum is
- * the only exchange after the ranking.  blp_rank_all_idx is the case source == table, S == N, ld_src == ld.
+ * the only exchange after the ranking.  The unsharded case: source == table, S == N, ld_src == ld.
  * Workspace: blp_rank_all_workspace_bytes(model, N, D, q_head, q_tail). */
 int blp_rank_all_shard(int model, const float *table, int64_t N, int D, int64_t ld, const float *source, int64_t S,
                        int64_t ld_src, const int64_t *fixed_row, const float *rel_emb, int64_t R, const int64_t *rel_id,
@@ -212,47 +194,39 @@ int blp_rank_all_shard(int model, const float *table, int64_t N, int D, int64_t 
  * whole batches; [all heads | all tails]: the throughput-bound kernels) and the counts scattered back: 3.1 ms instead of
  * 827 calls x 29 us for the FB15k-237 test set.  block_triples <= batch keeps one ranking pass per batch -- the reference's
  * own pass structure (one read of the table per eval_batch_size triples), issued back to back without a host round trip.
- * Workspace: blp_rank_all_batches_workspace_bytes(model, N, D, n_triples, batch, block_triples), 256-B aligned. */
-size_t blp_rank_all_batches_workspace_bytes(int model, int64_t N, int D, int64_t n_triples, int64_t batch, int64_t block_triples);
-int blp_rank_all_batches(int model, const float *table, int64_t N, int D, int64_t ld, const float *source, int64_t S,
-                         int64_t ld_src, const int64_t *fixed_row, const float *rel_emb, int64_t R, const int64_t *rel_id,
-                         const int64_t *true_row, int64_t n_triples, int64_t batch, int64_t block_triples,
-                         const blp_filter *filter, int32_t *counts, void *workspace, size_t workspace_bytes, int device,
-                         void *stream);
-
-/* THE SAME WITH THE CANDIDATE TABLE IN A 16-BIT STORAGE TYPE.  The table build can emit a half-precision copy of the entity
- * table next to the f32 one (train.py:96-121 builds `ent_emb` once per evaluation); `table` (N, D) is then IEEE half
- * (BLP_DTYPE_F16) or bfloat16 (BLP_DTYPE_BF16), row stride ld ELEMENTS, ld % 8 == 0, 16-byte aligned; BLP_DTYPE_F32 is
- * blp_rank_all_batches itself.  A 16-bit element widens to f32 exactly: every kernel widens first and then runs the f32
- * arithmetic of the reference in the reference's order, so the counts are what blp_rank_all_batches returns for the table
- * widened to f32, bit for bit.  `source` stays f32 -- the queries' own vectors, which the caller widens along with gathering
- * them (blp_gather_triple_vectors_t; they are a few thousand rows) -- as does everything else.
- * What the 16-bit copy buys: the reference's Wikidata5M batching (eval_batch_size = 2: 4 queries per pass over 4.6 M rows,
- * scripts/blp-*-wikidata5m.sh:18) is one read of the table per batch, HBM-bound; with block_triples <= batch <= 4 and
- * D = 128 or 256 the passes read the 16-bit table AS IT IS (half the bytes per pass; all passes in one launch).  Any other
+ *
+ * THE CANDIDATE TABLE MAY COME IN A 16-BIT STORAGE TYPE.  The table build can emit a half-precision copy of the entity table
+ * next to the f32 one (train.py:96-121 builds `ent_emb` once per evaluation); `table` (N, D) is f32 (BLP_DTYPE_F32, row
+ * stride ld floats, ld % 4 == 0), IEEE half (BLP_DTYPE_F16) or bfloat16 (BLP_DTYPE_BF16; row stride ld ELEMENTS, ld % 8 ==
+ * 0), 16-byte aligned.  A 16-bit element widens to f32 exactly: every kernel widens first and then runs the f32 arithmetic
+ * of the reference in the reference's order, so the counts are those of the table widened to f32, bit for bit.  `source`
+ * stays f32 -- the queries' own vectors, which the caller widens along with gathering them (blp_gather_triple_vectors; they
+ * are a few thousand rows) -- as does everything else.  What the 16-bit copy buys: the reference's Wikidata5M batching
+ * (eval_batch_size = 2: 4 queries per pass over 4.6 M rows, scripts/blp-*-wikidata5m.sh:18) is one read of the table per
+ * batch, HBM-bound; with block_triples <= batch <= 4 and D = 128 or 256 the passes read the 16-bit table AS IT IS (half the
+ * bytes per pass; all passes in one launch: blp_rank_all_batches_native16 says whether a call is such a one).  Any other
  * shape of call -- bound by arithmetic, not by the table read -- ranks a widened f32 copy made inside the call (the workspace
- * holds it: N x D x 4 bytes more).  Workspace: blp_rank_all_batches_t_workspace_bytes(...), 256-B aligned. */
-size_t blp_rank_all_batches_t_workspace_bytes(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
-                                              int64_t batch, int64_t block_triples);
-int blp_rank_all_batches_t(int model, const void *table, int table_dtype, int64_t N, int D, int64_t ld, const float *source,
-                           int64_t S, int64_t ld_src, const int64_t *fixed_row, const float *rel_emb, int64_t R,
-                           const int64_t *rel_id, const int64_t *true_row, int64_t n_triples, int64_t batch,
-                           int64_t block_triples, const blp_filter *filter, int32_t *counts, void *workspace,
-                           size_t workspace_bytes, int device, void *stream);
+ * holds it: N x D x 4 bytes more; a caller that has the f32 table should rank that one instead; blp_amd.ranking does).
+ * Workspace: blp_rank_all_batches_workspace_bytes(...), 256-B aligned. */
+size_t blp_rank_all_batches_workspace_bytes(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
+                                            int64_t batch, int64_t block_triples);
+int blp_rank_all_batches(int model, const void *table, int table_dtype, int64_t N, int D, int64_t ld, const float *source,
+                         int64_t S, int64_t ld_src, const int64_t *fixed_row, const float *rel_emb, int64_t R,
+                         const int64_t *rel_id, const int64_t *true_row, int64_t n_triples, int64_t batch,
+                         int64_t block_triples, const blp_filter *filter, int32_t *counts, void *workspace,
+                         size_t workspace_bytes, int device, void *stream);
+int blp_rank_all_batches_native16(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
+                                  int64_t block_triples);
 
 /* Producer of `source` for big tables: out (2n, D) f32 contiguous, out[t] = the vector of triple t's head, out[n + t] = of
  * its tail (train.py:141-142's `ent_emb[heads]` / `ent_emb[tails]` for the whole set of triples), filled only for the
  * entities whose global row ent2idx[id] (NULL: the id itself) lies in this shard's [row_base, row_base + N) and ZERO
  * otherwise -- so that one all-reduce (sum) over the ranks replicates all 2n vectors exactly (x + 0 = x).  With
- * blp_queries.by_position the queries then index this array. */
+ * blp_queries.by_position the queries then index this array.  `table` in any storage type (table_dtype: BLP_DTYPE_*; a 16-bit
+ * table: ld % 8 == 0); out stays f32: the vectors are widened exactly. */
 int blp_gather_triple_vectors(const int64_t *triples, int64_t n, const int64_t *ent2idx, int64_t ent2idx_len,
-                              const float *table, int64_t N, int D, int64_t ld, int64_t row_base, float *out, int device,
-                              void *stream);
-/* ... from a table of any storage type (table_dtype: BLP_DTYPE_*; a 16-bit table: ld % 8 == 0); out stays f32: the
- * vectors are widened exactly. */
-int blp_gather_triple_vectors_t(const int64_t *triples, int64_t n, const int64_t *ent2idx, int64_t ent2idx_len,
-                                const void *table, int table_dtype, int64_t N, int D, int64_t ld, int64_t row_base, float *out,
-                                int device, void *stream);
+                              const void *table, int table_dtype, int64_t N, int D, int64_t ld, int64_t row_base, float *out,
+                              int device, void *stream);
 
 /* Measurement aid (bench.py): the NEXT blp_rank_all issued by the calling thread records the two
  * hipEvent_t (created by the caller with timing enabled) on its stream immediately before and after
@@ -264,18 +238,10 @@ int blp_profile_next_rank_kernel(void *start_event, void *stop_event);
  * sizes covers -- every pass of the call when the streaming kernels take the passes of a reference-batched evaluation
  * (train.py:128-171 with eval_batch_size <= 4) in one launch, else 1 (0: nothing to rank).  What the events of
  * blp_profile_next_rank_kernel bracket divides by it. */
-int64_t blp_rank_all_batches_passes_per_launch(int model, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
-                                               int64_t block_triples);
-/* 1 if a blp_rank_all_batches_t call of these sizes READS the 16-bit table directly (the ring kernels of the reference-batched
- * passes: batch <= 4 triples, D = 128 / 256, a table long enough to stream) -- then a pass moves half the bytes of the f32
- * table; 0 if it would first widen the table to f32 inside its workspace (N * D * 4 more bytes and a pass over the table per
- * call: every other shape -- a caller that has the f32 table should rank that one instead; blp_amd.ranking does). */
-int blp_rank_all_batches_t_native(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples, int64_t batch,
-                                  int64_t block_triples);
-int64_t blp_rank_all_batches_t_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
-                                                 int64_t batch, int64_t block_triples);
+int64_t blp_rank_all_batches_passes_per_launch(int model, int table_dtype, int64_t N, int D, int64_t ld, int64_t n_triples,
+                                               int64_t batch, int64_t block_triples);
 
-/* Measurement aid (bench.py's `decided_frac`): what the pre-pass of the LAST blp_rank_all / _ex / _idx call that ran on
+/* Measurement aid (bench.py's `decided_frac`): what the pre-pass of the LAST blp_rank_all / blp_rank_all_shard call that ran on
  * `workspace` (same model, N, D, q_head, q_tail) left to the exact path.  out[0] = (query, candidate) pairs of the block,
  * out[1] = undecided pairs it listed one by one, out[2] = candidates inside the segments it flagged for wholesale exact
  * re-scoring (a workgroup's list was full), out[3] = the path: 0 = no pre-pass (exact kernels took the block), 1 = TransE
@@ -361,13 +327,13 @@ int blp_score_bwd(int model, int D, int64_t M0, int64_t M1,
  * -------------------------------------------------------------------------------------------- */
 #define BLP_INBATCH_TICKET_INTS 4
 size_t blp_inbatch_loss_save_floats(int model, int B, int K, int D);
-/* kernel launches of blp_inbatch_loss_fwd_t at these sizes: 1 (at most 96 scoring workgroups: the last one finishes the loss) or 2 */
+/* kernel launches of blp_inbatch_loss_fwd at these sizes: 1 (at most 96 scoring workgroups: the last one finishes the loss) or 2 */
 int blp_inbatch_loss_fwd_launches(int model, int B, int K, int D, float regularizer);
-int blp_inbatch_loss_fwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
+int blp_inbatch_loss_fwd(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
                            const void *rel_vecs, const int64_t *neg_idx, int B, int K, int D,
                            float regularizer, float *out_loss, float *save_pos, float *save_neg,
                            int32_t *ticket, int device, void *stream);
-int blp_inbatch_loss_bwd_t(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
+int blp_inbatch_loss_bwd(int model, int loss, int ent_dtype, int rel_dtype, const void *ent_embs,
                            const void *rel_vecs, const int64_t *neg_idx, int B, int K, int D,
                            float regularizer, const float *grad_loss, const float *save_pos,
                            const float *save_neg, void *grad_ent, void *grad_rel, int device,

@@ -65,30 +65,29 @@ def test_bad_arguments_return_status_not_crash(built_lib):
     from blp_amd import _lib
     L = _lib.lib()
     # argument validation happens before any device call, so this runs without a GPU
-    rc = L.blp_rank_all(7, None, 0, 128, 128, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    rc = L.blp_rank_all(7, None, 0, 128, 128, None, None, None, None, 1, 1, None, None, None, 0, 0, None)
     assert rc == -1 and b"unknown model" in L.blp_last_error()
-    rc = L.blp_rank_all(1, None, 0, 100, 100, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    rc = L.blp_rank_all(1, None, 0, 100, 100, None, None, None, None, 1, 1, None, None, None, 0, 0, None)
     assert rc == -2  # (DistMult at D = 100; TransE is taken at any D % 4 == 0)
-    rc = L.blp_rank_all(0, None, 0, 102, 104, None, None, None, None, None, 1, 1, None, None, None, None, 0, 0, None)
+    rc = L.blp_rank_all(0, None, 0, 102, 104, None, None, None, None, 1, 1, None, None, None, 0, 0, None)
     assert rc == -2
     rc = L.blp_score_fwd(1, 100, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
     assert rc == -1 and b"NULL" in L.blp_last_error()  # any width is scored; the pointers are what is wrong here
     rc = L.blp_score_fwd(2, 101, 1, 1, None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
     assert rc == -2 and b"halves" in L.blp_last_error()  # ComplEx / SimplE split the vector
     one = ctypes.c_void_p(16)  # non-NULL placeholders: validation fails before anything is dereferenced
-    rc = L.blp_inbatch_loss_fwd_t(0, 0, 5, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, one, 0, None)
+    rc = L.blp_inbatch_loss_fwd(0, 0, 5, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, one, 0, None)
     assert rc == -1 and b"dtype" in L.blp_last_error()
-    rc = L.blp_inbatch_loss_fwd_t(0, 0, 0, 1, one, one, one, 4, 4, 128, 0.0, one, one, one, one, 0, None)
+    rc = L.blp_inbatch_loss_fwd(0, 0, 0, 1, one, one, one, 4, 4, 128, 0.0, one, one, one, one, 0, None)
     assert rc == -1  # relation rows narrower than the embeddings
-    rc = L.blp_inbatch_loss_fwd_t(0, 0, 0, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, None, 0, None)
+    rc = L.blp_inbatch_loss_fwd(0, 0, 0, 0, one, one, one, 4, 4, 128, 0.0, one, one, one, None, 0, None)
     assert rc == -1 and b"ticket" in L.blp_last_error()  # the forward's last-workgroup ticket is the caller's (zeroed, per stream)
     rc = L.blp_rank_metric_sums(None, 5, None, None, 0, None)
     assert rc == -1
     # int32 counts: N >= 2^31 is refused; q_fixed / q_rel feed 16-byte vector loads
-    rc = L.blp_rank_all(0, one, 1 << 31, 128, 128, one, one, None, one, None, 1, 1, None, None, one, one, 1 << 40, 0, None)
+    rc = L.blp_rank_all(0, one, 1 << 31, 128, 128, one, one, one, None, 1, 1, None, one, one, 1 << 40, 0, None)
     assert rc == -1 and b"2^31" in L.blp_last_error()
-    rc = L.blp_rank_all(0, one, 10, 128, 128, ctypes.c_void_p(20), one, None, one, None, 1, 1, None, None, one, one,
-                        1 << 40, 0, None)
+    rc = L.blp_rank_all(0, one, 10, 128, 128, ctypes.c_void_p(20), one, one, None, 1, 1, None, one, one, 1 << 40, 0, None)
     assert rc == -1 and b"aligned" in L.blp_last_error()
 
 
@@ -133,7 +132,9 @@ def test_passes_per_launch_is_host_logic(built_lib):
     tables (the small-block kernels) and batches of more than 4 triples are not.  Pure host logic: runs without a GPU."""
     from blp_amd import _lib
     L = _lib.lib()
-    f = L.blp_rank_all_batches_passes_per_launch
+    def f(model, *sizes):  # (the float32 table: BLP_DTYPE_F32)
+        return L.blp_rank_all_batches_passes_per_launch(model, 0, *sizes)
+
     for model in range(4):
         assert f(model, 4_600_000, 128, 128, 128, 2, 2) == 64      # Wikidata5M, eval_batch_size 2 (scripts/blp-*-wikidata5m.sh:18)
         assert f(model, 575_000, 128, 128, 9, 4, 4) == 3            # a 1/8 shard, 4 + 4 queries, the last pass one triple
@@ -146,13 +147,16 @@ def test_passes_per_launch_is_host_logic(built_lib):
 
 
 def test_typed_batches_routes_and_workspace_are_host_logic(built_lib):
-    """blp_rank_all_batches_t with a 16-bit table: the reference-batched passes over a long table read it as it is (every pass
+    """blp_rank_all_batches with a 16-bit table: the reference-batched passes over a long table read it as it is (every pass
     in one launch, the workspace of the passes only); every other shape of call holds a widened float32 copy at the end of its
     workspace (N x D x 4 bytes on top of what the float32 call needs); BLP_DTYPE_F32 is the float32 entry.  No GPU needed."""
     from blp_amd import _lib
     L = _lib.lib()
-    ws, ppl = L.blp_rank_all_batches_t_workspace_bytes, L.blp_rank_all_batches_t_passes_per_launch
-    f32 = L.blp_rank_all_batches_workspace_bytes
+    ws, ppl = L.blp_rank_all_batches_workspace_bytes, L.blp_rank_all_batches_passes_per_launch
+
+    def f32(model, N, D, n, batch, block):
+        return ws(model, 0, N, D, D, n, batch, block)
+
     for model in range(4):
         for dt in (1, 2):
             assert ppl(model, dt, 4_600_000, 128, 128, 128, 2, 2) == 64 and ppl(model, dt, 4_600_000, 256, 256, 9, 4, 4) == 3
@@ -163,7 +167,6 @@ def test_typed_batches_routes_and_workspace_are_host_logic(built_lib):
             assert ws(model, dt, 2000, 128, 128, 128, 2, 2) >= 2000 * 128 * 4   # short table: small-block kernels on the copy
             assert ws(model, dt, 4_600_000, 64, 64, 128, 2, 2) >= 4_600_000 * 64 * 4  # D = 64: not the 16-bit ring
             assert ws(model, dt, 4_600_000, 128, 132, 128, 2, 2) >= 4_600_000 * 128 * 4  # (ld % 8 != 0 is refused by the call itself)
-        assert ws(model, 0, 4_600_000, 128, 128, 128, 2, 2) == f32(model, 4_600_000, 128, 128, 2, 2)
         assert ppl(model, 0, 4_600_000, 128, 128, 128, 2, 2) == 64
     assert ws(0, 5, 100, 128, 128, 4, 2, 2) == 0 and ppl(0, 5, 100, 128, 128, 4, 2, 2) == 0
 
@@ -175,7 +178,11 @@ def test_batches_workspace_covers_every_block_of_the_call(built_lib):
     hold every block's own requirement, plus the permutation arrays behind it when batches are merged.  Host logic only."""
     from blp_amd import _lib
     L = _lib.lib()
-    one, many = L.blp_rank_all_workspace_bytes, L.blp_rank_all_batches_workspace_bytes
+    one = L.blp_rank_all_workspace_bytes
+
+    def many(model, N, D, n, batch, block):
+        return L.blp_rank_all_batches_workspace_bytes(model, 0, N, D, D, n, batch, block)
+
     cases = 0
     for model in range(4):
         for D in (64, 128):
@@ -204,7 +211,7 @@ def test_batches_workspace_covers_every_block_of_the_call(built_lib):
     assert many(0, 14541, 64, 512 + 257, 512, 512) >= one(0, 14541, 64, 257, 257)
     # block sizes whose permutation grid / query count would overflow are refused, not truncated
     p16 = ctypes.c_void_p(16)
-    rc = L.blp_rank_all_batches(0, p16, 100, 128, 128, p16, 100, 128, p16, p16, 5, p16, p16, 1 << 31, 1 << 30, 1 << 30,
+    rc = L.blp_rank_all_batches(0, p16, 0, 100, 128, 128, p16, 100, 128, p16, p16, 5, p16, p16, 1 << 31, 1 << 30, 1 << 30,
                                 None, p16, p16, 1 << 40, 0, None)
     assert rc == -1 and b"2^29" in L.blp_last_error()
 

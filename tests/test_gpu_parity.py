@@ -635,8 +635,8 @@ def test_workspace_is_never_overrun(model, D, gemm_kernel, knobs):
         counts = torch.empty((Q, 4), dtype=torch.int32, device="cuda")
         need = L.blp_rank_all_workspace_bytes(_lib.MODEL_IDS[model], N, D, q_head, q_tail)
         ws = torch.full((need + guard,), 0xA5, dtype=torch.uint8, device="cuda")
-        rc = L.blp_rank_all(_lib.MODEL_IDS[model], table.data_ptr(), N, D, D, q_fixed.data_ptr(), q_rel.data_ptr(), None,
-                            true_row.data_ptr(), None, q_head, q_tail, None, None, counts.data_ptr(), ws.data_ptr(), need,
+        rc = L.blp_rank_all(_lib.MODEL_IDS[model], table.data_ptr(), N, D, D, q_fixed.data_ptr(), q_rel.data_ptr(),
+                            true_row.data_ptr(), None, q_head, q_tail, None, counts.data_ptr(), ws.data_ptr(), need,
                             0, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "blp_rank_all")
         torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""GPU: the candidate table in a 16-bit storage type (blp_rank_all_batches_t / blp_gather_triple_vectors_t; include/blp_hip.h,
+"""GPU: the candidate table in a 16-bit storage type (blp_rank_all_batches / blp_gather_triple_vectors; include/blp_hip.h,
 blp_amd/csrc/table_elem.h, rank_stream16.hip) -- the half-precision copy the table build can emit.  The
 reference has no such table (train.py:96-97 keeps `ent_emb` in float32); what has to hold is that a 16-bit table is ranked as
 the reference ranks the SAME VALUES in float32: every test compares with the CPU oracle on the table widened to float32
@@ -48,7 +48,7 @@ def _rank32(model, table32, rel_w, ent2idx, triples, index, batch, block_triples
                                                ("simple", 80000, 1, 2, 128)])
 def test_reference_batched_passes_read_the_16_bit_table(oracle, model, N, T, batch, D, dtype):
     """eval_batch_size <= 4 against a long table (scripts/blp-*-wikidata5m.sh:18; train.py:128-171): the ring kernels read the
-    16-bit table as it is, every pass in one launch (blp_rank_all_batches_t_passes_per_launch says so); counts == the oracle's
+    16-bit table as it is, every pass in one launch (blp_rank_all_batches_passes_per_launch says so); counts == the oracle's
     on the widened table == the float32 path's on the widened table, raw and filtered; T = 1 / a short last batch included."""
     from blp_amd import _lib, utils
     R = 5
@@ -57,7 +57,7 @@ def test_reference_batched_passes_read_the_16_bit_table(oracle, model, N, T, bat
     wide = table16.float()  # exact
     index = utils.FilterIndex(edges, num_relations=R)
     L, mid = _lib.lib(), _lib.MODEL_IDS[model]
-    assert L.blp_rank_all_batches_t_passes_per_launch(mid, {torch.float16: 1, torch.bfloat16: 2}[dtype], N, D, D, T, batch, batch) == -(-T // batch)
+    assert L.blp_rank_all_batches_passes_per_launch(mid, {torch.float16: 1, torch.bfloat16: 2}[dtype], N, D, D, T, batch, batch) == -(-T // batch)
     got = _rank16(model, table16, rel_w, ent2idx, triples, index, batch, batch)
     ref32 = _rank32(model, wide, rel_w, ent2idx, triples, index, batch, batch)
     assert torch.equal(got, ref32)
@@ -148,12 +148,12 @@ def test_bad_arguments_of_the_typed_entries():
     buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
     p = buf.data_ptr()
     args = lambda dt, ld, ws: (0, p, dt, 100, 128, ld, p, 100, 128, p, p, 5, p, p, 4, 2, 2, None, p, p, ws, 0, None)
-    assert L.blp_rank_all_batches_t(*args(7, 128, 1 << 16)) == -1
-    assert L.blp_rank_all_batches_t(*args(1, 132, 1 << 16)) == -1          # ld % 8 != 0
-    assert L.blp_rank_all_batches_t(*args(1, 128, 16)) == -4                # workspace
+    assert L.blp_rank_all_batches(*args(7, 128, 1 << 16)) == -1
+    assert L.blp_rank_all_batches(*args(1, 132, 1 << 16)) == -1          # ld % 8 != 0
+    assert L.blp_rank_all_batches(*args(1, 128, 16)) == -4                # workspace
     assert b"workspace" in L.blp_last_error()
-    assert L.blp_gather_triple_vectors_t(p, 4, None, 0, p, 9, 100, 128, 128, 0, p, 0, None) == -1
-    assert L.blp_rank_all_batches_t_workspace_bytes(0, 1, 100, 128, 128, 4, 2, 2) > 0
+    assert L.blp_gather_triple_vectors(p, 4, None, 0, p, 9, 100, 128, 128, 0, p, 0, None) == -1
+    assert L.blp_rank_all_batches_workspace_bytes(0, 1, 100, 128, 128, 4, 2, 2) > 0
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -185,7 +185,7 @@ def test_seeded_random_cases(oracle, seed):
 
 
 def test_integration_md_16_bit_stub_is_runnable(oracle):
-    """The second ctypes stub of INTEGRATION.md section 2 (blp_rank_all_batches_t + blp_gather_triple_vectors_t on a 16-bit copy
+    """The second ctypes stub of INTEGRATION.md section 2 (blp_rank_all_batches + blp_gather_triple_vectors on a 16-bit copy
     of the table), executed as printed on top of the first one: counts == the oracle's on the widened table, in the loop's
     layout, at the reference's Wikidata5M batching (a pass per 2 triples: the ring kernels) and at a batch of 5 (a widened copy)."""
     import os
@@ -195,7 +195,7 @@ def test_integration_md_16_bit_stub_is_runnable(oracle):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "INTEGRATION.md")).read()
     first = re.search(r"```python\n(# blp_hip\.py.*?)```", text, flags=re.S).group(1)
-    second = re.search(r"```python\n(_L\.blp_gather_triple_vectors_t\.argtypes.*?)```", text, flags=re.S).group(1)
+    second = re.search(r"```python\n(_L\.blp_gather_triple_vectors\.argtypes.*?)```", text, flags=re.S).group(1)
     stub = types.ModuleType("blp_hip_stub16")
     exec(first.replace('"libblp_hip.so"', repr(_lib.LIB_PATH)) + "\n" + second, stub.__dict__)
     N, D, R, T = 70000, 128, 5, 9

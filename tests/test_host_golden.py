@@ -388,7 +388,7 @@ def test_description_encoders_reproduce_the_reference(name):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_rank_triples_widens_a_16_bit_table_on_the_dense_routes(dtype):
     """A 16-bit copy of the table on a CPU tensor (the reference's dense route, no HIP library): ranked as the table widened to
-    float32 -- the rule the 16-bit entry of the library follows on the GPU (blp_rank_all_batches_t; tests/test_gpu_table16.py)."""
+    float32 -- the rule the 16-bit entry of the library follows on the GPU (blp_rank_all_batches; tests/test_gpu_table16.py)."""
     g = torch.Generator().manual_seed(4)
     N, D, T, R = 90, 16, 23, 3
     table = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=-1).to(dtype)

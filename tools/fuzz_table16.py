@@ -1,4 +1,4 @@
-"""Randomised soak of the 16-bit candidate-table entry (blp_rank_all_batches_t): random model / storage type / width / table
+"""Randomised soak of the 16-bit candidate-table entry (blp_rank_all_batches): random model / storage type / width / table
 length (short: the widened copy; long: the ring kernels of rank_stream16.hip) / batch and block sizes / row stride / data
 shapes (ties with the true entity, zero rows, outliers, NaN, Inf, tiny and mixed magnitudes) / filter, against the CPU oracle
 on the table widened to float32 (test infrastructure), for a wall-clock budget.

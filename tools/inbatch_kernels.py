@@ -27,9 +27,9 @@ for name in (sys.argv[1:] or list(bench.INBATCH_SHAPES)):
     args = (_lib.MODEL_IDS[c["model"]], _lib.LOSS_IDS[c["loss"]], _lib.DTYPE_NAMES.index(c["dtype"]), 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for _ in range(300):
-        _lib.check(L.blp_inbatch_loss_fwd_t(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+        _lib.check(L.blp_inbatch_loss_fwd(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
                                             loss.data_ptr(), pos.data_ptr(), neg.data_ptr(), ticket.data_ptr(), 0, stream), "fwd")
-        _lib.check(L.blp_inbatch_loss_bwd_t(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+        _lib.check(L.blp_inbatch_loss_bwd(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
                                             one.data_ptr(), pos.data_ptr(), neg.data_ptr(), g_ent.data_ptr(), g_rel.data_ptr(),
                                             0, stream), "bwd")
     torch.cuda.synchronize()

@@ -34,11 +34,11 @@ for name in (sys.argv[1:] or list(bench.INBATCH_SHAPES)):
         L = _lib.lib()
 
         def fwd():
-            _lib.check(L.blp_inbatch_loss_fwd_t(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+            _lib.check(L.blp_inbatch_loss_fwd(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
                                                 loss.data_ptr(), pos.data_ptr(), neg.data_ptr(), ticket.data_ptr(), 0, stream), "fwd")
 
         def bwd():
-            _lib.check(L.blp_inbatch_loss_bwd_t(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
+            _lib.check(L.blp_inbatch_loss_bwd(*args, ent.data_ptr(), rel.data_ptr(), neg_idx.data_ptr(), B, K, D, c["reg"],
                                                 one.data_ptr(), pos.data_ptr(), neg.data_ptr(), g_ent.data_ptr(), g_rel.data_ptr(), 0, stream), "bwd")
 
         fn = bwd if probe == 8 else fwd

@@ -1,6 +1,6 @@
 """Reference-batched passes over a Wikidata5M-scale table in float32 / float16 / bfloat16 storage: us per table pass.
     python tools/table16_probe.py [rows] [triples] [batch]
-(blp_rank_all_batches_t, block_triples = batch: a pass per batch, all passes in one launch of a ring kernel)"""
+(blp_rank_all_batches, block_triples = batch: a pass per batch, all passes in one launch of a ring kernel)"""
 import os
 import sys
 
