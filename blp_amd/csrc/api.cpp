@@ -299,9 +299,9 @@ size_t blp_rank_all_workspace_bytes(int model, int64_t N, int D, int64_t q_head,
 
 }  // extern "C"
 
-// Shared by blp_rank_all / _ex (dense query vectors) and blp_rank_all_idx (queries as rows of the table / of rel_emb)
+// Shared by blp_rank_all (dense query vectors) and blp_rank_all_shard (queries as rows of `source` / of rel_emb)
 static int rank_all_checked(int model, const float* table, int64_t N, int D, int64_t ld, const blp::QRows& q_fixed,
-                            const blp::QRows& q_rel, const int64_t* q_rel_id, const blp::QRows& q_true,
+                            const blp::QRows& q_rel, const blp::QRows& q_true,
                             int64_t q_head, int64_t q_tail, const blp_filter* filter, int32_t* counts, void* workspace,
                             size_t workspace_bytes, int device, void* stream) {
     if (!valid_model(model)) return fail(BLP_ERR_BAD_ARG, "blp_rank_all: unknown model %d", model);
@@ -345,7 +345,7 @@ static int rank_all_checked(int model, const float* table, int64_t N, int D, int
     if (int rc = compute_units(device, &cu)) return rc;
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
-    hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail,
+    hipError_t err = blp::launch_rank_all(model, D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail,
                                           spec, counts, workspace, cu, static_cast<hipStream_t>(stream), ev0, ev1);
     if (err != hipSuccess) return hip_fail(err, "blp_rank_all launch");
     return BLP_OK;
@@ -360,7 +360,7 @@ int blp_rank_all(int model, const float* table, int64_t N, int D, int64_t ld, co
     blp::QRows truth;  // stays empty (-> BAD_ARG below, after the model / size checks) unless exactly one form is given
     if ((true_row == nullptr) != (q_true == nullptr))
         truth = true_row ? blp::QRows::rows_of(table, true_row, ld) : blp::QRows::dense(q_true, D);
-    return rank_all_checked(model, table, N, D, ld, blp::QRows::dense(q_fixed, D), blp::QRows::dense(q_rel, D), nullptr, truth,
+    return rank_all_checked(model, table, N, D, ld, blp::QRows::dense(q_fixed, D), blp::QRows::dense(q_rel, D), truth,
                             q_head, q_tail, filter, counts, workspace, workspace_bytes, device, stream);
 }
 
@@ -373,7 +373,7 @@ int blp_rank_all_shard(int model, const float* table, int64_t N, int D, int64_t 
     if (ld_src < D || (ld_src & 3) || !aligned16(source))
         return fail(BLP_ERR_BAD_ARG, "blp_rank_all_shard: source must be 16-byte aligned with ld_src %% 4 == 0, ld_src >= D");
     return rank_all_checked(model, table, N, D, ld, blp::QRows::rows_of(source, fixed_row, ld_src),
-                            blp::QRows::rows_of(rel_emb, rel_id, D), /*q_rel_id: equal ids are equal rows by construction*/ rel_id,
+                            blp::QRows::rows_of(rel_emb, rel_id, D),
                             blp::QRows::rows_of(source, true_row, ld_src), q_head, q_tail, filter, counts, workspace,
                             workspace_bytes, device, stream);
 }

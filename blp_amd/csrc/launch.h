@@ -51,7 +51,7 @@ bool rank_sad_wide_applicable(int model, int D, int64_t q_head, int64_t q_tail);
 size_t rank_all_workspace_bytes(int model, int D, int64_t N, int64_t q_head, int64_t q_tail);
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
-                           const QRows q_fixed, const QRows q_rel, const int64_t* q_rel_id,
+                           const QRows q_fixed, const QRows q_rel,
                            const QRows q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void build_queries_kernel(QueryBuild a, unsign
         if (a.fixed_row) a.fixed_row[p] = fixed_row >= 0 ? fixed_row : 0;
         if (h_row < 0 || t_row < 0 || !rel_ok) atomicMin(a.ids_min, -1);  // train.py:137-138's assertion, left on the device
     }
-    if (!a.q_fixed) return;  // index form only (blp_rank_all_idx): no vectors
+    if (!a.q_fixed) return;  // index form only (blp_rank_all_shard / blp_rank_all_batches): no vectors
     // the two vectors: fixed entity and relation (an id that is no row: zeros -- the caller checks ids_min)
     const float* fsrc = a.source + (fixed_row >= 0 ? fixed_row : 0) * a.ld;
     const float* rsrc = a.rel_emb + (rel_ok ? r_id : 0) * (int64_t)a.D;
@@ -282,7 +282,7 @@ hipError_t launch_rank_all_batches16(int model, int D, const void* table, int dt
     float* wide = reinterpret_cast<float*>(static_cast<char*>(workspace) + batches_front_bytes(model, D, N, n, batch, block_triples));
     if (const hipError_t e = launch_widen_table(table, dtype, N, D, ld, wide, stream); e != hipSuccess) return e;
     if (n <= batch)  // one batch: one block of [heads | tails]
-        return launch_rank_all(model, D, wide, N, D, QRows::rows_of(source, fixed_row, ld_src), QRows::rows_of(rel_emb, rel_id, D), rel_id,
+        return launch_rank_all(model, D, wide, N, D, QRows::rows_of(source, fixed_row, ld_src), QRows::rows_of(rel_emb, rel_id, D),
                                QRows::rows_of(source, true_row, ld_src), n, n, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     return launch_rank_all_batches(model, D, wide, N, D, source, ld_src, fixed_row, rel_emb, rel_id, true_row, n, batch, block_triples,
                                    filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
@@ -320,7 +320,7 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
                 f.exclude = filter.exclude ? filter.exclude + q0 : nullptr;
             }
             const hipError_t err = launch_rank_all(model, D, table, N, ld, QRows::rows_of(source, fixed_row + q0, ld_src),
-                                                   QRows::rows_of(rel_emb, rel_id + q0, D), rel_id + q0,
+                                                   QRows::rows_of(rel_emb, rel_id + q0, D),
                                                    QRows::rows_of(source, true_row + q0, ld_src), m, m, f, counts + 4 * q0, workspace,
                                                    n_cu, stream, t0 == 0 ? ev_start : nullptr, t0 == 0 ? ev_stop : nullptr);
             if (err != hipSuccess) return err;
@@ -345,7 +345,7 @@ hipError_t launch_rank_all_batches(int model, int D, const float* table, int64_t
             f.exclude = filter.exclude ? perm + 5 * Q : nullptr;
         }
         const hipError_t err = launch_rank_all(model, D, table, N, ld, QRows::rows_of(source, perm, ld_src),
-                                               QRows::rows_of(rel_emb, perm + Q, D), perm + Q, QRows::rows_of(source, perm + 2 * Q, ld_src),
+                                               QRows::rows_of(rel_emb, perm + Q, D), QRows::rows_of(source, perm + 2 * Q, ld_src),
                                                m, m, f, reinterpret_cast<int32_t*>(pcounts), workspace, n_cu, stream,
                                                t0 == 0 ? ev_start : nullptr, t0 == 0 ? ev_stop : nullptr);
         if (err != hipSuccess) return err;

@@ -395,7 +395,7 @@ template <int MODEL, int D, bool STATIC>
 __global__ __launch_bounds__(kWaves * 64, (D == 256 ? 1 : (MODEL == TRANSE ? 3 : 2))) void rank_tiles_kernel(
     const float* __restrict__ table, int64_t N, int64_t ld, const float* __restrict__ coef_head,
     const float* __restrict__ coef_tail, const float* __restrict__ key_true, int q_head, int q_tail,
-    int n_tiles, int n_quad_groups, int q_chunk, const int64_t* __restrict__ q_rel_id,
+    int n_tiles, int n_quad_groups, int q_chunk,
     unsigned long long* __restrict__ acc, const Gate gate) {
     if (gate.counter != nullptr && !gate_heavy(gate)) return;  // (the pre-pass paths' exact fallback: only when the lists ran full)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -713,13 +713,13 @@ static hipError_t launch_static_pass(const float* table, int64_t N, int64_t ld, 
     const int64_t resident = (int64_t)n_cu * 3, groups = n_quads < resident ? n_quads : resident;
     const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)2 * kQB * kMaxCoef(D) * 4 + (size_t)kWaves * 2 * kQueryChunk * 4;
     rank_tiles_kernel<MODEL, D, true><<<dim3((unsigned)groups), kWaves * 64, lds, stream>>>(
-        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, (int)n_tiles, (int)groups, kQueryChunk, nullptr, acc, Gate{nullptr, 0u});
+        table, N, ld, coef_head, coef_tail, key_true, q_head, q_tail, (int)n_tiles, (int)groups, kQueryChunk, acc, Gate{nullptr, 0u});
     return hipGetLastError();
 }
 
 template <int MODEL, int D>
 static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                                const QRows q_rel, const int64_t* q_rel_id, const QRows q_true,
+                                const QRows q_rel, const QRows q_true,
                                 int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace,
                                 int n_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int64_t Q = q_head + q_tail;
@@ -790,7 +790,7 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
         } else
             rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)blocks), kWaves * 64, lds, stream>>>(
                 table, N, ld, w.coef_head, w.coef_tail, w.key_true, (int)q_head, (int)q_tail, (int)n_tiles,
-                (int)groups, q_chunk, q_rel_id, w.acc, Gate{nullptr, 0u});
+                (int)groups, q_chunk, w.acc, Gate{nullptr, 0u});
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
 
@@ -800,12 +800,12 @@ static hipError_t rank_all_impl(const float* table, int64_t N, int64_t ld, const
 
 template <int MODEL>
 static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld, const QRows q_fixed,
-                               const QRows q_rel, const int64_t* q_rel_id, const QRows q_true,
+                               const QRows q_rel, const QRows q_true,
                                int64_t q_head, int64_t q_tail, const FilterSpec& filter, int32_t* counts, void* workspace, int n_cu,
                                hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define BLP_RANK_CASE(DD)                                                                              \
     case DD:                                                                                           \
-        return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, \
+        return rank_all_impl<MODEL, DD>(table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, \
                                         filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     switch (D) {
         BLP_RANK_CASE(64)
@@ -818,7 +818,7 @@ static hipError_t rank_all_dim(int D, const float* table, int64_t N, int64_t ld,
 }
 
 hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int64_t ld,
-                           const QRows q_fixed, const QRows q_rel, const int64_t* q_rel_id,
+                           const QRows q_fixed, const QRows q_rel,
                            const QRows q_true, int64_t q_head, int64_t q_tail,
                            const FilterSpec& filter, int32_t* counts,
                            void* workspace, int n_cu, hipStream_t stream, hipEvent_t ev_start,
@@ -835,10 +835,10 @@ hipError_t launch_rank_all(int model, int D, const float* table, int64_t N, int6
                                    counts, workspace, n_cu, stream, ev_start, ev_stop);
     // everything else: the exact f32 kernels (few queries, D = 256 bilinear, or the rank_kernel knob)
     switch (model) {
-    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
-    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_rel_id, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case TRANSE:   return rank_all_dim<TRANSE>(D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case DISTMULT: return rank_all_dim<DISTMULT>(D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case COMPLEX:  return rank_all_dim<COMPLEX>(D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
+    case SIMPLE:   return rank_all_dim<SIMPLE>(D, table, N, ld, q_fixed, q_rel, q_true, q_head, q_tail, filter, counts, workspace, n_cu, stream, ev_start, ev_stop);
     default:       return hipErrorInvalidValue;
     }
 }
@@ -870,7 +870,7 @@ static hipError_t exact_fallback_impl(const float* table, int64_t N, int64_t ld,
     const size_t lds = (size_t)kWaves * kSlabFloats * 4 + (size_t)2 * kQB * kMaxCoef(D) * 4 + (size_t)kWaves * 2 * kQueryChunk * 4;
     if (groups * n_chunks > 0x7fffffff) return hipErrorInvalidValue;
     rank_tiles_kernel<MODEL, D, false><<<dim3((unsigned)(groups * n_chunks)), kWaves * 64, lds, stream>>>(
-        table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)groups, kQueryChunk, nullptr, acc, gate);
+        table, N, ld, coef_head, coef_tail, key_true, (int)q_head, (int)q_tail, (int)n_tiles, (int)groups, kQueryChunk, acc, gate);
     return hipGetLastError();
 }
 
