@@ -203,12 +203,19 @@ def _link_prediction(dataset, inductive, dim, model, rel_model, loss_fn, encoder
         elif torch.cuda.device_count() > 1:
             eval_on = dict(devices=list(range(torch.cuda.device_count())))
 
+    # Under a launcher only rank 0 WRITES the dataset's side files (maps.pt, the tokenised-text cache): the others wait for it and
+    # read them (two ranks writing and reading one file at once is a torn read).
+    first = RANK == 0
+    if distributed and not first:
+        dist.barrier()
     if model == 'transductive':
-        train_data = GraphDataset(triples_file, num_negatives, write_maps_file=True, num_devices=num_devices)
+        train_data = GraphDataset(triples_file, num_negatives, write_maps_file=first, num_devices=num_devices)
     else:
         train_data = TextGraphDataset(triples_file, num_negatives, max_len, _tokenizer(model, encoder_name, data_root),
-                                      drop_stopwords, write_maps_file=True, use_cached_text=use_cached_text,
+                                      drop_stopwords, write_maps_file=first, use_cached_text=use_cached_text or not first,
                                       num_devices=num_devices)
+    if distributed and first:
+        dist.barrier()
     if device_sampler and device != torch.device('cpu'):
         train_data.sampler_device = device
     train_loader = DataLoader(train_data, batch_size, shuffle=True, collate_fn=train_data.collate_fn,
