@@ -30,7 +30,7 @@ SYMBOLS = ("blp_version", "blp_last_error", "blp_device_caps", "blp_selftest", "
 HOOK_SYMBOLS = ("blp_debug_set_knob", "blp_debug_gemm_dump", "blp_debug_reset_selftest")  # libblp_hip.hooks.so only
 KNOBS = ("rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups", "sad_min_queries",
          "gemm_pass_words", "gemm_tiles_per_chunk", "exact_query_chunk",
-         "small_kernel", "stream_kernel", "dkrl_split", "mfma_selftest", "inbatch_probe")  # blp_amd/csrc/knobs.h
+         "small_kernel", "stream_kernel", "dkrl_split", "mfma_selftest", "inbatch_probe", "inbatch_shares")  # blp_amd/csrc/knobs.h
 
 
 DTYPE_NAMES = ("float32", "float16", "bfloat16")  # BLP_DTYPE_* of include/blp_hip.h

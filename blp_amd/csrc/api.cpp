@@ -88,7 +88,7 @@ std::atomic<long long> g_knobs[blp::KNOB_COUNT];  // zero-initialised: every kno
 const char* const kKnobNames[blp::KNOB_COUNT] = {"rank_kernel", "gemm_kernel", "sad_queries_per_group", "sad_pass_groups",
                                                  "sad_min_queries", "gemm_pass_words", "gemm_tiles_per_chunk",
                                                  "exact_query_chunk", "small_kernel",
-                                                 "stream_kernel", "dkrl_split", "mfma_selftest", "inbatch_probe"};
+                                                 "stream_kernel", "dkrl_split", "mfma_selftest", "inbatch_probe", "inbatch_shares"};
 #endif
 
 }  // namespace

@@ -985,9 +985,11 @@ static void launch_grad(int loss, const TE* ent, const TR* rel, const int64_t* n
                         const float* grad_loss, const float* pos, const float* neg, TE* grad_ent, TR* grad_rel, hipStream_t stream) {
     constexpr int WAVES = GradShape<SWEEP>::kWaves;
     // entity rows: S waves share a row's list (a wave adds its entries one batch of row loads after the other: a latency chain)
-    // while that keeps the number of waves near what the chip holds at once; a power of two
+    // while that keeps the grid near 2 048 waves -- [measured, tools/inbatch_probe.py] B = 64: S = 16 (7.9 us; S = 4: 11.4), B = 128:
+    // S = 8 (11.2; 16: 12.5), B = 1 024: S = 2 (40; 1: 48, 4: 45, 16: 72) --; a power of two, at least two
     int S = WAVES;
-    while (S > 1 && (int64_t)2 * B * S > 8192) S >>= 1;
+    while (S > 2 && (int64_t)2 * B * S > 2048) S >>= 1;
+    if (const long long forced = knob(KNOB_INBATCH_SHARES); forced > 0 && forced <= WAVES && (forced & (forced - 1)) == 0) S = (int)forced;
     const int R = WAVES / S;
     // relation rows: a workgroup per row (its K negatives over all the waves) while that does not flood the chip
     int rel_shares = WAVES;

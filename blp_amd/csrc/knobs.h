@@ -21,6 +21,7 @@ enum Knob : int {
     KNOB_DKRL_SPLIT,             // 1 / 2 / 4: waves per M-tile of the DKRL table-build kernel (dkrl.hip)
     KNOB_MFMA_SELFTEST,          // 1: the matrix-pipe accumulation self-test (rank_gemm.hip) reports a violation whatever it measured
     KNOB_INBATCH_PROBE,          // timing probe of the in-batch loss forward (wrong results!): bit 0: no index workgroups; bit 1: no tickets / final sum; bit 2: no redundant positives
+    KNOB_INBATCH_SHARES,         // waves per entity row of the in-batch loss backward (a power of two <= 16; 0: by batch size)
     KNOB_COUNT
 };
 

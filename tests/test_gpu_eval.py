@@ -366,9 +366,12 @@ def test_bench_line_keeps_the_contract(tmp_path):
         assert 0 < tb["fused_us"] < tb["stock_us"], (name, tb)
     co = r["call_overhead"]
     assert co["python_wrapper_us"] < 8.0 and co["library_call_us"] > 0 and co["launches_per_call"] == 3
-    # the training-side step: three launches; from Python with the autograd engine's worker threads and on the calling thread
+    # the training-side step: two launches (TransE at the FB15k-237 batch: the forward's last workgroup finishes the loss), three for
+    # the bilinear shapes; from Python with the autograd engine's worker threads and on the calling thread
     ib = r["inbatch_loss"]["inbatch-fb15k237"]
-    assert ib["launches_per_step"] == 3 and 0 < ib["us_per_step_kernels"] < ib["us_per_step_autograd"]
+    assert ib["launches_per_step"] == 2 and 0 < ib["us_per_step_kernels"] < ib["us_per_step_autograd"]
+    assert r["inbatch_loss"]["inbatch-wikidata5m-complex-fp16"]["launches_per_step"] == 3
+    assert ib["us_per_step_autograd_best"] <= ib["us_per_step_autograd"] <= ib["us_per_step_autograd_p90"] and len(ib["us_per_step_autograd_rounds"]) == 5
     # default autograd threading, settled state (measured 42 us at B = 64; the review's bar: 45): PyTorch's own floor -- the same
     # node without kernels, measured beside it (24 - 31 us settled, 50 - 65 us in the first seconds of a process: host behaviour)
     # -- plus what this package adds (12 us: three launches, two C-ABI calls, five allocations)

@@ -1088,8 +1088,8 @@ def test_two_threads_two_streams_concurrently(ops, oracle):
                     loss = ops.inbatch_loss(p["model"], "margin", e, r, neg_idx, 1e-3)
                     loss.backward()
                     if it % 5 == i:  # an error in THIS thread only
-                        rc = _lib.lib().blp_rank_all(9 + i, None, 0, 128, 128, None, None, None, None, None, 1, 1, None,
-                                                     None, None, None, 0, 0, None)
+                        rc = _lib.lib().blp_rank_all(9 + i, None, 0, 128, 128, None, None, None, None, 1, 1, None,
+                                                     None, None, 0, 0, None)
                         assert rc == -1 and f"unknown model {9 + i}".encode() in _lib.lib().blp_last_error()
                     stream.synchronize()
                     if not np.array_equal(got.cpu().numpy(), p["want"]):

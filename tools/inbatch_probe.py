@@ -57,4 +57,19 @@ for name in (sys.argv[1:] or list(bench.INBATCH_SHAPES)):
         ticket.zero_()
         out[{0: "full", 1: "no index", 2: "no tickets", 4: "no positives", 3: "no index, no tickets", 7: "scores only", 8: "backward"}[probe]] = round(a.elapsed_time(b) / n * 1e3, 2)
     _lib.reset_knobs()
+    for shares in (1, 2, 4, 8, 16):  # the backward with S waves per entity row
+        _lib.set_knob("inbatch_shares", shares)
+        L = _lib.lib()
+        fwd()
+        for _ in range(20):
+            bwd()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(300):
+            bwd()
+        b.record()
+        torch.cuda.synchronize()
+        out[f"backward S={shares}"] = round(a.elapsed_time(b) / 300 * 1e3, 2)
+    _lib.reset_knobs()
     print(name, out, flush=True)
