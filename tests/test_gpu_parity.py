@@ -885,11 +885,14 @@ def test_inbatch_loss_training_shape_vs_port(ops, model, loss_fn):
 @pytest.mark.default_routing
 @pytest.mark.parametrize("model,B,K,skew", [("transe", 1024, 64, None), ("complex", 1024, 64, None), ("distmult", 300, 7, None),
                                             ("simple", 200, 33, None), ("transe", 3, 2, None), ("distmult", 64, 80, "two_rows"),
-                                            ("complex", 96, 64, "one_row"), ("transe", 520, 9, "few_rows")])
+                                            ("complex", 96, 64, "one_row"), ("transe", 520, 9, "few_rows"),
+                                            ("distmult", 2100, 3, None), ("transe", 64, 1000, None), ("simple", 700, 1, "few_rows")])
 def test_inbatch_loss_backward_row_ownership_and_rounds(ops, model, B, K, skew):
-    """The backward's work split (inbatch_loss.hip): a workgroup owns R = 1 ... 16 entity rows and finds their negatives by
-    one stable compaction of neg_idx -- batches of 1 024 (R = 16), sizes that leave a short last workgroup, rows split over
-    waves (R < 4), and negatives that all name one or two rows (more hits than the LDS list holds: several rounds).
+    """The backward's work split (inbatch_loss.hip): S waves share an entity row and walk its negatives from the index of
+    neg_idx the forward leaves (chunks of 1 024 entries sorted stably by the row they name) -- batches of 1 024 (128 chunks:
+    two blocks of 64 chunk offsets per row; 2 048 rows: two passes of the index workgroups' 1 024-row histograms), 2 100 (five
+    passes), sizes that leave short last workgroups, K = 1 and K = 1 000, and negatives that all name one, two or four rows
+    (every lane of a slice names the same row: the in-slice ranks; lists of tens of thousands of entries per row).
     Against the torch port, the training-shape test's tolerances; and bit-reproducible."""
     from oracle import ref_port
     torch.manual_seed(B + K)
@@ -913,11 +916,78 @@ def test_inbatch_loss_backward_row_ownership_and_rounds(ops, model, B, K, skew):
         loss.backward()
         grads.append((e.grad.clone(), r.grad.clone()))
     assert loss.item() == pytest.approx(ref.item(), rel=2e-6, abs=1e-7)
-    # sums of up to 2 B K signed terms per row: a few ulps of the largest partial sum in absolute terms
+    # sums of up to 2 B K signed terms per row: a few ulps of the largest partial sum in absolute terms, and the more terms a
+    # row adds the more roundings both sides make (K = 1 000: 2 000 terms of 1 / (B K) per TransE row, the reference's
+    # index_put accumulation and this kernel's entry order differ by up to 1e-7 absolute on gradients of 0.025)
     scale = float(e_ref.grad.abs().max())
-    np.testing.assert_allclose(grads[0][0].cpu().numpy(), e_ref.grad.numpy(), rtol=2e-5, atol=2e-6 * max(scale, 1e-3))
-    np.testing.assert_allclose(grads[0][1].cpu().numpy(), r_ref.grad.numpy(), rtol=2e-5, atol=2e-6 * max(scale, 1e-3))
+    atol = 2e-6 * max(scale, 1e-3) * max(1.0, K / 250.0)
+    np.testing.assert_allclose(grads[0][0].cpu().numpy(), e_ref.grad.numpy(), rtol=2e-5, atol=atol)
+    np.testing.assert_allclose(grads[0][1].cpu().numpy(), r_ref.grad.numpy(), rtol=2e-5, atol=atol)
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.default_routing
+@pytest.mark.parametrize("model,B,K,skew", [("transe", 64, 64, None), ("distmult", 700, 5, None), ("transe", 1024, 64, None),
+                                            ("distmult", 40, 60, "one_row"), ("transe", 300, 11, "dups")])
+def test_inbatch_forward_leaves_a_stable_index_of_neg_idx(model, B, K, skew):
+    """What the backward walks (include/blp_hip.h: save_pos; inbatch_loss.hip: SaveLayout): for every chunk of 1 024 consecutive
+    entries of neg_idx.view(-1) the entries grouped by the row they name, IN ENTRY ORDER within a row, with the chunk's
+    exclusive row offsets -- read back here from the raw C-ABI call and held against a stable sort on the host, entry for
+    entry; and the ticket counter is left zero."""
+    import ctypes
+    from blp_amd import _lib
+    torch.manual_seed(B * K)
+    D = 128
+    ent = (torch.randn(B, 2, D) * 0.4).cuda()
+    rel = (torch.randn(B, D) * 0.3).cuda()
+    neg_idx = torch.randint(0, 2 * B, (B, K, 2))
+    if skew == "one_row":
+        neg_idx[..., 1] = 7
+    elif skew == "dups":  # runs of equal values inside 64-entry slices, other values in between
+        flat = neg_idx.view(-1)
+        flat[::3] = flat[0]
+        flat[1::7] = 2 * B - 1
+    mid = _lib.MODEL_IDS[model]
+    L = _lib.lib()
+    n = _lib.inbatch_save_floats(mid, B, K, D)
+    save = torch.full((n,), float("nan"), device="cuda")
+    neg = torch.empty(B, K, device="cuda")
+    loss = torch.empty((), device="cuda")
+    ticket = torch.zeros(_lib.INBATCH_TICKET_INTS, dtype=torch.int32, device="cuda")
+    dev_idx = neg_idx.cuda()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):  # (twice: the ticket comes back zeroed)
+        _lib.check(L.blp_inbatch_loss_fwd(mid, 0, 0, 0, ent.data_ptr(), rel.data_ptr(), dev_idx.data_ptr(), B, K, D, 1e-3, loss.data_ptr(),
+                                          save.data_ptr(), neg.data_ptr(), ticket.data_ptr(), 0, stream), "fwd")
+    torch.cuda.synchronize()
+    assert ticket.tolist() == [0] * _lib.INBATCH_TICKET_INTS and bool(torch.isfinite(loss))
+    per_block = 64 if model == "transe" else 8          # pairs per scoring workgroup at D = 128 (4 / 32 lanes per pair)
+    pair_blocks = -(-B * (K + 1) // per_block)
+    partials_at = (B + 1) // 2 * 2
+    regsh_at = partials_at + 4 * (pair_blocks + (B + 3) // 4)
+    off_at = (regsh_at + B + 1) // 2 * 2 + 6 * 64
+    chunk, entries = 1024, 2 * B * K
+    C = -(-entries // chunk)
+    sorted_at = off_at + C * (2 * B + 1)
+    assert sorted_at + entries == n
+    ints = save.view(torch.int32).cpu()
+    off = ints[off_at:sorted_at].reshape(C, 2 * B + 1)
+    got = ints[sorted_at:sorted_at + entries]
+    flat = neg_idx.view(-1)
+    for c in range(C):
+        lo, hi = c * chunk, min((c + 1) * chunk, entries)
+        vals = flat[lo:hi]
+        order = torch.sort(vals, stable=True).indices + lo        # by row, entry order within a row
+        assert torch.equal(got[lo:hi].long(), order), (c, "entries")
+        counts = torch.bincount(vals, minlength=2 * B)
+        want_off = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)))
+        assert torch.equal(off[c].long(), want_off), (c, "offsets")
+    assert launches_match(L, mid, B, K, D)
+
+
+def launches_match(L, mid, B, K, D):
+    blocks = -(-B * (K + 1) // (64 if mid == 0 else 8)) + (B + 3) // 4
+    return L.blp_inbatch_loss_fwd_launches(mid, B, K, D, 1e-3) == (1 if blocks <= 96 else 2)
 
 
 @pytest.mark.parametrize("model,D", [("distmult", 100), ("complex", 200), ("simple", 300), ("transe", 1000),
