@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/r05/ holds, in one go on the GPU box (writes gpurun_out/r/): per-workload bench lines (compact line + the
+# Everything profiles/rNN/ holds, in one go on the GPU box (writes gpurun_out/r/): per-workload bench lines (compact line + the
 # details file), rocprofv3 kernel stats and the seven PMC passes (tools/profile_all.sh), the default bench line, the in-batch
 # loss kernels, and the small logs (clustered sweep, compute_loss probes, reference-batched passes, shard model, loop layouts).
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -8,13 +8,8 @@ export WORKLOADS="${WORKLOADS:-fb15k237-transe fb15k237-distmult fb15k237-comple
 bash tools/profile_all.sh > gpurun_out/r/profile_all.log 2>&1
 [ -n "$ONLY_WORKLOADS" ] && { ls gpurun_out/r; exit 0; }
 python bench.py --steps 20 --warmup 5 --details gpurun_out/r/bench_default_details.json 2> gpurun_out/r/bench_default.stderr > gpurun_out/r/bench_default.json
-mkdir -p gpurun_out/r/inbatch
-cd /tmp && export TMPDIR=/tmp
-for shape in inbatch-fb15k237 inbatch-wikidata5m-complex-fp16 inbatch-wikidata5m-complex-fp16-b1024; do
-  rm -rf /tmp/ib && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ib -o t -- python $R/tools/inbatch_kernels.py $shape > /dev/null 2>&1
-  find /tmp/ib -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r/inbatch/$shape.kernel_stats.csv \;
-done
-cd $R
+bash tools/inbatch_profile.sh r/inbatch > gpurun_out/r/inbatch_profile.log 2>&1
+python tools/inbatch_probe.py 2>&1 | grep "^inbatch" > gpurun_out/r/inbatch_probe.log
 python tools/clustered_sweep.py 2>&1 | grep -v amdgpu > gpurun_out/r/clustered_sweep.log
 python tools/loss_step_probe.py 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > gpurun_out/r/loss_step_probe.log
 python tools/autograd_floor_probe.py 2>&1 | grep -v amdgpu > gpurun_out/r/autograd_floor_probe.log
@@ -26,5 +21,6 @@ python -c "
 import sys; sys.path.insert(0, '.')
 from blp_amd import _lib
 print('blp_selftest:', _lib.selftest(0)); print(_lib.device_caps(0))" 2>&1 | grep -v amdgpu > gpurun_out/r/selftest.log
+BLP_BENCH_BACKEND=gloo python bench.py --gpus 8 --dry-nccl 2> gpurun_out/r/dry_nccl_8_gloo.stderr > gpurun_out/r/dry_nccl_8_gloo.json
 BLP_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 2 --warmup 1 --details gpurun_out/r/bench_8_gloo_ranks_one_gpu_functional_details.json 2> gpurun_out/r/bench_8_gloo.stderr > gpurun_out/r/bench_8_gloo_ranks_one_gpu_functional.json
 ls gpurun_out/r; du -sh gpurun_out/r
