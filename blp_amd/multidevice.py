@@ -72,6 +72,7 @@ class DeviceGroup:
         self._barrier = threading.Barrier(self.world)
         self._slots = [None] * self.world
         self._failure = None
+        self.nccl_error = None  # set when an RCCL group launch failed and the group fell back to peer copies (said in a warning)
 
     @staticmethod
     def _device(d):
@@ -149,6 +150,16 @@ class DeviceGroup:
                 raise self._failure
             raise DeviceThreadError("the collective failed on the issuing thread")
 
+    def _issue_nccl(self, op, slots):
+        from torch.cuda import nccl
+        streams = [m.stream for m in self.members]
+        if op == "all_reduce":
+            nccl.all_reduce(list(slots), streams=streams)  # in place
+        else:
+            nccl.all_gather([part for _, part in slots], [full for full, _ in slots], streams=streams)
+        for s in streams:
+            s.synchronize()
+
     def _issue(self, op):
         """Member 0's thread, everybody else parked at the barrier: the collective for all members, then a synchronise of
         every device involved -- the members continue on their own streams with the result complete."""
@@ -158,16 +169,16 @@ class DeviceGroup:
         first = slots[0][1] if op == "all_gather" else slots[0]
         self.issued.append((op, first.numel() * first.element_size()))
         on_gpu = first.is_cuda
-        if self.exchange == "nccl" and on_gpu:
-            from torch.cuda import nccl
-            streams = [m.stream for m in self.members]
-            if op == "all_reduce":
-                nccl.all_reduce(list(slots), streams=streams)  # in place
-            else:
-                nccl.all_gather([part for _, part in slots], [full for full, _ in slots], streams=streams)
-            for s in streams:
-                s.synchronize()
-            return
+        if self.exchange == "nccl":
+            try:
+                self._issue_nccl(op, slots)
+                return
+            except Exception as exc:  # noqa: BLE001 -- RCCL's single-process group launch is not available here
+                # Same numbers either way (sums of int32 counts, x + 0 = x for the vectors): the exchange changes, not a result.
+                # Said out loud, once; the group stays on peer copies from here on.
+                import warnings
+                self.exchange, self.nccl_error = "copy", f"{type(exc).__name__}: {exc}"
+                warnings.warn(f"blp_amd.multidevice: RCCL group launch failed ({self.nccl_error}); exchanging by peer copies instead")
         if op == "all_reduce":
             home = slots[0].device
             total = slots[0].clone()

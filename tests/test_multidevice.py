@@ -54,6 +54,28 @@ def test_a_failing_thread_does_not_leave_the_others_waiting():
     assert [int(x) for x in group.run(lambda m: m.rank)] == [0, 1]
 
 
+def test_a_failed_rccl_group_launch_falls_back_to_peer_copies_and_says_so():
+    """RCCL's single-process group launch (torch.cuda.nccl) has never run between two GPUs of this package's: if it raises on a
+    box, the evaluation must not die in the reference's default launch -- the group says so in a warning (and in
+    `nccl_error`), exchanges by peer copies from then on, and the numbers are the same (here: the launch is MADE to fail by
+    handing it host tensors)."""
+    group = multidevice.DeviceGroup(["cpu", "cpu"])
+    group.exchange = "nccl"  # (what "auto" picks for distinct HIP devices)
+
+    def work(m):
+        x = torch.full((3,), float(m.rank + 1))
+        m.all_reduce(x)
+        full = torch.empty(4, dtype=torch.int32)
+        m.all_gather_into(full, torch.tensor([m.rank, 7], dtype=torch.int32))
+        return x, full
+
+    with pytest.warns(UserWarning, match="RCCL group launch failed"):
+        out = group.run(work)
+    assert group.exchange == "copy" and group.nccl_error
+    for x, full in out:
+        assert x.tolist() == [3.0, 3.0, 3.0] and full.tolist() == [0, 7, 1, 7]
+
+
 def test_device_list_checks():
     with pytest.raises(ValueError):
         multidevice.DeviceGroup([])
