@@ -64,6 +64,9 @@ struct SaveLayout {
     int64_t partials_at, regsh_at, red_at, off_at, sorted_at, total;  // in floats
     int pair_blocks, reg_blocks, chunk, n_chunks;
     bool fused;  // the scoring workgroups are few enough for the last one to add their partial sums itself (one launch)
+    bool rows;   // ... and each of them is ONE row of the batch: its K negatives and its positive side by side, in
+                 // max(256, (K + 1) x lanes per pair) threads -- no positive is scored twice
+    int threads; // of a forward workgroup
 };
 // Up to this many scoring workgroups finish the loss themselves (a ticket each: same-address device-scope atomics and the
 // uncached round trips behind them, ~3 us in all -- what a second launch costs); more take the second launch, which
@@ -83,10 +86,14 @@ __host__ __device__ inline SaveLayout save_layout(int model, int B, int K, int D
     const int64_t entries = 2ll * B * K;
     L.chunk = kIdxChunk;
     L.n_chunks = (int)((entries + L.chunk - 1) / L.chunk);
+    const int packed_blocks = L.pair_blocks, lanes = lanes_per_pair(model, D);
+    L.rows = K + 1 <= 256 && (int64_t)(K + 1) * lanes <= 1024 && B + L.reg_blocks <= kFusedForwardWgs;
+    if (L.rows) L.pair_blocks = B;
+    L.threads = L.rows && (K + 1) * lanes > 256 ? ((K + 1) * lanes + 63) / 64 * 64 : 256;
     L.fused = L.pair_blocks + L.reg_blocks <= kFusedForwardWgs;
     L.partials_at = (B + 1) / 2 * 2;  // (doubles: 8-byte aligned)
-    // (sized for a regularised call either way: the size must not depend on a float argument)
-    L.regsh_at = L.partials_at + 4ll * (L.pair_blocks + (B + 3) / 4);  // (many workgroups) the rows' shares of the regulariser
+    // (sized for a regularised call either way, and for either slot mapping: the size must not depend on a float argument)
+    L.regsh_at = L.partials_at + 4ll * ((packed_blocks > B ? packed_blocks : B) + (B + 3) / 4);  // (many workgroups) the rows' shares of the regulariser
     L.red_at = (L.regsh_at + B + 1) / 2 * 2;                           // (many workgroups) inbatch_reduce_kernel's partial sums
     L.off_at = L.red_at + 6 * kReduceBlocks;
     L.sorted_at = L.off_at + (int64_t)L.n_chunks * (2 * B + 1);
@@ -411,7 +418,7 @@ __device__ __forceinline__ void index_chunk(const int64_t* __restrict__ neg_idx,
 // that takes the LAST ticket adds the partials in workgroup order and writes the loss: a fixed summation order whoever comes
 // last, no float atomics, no second launch.  `ticket`: one counter, zero when the kernel starts, left zero.
 template <int MODEL, class TE, class TR>
-__global__ __launch_bounds__(256) void inbatch_forward_kernel(int loss, const TE* __restrict__ ent, const TR* __restrict__ rel,
+__global__ __launch_bounds__(1024) void inbatch_forward_kernel(int loss, const TE* __restrict__ ent, const TR* __restrict__ rel,
                                                              const int64_t* __restrict__ neg_idx, int B, int K, int D,
                                                              float regularizer, float* __restrict__ pos, float* __restrict__ neg,
                                                              float* __restrict__ out, unsigned* __restrict__ ticket, SaveLayout L,
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(256) void inbatch_forward_kernel(int loss, const TE
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* partials = reinterpret_cast<double*>(pos + L.partials_at);
     if ((int)blockIdx.x < L.n_chunks) {
+        if (tid >= 256) return;  // (a row-mode launch has more waves per workgroup: the index workgroups use four)
         index_chunk(neg_idx, 2ll * B * K, 2 * B, L.chunk, (int)blockIdx.x, reinterpret_cast<int*>(pos + L.off_at),
                     reinterpret_cast<int*>(pos + L.sorted_at));
         return;
@@ -429,6 +437,7 @@ __global__ __launch_bounds__(256) void inbatch_forward_kernel(int loss, const TE
     const int blk = (int)blockIdx.x - L.n_chunks, n_blocks = L.pair_blocks + L.reg_blocks;
     double part0 = 0.0, part1 = 0.0;
     if (blk >= L.pair_blocks) {  // the regulariser: four positive triples, a wave each
+        if (tid >= 256) return;
         const int b = (blk - L.pair_blocks) * 4 + wave;
         float sq = 0.0f;
         if (b < B) {
@@ -449,12 +458,15 @@ __global__ __launch_bounds__(256) void inbatch_forward_kernel(int loss, const TE
             for (int i = 0; i < 4; ++i) part0 += (double)term_neg[i];
     } else {
         const int64_t n_pairs = (int64_t)B * (K + 1);
-        const int per_pair = lanes_per_pair(MODEL, D), sub = tid & (per_pair - 1), groups = 256 / per_pair, gid = tid / per_pair;
-        const int64_t slot0 = (int64_t)blk * groups, slot = slot0 + gid;  // over B * (K + 1); k == K: positive
-        const int64_t slot_last = slot0 + groups < n_pairs ? slot0 + groups - 1 : n_pairs - 1;
+        const int per_pair = lanes_per_pair(MODEL, D), sub = tid & (per_pair - 1), groups = L.threads / per_pair, gid = tid / per_pair;
+        // slots: packed -- workgroup blk takes slots [blk groups, (blk + 1) groups) of the B (K + 1) (k == K: the positive) --
+        // or, row mode, workgroup blk IS row blk: group k scores negative k, group K the positive
+        const int64_t slot0 = L.rows ? (int64_t)blk * (K + 1) : (int64_t)blk * groups;
+        const int64_t slot = slot0 + gid;
+        const int64_t slot_last = L.rows ? slot0 + K : (slot0 + groups < n_pairs ? slot0 + groups - 1 : n_pairs - 1);
         const int b_first = (int)(slot0 / (K + 1)), b_last = (int)(slot_last / (K + 1));
-        const bool live = slot < n_pairs;
-        const int64_t pair = live ? slot : n_pairs - 1;  // (idle lanes redo the last pair: every lane has readable rows)
+        const bool live = L.rows ? gid <= K : slot < n_pairs;
+        const int64_t pair = live ? slot : slot_last;  // (idle lanes redo the last pair: every lane has readable rows)
         const int b = (int)(pair / (K + 1)), k = (int)(pair % (K + 1));
         const TE* h;
         const TE* t;
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(256) void inbatch_forward_kernel(int loss, const TE
         const int bp = b_first + gid <= b_last ? b_first + gid : b_last;
         const TE* hp = ent + (size_t)(2 * bp) * D;
         // (the positive first: its rows' loads do not wait for neg_idx, so they are in flight while the slot's indices arrive)
-        const float sp = (probe & 4) || !L.fused ? 0.0f : pair_score<MODEL>(hp, hp + D, rel + (size_t)bp * D, D, per_pair, sub, lane);
+        const float sp = (probe & 4) || !L.fused || L.rows ? 0.0f : pair_score<MODEL>(hp, hp + D, rel + (size_t)bp * D, D, per_pair, sub, lane);
         const float s = pair_score<MODEL>(h, t, rel + (size_t)b * D, D, per_pair, sub, lane);
         if (!L.fused) {  // many workgroups: the scores only; inbatch_reduce_kernel forms the loss from them
             if (live && sub == 0) {
@@ -481,7 +493,11 @@ __global__ __launch_bounds__(256) void inbatch_forward_kernel(int loss, const TE
             }
             return;
         }
-        if (sub == 0) pos_sh[gid] = sp;
+        if (L.rows) {
+            if (sub == 0 && live && k == K) pos_sh[0] = s;  // the row's positive, scored once, by its own group
+        } else if (sub == 0) {
+            pos_sh[gid] = sp;
+        }
         __syncthreads();
         if (sub == 0) {
             float tn = 0.0f, tp = 0.0f;
@@ -980,6 +996,267 @@ __global__ __launch_bounds__(GradShape<SWEEP>::kWaves * 64) void inbatch_grad_ke
     }
 }
 
+// ---------------------------------------------------------------- backward, rows of up to 128 elements (the scripts' dim)
+// The same grid and the same lists as inbatch_grad_kernel, another lane layout: a HALF-wave per contribution.  Lane (half, l)
+// owns elements 4 l .. 4 l + 3 of the row (D <= 128, D % 4 == 0; the split models D % 8 == 0 so that a lane's four elements lie
+// in one half of the vector), so one wave-instruction serves TWO list entries and every address is per lane: no scalar
+// broadcast of a pair's five values (v_readlane x 5), no scalar address arithmetic per pair -- [counted] ~35 -> ~15
+// wave-instructions per contribution.  A window of 64 list entries is fetched one entry per lane (entry, pair, rows, loss
+// gradient), the entries with a non-zero loss gradient are compacted into the wave's LDS slots in list order, and the halves
+// then take them alternately (half 0 the even slots, half 1 the odd ones), kUnroll slots' row loads in flight together.  A
+// half adds its contributions in list order; the two halves' sums are added at the end (half 0 + half 1), then the shares in
+// share order: fixed orders, bit-reproducible gradients.
+template <int MODEL, class TE, class TR>
+__device__ __forceinline__ void load_ops4(int op, const TE* __restrict__ h, const TE* __restrict__ t, const TR* __restrict__ r, int d,
+                                          int D, float (&x)[4][4]) {
+    if constexpr (MODEL == TRANSE) {
+        load4(h + d, x[0]); load4(t + d, x[1]); load4(r + d, x[2]);
+    } else if constexpr (MODEL == DISTMULT) {  // the derivative with respect to one operand reads the two others
+        if (op == 0) { load4(r + d, x[0]); load4(t + d, x[1]); }
+        else if (op == 1) { load4(h + d, x[0]); load4(r + d, x[1]); }
+        else { load4(h + d, x[0]); load4(t + d, x[1]); }
+    } else {
+        const int H = D / 2, j = d >= H ? d - H : d;  // (a lane's four elements lie in one half: H % 4 == 0)
+        if (op == 0) { load4(r + j, x[0]); load4(r + H + j, x[1]); load4(t + j, x[2]); load4(t + H + j, x[3]); }
+        else if (op == 1) { load4(h + j, x[0]); load4(h + H + j, x[1]); load4(r + j, x[2]); load4(r + H + j, x[3]); }
+        else { load4(h + j, x[0]); load4(h + H + j, x[1]); load4(t + j, x[2]); load4(t + H + j, x[3]); }
+    }
+}
+
+// d score / d operand `op` at the lane's four elements from what load_ops4 fetched (the formulas of dscore / dscore2)
+template <int MODEL>
+__device__ __forceinline__ void eval_ops4(int op, int d, int D, const float (&x)[4][4], float (&out)[4]) {
+    const bool second = d >= D / 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if constexpr (MODEL == TRANSE) {
+            const float sg = sign0(x[0][k] + x[2][k] - x[1][k]);
+            out[k] = op == 1 ? sg : -sg;
+        } else if constexpr (MODEL == DISTMULT) {
+            out[k] = x[0][k] * x[1][k];
+        } else if constexpr (MODEL == COMPLEX) {  // s = rr*hr*tr + rr*hi*ti + ri*hr*ti - ri*hi*tr ; x = {a0, a1, b0, b1}
+            const float a0 = x[0][k], a1 = x[1][k], b0 = x[2][k], b1 = x[3][k];
+            if (op == 1) out[k] = second ? b0 * a1 + b1 * a0 : b0 * a0 - b1 * a1;   // a = h, b = r
+            else out[k] = second ? a0 * b1 - a1 * b0 : a0 * b0 + a1 * b1;            // (a, b) = (r, t) or (h, t)
+        } else {                                   // s = (hh*ra*tt + th*rb*ht) / 2
+            const float a0 = x[0][k], a1 = x[1][k], b0 = x[2][k], b1 = x[3][k];
+            if (op == 1) out[k] = 0.5f * (second ? a0 * b0 : b1 * a1);               // a = h, b = r
+            else out[k] = 0.5f * (second ? b0 * a1 : a0 * b1);                        // (a, b) = (r, t) or (h, t)
+        }
+    }
+}
+
+constexpr int kGrad4Waves = 16;
+__host__ __device__ constexpr int grad4_unroll(int model) { return model == TRANSE || model == DISTMULT ? 4 : 2; }
+
+// The wave's compacted slots [0, n_live) (LDS: rows, relation row | operand << 30, loss gradient), the halves alternately.
+template <int MODEL, class TE, class TR>
+__device__ __forceinline__ void consume_slots4(float (&g)[4], const int2* __restrict__ slot_rows, const int2* __restrict__ slot_meta, int n_live,
+                                               const TE* __restrict__ ent, const TR* __restrict__ rel, int D, int d, bool active, int half) {
+    constexpr int U = grad4_unroll(MODEL);
+    for (int i0 = 0; i0 < n_live; i0 += 2 * U) {
+        float x[U][4][4], gn[U];
+        int op[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = i0 + 2 * u + half;
+            const bool ok = active && idx < n_live;
+            const int2 rows = slot_rows[ok ? idx : 0], meta = slot_meta[ok ? idx : 0];
+            op[u] = (unsigned)meta.x >> 30;
+            gn[u] = ok ? __builtin_bit_cast(float, meta.y) : 0.0f;
+            if (ok)
+                load_ops4<MODEL>(op[u], ent + (size_t)rows.x * D, ent + (size_t)rows.y * D, rel + (size_t)(meta.x & 0x3fffffff) * D, d, D, x[u]);
+            else
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[u][a][k] = 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v[4];
+            eval_ops4<MODEL>(op[u], d, D, x[u], v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] += gn[u] * v[k];
+        }
+    }
+}
+
+template <int MODEL, class TE, class TR>
+__global__ __launch_bounds__(kGrad4Waves * 64) void inbatch_grad4_kernel(
+    int loss, const TE* __restrict__ ent, const TR* __restrict__ rel, const int64_t* __restrict__ neg_idx, int B, int K,
+    int D, float regularizer, const float* __restrict__ grad_loss, const float* __restrict__ pos,
+    const float* __restrict__ neg, TE* __restrict__ grad_ent, TR* __restrict__ grad_rel, int ent_blocks, int S,
+    int rel_shares, const int* __restrict__ off, const int* __restrict__ sorted, int chunk, int C) {
+    constexpr int WAVES = kGrad4Waves;
+    __shared__ int run_at[WAVES][64];
+    __shared__ int run_from[WAVES][64];
+    __shared__ int2 slot_rows[WAVES][64], slot_meta[WAVES][64];
+    __shared__ float park[WAVES][128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, d = 4 * (lane & 31);
+    const bool lane_active = d < D;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const float gl = grad_loss[0];
+    const float reg_scale = regularizer > 0.0f ? regularizer * 2.0f / (3.0f * B * D) : 0.0f;
+    float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // one window of <= 64 candidate slots: lane-per-entry values in, compacted (gn != 0) into the wave's LDS, consumed
+    auto window = [&](bool in, int hv, int tv, int pb, int operand, float gn) {
+        const bool keep = in && gn != 0.0f;
+        const unsigned long long mask = __ballot(keep);
+        wave_lds_fence();  // the previous window's readers are done
+        if (keep) {
+            const int at = __popcll(mask & below);
+            slot_rows[wave][at] = make_int2(hv, tv);
+            slot_meta[wave][at] = make_int2(pb | (operand << 30), __builtin_bit_cast(int, gn));
+        }
+        wave_lds_fence();
+        consume_slots4<MODEL>(g, slot_rows[wave], slot_meta[wave], __popcll(mask), ent, rel, D, d, lane_active, half);
+    };
+    auto fold_halves = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = g[k] + __shfl_xor(g[k], 32);  // (half 0 + half 1: the same bits in both halves)
+    };
+
+    if ((int)blockIdx.x >= ent_blocks) {  // ---- relation rows: positive pair + its K negatives (models.py:67 broadcasts rels over K)
+        const int rows_here = WAVES / rel_shares;
+        const int b = ((int)blockIdx.x - ent_blocks) * rows_here + wave / rel_shares, my_share = wave % rel_shares;
+        const bool active = b < B;
+        const int bb = active ? b : B - 1;
+        const TR* r = rel + (size_t)bb * D;
+        const float pb = pos[bb];
+        const float gp = dloss_dpos_wave(loss, pb, neg + (size_t)bb * K, B, K, lane);
+        if (my_share == 0 && half == 0 && lane_active) {
+            float x[4][4], v[4];
+            load_ops4<MODEL>(2, ent + (size_t)(2 * bb) * D, ent + (size_t)(2 * bb + 1) * D, r, d, D, x);
+            eval_ops4<MODEL>(2, d, D, x, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = gp * v[k];
+        }
+        const int k_lo = (int)((int64_t)K * my_share / rel_shares), k_hi = (int)((int64_t)K * (my_share + 1) / rel_shares);
+        for (int kb = k_lo; kb < k_hi && active; kb += 64) {
+            const int k = kb + lane;
+            const bool in = k < k_hi;
+            const size_t pair = (size_t)bb * K + (in ? k : k_lo);
+            const float gn = in ? dloss_dneg(loss, pb, neg[pair], B, K) : 0.0f;
+            window(in, (int)neg_idx[2 * pair], (int)neg_idx[2 * pair + 1], bb, 2, gn);
+        }
+        fold_halves();
+        if (rel_shares > 1) {
+            __syncthreads();
+            if (half == 0)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) park[wave][d + k] = g[k];
+            __syncthreads();
+            if (my_share == 0 && half == 0)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    for (int s = 1; s < rel_shares; ++s) g[k] += park[wave + s][d + k];
+        }
+        if (active && my_share == 0 && half == 0 && lane_active) {
+            float rv[4];
+            load4(r + d, rv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) grad_rel[(size_t)b * D + d + k] = (TR)(gl * (g[k] + reg_scale * rv[k]));
+        }
+        return;
+    }
+
+    // ---- entity rows: wave = (row_local, share)
+    const int R = WAVES / S, row_local = wave / S, my_share = wave % S;
+    const int my_row = (int)blockIdx.x * R + row_local;
+    const bool active = my_row < 2 * B;
+    const int j = active ? my_row : 2 * B - 1;
+    const int stride = 2 * B + 1;
+    int n_list = 0;
+    for (int cb = 0; cb < C; cb += 64) {
+        const int c = cb + lane;
+        int cnt = c < C ? off[(size_t)c * stride + j + 1] - off[(size_t)c * stride + j] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        n_list += cnt;
+    }
+    const int my_lo = active ? (int)((int64_t)n_list * my_share / S) : 0, my_hi = active ? (int)((int64_t)n_list * (my_share + 1) / S) : 0;
+    const float gp_row = dloss_dpos_wave(loss, pos[j >> 1], neg + (size_t)(j >> 1) * K, B, K, lane);  // (the whole wave: it shuffles)
+    if (my_share == 0 && active && half == 0 && lane_active) {  // positive pair (2b, 2b + 1, rel b): the row is its head or its tail
+        const int b = j >> 1, slot = j & 1;
+        const float gp = gp_row;
+        float x[4][4], v[4];
+        load_ops4<MODEL>(slot, ent + (size_t)(2 * b) * D, ent + (size_t)(2 * b + 1) * D, rel + (size_t)b * D, d, D, x);
+        eval_ops4<MODEL>(slot, d, D, x, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = gp * v[k];
+    }
+    int at0 = 0;  // list position of the first entry of this block of 64 chunks
+    for (int cb = 0; cb < C && at0 < my_hi; cb += 64) {
+        const int c = cb + lane;
+        const int from = c < C ? off[(size_t)c * stride + j] : 0;
+        const int cnt = c < C ? off[(size_t)c * stride + j + 1] - from : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const int blk_n = __shfl(incl, 63);
+        wave_lds_fence();
+        run_at[wave][lane] = c < C ? incl - cnt : 0x7fffffff;
+        run_from[wave][lane] = from;
+        wave_lds_fence();
+        const int a = my_lo > at0 ? my_lo : at0, z = my_hi < at0 + blk_n ? my_hi : at0 + blk_n;
+        for (int w = a; w < z; w += 64) {
+            const bool in = w + lane < z;
+            const int q = (in ? w + lane : a) - at0;
+            int l = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (run_at[wave][l + step] <= q) l += step;
+            const int e = sorted[(size_t)(cb + l) * chunk + run_from[wave][l] + (q - run_at[wave][l])];
+            const int pair = e >> 1, pb = pair / K;
+            const float gn = in ? dloss_dneg(loss, pos[pb], neg[pair], B, K) : 0.0f;
+            window(in, (int)neg_idx[2 * (size_t)pair], (int)neg_idx[2 * (size_t)pair + 1], pb, e & 1, gn);
+        }
+        at0 += blk_n;
+    }
+    fold_halves();
+    if (S > 1) {
+        __syncthreads();
+        if (half == 0)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) park[wave][d + k] = g[k];
+        __syncthreads();
+        if (my_share == 0 && half == 0)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                for (int s = 1; s < S; ++s) g[k] += park[wave + s][d + k];
+    }
+    if (active && my_share == 0 && half == 0 && lane_active) {
+        float ev[4];
+        load4(ent + (size_t)my_row * D + d, ev);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) grad_ent[(size_t)my_row * D + d + k] = (TE)(gl * (g[k] + reg_scale * ev[k]));
+    }
+}
+
+template <int MODEL, class TE, class TR>
+static void launch_grad4(int loss, const TE* ent, const TR* rel, const int64_t* neg_idx, int B, int K, int D, float regularizer,
+                         const float* grad_loss, const float* pos, const float* neg, TE* grad_ent, TR* grad_rel, hipStream_t stream) {
+    constexpr int WAVES = kGrad4Waves;
+    // entity rows: S waves share a row's list while that keeps the grid near 2 048 waves; a power of two, at least two
+    int S = WAVES;
+    while (S > 2 && (int64_t)2 * B * S > 2048) S >>= 1;
+    if (const long long forced = knob(KNOB_INBATCH_SHARES); forced > 0 && forced <= WAVES && (forced & (forced - 1)) == 0) S = (int)forced;
+    const int R = WAVES / S;
+    int rel_shares = WAVES;
+    while (rel_shares > 1 && (int64_t)B * rel_shares > 4096) rel_shares >>= 1;
+    const int ent_blocks = (2 * B + R - 1) / R, rows_per_rel_block = WAVES / rel_shares;
+    const int rel_blocks = (B + rows_per_rel_block - 1) / rows_per_rel_block;
+    const SaveLayout L = save_layout(MODEL, B, K, D, regularizer > 0.0f);
+    inbatch_grad4_kernel<MODEL, TE, TR><<<dim3((unsigned)(ent_blocks + rel_blocks)), WAVES * 64, 0, stream>>>(
+        loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, pos, neg, grad_ent, grad_rel, ent_blocks, S, rel_shares,
+        reinterpret_cast<const int*>(pos + L.off_at), reinterpret_cast<const int*>(pos + L.sorted_at), L.chunk, L.n_chunks);
+}
+
 template <int MODEL, class TE, class TR, int SWEEP>
 static void launch_grad(int loss, const TE* ent, const TR* rel, const int64_t* neg_idx, int B, int K, int D, float regularizer,
                         const float* grad_loss, const float* pos, const float* neg, TE* grad_ent, TR* grad_rel, hipStream_t stream) {
@@ -1043,7 +1320,7 @@ hipError_t launch_inbatch_loss_fwd(int model, int loss, int ent_dtype, int rel_d
             if (probe & 1) L.n_chunks = 0;
             const int64_t blocks = (int64_t)L.n_chunks + L.pair_blocks + L.reg_blocks;
             if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-            inbatch_forward_kernel<decltype(m)::value, TE, TR><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+            inbatch_forward_kernel<decltype(m)::value, TE, TR><<<dim3((unsigned)blocks), (unsigned)L.threads, 0, stream>>>(
                 loss, static_cast<const TE*>(ent), static_cast<const TR*>(rel), neg_idx, B, K, D, regularizer, save_pos, save_neg,
                 out_loss, ticket, L, probe);
             if (!L.fused) {
@@ -1067,14 +1344,17 @@ hipError_t launch_inbatch_loss_bwd(int model, int loss, int ent_dtype, int rel_d
         return dispatch_types(ent_dtype, rel_dtype, [&](auto te, auto tr) {
             using TE = typename decltype(te)::type;
             using TR = typename decltype(tr)::type;
-            if (D <= 128 && D % 4 == 0)  // (element pairs per lane: rows and their halves start on even elements)
-                launch_grad<decltype(m)::value, TE, TR, 2>(loss, static_cast<const TE*>(ent), static_cast<const TR*>(rel), neg_idx, B, K, D,
-                                                           regularizer, grad_loss, save_pos, save_neg, static_cast<TE*>(grad_ent),
-                                                           static_cast<TR*>(grad_rel), stream);
+            constexpr int MODEL = decltype(m)::value;
+            // rows of up to 128 elements (the scripts' dim): a half-wave per contribution, four elements per lane (the split
+            // models: a lane's four elements inside one half of the vector); anything else: four waves, lane-strided elements
+            if (D <= 128 && D % 4 == 0 && (MODEL == TRANSE || MODEL == DISTMULT || D % 8 == 0))
+                launch_grad4<MODEL, TE, TR>(loss, static_cast<const TE*>(ent), static_cast<const TR*>(rel), neg_idx, B, K, D,
+                                            regularizer, grad_loss, save_pos, save_neg, static_cast<TE*>(grad_ent),
+                                            static_cast<TR*>(grad_rel), stream);
             else
-                launch_grad<decltype(m)::value, TE, TR, 8>(loss, static_cast<const TE*>(ent), static_cast<const TR*>(rel), neg_idx, B, K, D,
-                                                           regularizer, grad_loss, save_pos, save_neg, static_cast<TE*>(grad_ent),
-                                                           static_cast<TR*>(grad_rel), stream);
+                launch_grad<MODEL, TE, TR, 8>(loss, static_cast<const TE*>(ent), static_cast<const TR*>(rel), neg_idx, B, K, D,
+                                              regularizer, grad_loss, save_pos, save_neg, static_cast<TE*>(grad_ent),
+                                              static_cast<TR*>(grad_rel), stream);
             return hipGetLastError();
         });
     });

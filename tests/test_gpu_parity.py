@@ -964,7 +964,7 @@ def test_inbatch_forward_leaves_a_stable_index_of_neg_idx(model, B, K, skew):
     per_block = 64 if model == "transe" else 8          # pairs per scoring workgroup at D = 128 (4 / 32 lanes per pair)
     pair_blocks = -(-B * (K + 1) // per_block)
     partials_at = (B + 1) // 2 * 2
-    regsh_at = partials_at + 4 * (pair_blocks + (B + 3) // 4)
+    regsh_at = partials_at + 4 * (max(pair_blocks, B) + (B + 3) // 4)   # (sized for the packed and for the row-per-workgroup slot mapping)
     off_at = (regsh_at + B + 1) // 2 * 2 + 6 * 64
     chunk, entries = 1024, 2 * B * K
     C = -(-entries // chunk)
@@ -986,8 +986,13 @@ def test_inbatch_forward_leaves_a_stable_index_of_neg_idx(model, B, K, skew):
 
 
 def launches_match(L, mid, B, K, D):
-    blocks = -(-B * (K + 1) // (64 if mid == 0 else 8)) + (B + 3) // 4
-    return L.blp_inbatch_loss_fwd_launches(mid, B, K, D, 1e-3) == (1 if blocks <= 96 else 2)
+    """One forward launch iff at most 96 scoring + regulariser workgroups: with the slots packed, or -- when a row's K + 1 pairs
+    fit one workgroup -- with a workgroup per row of the batch."""
+    lanes = 4 if mid == 0 else 32
+    reg = (B + 3) // 4
+    packed = -(-B * (K + 1) // (256 // lanes)) + reg
+    per_row = B + reg if (K + 1 <= 256 and (K + 1) * lanes <= 1024) else packed
+    return L.blp_inbatch_loss_fwd_launches(mid, B, K, D, 1e-3) == (1 if min(packed, per_row) <= 96 else 2)
 
 
 @pytest.mark.parametrize("model,D", [("distmult", 100), ("complex", 200), ("simple", 300), ("transe", 1000),
