@@ -242,7 +242,22 @@ def make_filter_index(cfg, heads, tails, rels, seed=3):
         nodes = torch.multinomial(weight, 2 * extra, replacement=True, generator=g).reshape(2, extra)
         rel = torch.randint(0, cfg["R"], (extra,), generator=g)
         test = torch.cat((test, torch.stack((nodes[0], nodes[1], rel), dim=1)))
-    return utils.FilterIndex(test, num_relations=cfg["R"], device=heads.device)
+    # (timed: the one-off the evaluation's set-up pays -- the sort + unique of the graph's edges on the device, H2D of the edge
+    #  list included; generating the synthetic edges above is not part of it.  Built twice: the first build of a process also
+    #  loads the sort's code objects (100 - 200 ms once per process), the second is what the build itself costs)
+    def build():
+        if heads.is_cuda:
+            torch.cuda.synchronize(heads.device)
+        t0 = time.perf_counter()
+        index = utils.FilterIndex(test, num_relations=cfg["R"], device=heads.device)
+        if heads.is_cuda:
+            torch.cuda.synchronize(heads.device)
+        return index, (time.perf_counter() - t0) * 1e3
+
+    _, first_ms = build()
+    index, index.build_ms = build()
+    index.first_build_ms = first_ms
+    return index
 
 
 def workload_axis(cfg, world, shard_axis="auto"):
@@ -329,13 +344,9 @@ class Job:
         self.model = self.model.to(device)
         self.triples = torch.stack((heads, tails, rels), dim=1).contiguous()   # (T, 3) entity / relation ids
         self.ent2idx = torch.arange(self.N, device=device)                    # ids are table rows in the synthetic sets
-        # one-off cost outside the timed step, reported (the reference builds its networkx graph once as well, train.py:298-302):
-        # the sort + unique of the filtering graph's edges on the device (includes generating the synthetic edges' tensor copy)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
+        # one-off cost outside the timed step, reported (the reference builds its networkx graph once as well, train.py:298-302)
         self.index = make_filter_index(cfg, heads, tails, rels)
-        torch.cuda.synchronize(device)
-        self.filter_index_build_ms = (time.perf_counter() - t0) * 1e3
+        self.filter_index_build_ms, self.filter_index_first_build_ms = self.index.build_ms, self.index.first_build_ms
         self.index.segments(self.triples[:1], self.ent2idx, device)           # sorted arrays resident before the clock starts
         self.table_dtype = getattr(torch, cfg["table_dtype"]) if cfg.get("table_dtype") else torch.float32
         if self.table_dtype != torch.float32:  # the 16-bit copy IS the table of this workload; checks see it widened (exact)
@@ -578,6 +589,7 @@ class Job:
             "exchange_ms": max(exchange_per_rank), "exchange_ms_per_rank": exchange_per_rank,
             "shard_axis": self.axis, "ranks": self.world,
             "filter_index_build_ms": self.filter_index_build_ms,  # once per evaluation set-up, NOT inside ms_per_step
+            "filter_index_first_build_ms_in_this_process": self.filter_index_first_build_ms,  # (+ loading the sort's code objects)
             "filter_index_edges": self.index.num_edges,
         }
         return out, triples, counts

@@ -7,17 +7,19 @@
 //   fwd    inbatch_forward_kernel  the B (K + 1) pair scores with coalesced row reads: the bilinear models 32 lanes per
 //                                  pair (lane i = running sum i of torch.sum, then its fold by wavefront shuffles), TransE
 //                                  four lanes per pair (its L1 sum is one sequential chain walking through them) --
-//                                  scores bit-identical to the reference at the scripts' widths; every workgroup also
-//                                  forms its slots' loss terms (it re-scores the positives of its one or two rows) and
-//                                  leaves their f64 sum; the last workgroup (a ticket) adds the sums in workgroup order --
-//                                  or, with many workgroups, a second launch (inbatch_reduce_kernel) forms the loss from the scores; extra workgroups leave the
-//                                  rows' shares of the L2 regulariser, and others an INDEX of neg_idx (per chunk: the
+//                                  scores bit-identical to the reference at the scripts' widths.  Few scoring workgroups
+//                                  (<= 96: TransE at the scripts' batch sizes -- a workgroup per row of the batch, its K
+//                                  negatives and its positive side by side): each forms its slots' loss terms and leaves
+//                                  their f64 sum, the last one (a ticket) adds the sums in workgroup order.  Many: a second
+//                                  launch (inbatch_reduce_kernel) forms the loss from the scores.  Extra workgroups leave
+//                                  the rows' shares of the L2 regulariser, and others an INDEX of neg_idx (per chunk: the
 //                                  entries grouped by the row they name, stably) for the backward;
-//   bwd    inbatch_grad_kernel     entity rows and relation rows in one grid.  A wave (or S waves) owns a row of
-//                                  ent_embs.view(2B, D) and walks the negative pairs that reference it straight from the
-//                                  forward's index, in entry order: O(B K) work per step whatever the grid (round 5: every
-//                                  workgroup scanned all of neg_idx for its rows -- 92 us at B = 1 024, now 43), no float
-//                                  atomics, gradients bit-reproducible run to run.
+//   bwd    inbatch_grad4_kernel    (rows of up to 128 elements; inbatch_grad_kernel: any width) entity rows and relation
+//                                  rows in one grid.  S waves share a row of ent_embs.view(2B, D) and walk the negative
+//                                  pairs that reference it straight from the forward's index, in entry order, a half-wave
+//                                  per contribution: O(B K) work per step whatever the grid (round 5: every workgroup
+//                                  scanned all of neg_idx for its rows -- 92 us at B = 1 024, now 34), no float atomics,
+//                                  gradients bit-reproducible run to run.
 // Storage types: ent_embs / grad_ent in TE, rel_vecs / grad_rel in TR, each f32, f16 or bf16 (TR = TE or
 // f32: under autocast the encoder output is half while nn.Embedding rows stay f32).  Half operands are
 // widened exactly and every operation is the f32 one of the reference; gradients are rounded once on store.
@@ -702,75 +704,17 @@ __device__ __forceinline__ float dscore(int operand, const TE* __restrict__ h, c
     }
 }
 
-// Two shapes of the backward kernel: rows of up to 128 elements (the scripts' dim) keep 2 elements per lane, which leaves
-// room for 16 waves per workgroup (4 per SIMD hide the dependent loads of the walk); wider rows (up to 512 elements per
-// sweep, more: the scan repeats) take 4 waves.
+// Two shapes of the backward: rows of up to 128 elements (the scripts' dim) -- inbatch_grad4_kernel below: a half-wave per
+// contribution, four elements per lane, 16 waves per workgroup -- and wider rows / odd widths -- inbatch_grad_kernel: a wave per
+// contribution, lane-strided elements lane + 64 i (up to 512 elements per sweep, more: the walk repeats), 4 waves.
 template <int SWEEP> struct GradShape;
-template <> struct GradShape<2> { static constexpr int kWaves = 16; };
 template <> struct GradShape<8> { static constexpr int kWaves = 4; };
-// pairs whose row loads are in flight together: every pair in flight holds five wave-uniform values and three row
-// addresses in scalar registers -- eight pairs of a model that reads both halves of its rows spill them (and eight of
-// DistMult's in f32 make the compiler reserve a -- never touched -- stack slot for the spilled scalars: six)
-__host__ __device__ constexpr int grad_batch(int model, int sweep) { return sweep == 2 ? (model == TRANSE ? 8 : (model == DISTMULT ? 6 : 4)) : 4; }
+// pairs whose row loads are in flight together (every pair in flight holds five wave-uniform values and three row addresses
+// in scalar registers)
+__host__ __device__ constexpr int grad_batch(int, int) { return 4; }
 
-// Element i of a lane's share of a sweep.  SWEEP == 2 (rows of up to 128 elements, D % 4 == 0): the lane owns the two
-// CONSECUTIVE elements 2 lane, 2 lane + 1, so that every operand of a contribution is one 2-element load per half of the row
-// (the walk is bound by the number of load instructions: one lane-strided element per load was 12 loads per ComplEx pair,
-// this is 4); SWEEP == 8: lane-strided elements lane + 64 i (any width, scalar loads).
 template <int SWEEP>
-__device__ __forceinline__ int elem_at(int d0, int lane, int i) { return SWEEP == 2 ? d0 + 2 * lane + i : d0 + lane + 64 * i; }
-
-template <class T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2))); };
-template <class T>
-__device__ __forceinline__ void load2(const T* __restrict__ p, float (&v)[2]) {  // 2 consecutive elements, widened
-    const typename Vec2<T>::type x = *reinterpret_cast<const typename Vec2<T>::type*>(p);
-    v[0] = (float)x[0]; v[1] = (float)x[1];
-}
-
-// d score / d operand at the lane's element pair (d, d + 1), d even, D % 4 == 0; `operand` is wave-uniform, so only the rows
-// the derivative needs are loaded (the derivative with respect to one operand does not read it, except TransE's sign).
-template <int MODEL, class TE, class TR>
-__device__ __forceinline__ void dscore2(int operand, const TE* __restrict__ h, const TE* __restrict__ t, const TR* __restrict__ r,
-                                        int d, int D, float (&out)[2]) {
-    if constexpr (MODEL == TRANSE) {
-        float hv[2], tv[2], rv[2];
-        load2(h + d, hv); load2(t + d, tv); load2(r + d, rv);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float sg = sign0(hv[k] + rv[k] - tv[k]);
-            out[k] = operand == 1 ? sg : -sg;
-        }
-    } else if constexpr (MODEL == DISTMULT) {
-        float a[2], b[2];
-        if (operand == 0) { load2(r + d, a); load2(t + d, b); }
-        else if (operand == 1) { load2(h + d, a); load2(r + d, b); }
-        else { load2(h + d, a); load2(t + d, b); }
-        out[0] = a[0] * b[0];
-        out[1] = a[1] * b[1];
-    } else {
-        const int H = D / 2;
-        const bool second = d >= H;  // (H is even: a pair never straddles the halves)
-        const int j = second ? d - H : d;
-        float a0[2], a1[2], b0[2], b1[2];  // the two other operands' first- and second-half pairs
-        if (operand == 0) { load2(r + j, a0); load2(r + H + j, a1); load2(t + j, b0); load2(t + H + j, b1); }
-        else if (operand == 1) { load2(h + j, a0); load2(h + H + j, a1); load2(r + j, b0); load2(r + H + j, b1); }
-        else { load2(h + j, a0); load2(h + H + j, a1); load2(t + j, b0); load2(t + H + j, b1); }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if constexpr (MODEL == COMPLEX) {
-                // s = rr*hr*tr + rr*hi*ti + ri*hr*ti - ri*hi*tr
-                if (operand == 0) out[k] = second ? a0[k] * b1[k] - a1[k] * b0[k] : a0[k] * b0[k] + a1[k] * b1[k];       // a = r, b = t
-                else if (operand == 1) out[k] = second ? b0[k] * a1[k] + b1[k] * a0[k] : b0[k] * a0[k] - b1[k] * a1[k];  // a = h, b = r
-                else out[k] = second ? a0[k] * b1[k] - a1[k] * b0[k] : a0[k] * b0[k] + a1[k] * b1[k];                    // a = h, b = t
-            } else {
-                // s = (hh*ra*tt + th*rb*ht) / 2 ; h = [hh|ht], t = [th|tt], r = [ra|rb]
-                if (operand == 0) out[k] = 0.5f * (second ? b0[k] * a1[k] : a0[k] * b1[k]);       // a = r, b = t: ht' = th*rb ; hh' = ra*tt
-                else if (operand == 1) out[k] = 0.5f * (second ? a0[k] * b0[k] : b1[k] * a1[k]);  // a = h, b = r: tt' = hh*ra ; th' = rb*ht
-                else out[k] = 0.5f * (second ? b0[k] * a1[k] : a0[k] * b1[k]);                    // a = h, b = t: rb' = th*ht ; ra' = hh*tt
-            }
-        }
-    }
-}
+__device__ __forceinline__ int elem_at(int d0, int lane, int i) { return d0 + lane + 64 * i; }
 
 // g += gn[n] * d score / d operand op[n] of pair (rows ih[n], it[n], relation row pb[n]), n < cnt, in that order; the
 // loads of all cnt pairs are issued before the first dependent addition (cnt is wave-uniform).
@@ -778,22 +722,7 @@ template <int MODEL, int SWEEP, int BATCH, class TE, class TR>
 __device__ __forceinline__ void add_contributions(float (&g)[SWEEP], const TE* __restrict__ ent, const TR* __restrict__ rel,
                                                   int D, int d0, int lane, int cnt, const int (&ih)[BATCH], const int (&it)[BATCH],
                                                   const int (&pb)[BATCH], const float (&gn)[BATCH], const int (&op)[BATCH]) {
-    if constexpr (SWEEP == 2) {
-        const int d = d0 + 2 * lane;
-        float v[BATCH][2];
-#pragma unroll
-        for (int n = 0; n < BATCH; ++n) {
-            v[n][0] = v[n][1] = 0.0f;
-            if (n < cnt && d < D)  // (D % 4 == 0: d + 1 < D as well)
-                dscore2<MODEL>(op[n], ent + (size_t)ih[n] * D, ent + (size_t)it[n] * D, rel + (size_t)pb[n] * D, d, D, v[n]);
-        }
-#pragma unroll
-        for (int n = 0; n < BATCH; ++n)
-            if (n < cnt) {
-                g[0] += gn[n] * v[n][0];
-                g[1] += gn[n] * v[n][1];
-            }
-    } else {
+    {
 #pragma unroll
         for (int i = 0; i < SWEEP; ++i) {
             const int d = d0 + lane + 64 * i;
