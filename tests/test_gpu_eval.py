@@ -941,3 +941,33 @@ def test_integration_md_stub_is_runnable():
         got = stub.rank_all_batches(rel_model, table, fixed, rel_w, rid, true, T, batch)
         want = ops.rank_all_batches(rel_model, table, fixed, rel_w, rid, true, T, batch)
         assert got.shape == (2 * T, 4) and torch.equal(got, want)
+
+
+def test_integration_md_loss_stub_is_runnable():
+    """The ctypes stub INTEGRATION.md gives for the training-side call (compute_loss as blp_inbatch_loss_fwd / _bwd behind a
+    torch.autograd.Function, the caller-kept ticket included) is executed as printed -- only the library path is made absolute
+    -- and gives the loss and gradients of blp_amd.ops.inbatch_loss bit for bit, which the goldens hold against the reference."""
+    import os
+    import re
+    import types
+    from blp_amd import _lib, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# blp_hip_loss\.py.*?)```", text, flags=re.S).group(1)
+    stub = types.ModuleType("blp_hip_loss_stub")
+    exec(block.replace('"libblp_hip.so"', repr(_lib.LIB_PATH)), stub.__dict__)
+    g = torch.Generator().manual_seed(21)
+    for rel_model, loss_fn, B, K, reg in (("transe", "margin", 64, 64, 0.0), ("complex", "nll", 48, 17, 1e-3)):
+        D = 128
+        ent = (torch.randn(B, 2, D, generator=g) * 0.4).cuda()
+        rel = (torch.randn(B, 1, D, generator=g) * 0.3).cuda()
+        neg_idx = torch.randint(0, 2 * B, (B, K, 2), generator=g).cuda()
+        outs = []
+        for fn in (lambda e, r: stub.InBatchLoss.apply(e, r, neg_idx, rel_model, loss_fn, reg),
+                   lambda e, r: ops.inbatch_loss(rel_model, loss_fn, e, r, neg_idx, reg)):
+            e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+            loss = fn(e, r)
+            (loss * 3.0).backward()
+            outs.append((loss.detach(), e.grad, r.grad))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
