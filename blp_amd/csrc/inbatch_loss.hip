@@ -57,7 +57,9 @@ __device__ __forceinline__ float sign0(float x) { return x > 0.0f ? 1.0f : (x < 
 //   [0, B)                          the positives' scores
 //   partials  2 doubles per pair / regulariser workgroup of the forward: its slots' loss terms (f64, slot order)
 //   off       n_chunks x (2B + 1) int32: chunk c's exclusive offsets of row j's entries in ITS part of `sorted`
-//   sorted    2BK int32: the entries e of neg_idx.view(-1) (pair e >> 1, slot e & 1), chunk by chunk of `chunk` consecutive
+//   sorted    2BK x int2 {e, the row the OTHER slot of e's pair names}: the entries e of neg_idx.view(-1) (pair e >> 1, slot
+//             e & 1; with the partner row beside it the backward knows both rows of the pair without reading neg_idx),
+//             chunk by chunk of `chunk` consecutive
 //             entries, inside a chunk grouped by the row they name (neg_idx[e]) and in entry order within a row
 // The index is what makes the backward O(BK): the negatives that reference row j are off[c][j] .. off[c][j + 1] of every
 // chunk c, and walking the chunks in order visits them in ENTRY order -- a fixed summation order, so gradients are
@@ -99,7 +101,8 @@ __host__ __device__ inline SaveLayout save_layout(int model, int B, int K, int D
     L.red_at = (L.regsh_at + B + 1) / 2 * 2;                           // (many workgroups) inbatch_reduce_kernel's partial sums
     L.off_at = L.red_at + 6 * kReduceBlocks;
     L.sorted_at = L.off_at + (int64_t)L.n_chunks * (2 * B + 1);
-    L.total = L.sorted_at + entries;
+    L.sorted_at = (L.sorted_at + 1) / 2 * 2;  // (int2: 8-byte aligned)
+    L.total = L.sorted_at + 2 * entries;
     return L;
 }
 
@@ -303,7 +306,7 @@ __device__ __forceinline__ float pair_score(const TE* __restrict__ h, const TE* 
 // its rank among those lanes (ballots).  The waves' histograms are then prefixed across waves and across rows (one block
 // scan) and every entry is written to its place.  Rows beyond kIdxBins: further passes over the same chunk.
 __device__ __forceinline__ void index_chunk(const int64_t* __restrict__ neg_idx, int64_t entries, int n_rows, int chunk, int c,
-                                            int* __restrict__ off, int* __restrict__ sorted) {
+                                            int* __restrict__ off, int2* __restrict__ sorted) {
     __shared__ unsigned short hist[4][kIdxBins];
     __shared__ unsigned char tag[4][kIdxBins];
     __shared__ int start[kIdxBins];
@@ -314,14 +317,16 @@ __device__ __forceinline__ void index_chunk(const int64_t* __restrict__ neg_idx,
     const int64_t e_end = ((int64_t)c + 1) * chunk < entries ? ((int64_t)c + 1) * chunk : entries;
     const unsigned long long below = (1ull << lane) - 1ull;
     int* off_c = off + (size_t)c * (n_rows + 1);
-    int* sorted_c = sorted + (size_t)c * chunk;
+    int2* sorted_c = sorted + (size_t)c * chunk;
     int placed = 0;  // entries of the rows of earlier passes (block-uniform)
-    int raw[kIdxMaxSlices];  // the wave's entries: every slice's load in flight before the first LDS round trip
+    int raw[kIdxMaxSlices], partner[kIdxMaxSlices];  // the wave's entries: every slice's load in flight before the first LDS round trip
 #pragma unroll
     for (int i = 0; i < kIdxMaxSlices; ++i) {
         const int64_t e = e0 + 64 * i + lane;
         raw[i] = (i < n_slices && e < e_end) ? (int)neg_idx[e] : -1;
     }
+#pragma unroll
+    for (int i = 0; i < kIdxMaxSlices; ++i) partner[i] = __shfl_xor(raw[i], 1);  // (entries 2p, 2p + 1 of pair p sit in neighbouring lanes)
     for (int w0 = 0; w0 < n_rows; w0 += kIdxBins) {
         for (int i = tid; i < 4 * kIdxBins; i += 256) (&hist[0][0])[i] = 0;
         __syncthreads();
@@ -405,7 +410,7 @@ __device__ __forceinline__ void index_chunk(const int64_t* __restrict__ neg_idx,
 #pragma unroll
         for (int i = 0; i < kIdxMaxSlices; ++i)
             if (i < n_slices && val[i] >= 0)
-                sorted_c[start[val[i]] + hist[wave][val[i]] + rank[i]] = (int)(e0 + 64 * i + lane);
+                sorted_c[start[val[i]] + hist[wave][val[i]] + rank[i]] = make_int2((int)(e0 + 64 * i + lane), partner[i]);
         placed += pass_total;
         __syncthreads();
     }
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(1024) void inbatch_forward_kernel(int loss, const T
     if ((int)blockIdx.x < L.n_chunks) {
         if (tid >= 256) return;  // (a row-mode launch has more waves per workgroup: the index workgroups use four)
         index_chunk(neg_idx, 2ll * B * K, 2 * B, L.chunk, (int)blockIdx.x, reinterpret_cast<int*>(pos + L.off_at),
-                    reinterpret_cast<int*>(pos + L.sorted_at));
+                    reinterpret_cast<int2*>(pos + L.sorted_at));
         return;
     }
     const int blk = (int)blockIdx.x - L.n_chunks, n_blocks = L.pair_blocks + L.reg_blocks;
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(GradShape<SWEEP>::kWaves * 64) void inbatch_grad_ke
     int loss, const TE* __restrict__ ent, const TR* __restrict__ rel, const int64_t* __restrict__ neg_idx, int B, int K,
     int D, float regularizer, const float* __restrict__ grad_loss, const float* __restrict__ pos,
     const float* __restrict__ neg, TE* __restrict__ grad_ent, TR* __restrict__ grad_rel, int ent_blocks, int S,
-    int rel_shares, const int* __restrict__ off, const int* __restrict__ sorted, int chunk, int C) {
+    int rel_shares, const int* __restrict__ off, const int2* __restrict__ sorted, int chunk, int C) {
     constexpr int WAVES = GradShape<SWEEP>::kWaves, BATCH = grad_batch(MODEL, SWEEP);
     __shared__ int run_at[WAVES][64];    // exclusive prefix of the chunks' counts (INT_MAX past the last chunk)
     __shared__ int run_from[WAVES][64];  // where the row's run starts in the chunk's part of `sorted`
@@ -895,10 +900,10 @@ __global__ __launch_bounds__(GradShape<SWEEP>::kWaves * 64) void inbatch_grad_ke
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1)
                     if (run_at[wave][l + step] <= q) l += step;
-                const int e = sorted[(size_t)(cb + l) * chunk + run_from[wave][l] + (q - run_at[wave][l])];
-                const int pair = e >> 1, pb = pair / K;
+                const int2 ep = sorted[(size_t)(cb + l) * chunk + run_from[wave][l] + (q - run_at[wave][l])];
+                const int e = ep.x, pair = e >> 1, pb = pair / K;
                 const float gn = in ? dloss_dneg(loss, pos[pb], neg[pair], B, K) : 0.0f;
-                const int hv = (int)neg_idx[2 * (size_t)pair], tv = (int)neg_idx[2 * (size_t)pair + 1];
+                const int hv = (e & 1) ? ep.y : j, tv = (e & 1) ? j : ep.y;  // (the row itself and its pair's other row)
                 consume<MODEL, SWEEP, BATCH>(g, __ballot(in && gn != 0.0f), hv, tv, pb, gn, e & 1, ent, rel, D, d0, lane);
             }
             at0 += blk_n;
@@ -935,9 +940,11 @@ __global__ __launch_bounds__(GradShape<SWEEP>::kWaves * 64) void inbatch_grad_ke
 // then take them alternately (half 0 the even slots, half 1 the odd ones), kUnroll slots' row loads in flight together.  A
 // half adds its contributions in list order; the two halves' sums are added at the end (half 0 + half 1), then the shares in
 // share order: fixed orders, bit-reproducible gradients.
+__host__ __device__ constexpr int grad4_rows(int model) { return model == TRANSE ? 3 : (model == DISTMULT ? 2 : 4); }  // row pieces a contribution reads
+
 template <int MODEL, class TE, class TR>
 __device__ __forceinline__ void load_ops4(int op, const TE* __restrict__ h, const TE* __restrict__ t, const TR* __restrict__ r, int d,
-                                          int D, float (&x)[4][4]) {
+                                          int D, float (&x)[grad4_rows(MODEL)][4]) {
     if constexpr (MODEL == TRANSE) {
         load4(h + d, x[0]); load4(t + d, x[1]); load4(r + d, x[2]);
     } else if constexpr (MODEL == DISTMULT) {  // the derivative with respect to one operand reads the two others
@@ -954,7 +961,7 @@ __device__ __forceinline__ void load_ops4(int op, const TE* __restrict__ h, cons
 
 // d score / d operand `op` at the lane's four elements from what load_ops4 fetched (the formulas of dscore / dscore2)
 template <int MODEL>
-__device__ __forceinline__ void eval_ops4(int op, int d, int D, const float (&x)[4][4], float (&out)[4]) {
+__device__ __forceinline__ void eval_ops4(int op, int d, int D, const float (&x)[grad4_rows(MODEL)][4], float (&out)[4]) {
     const bool second = d >= D / 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -978,71 +985,112 @@ __device__ __forceinline__ void eval_ops4(int op, int d, int D, const float (&x)
 constexpr int kGrad4Waves = 16;
 __host__ __device__ constexpr int grad4_unroll(int model) { return model == TRANSE || model == DISTMULT ? 4 : 2; }
 
-// The wave's compacted slots [0, n_live) (LDS: rows, relation row | operand << 30, loss gradient), the halves alternately.
-template <int MODEL, class TE, class TR>
-__device__ __forceinline__ void consume_slots4(float (&g)[4], const int2* __restrict__ slot_rows, const int2* __restrict__ slot_meta, int n_live,
-                                               const TE* __restrict__ ent, const TR* __restrict__ rel, int D, int d, bool active, int half) {
-    constexpr int U = grad4_unroll(MODEL);
-    for (int i0 = 0; i0 < n_live; i0 += 2 * U) {
-        float x[U][4][4], gn[U];
-        int op[U];
+// Small batches are chains of dependent memory round trips, not arithmetic: there the pairs' rows are requested BEFORE their
+// loss gradient is known (which costs the row loads of the pairs whose hinge is inactive, and saves a round trip).
+constexpr int64_t kSpeculateEntries = 32768;
+
+// The wave's slots [0, n_live) (LDS: the pair's rows; relation row | operand << 30; loss gradient), the halves alternately:
+// issue = the row loads of slots i0 .. i0 + 2 U - 1, finish = their contributions added in slot order.
+template <int MODEL, class TE, class TR, int U>
+__device__ __forceinline__ void issue_slots4(float (&x)[U][grad4_rows(MODEL)][4], const int2* __restrict__ slot_rows,
+                                             const int* __restrict__ slot_pbop, int i0, int n_live, const TE* __restrict__ ent,
+                                             const TR* __restrict__ rel, int D, int d, bool active, int half) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = i0 + 2 * u + half;
-            const bool ok = active && idx < n_live;
-            const int2 rows = slot_rows[ok ? idx : 0], meta = slot_meta[ok ? idx : 0];
-            op[u] = (unsigned)meta.x >> 30;
-            gn[u] = ok ? __builtin_bit_cast(float, meta.y) : 0.0f;
-            if (ok)
-                load_ops4<MODEL>(op[u], ent + (size_t)rows.x * D, ent + (size_t)rows.y * D, rel + (size_t)(meta.x & 0x3fffffff) * D, d, D, x[u]);
-            else
+    for (int u = 0; u < U; ++u) {
+        const int idx = i0 + 2 * u + half;
+        const bool ok = active && idx < n_live;
+        const int2 rows = slot_rows[ok ? idx : 0];
+        const int pbop = slot_pbop[ok ? idx : 0];
+        if (ok)
+            load_ops4<MODEL>((int)((unsigned)pbop >> 30), ent + (size_t)rows.x * D, ent + (size_t)rows.y * D, rel + (size_t)(pbop & 0x3fffffff) * D, d, D, x[u]);
+        else
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < grad4_rows(MODEL); ++a)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) x[u][a][k] = 0.0f;
-        }
+                for (int k = 0; k < 4; ++k) x[u][a][k] = 0.0f;
+    }
+}
+template <int MODEL, int U>
+__device__ __forceinline__ void finish_slots4(float (&g)[4], const float (&x)[U][grad4_rows(MODEL)][4], const int* __restrict__ slot_pbop, const float* __restrict__ slot_gn,
+                                              int i0, int n_live, int D, int d, bool active, int half) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float v[4];
-            eval_ops4<MODEL>(op[u], d, D, x[u], v);
+    for (int u = 0; u < U; ++u) {
+        const int idx = i0 + 2 * u + half;
+        const bool ok = active && idx < n_live;
+        const float gn = ok ? slot_gn[idx] : 0.0f;
+        const int op = (int)((unsigned)slot_pbop[ok ? idx : 0] >> 30);  // (read again rather than kept: a per-lane array of them went to scratch)
+        float v[4];
+        eval_ops4<MODEL>(op, d, D, x[u], v);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] += gn[u] * v[k];
-        }
+        for (int k = 0; k < 4; ++k) g[k] += gn * v[k];
     }
 }
 
-template <int MODEL, class TE, class TR>
+// One window of <= 64 list entries, a lane each: (rows, relation row, operand) and the scores its loss gradient comes from.
+// Default: the entries with a non-zero loss gradient are compacted into the wave's LDS slots in list order, then consumed.
+// SPECULATE: every entry takes a slot and the first slots' row loads are issued BEFORE the loss gradients are computed.
+template <int MODEL, class TE, class TR, bool SPECULATE>
+__device__ __forceinline__ void window4(float (&g)[4], bool in, int hv, int tv, int pb, int operand, float pos_b, float neg_bk,
+                                        int2* __restrict__ slot_rows, int* __restrict__ slot_pbop, float* __restrict__ slot_gn,
+                                        const TE* __restrict__ ent, const TR* __restrict__ rel, int loss, int B, int K, int D, int d,
+                                        bool lane_active, int half, int lane) {
+    constexpr int U = SPECULATE ? 2 : grad4_unroll(MODEL);
+    wave_lds_fence();  // the previous window's readers are done
+    float x[U][grad4_rows(MODEL)][4];
+    int n_live;
+    if constexpr (SPECULATE) {
+        n_live = __popcll(__ballot(in));  // (the `in` lanes are the first n_live lanes)
+        slot_rows[lane] = make_int2(hv, tv);
+        slot_pbop[lane] = pb | (operand << 30);
+        wave_lds_fence();
+        issue_slots4<MODEL>(x, slot_rows, slot_pbop, 0, n_live, ent, rel, D, d, lane_active, half);
+        slot_gn[lane] = in ? dloss_dneg(loss, pos_b, neg_bk, B, K) : 0.0f;
+        wave_lds_fence();
+    } else {
+        const float gn = in ? dloss_dneg(loss, pos_b, neg_bk, B, K) : 0.0f;
+        const bool keep = in && gn != 0.0f;
+        const unsigned long long mask = __ballot(keep);
+        n_live = __popcll(mask);
+        if (keep) {
+            const int at = __popcll(mask & ((1ull << lane) - 1ull));
+            slot_rows[at] = make_int2(hv, tv);
+            slot_pbop[at] = pb | (operand << 30);
+            slot_gn[at] = gn;
+        }
+        wave_lds_fence();
+        issue_slots4<MODEL>(x, slot_rows, slot_pbop, 0, n_live, ent, rel, D, d, lane_active, half);
+    }
+    finish_slots4<MODEL>(g, x, slot_pbop, slot_gn, 0, n_live, D, d, lane_active, half);
+    for (int i0 = 2 * U; i0 < n_live; i0 += 2 * U) {
+        issue_slots4<MODEL>(x, slot_rows, slot_pbop, i0, n_live, ent, rel, D, d, lane_active, half);
+        finish_slots4<MODEL>(g, x, slot_pbop, slot_gn, i0, n_live, D, d, lane_active, half);
+    }
+}
+
+template <int MODEL, class TE, class TR, bool SPECULATE>
 __global__ __launch_bounds__(kGrad4Waves * 64) void inbatch_grad4_kernel(
     int loss, const TE* __restrict__ ent, const TR* __restrict__ rel, const int64_t* __restrict__ neg_idx, int B, int K,
     int D, float regularizer, const float* __restrict__ grad_loss, const float* __restrict__ pos,
     const float* __restrict__ neg, TE* __restrict__ grad_ent, TR* __restrict__ grad_rel, int ent_blocks, int S,
-    int rel_shares, const int* __restrict__ off, const int* __restrict__ sorted, int chunk, int C) {
+    int rel_shares, const int* __restrict__ off, const int2* __restrict__ sorted, int chunk, int C) {
     constexpr int WAVES = kGrad4Waves;
     __shared__ int run_at[WAVES][64];
     __shared__ int run_from[WAVES][64];
-    __shared__ int2 slot_rows[WAVES][64], slot_meta[WAVES][64];
+    __shared__ int2 slot_rows[WAVES][64];
+    __shared__ int slot_pbop[WAVES][64];
+    __shared__ float slot_gn[WAVES][64];
     __shared__ float park[WAVES][128];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, d = 4 * (lane & 31);
     const bool lane_active = d < D;
-    const unsigned long long below = (1ull << lane) - 1ull;
     const float gl = grad_loss[0];
     const float reg_scale = regularizer > 0.0f ? regularizer * 2.0f / (3.0f * B * D) : 0.0f;
     float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    // one window of <= 64 candidate slots: lane-per-entry values in, compacted (gn != 0) into the wave's LDS, consumed
-    auto window = [&](bool in, int hv, int tv, int pb, int operand, float gn) {
-        const bool keep = in && gn != 0.0f;
-        const unsigned long long mask = __ballot(keep);
-        wave_lds_fence();  // the previous window's readers are done
-        if (keep) {
-            const int at = __popcll(mask & below);
-            slot_rows[wave][at] = make_int2(hv, tv);
-            slot_meta[wave][at] = make_int2(pb | (operand << 30), __builtin_bit_cast(int, gn));
-        }
-        wave_lds_fence();
-        consume_slots4<MODEL>(g, slot_rows[wave], slot_meta[wave], __popcll(mask), ent, rel, D, d, lane_active, half);
+    auto window = [&](bool in, int hv, int tv, int pb, int operand, float pos_b, float neg_bk) __attribute__((always_inline)) {
+        window4<MODEL, TE, TR, SPECULATE>(g, in, hv, tv, pb, operand, pos_b, neg_bk, slot_rows[wave], slot_pbop[wave], slot_gn[wave], ent, rel,
+                                          loss, B, K, D, d, lane_active, half, lane);
     };
-    auto fold_halves = [&]() {
+    auto fold_halves = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = g[k] + __shfl_xor(g[k], 32);  // (half 0 + half 1: the same bits in both halves)
     };
@@ -1056,7 +1104,7 @@ __global__ __launch_bounds__(kGrad4Waves * 64) void inbatch_grad4_kernel(
         const float pb = pos[bb];
         const float gp = dloss_dpos_wave(loss, pb, neg + (size_t)bb * K, B, K, lane);
         if (my_share == 0 && half == 0 && lane_active) {
-            float x[4][4], v[4];
+            float x[grad4_rows(MODEL)][4], v[4];
             load_ops4<MODEL>(2, ent + (size_t)(2 * bb) * D, ent + (size_t)(2 * bb + 1) * D, r, d, D, x);
             eval_ops4<MODEL>(2, d, D, x, v);
 #pragma unroll
@@ -1067,8 +1115,7 @@ __global__ __launch_bounds__(kGrad4Waves * 64) void inbatch_grad4_kernel(
             const int k = kb + lane;
             const bool in = k < k_hi;
             const size_t pair = (size_t)bb * K + (in ? k : k_lo);
-            const float gn = in ? dloss_dneg(loss, pb, neg[pair], B, K) : 0.0f;
-            window(in, (int)neg_idx[2 * pair], (int)neg_idx[2 * pair + 1], bb, 2, gn);
+            window(in, (int)neg_idx[2 * pair], (int)neg_idx[2 * pair + 1], bb, 2, pb, neg[pair]);
         }
         fold_halves();
         if (rel_shares > 1) {
@@ -1097,8 +1144,15 @@ __global__ __launch_bounds__(kGrad4Waves * 64) void inbatch_grad4_kernel(
     const bool active = my_row < 2 * B;
     const int j = active ? my_row : 2 * B - 1;
     const int stride = 2 * B + 1;
-    int n_list = 0;
-    for (int cb = 0; cb < C; cb += 64) {
+    // the row's runs: offsets of up to 64 chunks per lane-load; one block of chunks (2 B K <= 65 536 entries) keeps them in
+    // registers for the walk, more blocks are counted first and read again
+    const int c0 = lane;
+    const int from0 = c0 < C ? off[(size_t)c0 * stride + j] : 0;
+    const int cnt0 = c0 < C ? off[(size_t)c0 * stride + j + 1] - from0 : 0;
+    int n_list = cnt0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_list += __shfl_xor(n_list, o);
+    for (int cb = 64; cb < C; cb += 64) {
         const int c = cb + lane;
         int cnt = c < C ? off[(size_t)c * stride + j + 1] - off[(size_t)c * stride + j] : 0;
 #pragma unroll
@@ -1109,18 +1163,17 @@ __global__ __launch_bounds__(kGrad4Waves * 64) void inbatch_grad4_kernel(
     const float gp_row = dloss_dpos_wave(loss, pos[j >> 1], neg + (size_t)(j >> 1) * K, B, K, lane);  // (the whole wave: it shuffles)
     if (my_share == 0 && active && half == 0 && lane_active) {  // positive pair (2b, 2b + 1, rel b): the row is its head or its tail
         const int b = j >> 1, slot = j & 1;
-        const float gp = gp_row;
-        float x[4][4], v[4];
+        float x[grad4_rows(MODEL)][4], v[4];
         load_ops4<MODEL>(slot, ent + (size_t)(2 * b) * D, ent + (size_t)(2 * b + 1) * D, rel + (size_t)b * D, d, D, x);
         eval_ops4<MODEL>(slot, d, D, x, v);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = gp * v[k];
+        for (int k = 0; k < 4; ++k) g[k] = gp_row * v[k];
     }
     int at0 = 0;  // list position of the first entry of this block of 64 chunks
     for (int cb = 0; cb < C && at0 < my_hi; cb += 64) {
         const int c = cb + lane;
-        const int from = c < C ? off[(size_t)c * stride + j] : 0;
-        const int cnt = c < C ? off[(size_t)c * stride + j + 1] - from : 0;
+        const int from = cb == 0 ? from0 : (c < C ? off[(size_t)c * stride + j] : 0);
+        const int cnt = cb == 0 ? cnt0 : (c < C ? off[(size_t)c * stride + j + 1] - from : 0);
         int incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1140,10 +1193,10 @@ __global__ __launch_bounds__(kGrad4Waves * 64) void inbatch_grad4_kernel(
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1)
                 if (run_at[wave][l + step] <= q) l += step;
-            const int e = sorted[(size_t)(cb + l) * chunk + run_from[wave][l] + (q - run_at[wave][l])];
-            const int pair = e >> 1, pb = pair / K;
-            const float gn = in ? dloss_dneg(loss, pos[pb], neg[pair], B, K) : 0.0f;
-            window(in, (int)neg_idx[2 * (size_t)pair], (int)neg_idx[2 * (size_t)pair + 1], pb, e & 1, gn);
+            const int2 ep = sorted[(size_t)(cb + l) * chunk + run_from[wave][l] + (q - run_at[wave][l])];
+            const int e = ep.x, pair = e >> 1, pb = pair / K;
+            // (the row itself and the row the other slot of the pair names: no read of neg_idx)
+            window(in, (e & 1) ? ep.y : j, (e & 1) ? j : ep.y, pb, e & 1, pos[pb], neg[pair]);
         }
         at0 += blk_n;
     }
@@ -1181,9 +1234,16 @@ static void launch_grad4(int loss, const TE* ent, const TR* rel, const int64_t* 
     const int ent_blocks = (2 * B + R - 1) / R, rows_per_rel_block = WAVES / rel_shares;
     const int rel_blocks = (B + rows_per_rel_block - 1) / rows_per_rel_block;
     const SaveLayout L = save_layout(MODEL, B, K, D, regularizer > 0.0f);
-    inbatch_grad4_kernel<MODEL, TE, TR><<<dim3((unsigned)(ent_blocks + rel_blocks)), WAVES * 64, 0, stream>>>(
-        loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, pos, neg, grad_ent, grad_rel, ent_blocks, S, rel_shares,
-        reinterpret_cast<const int*>(pos + L.off_at), reinterpret_cast<const int*>(pos + L.sorted_at), L.chunk, L.n_chunks);
+    const int* off = reinterpret_cast<const int*>(pos + L.off_at);
+    const int2* sorted = reinterpret_cast<const int2*>(pos + L.sorted_at);
+    if ((int64_t)2 * B * K <= kSpeculateEntries)
+        inbatch_grad4_kernel<MODEL, TE, TR, true><<<dim3((unsigned)(ent_blocks + rel_blocks)), WAVES * 64, 0, stream>>>(
+            loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, pos, neg, grad_ent, grad_rel, ent_blocks, S, rel_shares, off, sorted,
+            L.chunk, L.n_chunks);
+    else
+        inbatch_grad4_kernel<MODEL, TE, TR, false><<<dim3((unsigned)(ent_blocks + rel_blocks)), WAVES * 64, 0, stream>>>(
+            loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, pos, neg, grad_ent, grad_rel, ent_blocks, S, rel_shares, off, sorted,
+            L.chunk, L.n_chunks);
 }
 
 template <int MODEL, class TE, class TR, int SWEEP>
@@ -1205,7 +1265,7 @@ static void launch_grad(int loss, const TE* ent, const TR* rel, const int64_t* n
     const SaveLayout L = save_layout(MODEL, B, K, D, regularizer > 0.0f);
     inbatch_grad_kernel<MODEL, TE, TR, SWEEP><<<dim3((unsigned)(ent_blocks + rel_blocks)), WAVES * 64, 0, stream>>>(
         loss, ent, rel, neg_idx, B, K, D, regularizer, grad_loss, pos, neg, grad_ent, grad_rel, ent_blocks, S, rel_shares,
-        reinterpret_cast<const int*>(pos + L.off_at), reinterpret_cast<const int*>(pos + L.sorted_at), L.chunk, L.n_chunks);
+        reinterpret_cast<const int*>(pos + L.off_at), reinterpret_cast<const int2*>(pos + L.sorted_at), L.chunk, L.n_chunks);
 }
 
 // ---------------------------------------------------------------- launchers

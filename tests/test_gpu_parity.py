@@ -931,8 +931,8 @@ def test_inbatch_loss_backward_row_ownership_and_rounds(ops, model, B, K, skew):
                                             ("distmult", 40, 60, "one_row"), ("transe", 300, 11, "dups")])
 def test_inbatch_forward_leaves_a_stable_index_of_neg_idx(model, B, K, skew):
     """What the backward walks (include/blp_hip.h: save_pos; inbatch_loss.hip: SaveLayout): for every chunk of 1 024 consecutive
-    entries of neg_idx.view(-1) the entries grouped by the row they name, IN ENTRY ORDER within a row, with the chunk's
-    exclusive row offsets -- read back here from the raw C-ABI call and held against a stable sort on the host, entry for
+    entries of neg_idx.view(-1) the entries grouped by the row they name, IN ENTRY ORDER within a row, each with the row the
+    other slot of its pair names, and the chunk's exclusive row offsets -- read back here from the raw C-ABI call and held against a stable sort on the host, entry for
     entry; and the ticket counter is left zero."""
     import ctypes
     from blp_amd import _lib
@@ -968,17 +968,18 @@ def test_inbatch_forward_leaves_a_stable_index_of_neg_idx(model, B, K, skew):
     off_at = (regsh_at + B + 1) // 2 * 2 + 6 * 64
     chunk, entries = 1024, 2 * B * K
     C = -(-entries // chunk)
-    sorted_at = off_at + C * (2 * B + 1)
-    assert sorted_at + entries == n
+    sorted_at = (off_at + C * (2 * B + 1) + 1) // 2 * 2          # int2 {entry, the row the other slot of its pair names}
+    assert sorted_at + 2 * entries == n
     ints = save.view(torch.int32).cpu()
-    off = ints[off_at:sorted_at].reshape(C, 2 * B + 1)
-    got = ints[sorted_at:sorted_at + entries]
+    off = ints[off_at:off_at + C * (2 * B + 1)].reshape(C, 2 * B + 1)
+    got = ints[sorted_at:sorted_at + 2 * entries].reshape(entries, 2)
     flat = neg_idx.view(-1)
     for c in range(C):
         lo, hi = c * chunk, min((c + 1) * chunk, entries)
         vals = flat[lo:hi]
         order = torch.sort(vals, stable=True).indices + lo        # by row, entry order within a row
-        assert torch.equal(got[lo:hi].long(), order), (c, "entries")
+        assert torch.equal(got[lo:hi, 0].long(), order), (c, "entries")
+        assert torch.equal(got[lo:hi, 1].long(), flat[order ^ 1]), (c, "partner rows")
         counts = torch.bincount(vals, minlength=2 * B)
         want_off = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)))
         assert torch.equal(off[c].long(), want_off), (c, "offsets")
