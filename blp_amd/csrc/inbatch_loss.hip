@@ -626,25 +626,28 @@ __global__ __launch_bounds__(1024) void inbatch_reduce_kernel(int loss, const fl
         part[2] = block_sum(s, sh);
     }
     if (G > 1) {
+        // (what crosses workgroups goes through device-scope atomic stores / loads, as in the one-launch forward: no cache-wide
+        //  release / acquire per workgroup)
         if (tid == 0) {
-            for (int j = 0; j < 3; ++j) partials[3 * g + j] = part[j];
-            __threadfence();
-            ticket_sh = atomicAdd(ticket, 1u);
+            for (int j = 0; j < 3; ++j) publish(&partials[3 * g + j], part[j]);
+            ticket_sh = take_ticket(ticket);
         }
         __syncthreads();
         if (ticket_sh != (unsigned)(G - 1)) return;  // not the last workgroup to finish
-        __threadfence();
-        if (tid == 0) {
+        if (tid < 64) {  // block order, whoever finished last: lane b fetches block b's sums, lane 0 adds them in order
+            double v[3] = {0.0, 0.0, 0.0};
+            if (tid < G)
+                for (int j = 0; j < 3; ++j) v[j] = observe(&partials[3 * tid + j]);
             part[0] = part[1] = part[2] = 0.0;
-            for (int b = 0; b < G; ++b)  // block order, whoever finished last
-                for (int j = 0; j < 3; ++j) part[j] += __builtin_nontemporal_load(&partials[3 * b + j]);
+            for (int b = 0; b < G; ++b)
+                for (int j = 0; j < 3; ++j) part[j] += __shfl(v[j], b);
         }
     }
     if (tid == 0) {
         const double model_loss = loss == LOSS_MARGIN ? part[0] / (double)BK : (part[1] / B + part[0] / (double)BK) / 2.0;
         const double reg = regularizer > 0.0f ? (double)regularizer * part[2] / ((double)B * D) / 3.0 : 0.0;
         out[0] = (float)(model_loss + reg);
-        if (G > 1) *ticket = 0u;  // as found
+        if (G > 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // as found
     }
 }
 
